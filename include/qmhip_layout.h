@@ -1,0 +1,111 @@
+/*
+ * qmhip_layout.h — flat f64 "blob" layouts shared across the C-ABI boundary.
+ *
+ * Two read-only blobs describe everything the hot path needs from the reference's
+ * three input files (robot.urdf, task.info, reference.info):
+ *   - MODEL blob  : the kinematic tree / inertias as Pinocchio would build them from
+ *                   qm_description/urdf/qudraputed_manipulator/robot.urdf with the root joint
+ *                   composite(Translation, SphericalZYX)   (qm_interface/src/QMInterface.cpp:408-416)
+ *   - SETTINGS blob: the numbers of qm_controllers/config/task.info + reference.info that the
+ *                   OCP / SQP / WBC read (qm_interface/src/QMInterface.cpp:64-73,99-131,
+ *                   qm_wbc/src/WbcBase.cpp:69-116,565-595, qm_wbc/cfg/wbcWigeht.cfg:7-47)
+ * Integers are stored as exact doubles. All matrices row-major.
+ *
+ * This header only holds constants; it is included by the product (qm_control_amd/csrc) and may be
+ * included by the oracle (the oracle depends on the product's public headers, never the reverse).
+ */
+#ifndef QMHIP_LAYOUT_H
+#define QMHIP_LAYOUT_H
+
+/* ---- fixed dimensions of the 24-DoF quadruped-manipulator ---- */
+#define QM_NJ 18      /* actuated joints: LF(3) LH(3) RF(3) RH(3) arm(6) — Pinocchio/urdfdom order */
+#define QM_NB 19      /* bodies: base + one per joint (fixed-joint children merged)              */
+#define QM_NQ 24      /* generalized coordinates = 6 base + 18                                    */
+#define QM_NX 30      /* centroidal state  [h_lin/m, h_ang/m, p_base, zyx, q_j]                    */
+#define QM_NU 30      /* input             [F_LF, F_RF, F_LH, F_RH, qd_j]                          */
+#define QM_NF 5       /* frames of interest: LF_FOOT, RF_FOOT, LH_FOOT, RH_FOOT, arm end-effector   */
+#define QM_NREF 37    /* target state = 30 + EE pos(3) + EE quat xyzw(4)                           */
+#define QM_NRBD 55    /* measured rbd state, qm_estimation/src/StateEstimateBase.cpp:41-103        */
+#define QM_NWBC 36    /* WBC decision x = [vdot(24); F(12)], qm_wbc/src/WbcBase.cpp:36             */
+#define QM_NWBC_OUT 54
+
+/* ---- MODEL blob offsets ---- */
+#define MB_PARENT    0      /* [18]   parent body of joint j (0 = base, k = body of joint k-1)     */
+#define MB_JR        18     /* [18*9] joint placement rotation in the parent body frame           */
+#define MB_JP        180    /* [18*3] joint placement translation                                  */
+#define MB_AXIS      234    /* [18*3] joint axis in the joint frame                                */
+#define MB_QLO       288    /* [18]   lower position limit                                          */
+#define MB_QHI       306    /* [18]   upper position limit                                          */
+#define MB_TAUMAX    324    /* [18]   effort limit                                                  */
+#define MB_MASS      342    /* [19]   body mass (after merging fixed children)                      */
+#define MB_COM       361    /* [19*3] body COM in the body (joint) frame                            */
+#define MB_INERTIA   418    /* [19*9] body rotational inertia about its COM, body axes              */
+#define MB_FPARENT   589    /* [5]    parent body of frame f                                        */
+#define MB_FR        594    /* [5*9]  frame placement rotation in the parent body frame             */
+#define MB_FP        639    /* [5*3]  frame placement translation                                   */
+#define MB_ROBOTMASS 654    /* total mass                                                            */
+#define MB_INOM      655    /* [9]    centroidalInertiaNominal (SRBD)                               */
+#define MB_RNOM      664    /* [3]    comToBasePositionNominal                                      */
+#define MB_QNOM      667    /* [18]   defaultJointState (reference.info:6-26)                       */
+#define MB_SIZE      685
+
+/* ---- SETTINGS blob offsets ---- */
+#define ST_Q          0     /* [30]  diagonal of Q (task.info:192-233)                              */
+#define ST_R          30    /* [900] R after the JᵀR₁₂J leg-block transform (QMInterface.cpp:274-299) */
+#define ST_XINIT      930   /* [30]  initialState (task.info:150-189)                               */
+#define ST_MU_EE_POS  960   /* endEffector.muPosition                                               */
+#define ST_MU_EE_ORI  961
+#define ST_MU_EEF_POS 962   /* finalEndEffector.muPosition                                          */
+#define ST_MU_EEF_ORI 963
+#define ST_FRIC_COEF  964   /* frictionConeSoftConstraint.frictionCoefficient                       */
+#define ST_FRIC_MU    965   /* relaxed barrier mu                                                   */
+#define ST_FRIC_DELTA 966
+#define ST_FRIC_REG   967   /* FrictionConeConstraint::Config regularization (upstream default 25)  */
+#define ST_FRIC_SHIFT 968   /* hessianDiagonalShift (upstream default 1e-6)                         */
+#define ST_JPOS_MU    969
+#define ST_JPOS_DELTA 970
+#define ST_JVEL_MU    971
+#define ST_JVEL_DELTA 972
+#define ST_JVEL_LO    973   /* [6] */
+#define ST_JVEL_HI    979   /* [6] */
+#define ST_POS_ERR_GAIN 985
+#define ST_PHASE_TRANS_STANCE 986
+#define ST_LIFTOFF_VEL 987
+#define ST_TOUCHDOWN_VEL 988
+#define ST_SWING_HEIGHT 989
+#define ST_SWING_TIME_SCALE 990
+#define ST_SQP_DT     991
+#define ST_SQP_ITER   992
+#define ST_DELTA_TOL  993
+#define ST_G_MAX      994
+#define ST_G_MIN      995
+#define ST_TIME_HORIZON 996
+#define ST_WBC_FRIC   997   /* frictionConeTask.frictionCoefficient (task.info:346-349)             */
+#define ST_KP_SWING   998
+#define ST_KD_SWING   999
+#define ST_KP_BASE_H  1000
+#define ST_KD_BASE_H  1001
+#define ST_KP_BASE_LIN 1002
+#define ST_KD_BASE_LIN 1003
+#define ST_KP_BASE_ANG 1004
+#define ST_KD_BASE_ANG 1005
+#define ST_KP_ARM_J   1006  /* [6] */
+#define ST_KD_ARM_J   1012  /* [6] */
+#define ST_KP_EE_LIN  1018  /* [3] */
+#define ST_KD_EE_LIN  1021  /* [3] */
+#define ST_KP_EE_ANG  1024  /* [3] */
+#define ST_KD_EE_ANG  1027  /* [3] */
+#define ST_SIZE       1030
+
+/* contact-mode ids: 8*LF + 4*RF + 2*LH + 1*RH (ocs2_legged_robot MotionPhaseDefinition) */
+#define QM_MODE_STANCE 15
+#define QM_MODE_LF_RH  9
+#define QM_MODE_RF_LH  6
+#define QM_MODE_FLY    0
+
+/* node event tags of the SQP time grid (ocs2 AnnotatedTime::Event) */
+#define QM_EV_NONE 0
+#define QM_EV_PRE  1
+#define QM_EV_POST 2
+
+#endif

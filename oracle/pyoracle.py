@@ -1,0 +1,197 @@
+"""oracle/pyoracle.py — TEST INFRASTRUCTURE: ctypes binding of oracle/_build/libqm_oracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libqm_oracle.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip)
+
+
+class Oracle:
+    MAXN = 512
+
+    def __init__(self, model_blob, settings_blob):
+        build()
+        self.lib = C.CDLL(_LIB)
+        L = self.lib
+        L.qmo_create.restype = C.c_void_p
+        L.qmo_create.argtypes = [_dp, _dp]
+        L.qmo_swing_zvel.restype = C.c_double
+        L.qmo_swing_zvel.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.qmo_mode_at.argtypes = [C.c_void_p, C.c_double]
+        L.qmo_destroy.argtypes = [C.c_void_p]
+        self.mb = np.ascontiguousarray(model_blob, dtype=np.float64)
+        self.st = np.ascontiguousarray(settings_blob, dtype=np.float64)
+        self.h = C.c_void_p(L.qmo_create(_p(self.mb), _p(self.st)))
+
+    def __del__(self):
+        try:
+            self.lib.qmo_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_setting(self, idx, v):
+        self.lib.qmo_set_setting(self.h, C.c_int(idx), C.c_double(v))
+
+    # ---- probes ----
+    def flow_map(self, x, u, jac=False):
+        x = np.ascontiguousarray(x, float); u = np.ascontiguousarray(u, float)
+        f = np.zeros(30)
+        if jac:
+            A = np.zeros((30, 30)); B = np.zeros((30, 30))
+            self.lib.qmo_flow_map(self.h, _p(x), _p(u), _p(f), _p(A), _p(B))
+            return f, A, B
+        self.lib.qmo_flow_map(self.h, _p(x), _p(u), _p(f), None, None)
+        return f
+
+    def foot_pos_vel(self, x, u, i):
+        x = np.ascontiguousarray(x, float); u = np.ascontiguousarray(u, float)
+        p = np.zeros(3); v = np.zeros(3)
+        self.lib.qmo_foot_pos_vel(self.h, _p(x), _p(u), C.c_int(i), _p(p), _p(v))
+        return p, v
+
+    def ee_pose_error(self, x, pref, qref):
+        x = np.ascontiguousarray(x, float); pref = np.ascontiguousarray(pref, float); qref = np.ascontiguousarray(qref, float)
+        g = np.zeros(6)
+        self.lib.qmo_ee_pose_error(self.h, _p(x), _p(pref), _p(qref), _p(g))
+        return g
+
+    def frame_pose(self, q, f):
+        q = np.ascontiguousarray(q, float); p = np.zeros(3); R = np.zeros((3, 3))
+        self.lib.qmo_frame_pose(self.h, _p(q), C.c_int(f), _p(p), _p(R))
+        return p, R
+
+    def time_grid(self, t0, tf, dt, ev):
+        ev = np.ascontiguousarray(ev, float)
+        t = np.zeros(self.MAXN); e = np.zeros(self.MAXN, np.int32)
+        n = self.lib.qmo_time_grid(C.c_double(t0), C.c_double(tf), C.c_double(dt), C.c_int(len(ev)), _p(ev), C.c_int(self.MAXN), _p(t), _pi(e))
+        assert n > 0
+        return t[:n].copy(), e[:n].copy()
+
+    # ---- problem data ----
+    def set_schedule(self, ev, modes):
+        ev = np.ascontiguousarray(ev, float); modes = np.ascontiguousarray(modes, np.int32)
+        assert len(modes) == len(ev) + 1
+        return self.lib.qmo_set_schedule(self.h, C.c_int(len(ev)), _p(ev), _pi(modes))
+
+    def set_target(self, t, x37):
+        t = np.ascontiguousarray(t, float); x37 = np.ascontiguousarray(x37, float)
+        self.lib.qmo_set_target(self.h, C.c_int(len(t)), _p(t), _p(x37))
+
+    def swing_zvel(self, leg, t):
+        return self.lib.qmo_swing_zvel(self.h, C.c_int(leg), C.c_double(t))
+
+    def mode_at(self, t):
+        return self.lib.qmo_mode_at(self.h, C.c_double(t))
+
+    def desired_state(self, t):
+        x = np.zeros(37); p = np.zeros(3); q = np.zeros(4)
+        self.lib.qmo_desired_state(self.h, C.c_double(t), _p(x), _p(p), _p(q))
+        return x, p, q
+
+    # ---- MPC ----
+    def mpc_step(self, t0, tf, x0):
+        x0 = np.ascontiguousarray(x0, float)
+        n = C.c_int(0)
+        nt = np.zeros(self.MAXN); ne = np.zeros(self.MAXN, np.int32); nm = np.zeros(self.MAXN, np.int32)
+        xo = np.zeros((self.MAXN, 30)); uo = np.zeros((self.MAXN, 30)); perf = np.zeros(10)
+        rc = self.lib.qmo_mpc_step(self.h, C.c_double(t0), C.c_double(tf), _p(x0), C.c_int(self.MAXN), C.byref(n), _p(nt), _pi(ne), _pi(nm), _p(xo), _p(uo), _p(perf))
+        if rc != 0:
+            raise RuntimeError("oracle mpc_step failed rc=%d" % rc)
+        k = n.value
+        return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf,
+                    alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h))
+
+    def node_lq(self, i):
+        z = lambda *s: np.zeros(s)
+        d = dict(A=z(30, 30), B=z(30, 30), b=z(30), Q=z(30, 30), R=z(30, 30), P=z(30, 30), q=z(30), r=z(30), scal=z(4), C=z(16, 30), D=z(16, 30), e=z(16))
+        rc = self.lib.qmo_get_node_lq(self.h, C.c_int(i), *[_p(d[k]) for k in ("A", "B", "b", "Q", "R", "P", "q", "r", "scal", "C", "D", "e")])
+        assert rc == 0
+        d["c"], d["dt"], d["nc"], d["event"] = d["scal"][0], d["scal"][1], int(d["scal"][2]), int(d["scal"][3])
+        return d
+
+    def node_proj(self, i):
+        z = lambda *s: np.zeros(s)
+        keys = ("Px", "Pu", "Pe", "Ap", "Bp", "bp", "Qp", "Rp", "Pp", "qp", "rp", "scal", "K", "kff")
+        d = dict(Px=z(30, 30), Pu=z(30, 30), Pe=z(30), Ap=z(30, 30), Bp=z(30, 30), bp=z(30), Qp=z(30, 30), Rp=z(30, 30), Pp=z(30, 30), qp=z(30), rp=z(30), scal=z(2), K=z(30, 30), kff=z(30))
+        rc = self.lib.qmo_get_node_proj(self.h, C.c_int(i), *[_p(d[k]) for k in keys])
+        assert rc == 0
+        d["cp"], d["m"] = d["scal"][0], int(d["scal"][1])
+        return d
+
+    def terminal(self):
+        Q = np.zeros((30, 30)); q = np.zeros(30); c = C.c_double(0)
+        self.lib.qmo_get_terminal(self.h, _p(Q), _p(q), C.byref(c))
+        return Q, q, c.value
+
+    def step(self, n):
+        dx = np.zeros((n, 30)); du = np.zeros((n, 30))
+        self.lib.qmo_get_step(self.h, _p(dx), _p(du))
+        return dx, du[: n - 1]
+
+    def eval_policy(self, t):
+        x = np.zeros(30); u = np.zeros(30); m = C.c_int(0)
+        self.lib.qmo_eval_policy(self.h, C.c_double(t), _p(x), _p(u), C.byref(m))
+        return x, u, m.value
+
+    # ---- WBC ----
+    def wbc_reset(self):
+        self.lib.qmo_wbc_reset(self.h)
+
+    def wbc_set_input_last(self, u):
+        u = np.ascontiguousarray(u, float)
+        self.lib.qmo_wbc_set_input_last(self.h, _p(u))
+
+    def rbd_from_q(self, q, v=None):
+        q = np.ascontiguousarray(q, float); rbd = np.zeros(55)
+        vv = None if v is None else np.ascontiguousarray(v, float)
+        self.lib.qmo_rbd_from_q(self.h, _p(q), None if vv is None else _p(vv), _p(rbd))
+        return rbd
+
+    def wbc(self, xdes, udes, rbd, mode, period, time, mpc_variant=False, debug=False):
+        xdes = np.ascontiguousarray(xdes, float); udes = np.ascontiguousarray(udes, float); rbd = np.ascontiguousarray(rbd, float)
+        out = np.zeros(54); st = np.zeros(3, np.int32); dbg = np.zeros(24 * 4 + 6 + 24 + 36 * 3 + 576 + 288 + 288)
+        self.lib.qmo_wbc(self.h, _p(xdes), _p(udes), _p(rbd), C.c_int(mode), C.c_double(period), C.c_double(time), C.c_int(int(mpc_variant)), _p(out), _pi(st), _p(dbg))
+        if not debug:
+            return out, st
+        o = 0
+        d = {}
+        for k, n in (("qMeas", 24), ("vMeas", 24), ("qDes", 24), ("vDes", 24), ("baseAcc", 6), ("nle", 24), ("x0", 36), ("x1", 36), ("x2", 36), ("M", 576), ("J", 288), ("dJ", 288)):
+            d[k] = dbg[o:o + n].copy(); o += n
+        d["M"] = d["M"].reshape(24, 24); d["J"] = d["J"].reshape(12, 24); d["dJ"] = d["dJ"].reshape(12, 24)
+        return out, st, d
+
+
+def batch_step(model_blob, settings_blob, nthreads, t0, horizon, x0, ref_t, ref_x, ev, modes, period, time):
+    """cpu_baseline driver: B instances of (MPC step + policy eval at t0 + WBC) over nthreads."""
+    build()
+    lib = C.CDLL(_LIB)
+    mb = np.ascontiguousarray(model_blob, float); st = np.ascontiguousarray(settings_blob, float)
+    t0 = np.ascontiguousarray(t0, float); x0 = np.ascontiguousarray(x0, float)
+    ref_t = np.ascontiguousarray(ref_t, float); ref_x = np.ascontiguousarray(ref_x, float)
+    ev = np.ascontiguousarray(ev, float); modes = np.ascontiguousarray(modes, np.int32)
+    B = x0.shape[0]; K = ref_t.shape[1]; nev = ev.shape[1]
+    xf = np.zeros((B, 30)); uf = np.zeros((B, 30)); w = np.zeros((B, 54))
+    bad = lib.qmo_batch_step(_p(mb), _p(st), C.c_int(B), C.c_int(nthreads), _p(t0), C.c_double(horizon), _p(x0), C.c_int(K), _p(ref_t), _p(ref_x),
+                             C.c_int(nev), _p(ev), _pi(modes), C.c_double(period), C.c_double(time), _p(xf), _p(uf), _p(w))
+    return bad, xf, uf, w

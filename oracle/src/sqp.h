@@ -1,0 +1,243 @@
+// oracle/src/sqp.h — TEST INFRASTRUCTURE (CPU oracle). One multiple-shooting SQP iteration as the
+// reference runs it through ocs2::SqpMpc (qm_controllers/src/QMController.cpp:287-288; settings
+// qm_controllers/config/task.info:75-92).  Restates [upstream ocs2_sqp SqpSolver::runImpl] per
+// SURVEY.md §8 a11 / Appendix B.1, B.6.  PARITY UNPINNED.
+#pragma once
+#include "ocp.h"
+
+static const double kWeakEps = 1e-6;                       // numeric_traits::weakEpsilon<double>()
+static const double kLimitEps = 2.220446049250313e-16;     // numeric_traits::limitEpsilon<double>()
+
+struct Node { double t; int ev; };
+inline double intervalStart(const Node& n) { return n.ev == QM_EV_POST ? n.t + kWeakEps : n.t; }
+inline double intervalEnd(const Node& n) { return n.ev == QM_EV_PRE ? n.t - kWeakEps : n.t; }
+
+// [upstream timeDiscretizationWithEvents]
+inline std::vector<Node> timeDiscretizationWithEvents(double t0, double tf, double dt, const Vec& ev) {
+  const double dtMin = 10.0 * kLimitEps;
+  std::vector<Node> g; g.push_back({t0, QM_EV_NONE});
+  int k = findIndexInTimeArray(ev, t0);
+  Node next = g.back();
+  while (g.back().t < tf) {
+    next.t = next.t + dt; next.ev = QM_EV_NONE; bool post = false;
+    if (k < (int)ev.size() && next.t >= ev[k]) { next.t = ev[k]; next.ev = QM_EV_PRE; post = true; ++k; }
+    if (next.t >= tf) { next.t = tf; next.ev = QM_EV_NONE; post = false; }
+    if (next.t > g.back().t + dtMin) g.push_back(next); else g.back() = next;
+    if (post) g.push_back({next.t, QM_EV_POST});
+  }
+  return g;
+}
+
+struct NodeLQ {
+  // unprojected (K1 output)
+  Mat A, B; Vec b;                 // dx+ = A dx + B du + b
+  double c; Vec q, r; Mat Q, R, P; // cost model (already × dt)
+  Mat C, D; Vec e; int nc = 0;     // equality rows
+  double dt = 0; int event = 0;    // event==1: zero-duration PreEvent->PostEvent node (identity jump)
+  // projection (K2 output): du = Pe + Px dx + Pu ut
+  Mat Px, Pu; Vec Pe; int m = 0;
+  Mat Ap, Bp; Vec bp; double cp; Vec qp, rp; Mat Qp, Rp, Pp;
+  // Riccati (K3)
+  Mat K; Vec kff;
+};
+struct Performance { double merit = 0, cost = 0, dynSSE = 0, eqSSE = 0; };
+struct SqpResult {
+  std::vector<Node> grid; std::vector<int> mode; std::vector<Vec> x, u;   // u has grid.size() entries (primal solution)
+  std::vector<Vec> dx, du; std::vector<NodeLQ> lq; NodeLQ terminal;
+  Performance baseline, after; double alpha = 0; int lsTrials = 0; double armijo = 0; int status = 0;
+};
+
+// RK2 (Heun) flow value: x + dt/2 (k1 + k2)
+inline Vec rk2Step(const Model& M, const Vec& x, const Vec& u, double dt) {
+  Vec k1, k2; flowMapValue(M, x, u, k1);
+  Vec x2(QM_NX); for (int i = 0; i < QM_NX; ++i) x2[i] = x[i] + dt * k1[i];
+  flowMapValue(M, x2, u, k2);
+  Vec r(QM_NX); for (int i = 0; i < QM_NX; ++i) r[i] = x[i] + 0.5 * dt * k1[i] + 0.5 * dt * k2[i];
+  return r;
+}
+
+// K1: setupIntermediateNode
+inline void setupIntermediateNode(const Problem& P, double t, double dt, const Vec& x, const Vec& xn, const Vec& u, NodeLQ& n) {
+  const Model& M = *P.M;
+  Vec f1, f2; Mat A1, B1, A2, B2;
+  flowMapLinear(M, x, u, f1, A1, B1);
+  Vec x2(QM_NX); for (int i = 0; i < QM_NX; ++i) x2[i] = x[i] + dt * f1[i];
+  flowMapLinear(M, x2, u, f2, A2, B2);
+  Mat A2A1 = matmul(A2, A1), A2B1 = matmul(A2, B1);
+  n.A = Mat(QM_NX, QM_NX); n.B = Mat(QM_NX, QM_NU); n.b.assign(QM_NX, 0.0);
+  for (int i = 0; i < QM_NX; ++i) {
+    for (int j = 0; j < QM_NX; ++j) n.A(i, j) = 0.5 * dt * A1(i, j) + 0.5 * dt * (A2(i, j) + dt * A2A1(i, j)) + (i == j ? 1.0 : 0.0);
+    for (int j = 0; j < QM_NU; ++j) n.B(i, j) = 0.5 * dt * B1(i, j) + 0.5 * dt * (B2(i, j) + dt * A2B1(i, j));
+    n.b[i] = x[i] + 0.5 * dt * f1[i] + 0.5 * dt * f2[i] - xn[i];
+  }
+  CostQuad c; intermediateCost(P, t, x, u, true, c);
+  n.c = c.f * dt; n.q = vscaled(c.q, dt); n.r = vscaled(c.r, dt); n.Q = scaled(c.Q, dt); n.R = scaled(c.R, dt); n.P = scaled(c.P, dt);
+  equalityConstraints(P, t, x, u, true, n.e, n.C, n.D); n.nc = (int)n.e.size();
+  n.dt = dt; n.event = 0;
+}
+
+// K2: projectTranscription with the QR null-space projection
+inline void projectNode(NodeLQ& n) {
+  const int nc = n.nc, nu = QM_NU; n.m = nu - nc;
+  Mat Qf, Rf; householderQR(transpose(n.D), Qf, Rf);   // Dᵀ = Q1 R
+  // D† = Q1 R⁻ᵀ ; Pu = Q2
+  Mat Q1(nu, nc), Q2(nu, n.m);
+  for (int i = 0; i < nu; ++i) { for (int j = 0; j < nc; ++j) Q1(i, j) = Qf(i, j); for (int j = 0; j < n.m; ++j) Q2(i, j) = Qf(i, nc + j); }
+  // solve Rᵀ Y = [C e]  (Rᵀ lower triangular) -> Px = −Q1 Y_C, Pe = −Q1 y_e
+  Mat Y(nc, QM_NX); Vec ye(nc);
+  for (int col = 0; col <= QM_NX; ++col) {
+    for (int i = 0; i < nc; ++i) {
+      double s = (col < QM_NX) ? n.C(i, col) : n.e[i];
+      for (int k = 0; k < i; ++k) s -= Rf(k, i) * ((col < QM_NX) ? Y(k, col) : ye[k]);
+      s /= Rf(i, i);
+      if (col < QM_NX) Y(i, col) = s; else ye[i] = s;
+    }
+  }
+  n.Pu = Q2; n.Px = scaled(matmul(Q1, Y), -1.0); n.Pe = vscaled(matvec(Q1, ye), -1.0);
+  // dynamics
+  n.bp = vadd(n.b, matvec(n.B, n.Pe)); n.Ap = add(n.A, matmul(n.B, n.Px)); n.Bp = matmul(n.B, n.Pu);
+  // cost (changeOfInputVariables)
+  Vec RPe = matvec(n.R, n.Pe);
+  n.cp = n.c + vdot(n.r, n.Pe) + 0.5 * vdot(n.Pe, RPe);
+  Vec rr = vadd(n.r, RPe);
+  n.qp = vadd(vadd(n.q, matvecT(n.Px, rr)), matvecT(n.P, n.Pe));
+  n.rp = matvecT(n.Pu, rr);
+  Mat PRPx = add(n.P, matmul(n.R, n.Px));          // P + R Px   (nu x nx)
+  Mat PxtP = matmulTN(n.Px, n.P);
+  n.Qp = add(add(n.Q, PxtP), add(transpose(PxtP), matmulTN(n.Px, matmul(n.R, n.Px))));
+  n.Pp = matmulTN(n.Pu, PRPx);
+  n.Rp = matmulTN(n.Pu, matmul(n.R, n.Pu));
+}
+
+// performance of a trajectory (computePerformance)
+inline Performance computePerformance(const Problem& P, const std::vector<Node>& g, const Vec& x0, const std::vector<Vec>& x, const std::vector<Vec>& u) {
+  const Model& M = *P.M; const int N = (int)g.size() - 1; Performance p;
+  for (int i = 0; i < N; ++i) {
+    if (g[i].ev == QM_EV_PRE) {
+      double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = x[i][k] - x[i + 1][k]; s += d * d; }
+      p.dynSSE += s;
+    } else {
+      const double ti = intervalStart(g[i]); const double dt = intervalEnd(g[i + 1]) - ti;
+      Vec xe = rk2Step(M, x[i], u[i], dt);
+      double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = xe[k] - x[i + 1][k]; s += d * d; }
+      p.dynSSE += dt * s;
+      CostQuad c; intermediateCost(P, ti, x[i], u[i], false, c); p.cost += c.f * dt;
+      Vec e; Mat C, D; equalityConstraints(P, ti, x[i], u[i], false, e, C, D);
+      double se = 0; for (double v : e) se += v * v; p.eqSSE += dt * se;
+    }
+  }
+  { CostQuad c; terminalCost(P, intervalStart(g[N]), x[N], false, c); p.cost += c.f; }
+  { double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = x0[k] - x[0][k]; s += d * d; } p.dynSSE += s; }
+  p.merit = p.cost;
+  return p;
+}
+
+inline double trajectoryNorm(const std::vector<Vec>& v) { double s = 0; for (auto& a : v) for (double z : a) s += z * z; return std::sqrt(s); }
+
+// one SQP iteration, cold start (initializer a9) unless xInit/uInit are given
+inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, const std::vector<Vec>* xInit, const std::vector<Vec>* uInit, SqpResult& R) {
+  const Model& M = *P.M; const double* st = M.st;
+  R.grid = timeDiscretizationWithEvents(t0, tf, st[ST_SQP_DT], P.ms.ev);
+  const int N = (int)R.grid.size() - 1;
+  R.mode.resize(N + 1); for (int i = 0; i <= N; ++i) R.mode[i] = P.ms.modeAt(intervalStart(R.grid[i]));
+  // initializeStateInputTrajectories, cold start: QMInitializer::compute (QMInitializer.cpp:33-41)
+  std::vector<Vec> x(N + 1), u(N);
+  if (xInit) { x = *xInit; u = *uInit; }
+  else {
+    x[0] = x0;
+    for (int i = 0; i < N; ++i) {
+      if (R.grid[i].ev == QM_EV_PRE) { u[i] = Vec(QM_NU, 0.0); x[i + 1] = x[i]; }
+      else { bool fl[4]; modeToFlags(P.ms.modeAt(intervalStart(R.grid[i])), fl); u[i] = weightCompensatingInput(M, fl); x[i + 1] = x[i]; }
+    }
+  }
+  // ---- setupQuadraticSubproblem ----
+  R.lq.assign(N, NodeLQ()); Performance base;
+  for (int i = 0; i < N; ++i) {
+    NodeLQ& n = R.lq[i];
+    if (R.grid[i].ev == QM_EV_PRE) {   // setupEventNode: identity jump map, no pre-jump cost/constraints (QMInterface.cpp:79-142)
+      n.event = 1; n.m = 0; n.nc = 0; n.dt = 0;
+      n.Ap = Mat::identity(QM_NX); n.A = n.Ap; n.bp.assign(QM_NX, 0.0);
+      for (int k = 0; k < QM_NX; ++k) n.bp[k] = x[i][k] - x[i + 1][k];
+      n.b = n.bp; n.Qp = Mat(QM_NX, QM_NX); n.Q = n.Qp; n.qp.assign(QM_NX, 0.0); n.q = n.qp; n.cp = n.c = 0;
+      double s = 0; for (double v : n.bp) s += v * v; base.dynSSE += s;
+    } else {
+      const double ti = intervalStart(R.grid[i]); const double dt = intervalEnd(R.grid[i + 1]) - ti;
+      setupIntermediateNode(P, ti, dt, x[i], x[i + 1], u[i], n);
+      double s = 0; for (double v : n.b) s += v * v; base.dynSSE += dt * s;
+      base.cost += n.c;
+      double se = 0; for (double v : n.e) se += v * v; base.eqSSE += dt * se;
+      projectNode(n);
+    }
+  }
+  { CostQuad c; terminalCost(P, intervalStart(R.grid[N]), x[N], true, c); R.terminal.Qp = c.Q; R.terminal.qp = c.q; R.terminal.cp = c.f; base.cost += c.f; }
+  { double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = x0[k] - x[0][k]; s += d * d; } base.dynSSE += s; }
+  base.merit = base.cost; R.baseline = base;
+  // ---- QP solve: Riccati ----
+  Mat S = R.terminal.Qp; Vec s = R.terminal.qp;
+  for (int k = N - 1; k >= 0; --k) {
+    NodeLQ& n = R.lq[k];
+    Vec Sb = matvec(S, n.bp); Vec spSb = vadd(s, Sb);
+    Mat SA = matmul(S, n.Ap);
+    if (n.event) { S = matmulTN(n.Ap, SA); s = matvecT(n.Ap, spSb); }
+    else {
+      Mat BtS = matmulTN(n.Bp, S);
+      Mat Huu = add(n.Rp, matmul(BtS, n.Bp));
+      Mat Hux = add(n.Pp, matmul(BtS, n.Ap));
+      Vec hu = vadd(n.rp, matvecT(n.Bp, spSb));
+      for (int i = 0; i < Huu.r; ++i) for (int j = i + 1; j < Huu.c; ++j) { const double a = 0.5 * (Huu(i, j) + Huu(j, i)); Huu(i, j) = Huu(j, i) = a; }
+      Mat L; if (!cholesky(Huu, L)) { R.status = -2; return; }
+      n.K = scaled(cholSolve(L, Hux), -1.0); n.kff = vscaled(cholSolve(L, hu), -1.0);
+      Mat Snew = add(add(n.Qp, matmulTN(n.Ap, SA)), matmulTN(Hux, n.K));
+      for (int i = 0; i < QM_NX; ++i) for (int j = i + 1; j < QM_NX; ++j) { const double a = 0.5 * (Snew(i, j) + Snew(j, i)); Snew(i, j) = Snew(j, i) = a; }
+      s = vadd(vadd(n.qp, matvecT(n.Ap, spSb)), matvecT(Hux, n.kff));
+      S = Snew;
+    }
+  }
+  R.dx.assign(N + 1, Vec(QM_NX, 0.0)); R.du.assign(N, Vec(QM_NU, 0.0));
+  for (int k = 0; k < QM_NX; ++k) R.dx[0][k] = x0[k] - x[0][k];
+  double armijo = 0;
+  for (int k = 0; k < N; ++k) {
+    NodeLQ& n = R.lq[k];
+    if (n.event) { R.dx[k + 1] = vadd(matvec(n.Ap, R.dx[k]), n.bp); armijo += vdot(n.qp, R.dx[k]); continue; }
+    Vec ut = vadd(matvec(n.K, R.dx[k]), n.kff);
+    R.dx[k + 1] = vadd(vadd(matvec(n.Ap, R.dx[k]), matvec(n.Bp, ut)), n.bp);
+    armijo += vdot(n.qp, R.dx[k]) + vdot(n.rp, ut);
+    R.du[k] = vadd(vadd(n.Pe, matvec(n.Px, R.dx[k])), matvec(n.Pu, ut));   // remapProjectedInput
+  }
+  armijo += vdot(R.terminal.qp, R.dx[N]);
+  R.armijo = armijo;
+  // ---- takeStep: filter line-search ----
+  const double gMax = st[ST_G_MAX], gMin = st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
+  const double theta0 = std::sqrt(base.dynSSE + base.eqSSE);
+  const double duNorm = trajectoryNorm(R.du), dxNorm = trajectoryNorm(R.dx);
+  double alpha = 1.0; bool accepted = false; std::vector<Vec> xn(N + 1), un(N); Performance pn; R.lsTrials = 0;
+  do {
+    for (int i = 0; i <= N; ++i) { xn[i] = x[i]; for (int k = 0; k < QM_NX; ++k) xn[i][k] += alpha * R.dx[i][k]; }
+    for (int i = 0; i < N; ++i) { un[i] = u[i]; if (R.grid[i].ev != QM_EV_PRE) for (int k = 0; k < QM_NU; ++k) un[i][k] += alpha * R.du[i][k]; }
+    pn = computePerformance(P, R.grid, x0, xn, un); ++R.lsTrials;
+    const double theta = std::sqrt(pn.dynSSE + pn.eqSSE);
+    if (theta > gMax) accepted = theta < (1.0 - gammaC) * theta0;
+    else if (theta < gMin && theta0 < gMin && alpha * armijo < 0.0) accepted = pn.merit < base.merit + armijoFactor * alpha * armijo;
+    else accepted = pn.merit < (base.merit - gammaC * theta0) || theta < (1.0 - gammaC) * theta0;
+    if (accepted) break;
+    alpha *= alphaDecay;
+    if (alpha * duNorm < st[ST_DELTA_TOL] && alpha * dxNorm < st[ST_DELTA_TOL]) break;
+  } while (alpha >= alphaMin);
+  if (accepted) { x = xn; u = un; R.alpha = alpha; R.after = pn; } else { R.alpha = 0.0; R.after = base; }
+  // ---- toPrimalSolution: u at PreEvent nodes copied from the previous node, last u repeated
+  R.x = x; R.u.assign(N + 1, Vec(QM_NU, 0.0));
+  for (int i = 0; i < N; ++i) { if (R.grid[i].ev == QM_EV_PRE && i > 0) R.u[i] = R.u[i - 1]; else R.u[i] = u[i]; }
+  R.u[N] = R.u[N - 1];
+  R.status = 0;
+}
+
+// a12: MPC_MRT_Interface::evaluatePolicy [upstream]: linear interpolation of the primal solution
+inline void evaluatePolicy(const SqpResult& R, const ModeSchedule& ms, double t, Vec& x, Vec& u, int& mode) {
+  const int n = (int)R.grid.size(); Vec ta(n);
+  for (int i = 0; i < n; ++i) ta[i] = R.grid[i].t + (R.grid[i].ev == QM_EV_POST ? kLimitEps : (R.grid[i].ev == QM_EV_PRE ? -kLimitEps : 0.0));
+  int i; double a; timeSegment(t, ta, i, a);
+  x.assign(QM_NX, 0.0); u.assign(QM_NU, 0.0);
+  for (int k = 0; k < QM_NX; ++k) x[k] = a * R.x[i][k] + (1.0 - a) * R.x[i + 1][k];
+  for (int k = 0; k < QM_NU; ++k) u[k] = a * R.u[i][k] + (1.0 - a) * R.u[i + 1][k];
+  mode = ms.modeAt(t);
+}
