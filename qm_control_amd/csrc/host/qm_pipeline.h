@@ -1,0 +1,113 @@
+// qm_pipeline.h — launch sequence of the MPC+WBC step, independent of how kernels get launched.
+//
+// `BK` (backend) provides:  template<class K, class A> void launch(K kernel, int grid, int block, size_t lds_bytes, const A& args);
+//                           void* alloc(size_t bytes);  void free(void*);  void zero(void* p, size_t bytes);
+//                           void to_device(void* dst, const void* src, size_t);  void to_host(void* dst, const void* src, size_t);  void sync();
+// The product instantiates it with the HIP backend (qm_control_amd/csrc/host/qmhip.hip); the -m "not gpu" tests
+// instantiate it with the host emulator so the very same sequence is exercised without a GPU.
+//
+// Sequence of one control step (QMController's mpcThread_ + update(), qm_controllers/src/QMController.cpp:128-175,315-332):
+//   K0 grid  ->  K1 LQ+projection  ->  baseline performance  ->  K3 Riccati  ->  K4 line-search loop  ->  primal solution
+//   ->  policy evaluation at t0 + K5..K7 whole-body controller
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+#include "../kernels/k_grid.h"
+#include "../kernels/k_lq.h"
+#include "../kernels/k_riccati.h"
+#include "../kernels/k_ls.h"
+
+struct QmMpcBuffers {
+  int Bmax = 0, nmax = 0, nref = 0, nev = 0;
+  // model
+  double* mb = nullptr; double* st = nullptr;
+  // inputs (device copies)
+  double* t0 = nullptr; double* x0 = nullptr; double* ref_t = nullptr; double* ref_x = nullptr; double* ev = nullptr; int* modes = nullptr;
+  // grid
+  int* n_nodes = nullptr; double* node_t = nullptr; double* node_ts = nullptr; double* node_dt = nullptr; int* node_ev = nullptr; int* node_mode = nullptr;
+  double* zvel = nullptr; double* zpos = nullptr; double* xref = nullptr; double* eeref = nullptr; int* status = nullptr;
+  // iterate, step, stage data
+  double* x = nullptr; double* u = nullptr; double* dx = nullptr; double* du = nullptr; double* stage = nullptr; double* lqdbg = nullptr;
+  double* perf = nullptr; double* base_sum = nullptr; double* perf_sum = nullptr; double* step_info = nullptr;
+  double* alpha = nullptr; int* done = nullptr; double* xs = nullptr; double* us = nullptr; double* out_perf = nullptr;
+};
+
+template <class BK>
+struct QmMpcPipeline {
+  BK& bk; QmMpcBuffers d;
+  int ls_trials_run = 0;
+  explicit QmMpcPipeline(BK& b) : bk(b) {}
+
+  template <class T> T* A(size_t n) { T* p = (T*)bk.alloc(n * sizeof(T)); bk.zero(p, n * sizeof(T)); return p; }
+
+  void allocate(const double* mb_host, const double* st_host, int Bmax, int nmax, int nref, int nev, bool debug_lq) {
+    d.Bmax = Bmax; d.nmax = nmax; d.nref = nref; d.nev = nev;
+    const size_t NB = (size_t)nmax * Bmax;
+    d.mb = A<double>(MB_SIZE); d.st = A<double>(ST_SIZE);
+    bk.to_device(d.mb, mb_host, MB_SIZE * 8); bk.to_device(d.st, st_host, ST_SIZE * 8);
+    d.t0 = A<double>(Bmax); d.x0 = A<double>((size_t)Bmax * 30); d.ref_t = A<double>((size_t)Bmax * nref); d.ref_x = A<double>((size_t)Bmax * nref * QM_NREF);
+    d.ev = A<double>((size_t)Bmax * nev); d.modes = A<int>((size_t)Bmax * (nev + 1));
+    d.n_nodes = A<int>(Bmax); d.node_t = A<double>(NB); d.node_ts = A<double>(NB); d.node_dt = A<double>(NB); d.node_ev = A<int>(NB); d.node_mode = A<int>(NB);
+    d.zvel = A<double>(NB * 4); d.zpos = A<double>(NB * 4); d.xref = A<double>(NB * 30); d.eeref = A<double>(NB * 7); d.status = A<int>(Bmax);
+    d.x = A<double>(NB * 30); d.u = A<double>(NB * 30); d.dx = A<double>(NB * 30); d.du = A<double>(NB * 30);
+    d.stage = A<double>(NB * SR_SIZE); d.lqdbg = debug_lq ? A<double>(NB * LQ_DBG_SIZE) : nullptr;
+    d.perf = A<double>(NB * PF_SIZE); d.base_sum = A<double>((size_t)Bmax * 4); d.perf_sum = A<double>((size_t)Bmax * 4); d.step_info = A<double>((size_t)Bmax * 4);
+    d.alpha = A<double>(Bmax); d.done = A<int>(Bmax); d.xs = A<double>(NB * 30); d.us = A<double>(NB * 30); d.out_perf = A<double>((size_t)Bmax * 10);
+  }
+  void release() {
+    void* ps[] = {d.mb, d.st, d.t0, d.x0, d.ref_t, d.ref_x, d.ev, d.modes, d.n_nodes, d.node_t, d.node_ts, d.node_dt, d.node_ev, d.node_mode, d.zvel, d.zpos, d.xref, d.eeref, d.status,
+                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf};
+    for (void* p : ps) if (p) bk.free(p);
+    d = QmMpcBuffers();
+  }
+
+  // inputs are HOST pointers (instance-major, as the C ABI receives them)
+  void upload_inputs(int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes) {
+    bk.to_device(d.t0, t0, (size_t)B * 8); bk.to_device(d.x0, x0, (size_t)B * 30 * 8);
+    bk.to_device(d.ref_t, ref_t, (size_t)B * d.nref * 8); bk.to_device(d.ref_x, ref_x, (size_t)B * d.nref * QM_NREF * 8);
+    bk.to_device(d.ev, ev, (size_t)B * d.nev * 8); bk.to_device(d.modes, modes, (size_t)B * (d.nev + 1) * 4);
+  }
+
+  QmLsArgs ls_args(int B) {
+    QmLsArgs a; a.mb = d.mb; a.st = d.st; a.B = B; a.nmax = d.nmax; a.n_nodes = d.n_nodes; a.node_ts = d.node_ts; a.node_dt = d.node_dt; a.node_ev = d.node_ev; a.node_mode = d.node_mode;
+    a.zvel = d.zvel; a.zpos = d.zpos; a.xref = d.xref; a.eeref = d.eeref; a.x0 = d.x0; a.x = d.x; a.u = d.u; a.dx = d.dx; a.du = d.du; a.alpha = d.alpha; a.done = d.done;
+    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.with_alpha = 0;
+    return a;
+  }
+
+  // K0: grid + references + cold start (inputs already resident on the device)
+  void grid(int B, double horizon) {
+    QmGridArgs g; g.mb = d.mb; g.st = d.st; g.B = B; g.nmax = d.nmax; g.nref = d.nref; g.nev = d.nev; g.t0 = d.t0; g.x0 = d.x0; g.ref_t = d.ref_t; g.ref_x = d.ref_x; g.ev = d.ev; g.modes = d.modes;
+    g.horizon = horizon; g.n_nodes = d.n_nodes; g.node_t = d.node_t; g.node_ts = d.node_ts; g.node_dt = d.node_dt; g.node_ev = d.node_ev; g.node_mode = d.node_mode;
+    g.zvel = d.zvel; g.zpos = d.zpos; g.xref = d.xref; g.eeref = d.eeref; g.x = d.x; g.u = d.u; g.status = d.status;
+    bk.launch(qm_grid_kernel, (B + 63) / 64, 64, 0, g);
+  }
+  // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min)
+  void sqp_iteration(int B, int max_trials = 14) {
+    const int nodes_threads = d.nmax * B;
+    QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
+    q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg;
+    bk.launch(qm_lq_kernel, B * d.nmax, QM_BLOCK, LQ_LDS_BYTES, q);
+    QmLsArgs l = ls_args(B);
+    { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, (B + 63) / 64, 64, 0, lb); }
+    QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info;
+    bk.launch(qm_riccati_kernel, B, QM_BLOCK, RC_LDS_BYTES, r);
+    // line search: alpha = 1, done = 0
+    std::vector<double> ones((size_t)B, 1.0); bk.to_device(d.alpha, ones.data(), (size_t)B * 8); bk.zero(d.done, (size_t)B * 4);
+    std::vector<int> done_h((size_t)B);
+    ls_trials_run = 0;
+    for (int t = 0; t < max_trials; ++t) {
+      l.trial = t;
+      bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, 0, l);
+      { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, (B + 63) / 64, 64, 0, ls); }
+      bk.launch(qm_ls_accept_kernel, (B + 63) / 64, 64, 0, l);
+      ++ls_trials_run;
+      bk.to_host(done_h.data(), d.done, (size_t)B * 4);
+      bool all = true; for (int b = 0; b < B; ++b) if (done_h[b] == 0) { all = false; break; }
+      if (all) break;
+    }
+    bk.launch(qm_ls_apply_kernel, (nodes_threads + 63) / 64, 64, 0, l);
+    bk.launch(qm_ls_commit_kernel, (nodes_threads + 63) / 64, 64, 0, l);
+  }
+};

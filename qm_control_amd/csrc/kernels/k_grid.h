@@ -1,0 +1,135 @@
+// k_grid.h — K0: per-instance time grid, contact-mode lookup, swing-height references, reference
+// interpolation and cold-start trajectories.  One thread per instance (integer / scalar work; B threads).
+//
+// Restates [upstream] timeDiscretizationWithEvents, ModeSchedule::modeAtTime and
+// SwingTrajectoryPlanner (B.2, B.3; config qm_controllers/config/task.info:23-30), TargetTrajectories
+// interpolation incl. EndEffectorConstraint::interpolateEndEffectorPose
+// (qm_interface/src/constraint/EndEffectorConstraint.cpp:82-113) and QMInitializer::compute
+// (qm_interface/src/initialization/QMInitializer.cpp:33-41).  The integer outputs (node event tags,
+// modes) must be bit-exact with the reference semantics; event times are consumed as given.
+#pragma once
+#include "qm_dev_common.h"
+
+#define QM_WEAK_EPS 1e-6                       /* numeric_traits::weakEpsilon<double>  */
+#define QM_LIMIT_EPS 2.220446049250313e-16     /* numeric_traits::limitEpsilon<double> */
+
+struct QmGridArgs {
+  const double* mb; const double* st;
+  int B, nmax, nref, nev;
+  const double* t0;       // [B]
+  const double* x0;       // [B][30]
+  const double* ref_t;    // [B][nref]
+  const double* ref_x;    // [B][nref][37]
+  const double* ev;       // [B][nev]      event times of the mode schedule
+  const int* modes;       // [B][nev+1]
+  double horizon;
+  int* n_nodes;           // [B]
+  double* node_t;         // [nmax][B]
+  double* node_ts;        // [nmax][B]
+  double* node_dt;        // [nmax][B]
+  int* node_ev;           // [nmax][B]
+  int* node_mode;         // [nmax][B]
+  double* zvel; double* zpos;   // [nmax][B][4]
+  double* xref;           // [nmax][B][30]
+  double* eeref;          // [nmax][B][7]
+  double* x; double* u;   // [nmax][B][30] cold start
+  int* status;            // [B] 0 ok, -1 too many nodes, -2 swing phase not enclosed by stance
+};
+
+__device__ __forceinline__ int grid_find_index(const double* ev, int nev, double t) {   // std::lower_bound
+  int k = 0; while (k < nev && ev[k] < t) ++k; return k;
+}
+__device__ __forceinline__ void cubic_eval(double t0, double p0, double v0, double t1, double p1, double v1, double t, double* pos, double* vel) {
+  const double dt = t1 - t0, dp = p1 - p0, dv = v1 - v0;
+  const double c0 = p0, c1 = v0 * dt, c2 = -(3.0 * v0 + dv) * dt + 3.0 * dp, c3 = (2.0 * v0 + dv) * dt - 2.0 * dp;
+  const double s = (t - t0) / dt;
+  *pos = c3 * s * s * s + c2 * s * s + c1 * s + c0;
+  *vel = (3.0 * c3 * s * s + 2.0 * c2 * s + c1) / dt;
+}
+// [upstream LinearInterpolation::timeSegment]
+__device__ __forceinline__ void grid_time_segment(const double* ta, int n, double t, int* index, double* alpha) {
+  if (n <= 1) { *index = 0; *alpha = 1.0; return; }
+  const int part = grid_find_index(ta, n, t);
+  const int interval = (part == 0 && t == ta[0]) ? 0 : part - 1;
+  const int last = n - 1;
+  if (interval >= 0) {
+    if (interval < last) {
+      const double len = ta[interval + 1] - ta[interval], till = ta[interval + 1] - t;
+      *index = interval;
+      *alpha = (len > 2.0 * QM_WEAK_EPS) ? till / len : ((till > 0.5 * len) ? 1.0 : 0.0);
+    } else { *index = (last - 1 > 0) ? last - 1 : 0; *alpha = 0.0; }
+  } else { *index = 0; *alpha = 1.0; }
+}
+
+__global__ void qm_grid_kernel(QmGridArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const double* ev = a.ev + (size_t)b * a.nev; const int* modes = a.modes + (size_t)b * (a.nev + 1);
+  const double t0 = a.t0[b], tf = t0 + a.horizon, dt = a.st[ST_SQP_DT];
+  const double dtMin = 10.0 * QM_LIMIT_EPS;
+  int status = 0;
+  // ---- time discretisation with events ----
+  int n = 0;
+  a.node_t[0 * a.B + b] = t0; a.node_ev[0 * a.B + b] = QM_EV_NONE; n = 1;
+  int k = grid_find_index(ev, a.nev, t0);
+  double nt = t0; double backT = t0;
+  while (backT < tf) {
+    nt = nt + dt; int nevt = QM_EV_NONE; bool post = false;
+    if (k < a.nev && nt >= ev[k]) { nt = ev[k]; nevt = QM_EV_PRE; post = true; ++k; }
+    if (nt >= tf) { nt = tf; nevt = QM_EV_NONE; post = false; }
+    if (nt > backT + dtMin) { if (n >= a.nmax) { status = -1; break; } a.node_t[n * a.B + b] = nt; a.node_ev[n * a.B + b] = nevt; ++n; }
+    else { a.node_t[(n - 1) * a.B + b] = nt; a.node_ev[(n - 1) * a.B + b] = nevt; }
+    backT = nt;
+    if (post) { if (n >= a.nmax) { status = -1; break; } a.node_t[n * a.B + b] = nt; a.node_ev[n * a.B + b] = QM_EV_POST; ++n; }
+  }
+  a.n_nodes[b] = n;
+  const double mass = a.mb[MB_ROBOTMASS];
+  const double liftV = a.st[ST_LIFTOFF_VEL], touchV = a.st[ST_TOUCHDOWN_VEL], swingH = a.st[ST_SWING_HEIGHT], tScale = a.st[ST_SWING_TIME_SCALE];
+  const double* rt = a.ref_t + (size_t)b * a.nref; const double* rx = a.ref_x + (size_t)b * a.nref * QM_NREF;
+  for (int i = 0; i < n; ++i) {
+    const int nb = i * a.B + b;
+    const double t = a.node_t[nb]; const int e = a.node_ev[nb];
+    const double ts = (e == QM_EV_POST) ? t + QM_WEAK_EPS : t;
+    double d = 0.0;
+    if (i < n - 1 && e != QM_EV_PRE) { const double tn = a.node_t[(i + 1) * a.B + b]; const int en = a.node_ev[(i + 1) * a.B + b]; d = ((en == QM_EV_PRE) ? tn - QM_WEAK_EPS : tn) - ts; }
+    a.node_ts[nb] = ts; a.node_dt[nb] = d;
+    const int p = grid_find_index(ev, a.nev, ts); const int mode = modes[p];
+    a.node_mode[nb] = mode;
+    // swing z references per contact
+    for (int c = 0; c < 4; ++c) {
+      double zp = 0.0, zv = 0.0;
+      if (!mode_flag(mode, c)) {
+        int s = -1; for (int ip = p - 1; ip >= 0; --ip) if (mode_flag(modes[ip], c)) { s = ip; break; }
+        int f = -1; for (int ip = p + 1; ip <= a.nev; ++ip) if (mode_flag(modes[ip], c)) { f = ip - 1; break; }
+        if (s < 0 || f < 0) { status = (status == 0) ? -2 : status; }
+        else {
+          const double tsw = ev[s], tew = ev[f]; const double sc = fmin(1.0, (tew - tsw) / tScale); const double mid = (tsw + tew) / 2.0;
+          if (ts < mid) cubic_eval(tsw, 0.0, sc * liftV, mid, sc * swingH, 0.0, ts, &zp, &zv);
+          else cubic_eval(mid, sc * swingH, 0.0, tew, 0.0, sc * touchV, ts, &zp, &zv);
+        }
+      }
+      a.zvel[nb * 4 + c] = zv; a.zpos[nb * 4 + c] = zp;
+    }
+    // reference state / EE pose at ts
+    {
+      int idx; double al; grid_time_segment(rt, a.nref, ts, &idx, &al);
+      if (a.nref == 1) { for (int q = 0; q < 30; ++q) a.xref[nb * 30 + q] = rx[q]; for (int q = 0; q < 7; ++q) a.eeref[nb * 7 + q] = rx[30 + q]; }
+      else {
+        const double* l = rx + idx * QM_NREF; const double* r = rx + (idx + 1) * QM_NREF;
+        for (int q = 0; q < 30; ++q) a.xref[nb * 30 + q] = al * l[q] + (1.0 - al) * r[q];
+        for (int q = 0; q < 3; ++q) a.eeref[nb * 7 + q] = al * l[30 + q] + (1.0 - al) * r[30 + q];
+        // Eigen slerp(t = 1 - alpha)
+        const double* ql = l + 33; const double* qr = r + 33; const double tt = 1.0 - al; const double one = 1.0 - QM_LIMIT_EPS;
+        const double dd = ql[0] * qr[0] + ql[1] * qr[1] + ql[2] * qr[2] + ql[3] * qr[3]; const double ad = fabs(dd); double s0, s1;
+        if (ad >= one) { s0 = 1.0 - tt; s1 = tt; } else { const double th = acos(ad), sth = sin(th); s0 = sin((1.0 - tt) * th) / sth; s1 = sin(tt * th) / sth; }
+        if (dd < 0.0) s1 = -s1;
+        for (int q = 0; q < 4; ++q) a.eeref[nb * 7 + 3 + q] = s0 * ql[q] + s1 * qr[q];
+      }
+    }
+    // cold start: x_i = x0, u_i = weight compensating input of the node's mode (QMInitializer.cpp:33-41)
+    int nst = 0; for (int c = 0; c < 4; ++c) nst += mode_flag(mode, c);
+    for (int q = 0; q < 30; ++q) { a.x[nb * 30 + q] = a.x0[(size_t)b * 30 + q]; a.u[nb * 30 + q] = 0.0; }
+    if (e != QM_EV_PRE && nst > 0) for (int c = 0; c < 4; ++c) if (mode_flag(mode, c)) a.u[nb * 30 + 3 * c + 2] = mass * 9.81 / nst;
+  }
+  a.status[b] = status;
+}

@@ -1,0 +1,168 @@
+// k_ls.h — K4: filter line-search of the SQP step (SURVEY.md §8 a11 step 7, Appendix B.6 step 6;
+// [upstream ocs2_sqp SqpSolver::takeStep + FilterLinesearch::acceptStep], settings task.info:81-82).
+//
+//   qm_ls_eval_kernel    one THREAD per (instance, node): value-only Heun defect, cost and equality residual of the
+//                        trial trajectory x + alpha dx, u + alpha du   (scalar kinematics: lanes = instances)
+//   qm_perf_sum_kernel   one thread per instance: ordered sum over nodes (+ initial-state defect)
+//   qm_ls_accept_kernel  one thread per instance: filter acceptance, alpha <- alpha/2 or stop
+//   qm_ls_apply_kernel   one thread per (instance, node): x += alpha dx, u += alpha du and the primal solution
+//                        (u at PreEvent nodes copied from the previous node, last u repeated)
+#pragma once
+#include "qm_dev_kin.h"
+
+struct QmLsArgs {
+  const double* mb; const double* st;
+  int B, nmax;
+  const int* n_nodes; const double* node_ts; const double* node_dt; const int* node_ev; const int* node_mode;
+  const double* zvel; const double* zpos; const double* xref; const double* eeref;
+  const double* x0;
+  double* x; double* u;                 // [nmax][B][30] iterate (updated by apply)
+  const double* dx; const double* du;   // [nmax][B][30]
+  double* alpha;                        // [B] current trial step
+  int* done;                            // [B] 0: searching, 1: accepted, 2: no step
+  double* perf;                         // [nmax][B][PF_SIZE] node terms (baseline from K1, or trial)
+  double* perf_sum;                     // [B][4]  merit, cost, dynSSE, eqSSE  of `perf`
+  const double* base_sum;               // [B][4]
+  const double* step_info;              // [B][4]  armijo, |dx|², |du|²
+  double* xs; double* us;               // [nmax][B][30] primal solution out
+  double* out_perf;                     // [B][10] baseline(4) after(4) alpha armijo
+  int trial;                            // index of the current trial (0-based)
+  int with_alpha;                       // perf_sum: 1 = initial-state defect of the trial iterate, 0 = of the base iterate
+};
+
+// cost value of one intermediate node (a2 + a6 + a7 + a5), not yet × dt; K must hold base, legs and arm
+__device__ __forceinline__ double node_cost_value(const double* mb, const double* st, const double* x, const double* u, const double* K, int mode,
+                                                   const double* xref, const double* eeref, double muPos, double muOri, bool intermediate) {
+  double c = 0.0;
+  if (intermediate) {
+    int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
+    double du[30];
+    for (int i = 0; i < 30; ++i) { const double d = x[i] - xref[i]; c += 0.5 * st[ST_Q + i] * d * d; du[i] = u[i]; }
+    if (nst > 0) for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) du[3 * k + 2] -= mb[MB_ROBOTMASS] * 9.81 / nst;
+    for (int i = 0; i < 30; ++i) { double s = 0.0; for (int j = 0; j < 30; ++j) s += st[ST_R + 30 * i + j] * du[j]; c += 0.5 * du[i] * s; }
+    for (int i = 0; i < 6; ++i) {
+      const double lo = mb[MB_QLO + 12 + i], hi = mb[MB_QHI + 12 + i], z = x[24 + i], mu = st[ST_JPOS_MU], de = st[ST_JPOS_DELTA];
+      c += barrier_val(mu, de, z - lo) + barrier_val(mu, de, hi - z) - (barrier_val(mu, de, -lo) + barrier_val(mu, de, hi));
+      const double vlo = st[ST_JVEL_LO + i], vhi = st[ST_JVEL_HI + i], w = u[24 + i], mv = st[ST_JVEL_MU], dv = st[ST_JVEL_DELTA];
+      c += barrier_val(mv, dv, w - vlo) + barrier_val(mv, dv, vhi - w) - (barrier_val(mv, dv, -vlo) + barrier_val(mv, dv, vhi));
+    }
+    for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) {
+      const double Fx = u[3 * k], Fy = u[3 * k + 1], Fz = u[3 * k + 2];
+      const double h = st[ST_FRIC_COEF] * Fz - sqrt(Fx * Fx + Fy * Fy + st[ST_FRIC_REG]);
+      c += barrier_val(st[ST_FRIC_MU], st[ST_FRIC_DELTA], h);
+    }
+  }
+  double g[6], qee[4]; ee_error(K, eeref, eeref + 3, qee, g);
+  for (int r = 0; r < 6; ++r) c += 0.5 * (r < 3 ? muPos : muOri) * g[r] * g[r];
+  return c;
+}
+// squared norm of the equality residual of one intermediate node (a8)
+__device__ __forceinline__ double node_eq_sse(const double* st, const double* x, const double* u, const double* K, int mode, const double* zvel, const double* zpos) {
+  const double gain = st[ST_POS_ERR_GAIN]; double s = 0.0;
+  for (int k = 0; k < 4; ++k) {
+    double v[3]; foot_velocity(x, K, k, v); const double pz = kin_foot(K, k)[2];
+    if (mode_flag(mode, k)) { for (int r = 0; r < 3; ++r) { const double e = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); s += e * e; } }
+    else {
+      for (int r = 0; r < 3; ++r) s += u[3 * k + r] * u[3 * k + r];
+      double bb = -zvel[k]; if (gain != 0.0) bb -= gain * zpos[k];
+      const double e = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0); s += e * e;
+    }
+  }
+  return s;
+}
+
+__global__ void qm_ls_eval_kernel(QmLsArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g / a.B, b = g - i * a.B;
+  if (i >= a.nmax) return;
+  const int n = a.n_nodes[b];
+  if (i >= n || a.done[b] != 0) return;
+  const int nb = i * a.B + b; const double al = a.alpha[b];
+  double x[30], u[30], K[KW_SIZE];
+  for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
+  double* pf = a.perf + (size_t)nb * PF_SIZE;
+  const int ev = a.node_ev[nb];
+  if (i == n - 1) {
+    kin_base(a.mb, x, K); kin_arm(a.mb, x, K);
+    pf[0] = node_cost_value(a.mb, a.st, x, nullptr, K, 0, nullptr, a.eeref + nb * 7, a.st[ST_MU_EEF_POS], a.st[ST_MU_EEF_ORI], false); pf[1] = 0.0; pf[2] = 0.0;
+    return;
+  }
+  const int nbn = (i + 1) * a.B + b;
+  if (ev == QM_EV_PRE) {
+    double s = 0.0; for (int q = 0; q < 30; ++q) { const double d = x[q] - (a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]); s += d * d; }
+    pf[0] = 0.0; pf[1] = s; pf[2] = 0.0; return;
+  }
+  for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q] + al * a.du[nb * 30 + q];
+  const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
+  kin_base(a.mb, x, K); for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x, u, K); kin_arm(a.mb, x, K);
+  const double cost = node_cost_value(a.mb, a.st, x, u, K, mode, a.xref + nb * 30, a.eeref + nb * 7, a.st[ST_MU_EE_POS], a.st[ST_MU_EE_ORI], true);
+  const double eq = node_eq_sse(a.st, x, u, K, mode, a.zvel + nb * 4, a.zpos + nb * 4);
+  double f1[30], x2[30], f2[30];
+  flow_from_kin(a.mb, x, u, K, f1);
+  for (int q = 0; q < 30; ++q) x2[q] = x[q] + dt * f1[q];
+  kin_base(a.mb, x2, K); for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x2, u, K);
+  flow_from_kin(a.mb, x2, u, K, f2);
+  double s = 0.0;
+  for (int q = 0; q < 30; ++q) { const double d = x[q] + 0.5 * dt * f1[q] + 0.5 * dt * f2[q] - (a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]); s += d * d; }
+  pf[0] = cost * dt; pf[1] = dt * s; pf[2] = dt * eq;
+}
+
+// ordered sum of node terms -> perf_sum[b] = {merit, cost, dynSSE, eqSSE}; with_alpha: initial defect of the trial
+__global__ void qm_perf_sum_kernel(QmLsArgs a) {
+  const int with_alpha = a.with_alpha;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  if (with_alpha && a.done[b] != 0) return;
+  const int n = a.n_nodes[b]; double c = 0.0, d = 0.0, e = 0.0;
+  for (int i = 0; i < n; ++i) { const double* pf = a.perf + (size_t)(i * a.B + b) * PF_SIZE; c += pf[0]; d += pf[1]; e += pf[2]; }
+  const double al = with_alpha ? a.alpha[b] : 0.0; double s = 0.0;
+  for (int q = 0; q < 30; ++q) { const double dd = a.x0[(size_t)b * 30 + q] - (a.x[b * 30 + q] + al * a.dx[b * 30 + q]); s += dd * dd; }
+  d += s;
+  a.perf_sum[b * 4] = c; a.perf_sum[b * 4 + 1] = c; a.perf_sum[b * 4 + 2] = d; a.perf_sum[b * 4 + 3] = e;
+}
+
+__global__ void qm_ls_accept_kernel(QmLsArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  if (a.trial == 0) { for (int q = 0; q < 4; ++q) { a.out_perf[b * 10 + q] = a.base_sum[b * 4 + q]; a.out_perf[b * 10 + 4 + q] = a.base_sum[b * 4 + q]; } a.out_perf[b * 10 + 8] = 0.0; a.out_perf[b * 10 + 9] = a.step_info[b * 4]; }
+  if (a.done[b] != 0) return;
+  const double gMax = a.st[ST_G_MAX], gMin = a.st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
+  const double* bs = a.base_sum + b * 4; const double* ps = a.perf_sum + b * 4;
+  const double theta0 = sqrt(bs[2] + bs[3]), theta = sqrt(ps[2] + ps[3]);
+  double al = a.alpha[b]; const double armijo = a.step_info[b * 4];
+  bool acc;
+  if (theta > gMax) acc = theta < (1.0 - gammaC) * theta0;
+  else if (theta < gMin && theta0 < gMin && al * armijo < 0.0) acc = ps[0] < bs[0] + armijoFactor * al * armijo;
+  else acc = ps[0] < (bs[0] - gammaC * theta0) || theta < (1.0 - gammaC) * theta0;
+  if (acc) { a.done[b] = 1; for (int q = 0; q < 4; ++q) a.out_perf[b * 10 + 4 + q] = ps[q]; a.out_perf[b * 10 + 8] = al; return; }
+  al *= alphaDecay;
+  const double dxn = sqrt(a.step_info[b * 4 + 1]), dun = sqrt(a.step_info[b * 4 + 2]);
+  if ((al * dun < a.st[ST_DELTA_TOL] && al * dxn < a.st[ST_DELTA_TOL]) || !(al >= alphaMin)) { a.done[b] = 2; a.alpha[b] = 0.0; return; }
+  a.alpha[b] = al;
+}
+
+__global__ void qm_ls_apply_kernel(QmLsArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g / a.B, b = g - i * a.B;
+  if (i >= a.nmax) return;
+  const int n = a.n_nodes[b]; if (i >= n) return;
+  const double al = (a.done[b] == 1) ? a.alpha[b] : 0.0;
+  const int nb = i * a.B + b;
+  for (int q = 0; q < 30; ++q) a.xs[nb * 30 + q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
+  // input of the primal solution: own node, or the closest earlier non-event node
+  int j = (i == n - 1) ? n - 2 : i;
+  while (j > 0 && a.node_ev[j * a.B + b] == QM_EV_PRE) --j;
+  const int jb = j * a.B + b; const bool evj = (a.node_ev[jb] == QM_EV_PRE);
+  for (int q = 0; q < 30; ++q) a.us[nb * 30 + q] = evj ? 0.0 : a.u[jb * 30 + q] + al * a.du[jb * 30 + q];
+}
+// commit the accepted step into the iterate (separate launch: apply reads neighbours' u)
+__global__ void qm_ls_commit_kernel(QmLsArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g / a.B, b = g - i * a.B;
+  if (i >= a.nmax) return;
+  const int n = a.n_nodes[b]; if (i >= n) return;
+  const double al = (a.done[b] == 1) ? a.alpha[b] : 0.0;
+  const int nb = i * a.B + b;
+  const bool hasu = (i < n - 1) && a.node_ev[nb] != QM_EV_PRE;
+  for (int q = 0; q < 30; ++q) { a.x[nb * 30 + q] += al * a.dx[nb * 30 + q]; if (hasu) a.u[nb * 30 + q] += al * a.du[nb * 30 + q]; }
+}

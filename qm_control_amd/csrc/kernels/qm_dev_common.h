@@ -1,0 +1,127 @@
+// qm_dev_common.h — device-side building blocks shared by the gfx950 kernels of the MPC+WBC hot path.
+//
+//  * LDS "tile": a 32x32 f64 matrix stored row-major with leading dimension QM_LD = 34 doubles
+//    (34 keeps the ds_read_b64 operand-fragment reads of v_mfma_f64_16x16x4_f64 conflict free for the
+//    [i][k] pattern and at most 2-way for the [k][j] pattern; MI355X_MICROARCH.md §LDS).
+//    nx = nu = 30 and every constraint / projected-input dimension is <= 18, so every matrix of the path
+//    fits one tile.  Padding rows/cols are kept exactly zero.
+//  * wg_gemm: C(16·mt x 16·nt) = op(A)·op(B) on the matrix cores; a 256-thread workgroup's 4 waves take
+//    one 16x16 output tile each (64-wide wavefronts, one MFMA accumulator of 4 f64 per lane).
+//    Fragment maps (cdna_hip_programming.md §3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+//    D[row=(l>>4)+4r][col=l&15].
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../../include/qmhip_layout.h"
+
+#define QM_LD 34
+#define QM_TILE (32 * QM_LD)          /* doubles per LDS tile */
+#define QM_BLOCK 256                  /* threads per workgroup for the per-node / per-instance kernels */
+
+typedef double qm_d4 __attribute__((ext_vector_type(4)));
+
+// ---- 3-vector helpers (pointer based so operands may live in LDS, registers or global) ----
+__device__ __forceinline__ void v3_cross(const double* a, const double* b, double* c) {
+  const double c0 = a[1] * b[2] - a[2] * b[1], c1 = a[2] * b[0] - a[0] * b[2], c2 = a[0] * b[1] - a[1] * b[0];
+  c[0] = c0; c[1] = c1; c[2] = c2;
+}
+__device__ __forceinline__ void m3_mulv(const double* M, const double* v, double* r) {
+  const double r0 = M[0] * v[0] + M[1] * v[1] + M[2] * v[2], r1 = M[3] * v[0] + M[4] * v[1] + M[5] * v[2], r2 = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  r[0] = r0; r[1] = r1; r[2] = r2;
+}
+__device__ __forceinline__ void m3_mul(const double* A, const double* B, double* C) {   // C may not alias A or B
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ void m3_inv(const double* A, double* R) {   // cofactor inverse
+  const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[2] * A[7] - A[1] * A[8], c02 = A[1] * A[5] - A[2] * A[4];
+  const double c10 = A[5] * A[6] - A[3] * A[8], c11 = A[0] * A[8] - A[2] * A[6], c12 = A[2] * A[3] - A[0] * A[5];
+  const double c20 = A[3] * A[7] - A[4] * A[6], c21 = A[1] * A[6] - A[0] * A[7], c22 = A[0] * A[4] - A[1] * A[3];
+  const double id = 1.0 / (A[0] * c00 + A[1] * c10 + A[2] * c20);
+  R[0] = c00 * id; R[1] = c01 * id; R[2] = c02 * id; R[3] = c10 * id; R[4] = c11 * id; R[5] = c12 * id; R[6] = c20 * id; R[7] = c21 * id; R[8] = c22 * id;
+}
+__device__ __forceinline__ void rot_axis_angle(const double* a, double q, double* R) {
+  const double s = sin(q), c = cos(q), oc = 1.0 - c;
+  R[0] = c + oc * (a[0] * a[0]);        R[1] = oc * (a[0] * a[1]) - s * a[2]; R[2] = oc * (a[0] * a[2]) + s * a[1];
+  R[3] = oc * (a[1] * a[0]) + s * a[2]; R[4] = c + oc * (a[1] * a[1]);        R[5] = oc * (a[1] * a[2]) - s * a[0];
+  R[6] = oc * (a[2] * a[0]) - s * a[1]; R[7] = oc * (a[2] * a[1]) + s * a[0]; R[8] = c + oc * (a[2] * a[2]);
+}
+// R = Rz(z) Ry(y) Rx(x); E maps zyx rates to world angular velocity
+__device__ __forceinline__ void rot_zyx(double z, double y, double x, double* R) {
+  const double sz = sin(z), cz = cos(z), sy = sin(y), cy = cos(y), sx = sin(x), cx = cos(x);
+  R[0] = cz * cy; R[1] = cz * sy * sx - sz * cx; R[2] = cz * sy * cx + sz * sx;
+  R[3] = sz * cy; R[4] = sz * sy * sx + cz * cx; R[5] = sz * sy * cx - cz * sx;
+  R[6] = -sy;     R[7] = cy * sx;                R[8] = cy * cx;
+}
+__device__ __forceinline__ void euler_E(double z, double y, double* E) {
+  const double sz = sin(z), cz = cos(z), sy = sin(y), cy = cos(y);
+  E[0] = 0.0; E[1] = -sz; E[2] = cy * cz; E[3] = 0.0; E[4] = cz; E[5] = cy * sz; E[6] = 1.0; E[7] = 0.0; E[8] = -sy;
+}
+// relaxed log barrier (task.info:290-314 -> [upstream RelaxedBarrierPenalty])
+__device__ __forceinline__ double barrier_val(double mu, double delta, double h) { if (h > delta) return -mu * log(h); const double t = (h - 2.0 * delta) / delta; return mu * (-log(delta) + 0.5 * t * t - 0.5); }
+__device__ __forceinline__ double barrier_d1(double mu, double delta, double h) { return (h > delta) ? -mu / h : mu * (h - 2.0 * delta) / (delta * delta); }
+__device__ __forceinline__ double barrier_d2(double mu, double delta, double h) { return (h > delta) ? mu / (h * h) : mu / (delta * delta); }
+
+// contact index (LF,RF,LH,RH; ModelSettings.h:38) of leg chain c (joint order LF,LH,RF,RH; task.info:168-188)
+__device__ __forceinline__ int chain_to_contact(int c) { return (c == 1) ? 2 : (c == 2) ? 1 : c; }
+__device__ __forceinline__ int contact_to_chain(int i) { return (i == 1) ? 2 : (i == 2) ? 1 : i; }
+__device__ __forceinline__ bool mode_flag(int mode, int contact) { return (mode >> (3 - contact)) & 1; }   // 8*LF+4*RF+2*LH+RH
+
+// wave-level ordering point for LDS traffic inside ONE wavefront (no s_barrier: a wave's DS ops retire in order)
+__device__ __forceinline__ void qm_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// ---- LDS tile helpers (all threads of the workgroup participate; caller places the barriers) ----
+__device__ __forceinline__ void tile_zero(double* T, int ndoubles = QM_TILE) { for (int i = threadIdx.x; i < ndoubles; i += blockDim.x) T[i] = 0.0; }
+// copy a rows x cols row-major global matrix (leading dim sld) into a tile
+__device__ __forceinline__ void tile_load(double* T, const double* src, int rows, int cols, int sld) {
+  for (int idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) { const int r = idx / cols, c = idx - r * cols; T[r * QM_LD + c] = src[r * sld + c]; }
+}
+__device__ __forceinline__ void tile_store(const double* T, double* dst, int rows, int cols, int dld) {
+  for (int idx = threadIdx.x; idx < rows * cols; idx += blockDim.x) { const int r = idx / cols, c = idx - r * cols; dst[r * dld + c] = T[r * QM_LD + c]; }
+}
+
+// C = op(A) op(B) over k-slabs [ks0, ks1) of 4; op(A) is (16 mt) x K, op(B) is K x (16 nt).
+// TA: A holds Aᵀ (A[k][i]); TB: B holds Bᵀ (B[j][k]).  epi(row, col, value) consumes every output element.
+template <bool TA, bool TB, class Epi>
+__device__ __forceinline__ void wg_gemm(const double* A, const double* B, int mt, int nt, int ks0, int ks1, Epi epi) {
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int li = l & 15, lk = l >> 4;
+  for (int t = wave; t < mt * nt; t += nw) {
+    const int I = t / nt, J = t - I * nt;
+    qm_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = ks0; kk < ks1; ++kk) {
+      const double a = TA ? A[(4 * kk + lk) * QM_LD + 16 * I + li] : A[(16 * I + li) * QM_LD + 4 * kk + lk];
+      const double b = TB ? B[(16 * J + li) * QM_LD + 4 * kk + lk] : B[(4 * kk + lk) * QM_LD + 16 * J + li];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; ++r) epi(16 * I + lk + 4 * r, 16 * J + li, acc[r]);
+  }
+}
+
+// y(rows) = M(rows x cols tile) x   — one thread per row
+__device__ __forceinline__ double tile_row_dot(const double* T, int row, const double* x, int cols) {
+  double s = 0.0; for (int c = 0; c < cols; ++c) s += T[row * QM_LD + c] * x[c]; return s;
+}
+__device__ __forceinline__ double tile_col_dot(const double* T, int col, const double* x, int rows) {
+  double s = 0.0; for (int r = 0; r < rows; ++r) s += T[r * QM_LD + col] * x[r]; return s;
+}
+
+// ---- per-node stage record written by K1 (LQ + projection) and read by K3 (Riccati); doubles ----
+// dimensions: nx = 30, projected input dim m <= 18 (stance 18, trot 16); row-major, fixed strides
+#define QM_MMAX 18
+#define SR_AP   0                      /* [30][30]  A + B Px            */
+#define SR_BP   900                    /* [30][18]  B Pu                */
+#define SR_QP   1440                   /* [30][30]                      */
+#define SR_PP   2340                   /* [18][30]  Puᵀ(P + R Px)       */
+#define SR_RP   2880                   /* [18][18]  Puᵀ R Pu            */
+#define SR_PX   3204                   /* [30][30]  du = Pe + Px dx + Pu ut */
+#define SR_PU   4104                   /* [30][18]                      */
+#define SR_BPV  4644                   /* [30]      b + B Pe            */
+#define SR_QPV  4674                   /* [30]                          */
+#define SR_RPV  4704                   /* [18]                          */
+#define SR_PE   4722                   /* [30]                          */
+#define SR_K    4752                   /* [18][30]  Riccati feedback (written by K3) */
+#define SR_KFF  5292                   /* [18]                          */
+#define SR_SCAL 5310                   /* [0]=m (as double) [1]=cp      */
+#define SR_SIZE 5312
+
+// per-node performance terms: cost, dynamics defect SSE (dt weighted), equality SSE (dt weighted)
+#define PF_SIZE 4

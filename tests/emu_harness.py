@@ -1,0 +1,73 @@
+"""tests/emu_harness.py — TEST INFRASTRUCTURE: ctypes binding of the host-emulated kernels (tests/emu)."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "emu", "_build", "libqm_emu.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def build():
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "emu"), "-s"])
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return a.ctypes.data_as(_ip)
+
+
+class Emu:
+    def __init__(self, mb, st, Bmax, nmax, nref, nev):
+        build()
+        self.lib = C.CDLL(_LIB)
+        self.lib.emu_create.restype = C.c_void_p
+        self.lib.emu_buffer.restype = C.c_void_p
+        self.lib.emu_buffer.argtypes = [C.c_void_p, C.c_char_p]
+        self.lib.emu_destroy.argtypes = [C.c_void_p]
+        self.mb = np.ascontiguousarray(mb, float); self.st = np.ascontiguousarray(st, float)
+        self.Bmax, self.nmax, self.nref, self.nev = Bmax, nmax, nref, nev
+        self.h = C.c_void_p(self.lib.emu_create(_p(self.mb), _p(self.st), Bmax, nmax, nref, nev))
+        self.SR, self.DBG, self.PF = (self.lib.emu_sizes(i) for i in range(3))
+        self.B = 0
+
+    def __del__(self):
+        try:
+            self.lib.emu_destroy(self.h)
+        except Exception:
+            pass
+
+    def mpc_step(self, cfg, max_trials=14, batch=None):
+        B = cfg["B"] if batch is None else batch
+        self.B = B
+        a = lambda k, t=float: np.ascontiguousarray(cfg[k][:B], t)
+        t0, x0, rt, rx, ev, mo = a("t0"), a("x0"), a("ref_t"), a("ref_x"), a("ev"), a("modes", np.int32)
+        assert rt.shape[1] == self.nref and ev.shape[1] == self.nev
+        return self.lib.emu_mpc_step(self.h, C.c_int(B), _p(t0), _p(x0), _p(rt), _p(rx), _p(ev), _pi(mo), C.c_double(cfg["horizon"]), C.c_int(max_trials))
+
+    def buf(self, name, shape, dtype=np.float64):
+        ptr = self.lib.emu_buffer(self.h, name.encode())
+        assert ptr, name
+        n = int(np.prod(shape))
+        ct = C.c_double if dtype == np.float64 else C.c_int
+        arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,))
+        return arr.reshape(shape).copy()
+
+    # node-major [nmax][B][k] helpers (B = batch of the last call)
+    def node_arr(self, name, k, dtype=np.float64):
+        full = self.buf(name, (self.nmax * self.B * k,), dtype)
+        return full.reshape(self.nmax, self.B, k) if k > 1 else full.reshape(self.nmax, self.B)
+
+    def stage(self, b, i):
+        full = self.buf("stage", (self.Bmax * self.nmax * self.SR,))
+        return full.reshape(-1, self.SR)[b * self.nmax + i]
+
+    def lqdbg(self, b, i):
+        full = self.buf("lqdbg", (self.Bmax * self.nmax * self.DBG,))
+        return full.reshape(-1, self.DBG)[b * self.nmax + i]
