@@ -1,0 +1,107 @@
+/*
+ * qmhip.h — C ABI of libqmhip.so: the MI355X-native MPC + whole-body-control step of qm_control.
+ *
+ * The reference has no FFI; its seams are three C++ interfaces.  Each entry point below
+ * names the reference interface it stands behind; INTEGRATION.md shows the thin C++ adaptors
+ * (qm::QMInterface-, ocs2::MPC_BASE-, qm::WbcBase-shaped) a maintainer adds on the reference side.
+ *
+ * Conventions: plain pointers + sizes, no C++/torch types; f64 everywhere (ocs2::scalar_t); arrays are
+ * instance-major and caller owned; pointers are HOST memory unless the name says `_dev`.
+ * Return value 0 = ok, negative = error (qmhip_last_error gives the text).  A context is single-threaded.
+ */
+#ifndef QMHIP_H
+#define QMHIP_H
+#include <stdint.h>
+#include "qmhip_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qmhip_ctx qmhip_ctx;
+
+/* ---- construction: replaces qm::QMInterface(taskFile, urdfFile, referenceFile) + setupOptimalControlProblem
+ *      (qm_interface/include/qm_interface/QMInterface.h:31-35, qm_interface/src/QMInterface.cpp:37-142) and the
+ *      WBC constructor / loadTasksSetting (qm_wbc/include/qm_wbc/WbcBase.h:28-34).
+ *      Missing files -> QMHIP_ERR_FILE, like the reference's std::invalid_argument (QMInterface.cpp:45,53,61). */
+int qmhip_create(const char* urdf_file, const char* task_file, const char* reference_file,
+                 int device, int max_batch, int max_nodes, int max_ref_knots, int max_events, qmhip_ctx** out);
+/* same, from the flat MODEL / SETTINGS blobs of qmhip_layout.h (no file I/O) */
+int qmhip_create_from_blobs(const double* model_blob, const double* settings_blob,
+                            int device, int max_batch, int max_nodes, int max_ref_knots, int max_events, qmhip_ctx** out);
+void qmhip_destroy(qmhip_ctx* ctx);
+const char* qmhip_last_error(const qmhip_ctx* ctx);            /* ctx may be NULL: error of the last failed create */
+/* parse only (host): what getPinocchioInterface()/getCentroidalModelInfo()/settings getters expose
+ * (QMInterface.h:37-54), as blobs */
+int qmhip_parse_model(const char* urdf_file, const char* task_file, const char* reference_file,
+                      double* model_blob /*[MB_SIZE]*/, double* settings_blob /*[ST_SIZE]*/);
+int qmhip_export_blobs(const qmhip_ctx* ctx, double* model_blob, double* settings_blob);
+int qmhip_set_setting(qmhip_ctx* ctx, int settings_index, double value);   /* e.g. WBC gains: dynamic_reconfigure callback, WbcBase.cpp:69-116 */
+
+/* ---- MPC: replaces ocs2::MPC_BASE::run(t, x) on the SqpMpc the reference installs
+ *      (qm_controllers/src/QMController.cpp:287-288,315-323) for B independent instances: one multiple-shooting
+ *      SQP iteration (task.info:75-92) from a cold start.
+ *      Inputs per instance: initial time/state, target trajectory knots (37-dim, QmTargetTrajectoriesPublisher_node.cpp:44-68),
+ *      contact-mode schedule (event times + mode ids, modes has n_events+1 entries).
+ *      Outputs (any may be NULL): node count, node times / event tags / modes (int, bit-exact), optimal state and
+ *      input trajectories (primal solution: input of event nodes copied from the previous node, last input repeated),
+ *      perf[10] = baseline{merit,cost,dynSSE,eqSSE}, after-step{...}, step size alpha, armijo metric.
+ *      status[b]: 0 ok, -1 node buffer too small, -2 swing phase not enclosed by stance in the schedule, -4 Riccati not PD. */
+int qmhip_mpc_step(qmhip_ctx* ctx, int B, const double* t0, const double* x0 /*[B][30]*/,
+                   int n_ref, const double* ref_t /*[B][n_ref]*/, const double* ref_x /*[B][n_ref][37]*/,
+                   int n_events, const double* event_times /*[B][n_events]*/, const int32_t* modes /*[B][n_events+1]*/,
+                   double horizon,
+                   int32_t* out_num_nodes /*[B]*/, double* out_t /*[B][max_nodes]*/, int32_t* out_event /*[B][max_nodes]*/,
+                   int32_t* out_mode /*[B][max_nodes]*/, double* out_x /*[B][max_nodes][30]*/, double* out_u /*[B][max_nodes][30]*/,
+                   double* out_perf /*[B][10]*/, int32_t* status /*[B]*/);
+
+/* split form used by the benchmark (inputs resident in HBM before the timed region):
+ * upload -> solve (device only, asynchronous on the context stream) -> download */
+int qmhip_mpc_upload(qmhip_ctx* ctx, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x,
+                     int n_events, const double* event_times, const int32_t* modes);
+int qmhip_mpc_solve_resident(qmhip_ctx* ctx, int B, double horizon);
+int qmhip_mpc_download(qmhip_ctx* ctx, int B, int32_t* out_num_nodes, double* out_t, int32_t* out_event, int32_t* out_mode,
+                       double* out_x, double* out_u, double* out_perf, int32_t* status);
+
+/* ---- policy evaluation: replaces MPC_MRT_Interface::evaluatePolicy (call site QMController.cpp:139-142):
+ *      linear interpolation of the last primal solution at time t[b] */
+int qmhip_policy_eval(qmhip_ctx* ctx, int B, const double* t, double* x_des /*[B][30]*/, double* u_des /*[B][30]*/, int32_t* mode /*[B]*/);
+
+/* ---- WBC: replaces qm::WbcBase::update / HierarchicalWbc::update (qm_wbc/include/qm_wbc/WbcBase.h:31-32,
+ *      qm_wbc/src/HierarchicalWbc.cpp:18-44; variant 1 = HierarchicalMpcWbc.cpp:18-34).
+ *      out[b] = [vdot(24), F(12), tau(18)]; qp_status[b][3] per priority level (0 ok, 1 iteration limit).
+ *      The joint-acceleration state `inputLast_` (WbcBase.cpp:212-213) lives in the context per instance;
+ *      qmhip_wbc_reset zeroes it. */
+int qmhip_wbc_step(qmhip_ctx* ctx, int B, const double* x_des, const double* u_des, const double* rbd_meas /*[B][55]*/,
+                   const int32_t* mode, double period, const double* time /*[B]*/, int variant,
+                   double* out /*[B][54]*/, int32_t* qp_status /*[B][3]*/);
+int qmhip_wbc_reset(qmhip_ctx* ctx);
+
+/* ---- whole control step on resident data (benchmark "step"): SQP iteration + policy evaluation at t0 + WBC with
+ *      the measured state built from x0 (zero velocities, EE pose by FK) */
+int qmhip_control_step_resident(qmhip_ctx* ctx, int B, double horizon, double period, double time);
+int qmhip_wbc_download(qmhip_ctx* ctx, int B, double* out /*[B][54]*/, int32_t* qp_status /*[B][3]*/);
+
+/* ---- instrumentation (ocs2 benchmark::RepeatedTimer analogue, QMController.cpp:145-147,321-323) ----
+ * per-kernel HIP-event timing on the context stream; names: "grid","lq","riccati","ls_eval","ls_misc","wbc" */
+int qmhip_set_profiling(qmhip_ctx* ctx, int enable);
+int qmhip_get_kernel_ms(qmhip_ctx* ctx, const char* name, double* total_ms, int* launches);
+int qmhip_reset_kernel_ms(qmhip_ctx* ctx);
+int qmhip_synchronize(qmhip_ctx* ctx);
+int qmhip_last_ls_trials(const qmhip_ctx* ctx);
+/* debug/parity access to a device buffer by name (see QmMpcBuffers); copies `bytes` to host */
+int qmhip_debug_read(qmhip_ctx* ctx, const char* buffer, void* dst, size_t bytes);
+/* micro-benchmarks used to anchor the FP64 roofline: returns achieved TFLOP/s */
+int qmhip_microbench_fp64(qmhip_ctx* ctx, int use_mfma, double* tflops);
+
+#define QMHIP_OK 0
+#define QMHIP_ERR_ARG  -1
+#define QMHIP_ERR_FILE -2
+#define QMHIP_ERR_MODEL -3
+#define QMHIP_ERR_HIP  -4
+#define QMHIP_ERR_STATE -5
+
+#ifdef __cplusplus
+}
+#endif
+#endif

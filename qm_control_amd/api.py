@@ -1,0 +1,209 @@
+"""Host-side mirror of the reference's interfaces for the hot path, over the C ABI of libqmhip.so.
+
+    QMInterface   <- qm::QMInterface            (qm_interface/include/qm_interface/QMInterface.h:31-54)
+    SqpMpc        <- ocs2::MPC_BASE / SqpMpc    (qm_controllers/src/QMController.cpp:287-288; run(), policy)
+    HierarchicalWbc <- qm::HierarchicalWbc      (qm_wbc/src/HierarchicalWbc.cpp:18-44; update(), loadTasksSetting)
+
+There is NO CPU fallback: if libqmhip.so is missing, or no HIP device is present, construction raises.
+Arrays are numpy f64, instance-major (batch first).  torch is not needed by this module.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqmhip.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+MB_SIZE, ST_SIZE = 685, 1030
+
+EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
+           "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_download", "qmhip_policy_eval",
+           "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
+           "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_microbench_fp64"]
+
+
+class QmhipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libqmhip.so (built by __graft_entry__.build()); raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QmhipError("libqmhip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.qmhip_last_error.restype = C.c_char_p
+        _lib.qmhip_last_error.argtypes = [C.c_void_p]
+        _lib.qmhip_destroy.argtypes = [C.c_void_p]
+        _lib.qmhip_destroy.restype = None
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def _f(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def parse_model(urdf_file, task_file, reference_file):
+    """host-only parse (no GPU needed): returns (model_blob, settings_blob); raises ValueError for missing files
+    like the reference constructor's std::invalid_argument (QMInterface.cpp:45,53,61)."""
+    lib = load_library()
+    mb = np.zeros(MB_SIZE); st = np.zeros(ST_SIZE)
+    rc = lib.qmhip_parse_model(urdf_file.encode(), task_file.encode(), reference_file.encode(), _p(mb), _p(st))
+    if rc != 0:
+        msg = lib.qmhip_last_error(None).decode()
+        raise (ValueError if rc == -2 else QmhipError)(msg)
+    return mb, st
+
+
+class QMInterface:
+    """Owns the device context (model + settings + all HBM buffers) — qm::QMInterface's role."""
+
+    def __init__(self, task_file=None, urdf_file=None, reference_file=None, *, blobs=None, device=0, max_batch=1, max_nodes=128, max_ref_knots=2, max_events=8):
+        self.lib = load_library()
+        h = C.c_void_p()
+        if blobs is not None:
+            mb, st = _f(blobs[0], (MB_SIZE,)), _f(blobs[1], (ST_SIZE,))
+            rc = self.lib.qmhip_create_from_blobs(_p(mb), _p(st), device, max_batch, max_nodes, max_ref_knots, max_events, C.byref(h))
+        else:
+            rc = self.lib.qmhip_create(urdf_file.encode(), task_file.encode(), reference_file.encode(), device, max_batch, max_nodes, max_ref_knots, max_events, C.byref(h))
+        if rc != 0:
+            msg = self.lib.qmhip_last_error(None).decode()
+            raise (ValueError if rc == -2 else QmhipError)("qmhip_create failed (%d): %s" % (rc, msg))
+        self.h = h
+        self.max_batch, self.max_nodes, self.max_ref_knots, self.max_events = max_batch, max_nodes, max_ref_knots, max_events
+        self.model_blob = np.zeros(MB_SIZE); self.settings_blob = np.zeros(ST_SIZE)
+        self.lib.qmhip_export_blobs(self.h, _p(self.model_blob), _p(self.settings_blob))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.qmhip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise QmhipError("%s failed (%d): %s" % (what, rc, self.lib.qmhip_last_error(self.h).decode()))
+
+    # getters named after the reference's
+    def getInitialState(self):
+        return self.settings_blob[930:960].copy()
+
+    def getCentroidalModelInfo(self):
+        mb = self.model_blob
+        return dict(robotMass=mb[654], centroidalInertiaNominal=mb[655:664].reshape(3, 3).copy(), comToBasePositionNominal=mb[664:667].copy(),
+                    qPinocchioNominal=np.concatenate([np.zeros(6), mb[667:685]]), stateDim=30, inputDim=30, generalizedCoordinatesNum=24, actuatedDofNum=18, numThreeDofContacts=4)
+
+    def set_setting(self, index, value):
+        self._check(self.lib.qmhip_set_setting(self.h, C.c_int(index), C.c_double(value)), "qmhip_set_setting")
+        self.settings_blob[index] = value
+
+    # instrumentation
+    def set_profiling(self, on):
+        self.lib.qmhip_set_profiling(self.h, int(on))
+
+    def kernel_ms(self, name):
+        ms = C.c_double(0); n = C.c_int(0)
+        self.lib.qmhip_get_kernel_ms(self.h, name.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def reset_kernel_ms(self):
+        self.lib.qmhip_reset_kernel_ms(self.h)
+
+    def synchronize(self):
+        self._check(self.lib.qmhip_synchronize(self.h), "qmhip_synchronize")
+
+    def microbench_fp64(self, use_mfma):
+        v = C.c_double(0)
+        self._check(self.lib.qmhip_microbench_fp64(self.h, int(use_mfma), C.byref(v)), "qmhip_microbench_fp64")
+        return v.value
+
+    def debug_read(self, name, shape, dtype=np.float64):
+        out = np.zeros(shape, dtype=dtype)
+        self._check(self.lib.qmhip_debug_read(self.h, name.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)), "qmhip_debug_read")
+        return out
+
+
+class SqpMpc:
+    """ocs2::MPC_BASE-shaped front: run() = one multiple-shooting SQP iteration per instance (cold start)."""
+
+    def __init__(self, interface):
+        self.itf = interface
+        self.lib = interface.lib
+        self.B = 0
+
+    def set_problem(self, t0, x0, ref_t, ref_x, event_times, modes):
+        B = len(t0)
+        t0 = _f(t0, (B,)); x0 = _f(x0, (B, 30)); ref_t = _f(ref_t); ref_x = _f(ref_x); ev = _f(event_times)
+        modes = np.ascontiguousarray(modes, dtype=np.int32)
+        assert ref_x.shape == (B, ref_t.shape[1], 37) and modes.shape == (B, ev.shape[1] + 1)
+        self.itf._check(self.lib.qmhip_mpc_upload(self.itf.h, B, _p(t0), _p(x0), ref_t.shape[1], _p(ref_t), _p(ref_x), ev.shape[1], _p(ev), _pi(modes)), "qmhip_mpc_upload")
+        self.B = B
+
+    def solve_resident(self, horizon):
+        self.itf._check(self.lib.qmhip_mpc_solve_resident(self.itf.h, self.B, C.c_double(horizon)), "qmhip_mpc_solve_resident")
+
+    def control_step_resident(self, horizon, period, time):
+        self.itf._check(self.lib.qmhip_control_step_resident(self.itf.h, self.B, C.c_double(horizon), C.c_double(period), C.c_double(time)), "qmhip_control_step_resident")
+
+    def download(self):
+        B, nm = self.B, self.itf.max_nodes
+        nn = np.zeros(B, np.int32); t = np.zeros((B, nm)); ev = np.zeros((B, nm), np.int32); mode = np.zeros((B, nm), np.int32)
+        x = np.zeros((B, nm, 30)); u = np.zeros((B, nm, 30)); perf = np.zeros((B, 10)); status = np.zeros(B, np.int32)
+        self.itf._check(self.lib.qmhip_mpc_download(self.itf.h, B, _pi(nn), _p(t), _pi(ev), _pi(mode), _p(x), _p(u), _p(perf), _pi(status)), "qmhip_mpc_download")
+        return dict(num_nodes=nn, t=t, event=ev, mode=mode, x=x, u=u, perf=perf, status=status, ls_trials=self.lib.qmhip_last_ls_trials(self.itf.h))
+
+    def run(self, t0, x0, ref_t, ref_x, event_times, modes, horizon):
+        self.set_problem(t0, x0, ref_t, ref_x, event_times, modes)
+        self.solve_resident(horizon)
+        return self.download()
+
+    def evaluatePolicy(self, t):
+        t = _f(t, (self.B,))
+        x = np.zeros((self.B, 30)); u = np.zeros((self.B, 30)); mode = np.zeros(self.B, np.int32)
+        self.itf._check(self.lib.qmhip_policy_eval(self.itf.h, self.B, _p(t), _p(x), _p(u), _pi(mode)), "qmhip_policy_eval")
+        return x, u, mode
+
+
+class HierarchicalWbc:
+    """qm::HierarchicalWbc-shaped front: update(stateDesired, inputDesired, rbdStateMeasured, mode, period, time) -> [x(36); tau(18)]."""
+
+    def __init__(self, interface, mpc_variant=False):
+        self.itf = interface
+        self.lib = interface.lib
+        self.variant = 1 if mpc_variant else 0
+
+    def reset(self):
+        self.itf._check(self.lib.qmhip_wbc_reset(self.itf.h), "qmhip_wbc_reset")
+
+    def update(self, stateDesired, inputDesired, rbdStateMeasured, mode, period, time):
+        xd = _f(stateDesired); B = xd.shape[0]
+        ud = _f(inputDesired, (B, 30)); rbd = _f(rbdStateMeasured, (B, 55)); mode = np.ascontiguousarray(mode, np.int32); time = _f(np.broadcast_to(time, (B,)))
+        out = np.zeros((B, 54)); st = np.zeros((B, 3), np.int32)
+        self.itf._check(self.lib.qmhip_wbc_step(self.itf.h, B, _p(xd), _p(ud), _p(rbd), _pi(mode), C.c_double(period), _p(time), self.variant, _p(out), _pi(st)), "qmhip_wbc_step")
+        return out, st
+
+    def download(self, B):
+        out = np.zeros((B, 54)); st = np.zeros((B, 3), np.int32)
+        self.itf._check(self.lib.qmhip_wbc_download(self.itf.h, B, _p(out), _pi(st)), "qmhip_wbc_download")
+        return out, st

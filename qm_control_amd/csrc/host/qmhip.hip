@@ -1,0 +1,220 @@
+// qmhip.hip — libqmhip.so: HIP backend of the launch sequence (qm_pipeline.h) + the C ABI of include/qmhip.h.
+// gfx950 only.  One context = one device, one HIP stream, all buffers resident in HBM for max_batch instances.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../../include/qmhip.h"
+#include "qm_model_io.h"
+#include "qm_pipeline.h"
+#include "qm_wbc_pipeline.h"
+
+static std::string g_create_error;
+
+#define HIP_TRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->fail(std::string(#expr) + ": " + hipGetErrorString(e_)); return QMHIP_ERR_HIP; } } while (0)
+
+struct HipBackend {
+  hipStream_t stream = nullptr; bool profiling = false; std::string error;
+  struct Span { std::string name; hipEvent_t a, b; };
+  std::vector<Span> spans; std::vector<hipEvent_t> pool;
+  std::map<std::string, std::pair<double, int>> acc;
+  std::map<const void*, int> lds_set;
+  hipEvent_t ev() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; hipEventCreate(&e); return e; }
+  void check(hipError_t e, const char* what) { if (e != hipSuccess && error.empty()) error = std::string(what) + ": " + hipGetErrorString(e); }
+  template <class K> const char* name_of(K k) {
+    const void* p = (const void*)k;
+    if (p == (const void*)qm_grid_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_riccati_kernel) return "riccati";
+    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_wbc_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel) return "policy";
+    return "ls_misc";
+  }
+  template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {
+    if (grid <= 0) return;
+    if (lds > 48 * 1024) {
+      const void* p = (const void*)kernel; auto it = lds_set.find(p);
+      if (it == lds_set.end() || it->second < (int)lds) { check(hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); lds_set[p] = (int)lds; }
+    }
+    Span s; if (profiling) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); hipEventRecord(s.a, stream); }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, args);
+    check(hipGetLastError(), "kernel launch");
+    if (profiling) { hipEventRecord(s.b, stream); spans.push_back(s); }
+  }
+  void resolve() {
+    if (spans.empty()) return;
+    hipStreamSynchronize(stream);
+    for (auto& s : spans) { float ms = 0; hipEventElapsedTime(&ms, s.a, s.b); auto& a = acc[s.name]; a.first += ms; a.second += 1; pool.push_back(s.a); pool.push_back(s.b); }
+    spans.clear();
+  }
+  void* alloc(size_t n) { void* p = nullptr; check(hipMalloc(&p, n ? n : 8), "hipMalloc"); return p; }
+  void free(void* p) { hipFree(p); }
+  void zero(void* p, size_t n) { check(hipMemsetAsync(p, 0, n, stream), "hipMemsetAsync"); }
+  void to_device(void* d, const void* s, size_t n) { check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "H2D"); check(hipStreamSynchronize(stream), "sync"); }
+  void to_host(void* d, const void* s, size_t n) { check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "D2H"); check(hipStreamSynchronize(stream), "sync"); }
+  void sync() { check(hipStreamSynchronize(stream), "sync"); }
+};
+
+struct qmhip_ctx {
+  int device = 0, max_batch = 0, max_nodes = 0, max_ref = 0, max_ev = 0;
+  double mb[MB_SIZE], st[ST_SIZE];
+  HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc;
+  std::string error; int lastB = 0; bool have_solution = false;
+  qmhip_ctx() : mpc(bk), wbc(bk) {}
+  void fail(const std::string& m) { error = m; }
+  int hipstate() { if (!bk.error.empty()) { error = bk.error; bk.error.clear(); return QMHIP_ERR_HIP; } return QMHIP_OK; }
+};
+
+// ---- FP64 micro-benchmarks (roofline denominators) ----
+__global__ void qm_bench_fma_kernel(double* out, int iters) {
+  double a0 = threadIdx.x * 1e-9, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; const double m = 1.0000001, c = 1e-9;
+  for (int i = 0; i < iters; ++i) { a0 = fma(a0, m, c); a1 = fma(a1, m, c); a2 = fma(a2, m, c); a3 = fma(a3, m, c); a4 = fma(a4, m, c); a5 = fma(a5, m, c); a6 = fma(a6, m, c); a7 = fma(a7, m, c); }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+__global__ void qm_bench_mfma_kernel(double* out, int iters) {
+  qm_d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0; const double a = 1.0 + threadIdx.x * 1e-9, b = 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0); c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0); c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+
+static int create_common(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
+  if (!out || max_batch <= 0 || max_nodes < 3 || max_ref < 1 || max_ev < 1) { g_create_error = "qmhip_create: bad argument"; return QMHIP_ERR_ARG; }
+  std::string err; if (!qmio::validateModelBlob(mb, err)) { g_create_error = err; return QMHIP_ERR_MODEL; }
+  int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (libqmhip has no CPU fallback)"; return QMHIP_ERR_HIP; }
+  if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return QMHIP_ERR_ARG; }
+  if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return QMHIP_ERR_HIP; }
+  qmhip_ctx* c = new qmhip_ctx(); c->device = device; c->max_batch = max_batch; c->max_nodes = max_nodes; c->max_ref = max_ref; c->max_ev = max_ev;
+  memcpy(c->mb, mb, sizeof(c->mb)); memcpy(c->st, st, sizeof(c->st));
+  if (hipStreamCreate(&c->bk.stream) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
+  c->mpc.allocate(c->mb, c->st, max_batch, max_nodes, max_ref, max_ev, false);
+  c->wbc.allocate(max_batch);
+  c->bk.sync();
+  if (!c->bk.error.empty()) { g_create_error = c->bk.error; c->mpc.release(); c->wbc.release(); hipStreamDestroy(c->bk.stream); delete c; return QMHIP_ERR_HIP; }
+  *out = c; return QMHIP_OK;
+}
+
+extern "C" {
+
+int qmhip_parse_model(const char* urdf, const char* task, const char* ref, double* mb, double* st) {
+  if (!urdf || !task || !ref || !mb || !st) { g_create_error = "qmhip_parse_model: null argument"; return QMHIP_ERR_ARG; }
+  // same checks (and order) as QMInterface's constructor, QMInterface.cpp:40-62
+  if (!qmio::fileExists(task)) { g_create_error = std::string("[QMInterface] Task file not found: ") + task; return QMHIP_ERR_FILE; }
+  if (!qmio::fileExists(urdf)) { g_create_error = std::string("[QMInterface] URDF file not found: ") + urdf; return QMHIP_ERR_FILE; }
+  if (!qmio::fileExists(ref)) { g_create_error = std::string("[QMInterface] targetCommand file not found: ") + ref; return QMHIP_ERR_FILE; }
+  std::string ee, err;
+  if (!qmio::loadEeFrameName(task, ee, err) || !qmio::buildModelBlob(urdf, ref, ee, mb, nullptr, err) || !qmio::buildSettingsBlob(task, mb, st, err)) { g_create_error = err; return QMHIP_ERR_MODEL; }
+  return QMHIP_OK;
+}
+int qmhip_create(const char* urdf, const char* task, const char* ref, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
+  static double mb[MB_SIZE], st[ST_SIZE];
+  const int rc = qmhip_parse_model(urdf, task, ref, mb, st); if (rc != QMHIP_OK) return rc;
+  return create_common(mb, st, device, max_batch, max_nodes, max_ref, max_ev, out);
+}
+int qmhip_create_from_blobs(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
+  if (!mb || !st) { g_create_error = "qmhip_create_from_blobs: null blob"; return QMHIP_ERR_ARG; }
+  return create_common(mb, st, device, max_batch, max_nodes, max_ref, max_ev, out);
+}
+void qmhip_destroy(qmhip_ctx* c) {
+  if (!c) return; hipSetDevice(c->device); c->bk.sync(); c->mpc.release(); c->wbc.release();
+  for (auto e : c->bk.pool) hipEventDestroy(e); hipStreamDestroy(c->bk.stream); delete c;
+}
+const char* qmhip_last_error(const qmhip_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
+int qmhip_set_setting(qmhip_ctx* c, int idx, double v) {
+  if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
+}
+
+int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) {
+  if (!c) return QMHIP_ERR_ARG;
+  if (B <= 0 || B > c->max_batch || n_ref != c->max_ref || n_ev != c->max_ev || !t0 || !x0 || !ref_t || !ref_x || !ev || !modes) { c->fail("qmhip_mpc_upload: bad argument (B <= max_batch, n_ref == max_ref_knots, n_events == max_events required)"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); c->lastB = B; c->have_solution = false; return c->hipstate();
+}
+int qmhip_mpc_solve_resident(qmhip_ctx* c, int B, double horizon) {
+  if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident: bad argument"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->mpc.grid(B, horizon); c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
+}
+int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) {
+  if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG;
+  if (!c->have_solution) { c->fail("qmhip_mpc_download: no solution available"); return QMHIP_ERR_STATE; }
+  hipSetDevice(c->device); const int nm = c->max_nodes; const QmMpcBuffers& d = c->mpc.d;
+  std::vector<int> n_h(B), st_h(B); c->bk.to_host(n_h.data(), d.n_nodes, (size_t)B * 4); c->bk.to_host(st_h.data(), d.status, (size_t)B * 4);
+  std::vector<double> si((size_t)B * 4); c->bk.to_host(si.data(), d.step_info, si.size() * 8);
+  for (int b = 0; b < B; ++b) { if (st_h[b] == 0 && si[(size_t)b * 4 + 3] != 0.0) st_h[b] = -4; if (nn) nn[b] = n_h[b]; if (status) status[b] = st_h[b]; }
+  auto gather_d = [&](const double* dev, int k, double* out) {   // node-major [nmax][B][k] -> instance-major [B][nmax][k]
+    if (!out) return; std::vector<double> h((size_t)nm * B * k); c->bk.to_host(h.data(), dev, h.size() * 8);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < nm; ++i) memcpy(out + ((size_t)b * nm + i) * k, h.data() + ((size_t)i * B + b) * k, (size_t)k * 8);
+  };
+  auto gather_i = [&](const int* dev, int32_t* out) {
+    if (!out) return; std::vector<int> h((size_t)nm * B); c->bk.to_host(h.data(), dev, h.size() * 4);
+    for (int b = 0; b < B; ++b) for (int i = 0; i < nm; ++i) out[(size_t)b * nm + i] = h[(size_t)i * B + b];
+  };
+  gather_d(d.node_t, 1, ot); gather_i(d.node_ev, oev); gather_i(d.node_mode, omode); gather_d(d.xs, 30, ox); gather_d(d.us, 30, ou);
+  if (operf) c->bk.to_host(operf, d.out_perf, (size_t)B * 10 * 8);
+  return c->hipstate();
+}
+int qmhip_mpc_step(qmhip_ctx* c, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes, double horizon,
+                   int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) {
+  int rc = qmhip_mpc_upload(c, B, t0, x0, n_ref, ref_t, ref_x, n_ev, ev, modes); if (rc) return rc;
+  rc = qmhip_mpc_solve_resident(c, B, horizon); if (rc) return rc;
+  return qmhip_mpc_download(c, B, nn, ot, oev, omode, ox, ou, operf, status);
+}
+
+int qmhip_policy_eval(qmhip_ctx* c, int B, const double* t, double* xd, double* ud, int32_t* mode) {
+  if (!c || B <= 0 || B > c->max_batch || !t) return QMHIP_ERR_ARG;
+  if (!c->have_solution) { c->fail("qmhip_policy_eval: no policy received yet"); return QMHIP_ERR_STATE; }
+  hipSetDevice(c->device); c->wbc.policy_eval(c->mpc.d, B, t);
+  if (xd) c->bk.to_host(xd, c->wbc.w.x_des, (size_t)B * 30 * 8); if (ud) c->bk.to_host(ud, c->wbc.w.u_des, (size_t)B * 30 * 8); if (mode) c->bk.to_host(mode, c->wbc.w.mode, (size_t)B * 4);
+  return c->hipstate();
+}
+int qmhip_wbc_reset(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->wbc.reset(); return c->hipstate(); }
+int qmhip_wbc_step(qmhip_ctx* c, int B, const double* xd, const double* ud, const double* rbd, const int32_t* mode, double period, const double* time, int variant, double* out, int32_t* qps) {
+  if (!c || B <= 0 || B > c->max_batch || !xd || !ud || !rbd || !mode || !time || !(period > 0)) { if (c) c->fail("qmhip_wbc_step: bad argument"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->wbc.upload(B, xd, ud, rbd, mode, time); c->wbc.step(c->mpc.d, B, period, variant);
+  return qmhip_wbc_download(c, B, out, qps);
+}
+int qmhip_wbc_download(qmhip_ctx* c, int B, double* out, int32_t* qps) {
+  if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG; hipSetDevice(c->device);
+  if (out) c->bk.to_host(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); if (qps) c->bk.to_host(qps, c->wbc.w.qp_status, (size_t)B * 3 * 4);
+  return c->hipstate();
+}
+int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double period, double time) {
+  int rc = qmhip_mpc_solve_resident(c, B, horizon); if (rc) return rc;
+  c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time); c->wbc.step(c->mpc.d, B, period, 0);
+  return c->hipstate();
+}
+
+int qmhip_set_profiling(qmhip_ctx* c, int en) { if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.profiling = en != 0; return QMHIP_OK; }
+int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launches) {
+  if (!c || !name) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.resolve(); auto it = c->bk.acc.find(name);
+  if (ms) *ms = it == c->bk.acc.end() ? 0.0 : it->second.first; if (launches) *launches = it == c->bk.acc.end() ? 0 : it->second.second; return QMHIP_OK;
+}
+int qmhip_reset_kernel_ms(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.acc.clear(); return QMHIP_OK; }
+int qmhip_synchronize(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
+int qmhip_last_ls_trials(const qmhip_ctx* c) { return c ? c->mpc.ls_trials_run : -1; }
+int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) {
+  if (!c || !name || !dst) return QMHIP_ERR_ARG; hipSetDevice(c->device); const QmMpcBuffers& d = c->mpc.d; const void* p = nullptr;
+#define F(n) if (!strcmp(name, #n)) p = d.n;
+  F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf)
+#undef F
+  if (!p) p = c->wbc.buffer(name);
+  if (!p) { c->fail(std::string("qmhip_debug_read: unknown buffer ") + name); return QMHIP_ERR_ARG; }
+  c->bk.to_host(dst, p, bytes); return c->hipstate();
+}
+int qmhip_microbench_fp64(qmhip_ctx* c, int use_mfma, double* tflops) {
+  if (!c || !tflops) return QMHIP_ERR_ARG; hipSetDevice(c->device);
+  const int blocks = 256 * 8, threads = 256, iters = 20000; double* out = (double*)c->bk.alloc((size_t)blocks * threads * 8);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  for (int rep = 0; rep < 2; ++rep) {
+    hipEventRecord(a, c->bk.stream);
+    if (use_mfma) hipLaunchKernelGGL(qm_bench_mfma_kernel, dim3(blocks), dim3(threads), 0, c->bk.stream, out, iters);
+    else hipLaunchKernelGGL(qm_bench_fma_kernel, dim3(blocks), dim3(threads), 0, c->bk.stream, out, iters);
+    hipEventRecord(b, c->bk.stream); hipEventSynchronize(b);
+  }
+  float ms = 0; hipEventElapsedTime(&ms, a, b);
+  const double flops = use_mfma ? (double)blocks * (threads / 64) * iters * 4.0 * (2.0 * 16 * 16 * 4) : (double)blocks * threads * iters * 8.0 * 2.0;
+  *tflops = flops / (ms * 1e-3) / 1e12; hipEventDestroy(a); hipEventDestroy(b); c->bk.free(out); return c->hipstate();
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// k_policy.h — K5: policy evaluation (MPC_MRT_Interface::evaluatePolicy [upstream], call site
+// qm_controllers/src/QMController.cpp:139-142) and the synthetic measured state of the benchmark step.
+// One thread per instance.
+#pragma once
+#include "k_grid.h"
+#include "qm_dev_kin.h"
+
+struct QmPolicyArgs {
+  const double* mb;
+  int B, nmax, nev;
+  const int* n_nodes; const double* node_t; const int* node_ev;   // grid
+  const double* xs; const double* us;                              // primal solution [nmax][B][30]
+  const double* ev; const int* modes;                              // schedule [B][nev], [B][nev+1]
+  const double* t;                                                 // [B] evaluation time (t0 for the benchmark step)
+  double* x_des; double* u_des; int* mode;                         // [B][30], [B][30], [B]
+};
+
+__global__ void qm_policy_kernel(QmPolicyArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int n = a.n_nodes[b]; const double t = a.t[b];
+  // interpolation times: PreEvent nodes nudged down, PostEvent nodes nudged up by limitEpsilon ([upstream] toInterpolationTime)
+  // timeSegment over the node times without materialising the array
+  auto tt = [&](int i) { const int e = a.node_ev[i * a.B + b]; return a.node_t[i * a.B + b] + (e == QM_EV_POST ? QM_LIMIT_EPS : (e == QM_EV_PRE ? -QM_LIMIT_EPS : 0.0)); };
+  int part = 0; while (part < n && tt(part) < t) ++part;
+  const int interval = (part == 0 && t == tt(0)) ? 0 : part - 1; const int last = n - 1;
+  int idx; double al;
+  if (n <= 1) { idx = 0; al = 1.0; }
+  else if (interval >= 0) {
+    if (interval < last) { const double len = tt(interval + 1) - tt(interval), till = tt(interval + 1) - t; idx = interval; al = (len > 2.0 * QM_WEAK_EPS) ? till / len : ((till > 0.5 * len) ? 1.0 : 0.0); }
+    else { idx = (last - 1 > 0) ? last - 1 : 0; al = 0.0; }
+  } else { idx = 0; al = 1.0; }
+  const int i0 = idx * a.B + b, i1 = ((n > 1 ? idx + 1 : idx)) * a.B + b;
+  for (int q = 0; q < 30; ++q) { a.x_des[(size_t)b * 30 + q] = al * a.xs[i0 * 30 + q] + (1.0 - al) * a.xs[i1 * 30 + q]; a.u_des[(size_t)b * 30 + q] = al * a.us[i0 * 30 + q] + (1.0 - al) * a.us[i1 * 30 + q]; }
+  a.mode[b] = a.modes[(size_t)b * (a.nev + 1) + grid_find_index(a.ev + (size_t)b * a.nev, a.nev, t)];
+}
+
+// measured rbd state (55) built from x0: zero velocities, EE pose by FK (layout of
+// qm_estimation/src/StateEstimateBase.cpp:41-103)
+struct QmMeasArgs { const double* mb; int B; const double* x0; double time; double* rbd; double* time_out; };
+__global__ void qm_measured_kernel(QmMeasArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const double* x = a.x0 + (size_t)b * 30; double* r = a.rbd + (size_t)b * QM_NRBD;
+  for (int q = 0; q < QM_NRBD; ++q) r[q] = 0.0;
+  for (int q = 0; q < 3; ++q) { r[q] = x[9 + q]; r[3 + q] = x[6 + q]; }
+  for (int j = 0; j < QM_NJ; ++j) r[6 + j] = x[12 + j];
+  double K[KW_SIZE]; kin_base(a.mb, x, K); kin_arm(a.mb, x, K);
+  double qq[4]; mat_to_quat(K + KW_ARM + 39, qq);
+  for (int q = 0; q < 3; ++q) r[48 + q] = K[KW_ARM + 36 + q];
+  for (int q = 0; q < 4; ++q) r[51 + q] = qq[q];
+  a.time_out[b] = a.time;
+}

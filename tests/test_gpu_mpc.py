@@ -1,0 +1,74 @@
+"""GPU parity tests of the MPC path (K0..K4) through the C ABI, against the CPU oracle.
+
+Tolerance: BASELINE.json north_star — optimal state/input trajectories within 1e-6 relative; integer
+contact-mode schedules / node event tags bit-exact.
+"""
+import numpy as np
+import pytest
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _oracle_solve(oracle, cfg, b):
+    oracle.set_schedule(cfg["ev"][b], cfg["modes"][b])
+    oracle.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+    return oracle.mpc_step(cfg["t0"][b], cfg["t0"][b] + cfg["horizon"], cfg["x0"][b])
+
+
+def _gpu_solve(blobs, cfg, B, max_nodes):
+    from qm_control_amd import api
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=max_nodes, max_ref_knots=cfg["ref_t"].shape[1], max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf)
+    res = mpc.run(cfg["t0"][:B], cfg["x0"][:B], cfg["ref_t"][:B], cfg["ref_x"][:B], cfg["ev"][:B], cfg["modes"][:B], cfg["horizon"])
+    return itf, mpc, res
+
+
+def _compare(res, b, r):
+    n = len(r["t"])
+    assert res["status"][b] == 0
+    assert res["num_nodes"][b] == n
+    assert np.array_equal(res["t"][b, :n], r["t"])                    # same f64 operations -> identical times
+    assert np.array_equal(res["event"][b, :n], r["ev"])                # integer: bit-exact
+    assert np.array_equal(res["mode"][b, :n], r["mode"])               # integer: bit-exact
+    assert rel_err(res["x"][b, :n], r["x"]) <= TOL
+    assert rel_err(res["u"][b, :n], r["u"]) <= TOL
+    assert res["perf"][b, 8] == r["alpha"]
+    assert rel_err(res["perf"][b, :8], r["perf"][:8]) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["C1", "C2"])
+def test_single_instance(blobs, oracle, name):
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config(name)
+    r = _oracle_solve(oracle, cfg, 0)
+    itf, mpc, res = _gpu_solve(blobs, cfg, 1, len(r["t"]) + 4)
+    _compare(res, 0, r)
+    itf.close()
+
+
+def test_batch_random_trot(blobs, oracle):
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config("C3", batch=64, n_intervals=40)
+    itf, mpc, res = _gpu_solve(blobs, cfg, 64, 64)
+    for b in (0, 1, 7, 31, 63):
+        _compare(res, b, _oracle_solve(oracle, cfg, b))
+    itf.close()
+
+
+def test_ee_tracking_schedule_switch(blobs, oracle):
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config("C5", batch=16, n_intervals=150)
+    itf, mpc, res = _gpu_solve(blobs, cfg, 16, 180)
+    for b in (0, 5, 15):
+        _compare(res, b, _oracle_solve(oracle, cfg, b))
+    itf.close()
+
+
+def test_node_buffer_too_small_is_reported(blobs):
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config("C2")
+    itf, mpc, res = _gpu_solve(blobs, cfg, 1, 32)
+    assert res["status"][0] == -1
+    itf.close()
