@@ -1,0 +1,123 @@
+"""bench.py — MPC+WBC control steps/sec of the 24-DoF quadruped-manipulator at horizon N=100 (BASELINE.json metric).
+
+One "step" = one multiple-shooting SQP iteration over the horizon + policy evaluation at t0 + one 3-level
+hierarchical WBC solve, for one instance.  Workload per GPU: configuration C3/C4 of
+BASELINE.md — trot gait, N=100, 1024 independent instances with random initial states (seeded), inputs resident
+in HBM before the timed region.  Instances are independent, so N GPUs run N shards with no data-path
+collective (weak scaling); torch.distributed (RCCL) only carries the barrier and the max-over-ranks time.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+        N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FP64 work: flops per unit of each kernel
+FLOP_LQ_PER_NODE = 190e3 + 410e3        # K1: LQ approximation + projection, per non-event shooting interval
+FLOP_RICCATI_PER_NODE = 250e3           # K3: per non-event stage
+FLOP_LS_PER_NODE_TRIAL = 15e3           # K4
+FLOP_WBC_PER_INSTANCE = 2.0e6           # K5-K7
+FP64_MFMA_PEAK_TFLOPS = 78.6            # MI355X dense FP64 matrix peak (AMD public figure; v_mfma_f64_16x16x4 micro-benchmark: 77.7, profiles/)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    from qm_control_amd import api, scenarios
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local)
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        dist = dist_mod
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier(); torch.cuda.synchronize()
+
+    B = args.batch
+    blobs = scenarios.load_blobs()
+    # C4: seed 1235, contiguous shard of the global batch for this rank
+    cfg_all = scenarios.make_config("C4", batch=B * world)
+    sl = slice(rank * B, (rank + 1) * B)
+    cfg = {k: (v[sl] if hasattr(v, "shape") and getattr(v, "ndim", 0) >= 1 and v.shape[0] == B * world else v) for k, v in cfg_all.items()}
+    itf = api.QMInterface(blobs=blobs, device=local, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])     # inputs resident in HBM from here on
+
+    def step():
+        wbc.reset()
+        mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+
+    for _ in range(args.warmup):
+        step()
+    itf.synchronize()
+    itf.set_profiling(True); itf.reset_kernel_ms()
+    barrier(); itf.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    itf.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+
+    # per-kernel HIP-event times over the timed region (events recorded on the stream the kernels run on)
+    kms = {k: itf.kernel_ms(k) for k in ("grid", "lq", "riccati", "ls_eval", "ls_misc", "policy", "wbc")}
+    res = mpc.download(); out, qps = wbc.download(B)
+    ok = bool((res["status"] == 0).all() and (qps == 0).all())
+    n_intervals = int(sum(int(res["num_nodes"][b]) - 1 - int((res["event"][b, :res["num_nodes"][b]] == 1).sum()) for b in range(B)))
+    dom = "lq" if kms["lq"][0] >= kms["riccati"][0] else "riccati"
+    per_node = FLOP_LQ_PER_NODE if dom == "lq" else FLOP_RICCATI_PER_NODE
+    avg_ms = kms[dom][0] / max(1, kms[dom][1])
+    achieved = per_node * n_intervals / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+
+    if rank == 0:
+        total_steps = B * world * args.steps
+        line = {
+            "metric": "MPC+WBC control steps/sec (24-DoF quadruped-manipulator, SQP horizon N=100)", "value": total_steps / elapsed, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3/C4: trot gait, horizon N=100 (dt 0.015), %d random initial states per GPU (seed 1235), cold start, 1 SQP iteration + policy eval + 3-level WBC" % B,
+                       "instances_per_gpu": B, "parallelism": "shard%d" % world, "all_status_ok": ok, "ls_trials": int(res["ls_trials"])},
+            "roofline": {"bound": "mfma", "kernel": "qm_%s_kernel" % dom, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "avg_launch_ms": avg_ms, "flop_per_launch": per_node * n_intervals},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kms.items()},
+        }
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import pyoracle
+            cores = min(os.cpu_count() or 1, 64); S = min(B, 128)
+            tb = time.perf_counter()
+            bad, _, _, w = pyoracle.batch_step(blobs[0], blobs[1], cores, cfg["t0"][:S], cfg["horizon"], cfg["x0"][:S], cfg["ref_t"][:S], cfg["ref_x"][:S], cfg["ev"][:S], cfg["modes"][:S], cfg["period"], cfg["time"])
+            tcpu = time.perf_counter() - tb
+            err = float(np.abs(out[:S] - w).max() / np.abs(w).max())
+            line["cpu_baseline"] = {"value": S / tcpu, "unit": "steps/s", "cores": cores, "kind": "port",
+                                    "sample": "first %d instances of the same batch, CPU oracle (C++ restatement, AD Jacobians), %d threads over instances; max rel diff of GPU torques on the sample %.1e" % (S, cores, err)}
+        print(json.dumps(line))
+    itf.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,8 @@
 // uses recursive algorithms instead, so the two are independent.  PARITY UNPINNED.
 #pragma once
 #include "ocp.h"
+#include <cstdio>
+#include <cstdlib>
 
 // 6x24 LOCAL_WORLD_ALIGNED Jacobian [lin; ang] of a point rigidly attached to body b
 template <class T> inline void pointJacobian(const Model& M, const Kin<T>& k, const T* q, int b, const V3<T>& pt, T J[6][QM_NQ]) {
@@ -160,37 +162,43 @@ inline HoLevel solveHoLevel(const Task& task, const HoLevel* prev, int nx) {
       bool same = true; Vec Dzn = matvec(DZ, z);
       for (int i = 0; i < ms; ++i) { const char na_i = (Dzn[i] - fb[i] > 0.0); if (na_i != act[i]) same = false; act[i] = na_i; }
       if (same && a == 1.0) break;
+      double pn = 0, zs = 1.0; for (int j = 0; j < n; ++j) { pn = std::max(pn, std::fabs(a * p[j])); zs = std::max(zs, std::fabs(z[j])); }
+      if (pn <= 1e-12 * zs) break;                        // minimiser sits on a kink: both active sets give the same z
     }
     if (L.iters >= 100) L.status = 1;                      // nWSR exhausted
     Vec Dzn = matvec(DZ, z); L.w.assign(ms, 0.0); for (int i = 0; i < ms; ++i) L.w[i] = std::max(0.0, Dzn[i] - fb[i]);
   } else if (hasPrevIneq) {
     // hard rows of the higher levels: primal active-set (Nocedal & Wright alg. 16.3) from the feasible z = 0
     Mat DZ = matmul(prev->Dstack, Zp); Vec fb = vadd(vsub(prev->fstack, matvec(prev->Dstack, xp)), prev->wstack); const int mh = DZ.r;
-    std::vector<int> W;
+    std::vector<int> W; bool degenerate = false; double pscale = 0.0;
     for (L.iters = 0; L.iters < 100; ++L.iters) {
       Mat E((int)W.size(), n); Vec e(W.size());
       for (size_t a = 0; a < W.size(); ++a) { for (int j = 0; j < n; ++j) E((int)a, j) = DZ(W[a], j); e[a] = fb[W[a]]; }
       Vec zn, lam; eqConstrainedLS(G0, g0, E, e, zn, lam);
       Vec p = vsub(zn, z); double pn = 0; for (double v : p) pn = std::max(pn, std::fabs(v));
       double zs = 1.0; for (double v : z) zs = std::max(zs, std::fabs(v));
-      if (pn <= 1e-13 * zs) {
-        int worst = -1; double lw = -1e-10; for (size_t a = 0; a < W.size(); ++a) if (lam[a] < lw) { lw = lam[a]; worst = (int)a; }
+      pscale = std::max(pscale, pn);
+      if (pn <= 1e-9 * std::max(zs, pscale)) {      // relative to the largest step seen: the problem's own length scale
+        // stationary on the working set: drop a row with a negative multiplier (most negative; lowest index after a degenerate step — Bland)
+        int worst = -1; double lw = 0.0; double lscale = 1.0; for (double v : lam) lscale = std::max(lscale, std::fabs(v));
+        for (size_t a = 0; a < W.size(); ++a) if (lam[a] < -1e-9 * lscale) { if (degenerate) { if (worst < 0 || W[a] < W[worst]) worst = (int)a; } else if (lam[a] < lw) { lw = lam[a]; worst = (int)a; } }
         if (worst < 0) break;
         W.erase(W.begin() + worst);
       } else {
         double alpha = 1.0; int block = -1; Vec Dz = matvec(DZ, z), Dp = matvec(DZ, p);
         for (int i = 0; i < mh; ++i) {
           if (std::find(W.begin(), W.end(), i) != W.end()) continue;
-          if (Dp[i] > 1e-12) { const double a = std::max(0.0, (fb[i] - Dz[i]) / Dp[i]); if (a < alpha) { alpha = a; block = i; } }
+          if (Dp[i] > 1e-10 * std::max(1.0, pn)) { const double a = std::max(0.0, (fb[i] - Dz[i]) / Dp[i]); if (a < alpha) { alpha = a; block = i; } }   // relative threshold: E p = 0 only to round-off; ties: lowest index
         }
         for (int j = 0; j < n; ++j) z[j] += alpha * p[j];
+        degenerate = (alpha <= 1e-12);
         if (block >= 0) {
-          // keep E full row rank: skip a blocking row that is (numerically) dependent on the working set
           if ((int)W.size() < n) W.push_back(block);
+          else { L.status = 2; break; }                   // more than n independent rows cannot be active
         }
       }
     }
-    if (L.iters >= 100) L.status = 1;
+    if (L.iters >= 100 && L.status == 0) L.status = 1;
   } else {
     Vec lam; eqConstrainedLS(G0, g0, Mat(0, n), Vec(), z, lam);
   }

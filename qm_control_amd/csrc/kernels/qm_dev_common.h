@@ -68,6 +68,14 @@ __device__ __forceinline__ bool mode_flag(int mode, int contact) { return (mode 
 // wave-level ordering point for LDS traffic inside ONE wavefront (no s_barrier: a wave's DS ops retire in order)
 __device__ __forceinline__ void qm_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
+// strided view of a per-instance array living in a lane-interleaved HBM workspace: element i of instance b sits at
+// base[i * stride + b], so the 64 lanes of a wave (consecutive instances) touch consecutive addresses
+struct QmSPtr {
+  double* p; int s;
+  __device__ __forceinline__ double& operator[](int i) const { return p[(size_t)i * s]; }
+  __device__ __forceinline__ QmSPtr operator+(int o) const { QmSPtr r; r.p = p + (size_t)o * s; r.s = s; return r; }
+};
+
 // ---- LDS tile helpers (all threads of the workgroup participate; caller places the barriers) ----
 __device__ __forceinline__ void tile_zero(double* T, int ndoubles = QM_TILE) { for (int i = threadIdx.x; i < ndoubles; i += blockDim.x) T[i] = 0.0; }
 // copy a rows x cols row-major global matrix (leading dim sld) into a tile

@@ -64,10 +64,10 @@ __device__ __forceinline__ void body_state(const double* mb, int body, const dou
 //  M, nle (may be null): fills entries of the chain's dofs against themselves and the base dofs (both triangles)
 //  cm/ch/cI/F/NO: composite + bias wrench of the whole chain added to the caller's accumulators (for the base block)
 //  Jt (may be null): 6x24 tip Jacobian [lin; ang] columns of this chain's joints (base columns are the caller's job)
-template <int NJ>
+template <int NJ, class PM, class PJ>
 __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, const double* q, const double* v, const RbdBase& B,
-                                          double* M /*[24][24]*/, double* nle /*[24]*/, double& cm, double* ch, double* cI, double* F, double* NO, RbdSums* S,
-                                          RbdTip& tip, double* Jt /*[6][24]*/) {
+                                          PM M /*[24][24]*/, double* nle /*[24]*/, bool wantM, double& cm, double* ch, double* cI, double* F, double* NO, RbdSums* S,
+                                          RbdTip& tip, PJ Jt /*[6][24]*/, bool wantJ) {
   double a[NJ][3], o[NJ][3];                        // world axes / joint origins
   double bm[NJ], bh[NJ][3], bI[NJ][9], bF[NJ][3], bN[NJ][3];   // per-joint subtree composites (accumulated tip->root)
   double Rp[9], op[3], vp[3], wp[3], ap[3], alp[3];
@@ -95,14 +95,14 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
     double wr[3], wwr[3], alr[3]; v3_cross(wp, r, wr); v3_cross(wp, wr, wwr); v3_cross(alp, r, alr);
     for (int i = 0; i < 3; ++i) { tip.p[i] = op[i] + r[i]; tip.v[i] = vp[i] + wr[i]; tip.w[i] = wp[i]; tip.a[i] = ap[i] + alr[i] + wwr[i]; tip.al[i] = alp[i]; }
   }
-  if (Jt) for (int jj = 0; jj < NJ; ++jj) {
+  if (wantJ) for (int jj = 0; jj < NJ; ++jj) {
     const double d[3] = {tip.p[0] - o[jj][0], tip.p[1] - o[jj][1], tip.p[2] - o[jj][2]}; double l[3]; v3_cross(a[jj], d, l);
     for (int i = 0; i < 3; ++i) { Jt[i * QM_NQ + 6 + j0 + jj] = l[i]; Jt[(3 + i) * QM_NQ + 6 + j0 + jj] = a[jj][i]; }
   }
   // tip -> root accumulation
   for (int jj = NJ - 2; jj >= 0; --jj) { bm[jj] += bm[jj + 1]; for (int i = 0; i < 3; ++i) { bh[jj][i] += bh[jj + 1][i]; bF[jj][i] += bF[jj + 1][i]; bN[jj][i] += bN[jj + 1][i]; } for (int i = 0; i < 9; ++i) bI[jj][i] += bI[jj + 1][i]; }
   cm += bm[0]; for (int i = 0; i < 3; ++i) { ch[i] += bh[0][i]; F[i] += bF[0][i]; NO[i] += bN[0][i]; } for (int i = 0; i < 9; ++i) cI[i] += bI[0][i];
-  if (M) {
+  if (wantM) {
     for (int jj = 0; jj < NJ; ++jj) {
       const int dj = 6 + j0 + jj;
       // S_j = (a_j, o_j × a_j);  momentum of the subtree composite: f = m vO + w × h ; nO = I_O w + h × vO
@@ -127,12 +127,12 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
 
 // Whole-tree pass.  Outputs (any pointer may be null):
 //   M[24][24], nle[24]; feet tips [4] (contact order LF,RF,LH,RH), arm tip; Jfeet [12][24] linear rows; Jarm [6][24]; sums
-__device__ __forceinline__ void rbd_tree(const double* mb, const double* q, const double* v, RbdBase& B, double* M, double* nle, RbdTip* feet, RbdTip* arm,
-                                         double* Jfeet, double* Jarm, RbdSums* S) {
+template <class PM, class PJ>
+__device__ __forceinline__ void rbd_tree(const double* mb, const double* q, const double* v, RbdBase& B, PM M, double* nle, bool wantM, RbdTip* feet, RbdTip* arm,
+                                         PJ Jfeet, PJ Jarm, bool wantJ, RbdSums* S) {
   rbd_base(q, v, B);
-  if (M) for (int i = 0; i < QM_NQ * QM_NQ; ++i) M[i] = 0.0;
-  if (Jfeet) for (int i = 0; i < 12 * QM_NQ; ++i) Jfeet[i] = 0.0;
-  if (Jarm) for (int i = 0; i < 6 * QM_NQ; ++i) Jarm[i] = 0.0;
+  if (wantM) for (int i = 0; i < QM_NQ * QM_NQ; ++i) M[i] = 0.0;
+  if (wantJ) { for (int i = 0; i < 12 * QM_NQ; ++i) Jfeet[i] = 0.0; for (int i = 0; i < 6 * QM_NQ; ++i) Jarm[i] = 0.0; }
   if (S) { S->mass = 0.0; for (int i = 0; i < 3; ++i) { S->mc[i] = S->hl[i] = S->hO[i] = S->Fb[i] = S->NbO[i] = 0.0; } }
   double cm = 0.0, ch[3] = {0, 0, 0}, cI[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[3] = {0, 0, 0}, NO[3] = {0, 0, 0};
   { // root body
@@ -143,23 +143,23 @@ __device__ __forceinline__ void rbd_tree(const double* mb, const double* q, cons
   double Jt[6 * QM_NQ];
   for (int chain = 0; chain < 4; ++chain) {
     const int contact = chain_to_contact(chain); RbdTip tip;
-    if (Jfeet) for (int i = 0; i < 6 * QM_NQ; ++i) Jt[i] = 0.0;
-    rbd_chain<3>(mb, 3 * chain, contact, q, v, B, M, nle, cm, ch, cI, F, NO, S, tip, Jfeet ? Jt : nullptr);
+    if (wantJ) for (int i = 0; i < 6 * QM_NQ; ++i) Jt[i] = 0.0;
+    rbd_chain<3, PM, double*>(mb, 3 * chain, contact, q, v, B, M, nle, wantM, cm, ch, cI, F, NO, S, tip, Jt, wantJ);
     if (feet) feet[contact] = tip;
-    if (Jfeet) {
+    if (wantJ) {
       for (int r = 0; r < 3; ++r) { for (int cidx = 6 + 3 * chain; cidx < 9 + 3 * chain; ++cidx) Jfeet[(3 * contact + r) * QM_NQ + cidx] = Jt[r * QM_NQ + cidx]; Jfeet[(3 * contact + r) * QM_NQ + r] = 1.0; }
       for (int k = 0; k < 3; ++k) { const double e[3] = {B.E[k], B.E[3 + k], B.E[6 + k]}, d[3] = {tip.p[0] - B.p[0], tip.p[1] - B.p[1], tip.p[2] - B.p[2]}; double l[3]; v3_cross(e, d, l); for (int r = 0; r < 3; ++r) Jfeet[(3 * contact + r) * QM_NQ + 3 + k] = l[r]; }
     }
   }
   {
-    RbdTip tip; rbd_chain<6>(mb, 12, 4, q, v, B, M, nle, cm, ch, cI, F, NO, S, tip, Jarm);
+    RbdTip tip; rbd_chain<6, PM, PJ>(mb, 12, 4, q, v, B, M, nle, wantM, cm, ch, cI, F, NO, S, tip, Jarm, wantJ);
     if (arm) *arm = tip;
-    if (Jarm) {
+    if (wantJ) {
       for (int r = 0; r < 3; ++r) Jarm[r * QM_NQ + r] = 1.0;
       for (int k = 0; k < 3; ++k) { const double e[3] = {B.E[k], B.E[3 + k], B.E[6 + k]}, d[3] = {tip.p[0] - B.p[0], tip.p[1] - B.p[1], tip.p[2] - B.p[2]}; double l[3]; v3_cross(e, d, l); for (int r = 0; r < 3; ++r) { Jarm[r * QM_NQ + 3 + k] = l[r]; Jarm[(3 + r) * QM_NQ + 3 + k] = e[r]; } }
     }
   }
-  if (M) {   // base block from the whole-tree composite; base rows of nle from the whole-tree bias wrench
+  if (wantM) {   // base block from the whole-tree composite; base rows of nle from the whole-tree bias wrench
     for (int d = 0; d < 6; ++d) {
       double w[3], vO[3]; rbd_S_base(B, d, w, vO);
       double wh[3], hv[3], Iw_[3]; v3_cross(w, ch, wh); v3_cross(ch, vO, hv); m3_mulv(cI, w, Iw_);

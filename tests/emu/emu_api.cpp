@@ -2,6 +2,7 @@
 // emulator and exposes it to pytest through ctypes.  Never linked into the product.
 #include "hip_emu.h"
 #include "../../qm_control_amd/csrc/host/qm_pipeline.h"
+#include "../../qm_control_amd/csrc/host/qm_wbc_pipeline.h"
 
 struct EmuBackend {
   template <class K, class A> void launch(K kernel, int grid, int block, size_t, const A& args) { emu::launch(dim3(grid), dim3(block), [&]() { kernel(args); }); }
@@ -13,13 +14,13 @@ struct EmuBackend {
   void sync() {}
 };
 
-struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; EmuCtx() : mpc(bk) {} };
+struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; EmuCtx() : mpc(bk), wbc(bk) {} };
 
 extern "C" {
 void* emu_create(const double* mb, const double* st, int Bmax, int nmax, int nref, int nev) {
-  EmuCtx* c = new EmuCtx(); c->mpc.allocate(mb, st, Bmax, nmax, nref, nev, true); return c;
+  EmuCtx* c = new EmuCtx(); c->mpc.allocate(mb, st, Bmax, nmax, nref, nev, true); c->wbc.allocate(Bmax, true); return c;
 }
-void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; c->mpc.release(); delete c; }
+void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; c->mpc.release(); c->wbc.release(); delete c; }
 int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes, double horizon, int max_trials) {
   EmuCtx* c = (EmuCtx*)h;
   c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes);
@@ -27,6 +28,7 @@ int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const doubl
   c->mpc.sqp_iteration(B, max_trials);
   return c->mpc.ls_trials_run;
 }
+void emu_upload(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes) { ((EmuCtx*)h)->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); }
 // raw buffer access for parity tests: name -> pointer
 void* emu_buffer(void* h, const char* name) {
   QmMpcBuffers& d = ((EmuCtx*)h)->mpc.d;
@@ -36,5 +38,20 @@ void* emu_buffer(void* h, const char* name) {
 #undef F
   return nullptr;
 }
-int emu_sizes(int which) { int v[] = {SR_SIZE, LQ_DBG_SIZE, PF_SIZE, LQ_LDS_BYTES, RC_LDS_BYTES}; return v[which]; }
+void emu_policy_eval(void* h, int B, const double* t, double* xd, double* ud, int* mode) {
+  EmuCtx* c = (EmuCtx*)h; c->wbc.policy_eval(c->mpc.d, B, t);
+  memcpy(xd, c->wbc.w.x_des, (size_t)B * 30 * 8); memcpy(ud, c->wbc.w.u_des, (size_t)B * 30 * 8); memcpy(mode, c->wbc.w.mode, (size_t)B * 4);
+}
+void emu_wbc_reset(void* h) { ((EmuCtx*)h)->wbc.reset(); }
+void emu_wbc_step(void* h, int B, const double* xd, const double* ud, const double* rbd, const int* mode, double period, const double* time, int variant, double* out, int* status, double* dbg) {
+  EmuCtx* c = (EmuCtx*)h; c->wbc.upload(B, xd, ud, rbd, mode, time); c->wbc.step(c->mpc.d, B, period, variant);
+  memcpy(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); memcpy(status, c->wbc.w.qp_status, (size_t)B * 3 * 4); if (dbg) memcpy(dbg, c->wbc.w.dbg, (size_t)B * WBC_DBG_SIZE * 8);
+}
+// the benchmark's whole control step on resident data (same calls as qmhip_control_step_resident)
+void emu_control_step(void* h, int B, double horizon, double period, double time, double* out, int* status, double* rbd_out) {
+  EmuCtx* c = (EmuCtx*)h; c->mpc.grid(B, horizon); c->mpc.sqp_iteration(B);
+  c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time); c->wbc.step(c->mpc.d, B, period, 0);
+  memcpy(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); memcpy(status, c->wbc.w.qp_status, (size_t)B * 3 * 4); if (rbd_out) memcpy(rbd_out, c->wbc.w.rbd, (size_t)B * QM_NRBD * 8);
+}
+int emu_sizes(int which) { int v[] = {SR_SIZE, LQ_DBG_SIZE, PF_SIZE, LQ_LDS_BYTES, RC_LDS_BYTES, WBC_DBG_SIZE}; return v[which]; }
 }

@@ -71,3 +71,38 @@ class Emu:
     def lqdbg(self, b, i):
         full = self.buf("lqdbg", (self.Bmax * self.nmax * self.DBG,))
         return full.reshape(-1, self.DBG)[b * self.nmax + i]
+
+    # ---- policy / WBC ----
+    def policy_eval(self, t):
+        t = np.ascontiguousarray(t, float); B = len(t)
+        xd = np.zeros((B, 30)); ud = np.zeros((B, 30)); mode = np.zeros(B, np.int32)
+        self.lib.emu_policy_eval(self.h, C.c_int(B), _p(t), _p(xd), _p(ud), _pi(mode))
+        return xd, ud, mode
+
+    def wbc_reset(self):
+        self.lib.emu_wbc_reset(self.h)
+
+    def wbc_step(self, xd, ud, rbd, mode, period, time, variant=0):
+        xd = np.ascontiguousarray(xd, float); B = xd.shape[0]
+        ud = np.ascontiguousarray(ud, float); rbd = np.ascontiguousarray(rbd, float); mode = np.ascontiguousarray(mode, np.int32)
+        time = np.ascontiguousarray(np.broadcast_to(time, (B,)), float)
+        out = np.zeros((B, 54)); st = np.zeros((B, 3), np.int32); nd = self.lib.emu_sizes(5); dbg = np.zeros((B, nd))
+        self.lib.emu_wbc_step(self.h, C.c_int(B), _p(xd), _p(ud), _p(rbd), _pi(mode), C.c_double(period), _p(time), C.c_int(variant), _p(out), _pi(st), _p(dbg))
+        d = []
+        for b in range(B):
+            o = 0; e = {}
+            for k, n in (("qMeas", 24), ("vMeas", 24), ("qDes", 24), ("vDes", 24), ("baseAcc", 6), ("nle", 24), ("x0", 36), ("x1", 36), ("x2", 36), ("M", 576), ("J", 288), ("dJv", 12)):
+                e[k] = dbg[b, o:o + n].copy(); o += n
+            e["M"] = e["M"].reshape(24, 24); e["J"] = e["J"].reshape(12, 24); d.append(e)
+        return out, st, d
+
+    def control_step(self, cfg, batch=None):
+        """upload + the benchmark's whole control step (MPC iteration, policy at t0, WBC on the synthetic measured state)"""
+        B = cfg["B"] if batch is None else batch
+        self.B = B
+        a = lambda k, t=float: np.ascontiguousarray(cfg[k][:B], t)
+        t0, x0, rt, rx, ev, mo = a("t0"), a("x0"), a("ref_t"), a("ref_x"), a("ev"), a("modes", np.int32)
+        self.lib.emu_upload(self.h, C.c_int(B), _p(t0), _p(x0), _p(rt), _p(rx), _p(ev), _pi(mo))
+        out = np.zeros((B, 54)); st = np.zeros((B, 3), np.int32); rbd = np.zeros((B, 55))
+        self.lib.emu_control_step(self.h, C.c_int(B), C.c_double(cfg["horizon"]), C.c_double(cfg["period"]), C.c_double(cfg["time"]), _p(out), _pi(st), _p(rbd))
+        return out, st, rbd

@@ -1,0 +1,74 @@
+"""GPU parity tests of policy evaluation + the hierarchical WBC (K5..K7) and of the whole control step,
+through the C ABI, against the CPU oracle.  Tolerance 1e-6 relative on torques / decision vector
+(BASELINE.json north_star); qp status must be 0 on both sides."""
+import numpy as np
+import pytest
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _random_wbc_inputs(oracle, blobs, n, seed, vel_scale):
+    mb, st = blobs
+    rng = np.random.default_rng(seed)
+    xbar = st[930:960]
+    cases = []
+    for k in range(n):
+        mode = [15, 9, 6, 15, 9, 6][k % 6]
+        q = xbar[6:30] + 0.1 * rng.normal(size=24); q[18:] = xbar[24:] + 0.05 * rng.normal(size=6)
+        v = vel_scale * rng.normal(size=24)
+        rbd = oracle.rbd_from_q(q, v)
+        xd = xbar + 0.05 * rng.normal(size=30); xd[24:] = xbar[24:] + 0.02 * rng.normal(size=6)
+        ud = np.zeros(30); fl = [(mode >> 3) & 1, (mode >> 2) & 1, (mode >> 1) & 1, mode & 1]
+        for c in range(4):
+            if fl[c]:
+                ud[3 * c:3 * c + 3] = [5 * rng.normal(), 5 * rng.normal(), mb[654] * 9.81 / sum(fl) + 10 * rng.normal()]
+        ud[12:] = vel_scale * rng.normal(size=18)
+        il = vel_scale * rng.normal(size=30)
+        cases.append(dict(mode=mode, rbd=rbd, xd=xd, ud=ud, il=il, time=20.0 if k % 4 != 3 else 5.0))
+    return cases
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_wbc_random_states(blobs, oracle, variant):
+    from qm_control_amd import api
+    cases = _random_wbc_inputs(oracle, blobs, 24, 11 + variant, 0.05)
+    B = len(cases)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=8, max_ref_knots=2, max_events=2)
+    wbc = api.HierarchicalWbc(itf, mpc_variant=bool(variant))
+    arr = lambda k: np.array([c[k] for c in cases])
+    wbc.reset()
+    wbc.update(arr("xd"), arr("il"), arr("rbd"), arr("mode"), 0.002, arr("time"))       # primes inputLast_
+    out, st = wbc.update(arr("xd"), arr("ud"), arr("rbd"), arr("mode"), 0.002, arr("time"))
+    for b, c in enumerate(cases):
+        oracle.wbc_reset(); oracle.wbc(c["xd"], c["il"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant))
+        ref, sto = oracle.wbc(c["xd"], c["ud"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant))
+        assert list(sto) == [0, 0, 0], (b, sto)
+        assert list(st[b]) == [0, 0, 0], (b, st[b])
+        assert rel_err(out[b], ref) <= TOL, b
+        assert rel_err(out[b, 36:], ref[36:]) <= TOL, b
+    itf.close()
+
+
+@pytest.mark.parametrize("name,B,N", [("C2", 1, 100), ("C3", 32, 40), ("C5", 8, 150)])
+def test_control_step_vs_oracle(blobs, oracle, name, B, N):
+    """whole benchmark step: SQP iteration + policy at t0 + WBC on the synthetic measured state"""
+    import pyoracle
+    from qm_control_amd import api, scenarios
+    cfg = scenarios.make_config(name, batch=B, n_intervals=N)
+    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 8, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
+    assert bad == 0
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=N + 40, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+    wbc.reset()
+    mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+    out, st = wbc.download(B)
+    xd, ud, mode = mpc.evaluatePolicy(cfg["t0"])
+    assert rel_err(xd, xf) <= TOL and rel_err(ud, uf) <= TOL
+    assert (st == 0).all()
+    for b in range(B):
+        assert rel_err(out[b], w[b]) <= TOL, b
+        assert rel_err(out[b, 36:], w[b, 36:]) <= TOL, b
+    itf.close()
