@@ -41,6 +41,6 @@ struct QmWbcPipeline {
   void step(const QmMpcBuffers& d, int B, double period, int variant) {
     QmWbcArgs a; a.mb = d.mb; a.st = d.st; a.B = B; a.x_des = w.x_des; a.u_des = w.u_des; a.rbd = w.rbd; a.mode = w.mode; a.time = w.time; a.period = period; a.variant = variant;
     a.input_last = w.input_last; a.out = w.out; a.qp_status = w.qp_status; a.scratch = w.scratch; a.sstride = w.Bmax; a.dbg = w.dbg;
-    bk.launch(qm_wbc_kernel, (B + WBC_BLOCK - 1) / WBC_BLOCK, WBC_BLOCK, WBC_LDS_BYTES, a);
+    bk.launch(qm_wbc_kernel, B, WBC_BLOCK, WBC_LDS_BYTES, a);   // one wavefront per instance
   }
 };

@@ -1,18 +1,22 @@
-// k_wbc.h — K6/K7: hierarchical whole-body controller, one THREAD per instance (v1).
+// k_wbc.h — K6/K7: hierarchical whole-body controller, ONE WAVEFRONT PER INSTANCE, all matrices in LDS.
 //
 // Restates qm_wbc (WbcBase.cpp:118-563, HierarchicalWbc.cpp:18-44, HierarchicalMpcWbc.cpp:18-34, HoQp.cpp:12-158,
 // Task.h:17-66) — SURVEY.md §8 a13–a19:
-//   updateMeasured / updateDesired  -> recursive rigid-body passes (qm_dev_rbd.h)
+//   updateMeasured / updateDesired  -> recursive rigid-body passes (qm_dev_rbd.h); the 5 chains of the measured pass,
+//                                      of the desired pass and of the joint-acceleration pass run on 15 lanes at once
 //   13 task formulators             -> rows of A_k x = b_k and the structured inequality block D0 x <= f0
 //   HoQp cascade (3 levels)         -> each level is an inequality-constrained least-squares problem
 //        min ½|A Zp z + A xp − b|² + ½ rho |z|² + ½|w|²  s.t.  w >= 0, D Zp z − w <= f − D xp,  Dp Zp z <= fp − Dp xp + wp*
-//      solved exactly by an active-set method on orthogonal factorisations (stands in for qpOASES, whose return code
-//      the reference ignores, HoQp.cpp:143-146; we report qp_status instead).  rho = 1e-12 (HoQp.cpp:66).
+//      solved exactly by an active-set method on Householder factorisations, lane = matrix column (stands in for
+//      qpOASES, whose return code the reference ignores, HoQp.cpp:143-146; we report qp_status).  rho = 1e-12 (HoQp.cpp:66).
 //   updateCmd                        -> tau = [M_j, −J_jᵀ] x + h_j
 // D0 (torque limits ± and friction pyramids) is never materialised: products D0·x use tau(x) and the 5x3 pyramid.
-// Only the shipped hierarchy shapes are supported (own inequality rows only at level 0); anything else -> qp_status −3.
+// Control flow is wave-uniform: every decision is taken on values all 64 lanes read from LDS or get from a wave reduction,
+// and a wave's DS operations retire in order, so no s_barrier is needed (qm_wave_sync = compiler fence only).
+// Only the shipped hierarchy shapes are supported (own inequality rows only at level 0).
 #pragma once
 #include "qm_dev_rbd.h"
+#include "qm_dev_kin.h"
 
 struct QmWbcArgs {
   const double* mb; const double* st;
@@ -24,34 +28,63 @@ struct QmWbcArgs {
   double period; int variant;                 // 0: HierarchicalWbc, 1: HierarchicalMpcWbc
   double* input_last;                         // [B][30] state (WbcBase.cpp:212-213)
   double* out;                                // [B][54]
-  int* qp_status;                             // [B][3]
-  double* scratch; int sstride;               // lane-interleaved workspace [WBC_SCRATCH][sstride]
+  int* qp_status;                             // [B][3]  0 ok, 1 iteration limit (nWSR=100), 2 working set overflow
+  double* scratch; int sstride;               // unused by the wave kernel (kept so the pipeline ABI is stable)
   double* dbg;                                // optional [B][WBC_DBG_SIZE]: qMeas vMeas qDes vDes baseAcc nle x0 x1 x2 M J dJv
 };
+#define WBC_SCRATCH 8
+#define WBC_DBG_SIZE (24 * 4 + 6 + 24 + 36 * 3 + 576 + 288 + 12)
+#define WBC_BLOCK 64
+
 #define WNV 36
 #define WMAXA 22        /* max equality-task rows of one level */
 #define WMAXACT 20      /* cap on simultaneously active inequality rows */
 #define WMAXINEQ 56
 #define WG_ROWS (WMAXA + WNV + WMAXACT)
+#define WGLD 38         /* leading dim of the working matrix: up to 36 columns + rhs */
 #define WRHO 1e-12
-// lane-interleaved HBM workspace per instance (doubles)
-#define WS_M     0
-#define WS_JF    (WS_M + 576)
-#define WS_JARM  (WS_JF + 288)
-#define WS_A     (WS_JARM + 144)
-#define WS_G0    (WS_A + WMAXA * WNV)
-#define WS_GW    (WS_G0 + (WMAXA + WNV) * WNV)
-#define WS_AZ    (WS_GW + WG_ROWS * WNV)
-#define WS_ZP    (WS_AZ + WMAXA * WNV)
-#define WS_ZN    (WS_ZP + WNV * WNV)
-#define WS_VQ    (WS_ZN + WNV * WNV)
-#define WS_RQ    (WS_VQ + WMAXACT * WNV)
-#define WS_EROWS (WS_RQ + WMAXACT * WMAXACT)
-#define WBC_SCRATCH (WS_EROWS + WMAXACT * WNV)
-#define WBC_DBG_SIZE (24 * 4 + 6 + 24 + 36 * 3 + 576 + 288 + 12)
-#define WBC_LDS_BYTES 0
-#define WBC_BLOCK 64
 
+// ---- LDS carve (doubles) ----
+#define WL_M      0
+#define WL_NLE    (WL_M + 576)
+#define WL_JF     (WL_NLE + 24)
+#define WL_JARM   (WL_JF + 288)
+#define WL_BB     (WL_JARM + 144)                 /* [22] */
+#define WL_AZ     (WL_BB + WMAXA)                 /* [22][36] (ld 36) */
+#define WL_G      (WL_AZ + WMAXA * WNV)           /* [78][38] working matrix (+ null-space workspace; RBD sums/accumulators before the cascade) */
+#define WL_ZP     (WL_G + WG_ROWS * WGLD)         /* [36][n] */
+#define WL_HV     (WL_ZP + WNV * WNV)             /* [80] Householder vector */
+#define WL_X      (WL_HV + 80)
+#define WL_Z      (WL_X + WNV)
+#define WL_ZN     (WL_Z + WNV)
+#define WL_P      (WL_ZN + WNV)
+#define WL_ZZ     (WL_P + WNV)                    /* Zp z */
+#define WL_ZPV    (WL_ZZ + WNV)                   /* Zp p */
+#define WL_G0RHS  (WL_ZPV + WNV)                  /* [58] g0 */
+#define WL_F0     (WL_G0RHS + 64)
+#define WL_W0     (WL_F0 + WMAXINEQ)
+#define WL_FB     (WL_W0 + WMAXINEQ)
+#define WL_DZ     (WL_FB + WMAXINEQ)
+#define WL_DP     (WL_DZ + WMAXINEQ)
+#define WL_TAU    (WL_DP + WMAXINEQ)              /* [18] */
+#define WL_V      (WL_TAU + 24)                   /* [20][36] reflectors of the working-set QR */
+#define WL_A      WL_V                            /* [22][36] task rows: only live while AZ / g0 are formed, aliases V..EROWS */
+#define WL_BETA   (WL_V + WMAXACT * WNV)
+#define WL_R      (WL_BETA + WMAXACT)             /* [20][20] */
+#define WL_EROWS  (WL_R + WMAXACT * WMAXACT)      /* [20][36] */
+#define WL_ERHS   (WL_EROWS + WMAXACT * WNV)
+#define WL_LAM    (WL_ERHS + WMAXACT)
+#define WL_Y      (WL_LAM + WMAXACT)              /* [36] */
+#define WL_W36    (WL_Y + WNV)
+#define WL_ACC    (WL_G + 18 * 16)                /* chain accumulators: 3 passes x 6 slots x 20 (inside G, after the momentum sums) */
+#define WL_MISC   (WL_W36 + WNV)                  /* q v qd vd w2 (5 x 24), baseAcc(6) */
+#define WL_TIPS   (WL_MISC + 5 * 24 + 8)          /* 10 tips x 27 doubles: measured feet 0-3, arm 4, desired feet 5-8, arm 9 */
+#define WL_XLEV   (WL_TIPS + 10 * 27)             /* [3][36] */
+#define WL_TOTAL  (WL_XLEV + 3 * WNV)
+#define WBC_LDS_BYTES (WL_TOTAL * 8)
+
+__device__ __forceinline__ double wv_sum(double v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64); return v; }
+__device__ __forceinline__ double wv_max(double v) { for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64)); return v; }
 
 // rotation error log(R_l R_rᵀ) [upstream rotationErrorInWorld]
 __device__ __forceinline__ void dev_rot_error(const double* Rl, const double* Rr, double* err) {
@@ -62,306 +95,406 @@ __device__ __forceinline__ void dev_rot_error(const double* Rl, const double* Rr
   for (int i = 0; i < 3; ++i) err[i] = s * v[i];
 }
 
-// ---- dense helpers on thread-private row-major arrays ----
-// Householder least squares: min |G z − g|, G is rows x n (leading dim ld), rows >= n; G and g are overwritten
-template <class PG>
-__device__ __forceinline__ void dev_ls_qr(PG G, int ld, int rows, int n, double* g, double* z) {
+// ---- wave-cooperative dense helpers (LDS, row-major) ----
+// Householder least squares: min |G[:, :n] z − G[:, n]|, rows >= n; lane j owns column j (j = n is the rhs). z -> LDS vector.
+__device__ __forceinline__ void wv_ls_qr(double* G, int ld, int rows, int n, double* hv, double* z) {
+  const int l = threadIdx.x & 63;
   for (int k = 0; k < n; ++k) {
-    double nrm = 0.0; for (int i = k; i < rows; ++i) nrm += G[i * ld + k] * G[i * ld + k]; nrm = sqrt(nrm);
-    if (nrm == 0.0) continue;
-    const double alpha = G[k * ld + k] > 0.0 ? -nrm : nrm;
-    const double vk = G[k * ld + k] - alpha; double vn = vk * vk; for (int i = k + 1; i < rows; ++i) vn += G[i * ld + k] * G[i * ld + k];
+    double part = 0.0; for (int i = k + l; i < rows; i += 64) part += G[i * ld + k] * G[i * ld + k];
+    const double nrm2 = wv_sum(part);
+    if (nrm2 == 0.0) continue;
+    const double nrm = sqrt(nrm2), gkk = G[k * ld + k]; const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = nrm2 - gkk * gkk + vk * vk;
     if (vn == 0.0) continue;
-    for (int j = k + 1; j <= n; ++j) {   // j == n: the rhs
-      double s = vk * ((j < n) ? G[k * ld + j] : g[k]); for (int i = k + 1; i < rows; ++i) s += G[i * ld + k] * ((j < n) ? G[i * ld + j] : g[i]);
-      s *= 2.0 / vn;
-      if (j < n) { G[k * ld + j] -= s * vk; for (int i = k + 1; i < rows; ++i) G[i * ld + j] -= s * G[i * ld + k]; }
-      else { g[k] -= s * vk; for (int i = k + 1; i < rows; ++i) g[i] -= s * G[i * ld + k]; }
-    }
-    G[k * ld + k] = alpha; for (int i = k + 1; i < rows; ++i) G[i * ld + k] = 0.0;
+    for (int i = k + l; i < rows; i += 64) hv[i] = (i == k) ? vk : G[i * ld + k];
+    qm_wave_sync();
+    if (l > k && l <= n) { double s = 0.0; for (int i = k; i < rows; ++i) s += hv[i] * G[i * ld + l]; s *= 2.0 / vn; for (int i = k; i < rows; ++i) G[i * ld + l] -= s * hv[i]; }
+    if (l == k) G[k * ld + k] = alpha;
+    qm_wave_sync();
   }
-  for (int i = n - 1; i >= 0; --i) { double s = g[i]; for (int j = i + 1; j < n; ++j) s -= G[i * ld + j] * z[j]; z[i] = s / G[i * ld + i]; }
+  double zj = 0.0;
+  for (int i = n - 1; i >= 0; --i) {
+    const double s = wv_sum((l > i && l < n) ? G[i * ld + l] * zj : 0.0);
+    const double zi = (G[i * ld + n] - s) / G[i * ld + i];
+    if (l == i) zj = zi;
+  }
+  if (l < n) z[l] = zj;
+  qm_wave_sync();
 }
-// Householder QR of Eᵀ (n x me) given E (me x n, ld): stores reflectors v_k in V (me x n, v_k[i] for i>=k) with beta_k = 2/|v_k|², R (upper me x me)
-template <class PE, class PV, class PR>
-__device__ __forceinline__ void dev_qr_Et(PE E, int ld, int me, int n, PV V, double* beta, PR R) {
-  // work on W = Eᵀ column by column: column c of W = row c of E
-  for (int c = 0; c < me; ++c) for (int i = 0; i < n; ++i) V[c * n + i] = E[c * ld + i];   // V temporarily holds W columns
+// Householder QR of Eᵀ (n x me) for E (me x n, ld = WNV): reflectors V[k][0..n) (zero above k), beta[k], R (me x me upper, ld = WMAXACT)
+__device__ __forceinline__ void wv_qr_Et(const double* E, int me, int n, double* V, double* beta, double* R) {
+  const int l = threadIdx.x & 63;
+  for (int idx = l; idx < me * n; idx += 64) { const int c = idx / n, i = idx - c * n; V[c * WNV + i] = E[c * WNV + i]; }
+  qm_wave_sync();
   for (int k = 0; k < me; ++k) {
-    PV wk = V + k * n;
-    double nrm = 0.0; for (int i = k; i < n; ++i) nrm += wk[i] * wk[i]; nrm = sqrt(nrm);
-    const double alpha = wk[k] > 0.0 ? -nrm : nrm;
-    for (int i = 0; i < k; ++i) R[i * me + k] = wk[i];
-    R[k * me + k] = alpha;
-    wk[k] -= alpha; double vn = 0.0; for (int i = k; i < n; ++i) vn += wk[i] * wk[i];
-    beta[k] = (vn > 0.0) ? 2.0 / vn : 0.0;
-    for (int i = 0; i < k; ++i) wk[i] = 0.0;
-    for (int c = k + 1; c < me; ++c) { PV wc = V + c * n; double s = 0.0; for (int i = k; i < n; ++i) s += wk[i] * wc[i]; s *= beta[k]; for (int i = k; i < n; ++i) wc[i] -= s * wk[i]; }
+    double* wk = V + k * WNV;
+    const double nrm2 = wv_sum((l >= k && l < n) ? wk[l] * wk[l] : 0.0); const double nrm = sqrt(nrm2);
+    const double wkk = wk[k]; const double alpha = wkk > 0.0 ? -nrm : nrm; const double vn = nrm2 - wkk * wkk + (wkk - alpha) * (wkk - alpha);
+    qm_wave_sync();
+    if (l < k) { R[l * WMAXACT + k] = wk[l]; wk[l] = 0.0; }
+    if (l == k) { R[k * WMAXACT + k] = alpha; wk[k] = wkk - alpha; beta[k] = (vn > 0.0) ? 2.0 / vn : 0.0; }
+    qm_wave_sync();
+    if (l > k && l < me) { double* wc = V + l * WNV; double s = 0.0; for (int i = k; i < n; ++i) s += wk[i] * wc[i]; s *= beta[k]; for (int i = k; i < n; ++i) wc[i] -= s * wk[i]; }
+    qm_wave_sync();
   }
 }
-template <class PV>
-__device__ __forceinline__ void dev_apply_Qt(PV V, const double* beta, int me, int n, double* x) { for (int k = 0; k < me; ++k) { PV v = V + k * n; double s = 0.0; for (int i = k; i < n; ++i) s += v[i] * x[i]; s *= beta[k]; for (int i = k; i < n; ++i) x[i] -= s * v[i]; } }   // x <- Qᵀ x
-template <class PV>
-__device__ __forceinline__ void dev_apply_Q(PV V, const double* beta, int me, int n, double* x) { for (int k = me - 1; k >= 0; --k) { PV v = V + k * n; double s = 0.0; for (int i = k; i < n; ++i) s += v[i] * x[i]; s *= beta[k]; for (int i = k; i < n; ++i) x[i] -= s * v[i]; } }   // x <- Q x
-// rows of G (rows x n) <- rows · Q   (right multiplication by H_0 H_1 ... H_{me-1})
-template <class PV, class PG>
-__device__ __forceinline__ void dev_right_Q(PV V, const double* beta, int me, int n, PG G, int ld, int rows) {
-  for (int r = 0; r < rows; ++r) { PG g = G + r * ld; for (int k = 0; k < me; ++k) { PV v = V + k * n; double s = 0.0; for (int i = k; i < n; ++i) s += g[i] * v[i]; s *= beta[k]; for (int i = k; i < n; ++i) g[i] -= s * v[i]; } }
+__device__ __forceinline__ void wv_apply_Qt(const double* V, const double* beta, int me, int n, double* x) {   // x <- Qᵀ x
+  const int l = threadIdx.x & 63;
+  for (int k = 0; k < me; ++k) { const double* v = V + k * WNV; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
+}
+__device__ __forceinline__ void wv_apply_Q(const double* V, const double* beta, int me, int n, double* x) {    // x <- Q x
+  const int l = threadIdx.x & 63;
+  for (int k = me - 1; k >= 0; --k) { const double* v = V + k * WNV; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
 }
 
-struct WbcCtx {   // everything the D0 block and the torque map need
-  QmSPtr M; QmSPtr Jf; const double* nle; double tauMax[18]; int nc; int contactOf[4]; double mu; int nIneq; bool fl[4];
+struct WbcCtx {   // everything the D0 block and the torque map need (all wave-uniform)
+  const double* M; const double* Jf; const double* nle; double tauMax[18]; int nc; int contactOf[4]; double mu; int nIneq; bool fl[4];
 };
-__device__ __forceinline__ void wbc_tau_lin(const WbcCtx& c, const double* x, double* tau) {   // [M_j, −J_jᵀ] x  (no h_j)
-  for (int r = 0; r < 18; ++r) { double s = 0.0; for (int k = 0; k < 24; ++k) s += c.M[(6 + r) * 24 + k] * x[k]; for (int k = 0; k < 12; ++k) s -= c.Jf[k * 24 + 6 + r] * x[24 + k]; tau[r] = s; }
+// out = D0 x ; lanes cooperate, tau scratch in LDS
+__device__ __forceinline__ void wv_d0_apply(const WbcCtx& c, const double* x, double* tau, double* out) {
+  const int l = threadIdx.x & 63;
+  if (l < 18) { double s = 0.0; for (int k = 0; k < 24; ++k) s += c.M[(6 + l) * 24 + k] * x[k]; for (int k = 0; k < 12; ++k) s -= c.Jf[k * 24 + 6 + l] * x[24 + k]; tau[l] = s; out[l] = s; out[18 + l] = -s; }
+  if (l >= 36 && l < c.nIneq) {
+    const int r = l - 36; double v = 0.0;
+    if (r < 5 * c.nc) { const int j = r / 5, q = r - 5 * j; const double* F = x + 24 + 3 * c.contactOf[j]; v = (q == 0) ? -F[2] : (q == 1) ? F[0] - c.mu * F[2] : (q == 2) ? -F[0] - c.mu * F[2] : (q == 3) ? F[1] - c.mu * F[2] : -F[1] - c.mu * F[2]; }
+    out[l] = v;
+  }
+  qm_wave_sync();
 }
-__device__ __forceinline__ void wbc_d0_apply(const WbcCtx& c, const double* x, double* out) {   // out = D0 x
-  double tau[18]; wbc_tau_lin(c, x, tau);
-  for (int r = 0; r < 18; ++r) { out[r] = tau[r]; out[18 + r] = -tau[r]; }
-  int row = 36;
-  for (int j = 0; j < c.nc; ++j) { const double* F = x + 24 + 3 * c.contactOf[j]; out[row] = -F[2]; out[row + 1] = F[0] - c.mu * F[2]; out[row + 2] = -F[0] - c.mu * F[2]; out[row + 3] = F[1] - c.mu * F[2]; out[row + 4] = -F[1] - c.mu * F[2]; row += 5; }
-  for (; row < c.nIneq; ++row) out[row] = 0.0;
+__device__ __forceinline__ double wbc_d0_entry(const WbcCtx& c, int i, int k) {   // D0[i][k]
+  if (i < 36) { const int r = (i < 18) ? i : i - 18; const double sg = (i < 18) ? 1.0 : -1.0; return (k < 24) ? sg * c.M[(6 + r) * 24 + k] : -sg * c.Jf[(k - 24) * 24 + 6 + r]; }
+  if (i < 36 + 5 * c.nc) { const int j = (i - 36) / 5, q = (i - 36) - 5 * j; const int k0 = 24 + 3 * c.contactOf[j]; if (k < k0 || k >= k0 + 3) return 0.0; const int a = k - k0;
+    if (q == 0) return a == 2 ? -1.0 : 0.0; if (a == 2) return -c.mu; if (q == 1) return a == 0 ? 1.0 : 0.0; if (q == 2) return a == 0 ? -1.0 : 0.0; if (q == 3) return a == 1 ? 1.0 : 0.0; return a == 1 ? -1.0 : 0.0; }
+  return 0.0;
 }
-__device__ __forceinline__ void wbc_d0_row(const WbcCtx& c, int i, double* row) {
-  for (int k = 0; k < WNV; ++k) row[k] = 0.0;
-  if (i < 36) { const int r = (i < 18) ? i : i - 18; const double sg = (i < 18) ? 1.0 : -1.0; for (int k = 0; k < 24; ++k) row[k] = sg * c.M[(6 + r) * 24 + k]; for (int k = 0; k < 12; ++k) row[24 + k] = -sg * c.Jf[k * 24 + 6 + r]; }
-  else if (i < 36 + 5 * c.nc) { const int j = (i - 36) / 5, r = (i - 36) - 5 * j; double* F = row + 24 + 3 * c.contactOf[j];
-    if (r == 0) F[2] = -1.0; else if (r == 1) { F[0] = 1.0; F[2] = -c.mu; } else if (r == 2) { F[0] = -1.0; F[2] = -c.mu; } else if (r == 3) { F[1] = 1.0; F[2] = -c.mu; } else { F[1] = -1.0; F[2] = -c.mu; } }
+// row i of D0 times Zp (36 x n)  ->  dst[0..n)  (lane k = column k)
+__device__ __forceinline__ void wv_d0_row_Z(const WbcCtx& c, int i, const double* Zp, int n, double* dst) {
+  const int l = threadIdx.x & 63;
+  if (l < n) { double s = 0.0; for (int r = 0; r < WNV; ++r) { const double d = wbc_d0_entry(c, i, r); if (d != 0.0) s += d * Zp[r * n + l]; } dst[l] = s; }
 }
-__device__ __forceinline__ void wbc_d0_f(const WbcCtx& c, double* f) {
-  for (int r = 0; r < 18; ++r) { f[r] = c.tauMax[r] - c.nle[6 + r]; f[18 + r] = c.tauMax[r] + c.nle[6 + r]; }
-  for (int r = 36; r < c.nIneq; ++r) f[r] = 0.0;
-}
-
-// min |G0 z − g0|² (+ equality rows E z = e): returns z (and multipliers lam for the equality rows)
-// G0: rows0 x n (ld = WNV) original (not modified); Gw: workspace (WG_ROWS x WNV)
-__device__ __forceinline__ void wbc_eq_ls(QmSPtr G0, const double* g0, int rows0, int n, QmSPtr E, const double* e, int me,
-                                          QmSPtr Gw, double* gw, QmSPtr V, double* beta, QmSPtr Rr, double* z, double* lam) {
-  for (int r = 0; r < rows0; ++r) { for (int k = 0; k < n; ++k) Gw[r * WNV + k] = G0[r * WNV + k]; gw[r] = g0[r]; }
-  if (me == 0) { dev_ls_qr(Gw, WNV, rows0, n, gw, z); return; }
-  dev_qr_Et(E, WNV, me, n, V, beta, Rr);
-  double y[WNV];
-  for (int i = 0; i < me; ++i) { double s = e[i]; for (int k = 0; k < i; ++k) s -= Rr[k * me + i] * y[k]; y[i] = s / Rr[i * me + i]; }   // Rᵀ y1 = e
-  dev_right_Q(V, beta, me, n, Gw, WNV, rows0);                                   // Gw <- G Q = [G Y | G N]
-  for (int r = 0; r < rows0; ++r) { double s = 0.0; for (int k = 0; k < me; ++k) s += Gw[r * WNV + k] * y[k]; gw[r] -= s; }
-  if (n - me > 0) dev_ls_qr(Gw + me, WNV, rows0, n - me, gw, y + me);
-  for (int k = 0; k < n; ++k) z[k] = y[k];
-  dev_apply_Q(V, beta, me, n, z);                                                // z = Q [y1; y2]
-  // multipliers: R lam = −(Qᵀ Gᵀ (G z − g))[0:me]
-  double w[WNV]; for (int k = 0; k < n; ++k) w[k] = 0.0;
-  for (int r = 0; r < rows0; ++r) { double s = -g0[r]; for (int k = 0; k < n; ++k) s += G0[r * WNV + k] * z[k]; for (int k = 0; k < n; ++k) w[k] += G0[r * WNV + k] * s; }
-  dev_apply_Qt(V, beta, me, n, w);
-  for (int i = me - 1; i >= 0; --i) { double s = -w[i]; for (int j = i + 1; j < me; ++j) s -= Rr[i * me + j] * lam[j]; lam[i] = s / Rr[i * me + i]; }
+// y(36) = Zp (36 x n) z
+__device__ __forceinline__ void wv_Z_times(const double* Zp, int n, const double* z, double* y) {
+  const int l = threadIdx.x & 63;
+  if (l < WNV) { double s = 0.0; for (int k = 0; k < n; ++k) s += Zp[l * n + k] * z[k]; y[l] = s; }
+  qm_wave_sync();
 }
 
-// orthonormal null-space basis of AZ (r x n): Znew (36 x (n − rank)) = Zp (36 x n) · Q[:, rank:], Householder QR with column pivoting of (AZ)ᵀ
-__device__ __forceinline__ int wbc_null_space(QmSPtr AZ, int r, int n, QmSPtr Zp, QmSPtr Znew, QmSPtr W /*n x r workspace*/, QmSPtr ZQ /*36 x n workspace*/) {
-  for (int i = 0; i < n; ++i) for (int j = 0; j < r; ++j) W[i * r + j] = AZ[j * WNV + i];
-  for (int i = 0; i < WNV * n; ++i) ZQ[i] = Zp[i];
-  int rank = 0; double maxnorm0 = 0.0; const int steps = (n < r) ? n : r;
+// min |G0 z − g0|² s.t. E z = e (me active rows).  G0 = [AZ; sqrt(rho) I] is rebuilt into G each call.  lam: multipliers.
+__device__ __forceinline__ void wv_eq_ls(double* S, int ra, int n, int me, double* zout) {
+  const int l = threadIdx.x & 63;
+  double* G = S + WL_G; const double* AZ = S + WL_AZ; const double* g0 = S + WL_G0RHS;
+  const int rows0 = ra + n;
+  for (int idx = l; idx < rows0 * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (k == n) ? g0[r] : (r < ra ? AZ[r * WNV + k] : ((r - ra) == k ? sqrt(WRHO) : 0.0)); }
+  qm_wave_sync();
+  if (me == 0) { wv_ls_qr(G, WGLD, rows0, n, S + WL_HV, zout); return; }
+  double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
+  wv_qr_Et(S + WL_EROWS, me, n, V, beta, R);
+  if (l == 0) for (int i = 0; i < me; ++i) { double s = e[i]; for (int k = 0; k < i; ++k) s -= R[k * WMAXACT + i] * y[k]; y[i] = s / R[i * WMAXACT + i]; }   // Rᵀ y1 = e
+  // G <- G Q (row-wise reflections; lane = row), rhs column untouched
+  for (int k = 0; k < me; ++k) { const double* v = V + k * WNV; for (int r = l; r < rows0; r += 64) { double* g = G + r * WGLD; double s = 0.0; for (int i = k; i < n; ++i) s += g[i] * v[i]; s *= beta[k]; for (int i = k; i < n; ++i) g[i] -= s * v[i]; } }
+  qm_wave_sync();
+  for (int r = l; r < rows0; r += 64) { double s = 0.0; for (int k = 0; k < me; ++k) s += G[r * WGLD + k] * y[k]; G[r * WGLD + n] -= s; }
+  qm_wave_sync();
+  if (n - me > 0) {
+    // reduced problem on columns me..n-1; its rhs must sit right after them: move column n to column n (already there relative to G + me)
+    wv_ls_qr(G + me, WGLD, rows0, n - me, S + WL_HV, y + me);
+  }
+  if (l < n) zout[l] = y[l];
+  qm_wave_sync();
+  wv_apply_Q(V, beta, me, n, zout);
+  // multipliers: R lam = −(Qᵀ G0ᵀ (G0 z − g0))[0:me]
+  double* w = S + WL_W36; double* res = S + WL_HV;
+  for (int r = l; r < rows0; r += 64) { double s = -g0[r]; if (r < ra) { for (int k = 0; k < n; ++k) s += AZ[r * WNV + k] * zout[k]; } else s += sqrt(WRHO) * zout[r - ra]; res[r] = s; }
+  qm_wave_sync();
+  if (l < n) { double acc = 0.0; for (int r = 0; r < ra; ++r) acc += AZ[r * WNV + l] * res[r]; acc += sqrt(WRHO) * res[ra + l]; w[l] = acc; }
+  qm_wave_sync();
+  wv_apply_Qt(V, beta, me, n, w);
+  if (l == 0) for (int i = me - 1; i >= 0; --i) { double s = -w[i]; for (int j = i + 1; j < me; ++j) s -= R[i * WMAXACT + j] * lam[j]; lam[i] = s / R[i * WMAXACT + i]; }
+  qm_wave_sync();
+}
+
+// orthonormal null space of AZ (ra x n): Zp (36 x n) <- Zp · Q[:, rank:]  (Householder QR with column pivoting of (AZ)ᵀ); returns n − rank
+__device__ __forceinline__ int wv_null_space(double* S, int ra, int n) {
+  const int l = threadIdx.x & 63;
+  double* W = S + WL_G; double* ZQ = S + WL_G + WMAXA * WNV; double* Zp = S + WL_ZP; const double* AZ = S + WL_AZ; double* hv = S + WL_HV;
+  for (int idx = l; idx < n * ra; idx += 64) { const int i = idx / ra, j = idx - i * ra; W[i * ra + j] = AZ[j * WNV + i]; }
+  for (int idx = l; idx < WNV * n; idx += 64) ZQ[idx] = Zp[idx];
+  qm_wave_sync();
+  int rank = 0; double maxnorm0 = 0.0; const int steps = (n < ra) ? n : ra;
   for (int k = 0; k < steps; ++k) {
-    int best = k; double bn = -1.0;
-    for (int j = k; j < r; ++j) { double s = 0.0; for (int i = k; i < n; ++i) s += W[i * r + j] * W[i * r + j]; if (s > bn) { bn = s; best = j; } }
+    double cn = -1.0; if (l >= k && l < ra) { cn = 0.0; for (int i = k; i < n; ++i) cn += W[i * ra + l] * W[i * ra + l]; }
+    const double bn = wv_max(cn);
+    int cand = (cn == bn && l >= k && l < ra) ? l : (1 << 20); for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(cand, off, 64); cand = (o < cand) ? o : cand; }
+    const int best = cand;
     if (k == 0) maxnorm0 = sqrt(bn);
     if (sqrt(bn) <= 1e-9 * fmax(1.0, maxnorm0)) break;
-    if (best != k) for (int i = 0; i < n; ++i) { const double t = W[i * r + k]; W[i * r + k] = W[i * r + best]; W[i * r + best] = t; }
-    const double nrm = sqrt(bn); const double alpha = W[k * r + k] > 0.0 ? -nrm : nrm;
-    double v[WNV]; for (int i = 0; i < n; ++i) v[i] = (i >= k) ? W[i * r + k] : 0.0; v[k] -= alpha;
-    double vn = 0.0; for (int i = k; i < n; ++i) vn += v[i] * v[i];
+    if (best != k) { for (int i = l; i < n; i += 64) { const double t = W[i * ra + k]; W[i * ra + k] = W[i * ra + best]; W[i * ra + best] = t; } }
+    qm_wave_sync();
+    const double nrm = sqrt(bn), wkk = W[k * ra + k]; const double alpha = wkk > 0.0 ? -nrm : nrm;
+    if (l < n) hv[l] = (l < k) ? 0.0 : ((l == k) ? wkk - alpha : W[l * ra + k]);
+    qm_wave_sync();
+    const double vn = wv_sum((l >= k && l < n) ? hv[l] * hv[l] : 0.0);
     if (vn > 0.0) {
-      for (int j = k; j < r; ++j) { double s = 0.0; for (int i = k; i < n; ++i) s += v[i] * W[i * r + j]; s *= 2.0 / vn; for (int i = k; i < n; ++i) W[i * r + j] -= s * v[i]; }
-      for (int row = 0; row < WNV; ++row) { double s = 0.0; for (int i = k; i < n; ++i) s += ZQ[row * n + i] * v[i]; s *= 2.0 / vn; for (int i = k; i < n; ++i) ZQ[row * n + i] -= s * v[i]; }
+      if (l >= k && l < ra) { double s = 0.0; for (int i = k; i < n; ++i) s += hv[i] * W[i * ra + l]; s *= 2.0 / vn; for (int i = k; i < n; ++i) W[i * ra + l] -= s * hv[i]; }
+      if (l < WNV) { double s = 0.0; for (int i = k; i < n; ++i) s += ZQ[l * n + i] * hv[i]; s *= 2.0 / vn; for (int i = k; i < n; ++i) ZQ[l * n + i] -= s * hv[i]; }
     }
+    qm_wave_sync();
     ++rank;
   }
   const int nn = n - rank;
-  for (int row = 0; row < WNV; ++row) for (int j = 0; j < nn; ++j) Znew[row * nn + j] = ZQ[row * n + rank + j];
+  qm_wave_sync();
+  for (int idx = l; idx < WNV * nn; idx += 64) { const int r = idx / nn, j = idx - r * nn; Zp[idx] = ZQ[r * n + rank + j]; }
+  qm_wave_sync();
   return nn;
 }
 
-__global__ void qm_wbc_kernel(QmWbcArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tip_store(double* dst, const RbdTip& t) { for (int i = 0; i < 3; ++i) { dst[i] = t.p[i]; dst[12 + i] = t.v[i]; dst[15 + i] = t.w[i]; dst[18 + i] = t.a[i]; dst[21 + i] = t.al[i]; } for (int i = 0; i < 9; ++i) dst[3 + i] = t.R[i]; }
+#define TIP_P(t) (t)
+#define TIP_R(t) ((t) + 3)
+#define TIP_V(t) ((t) + 12)
+#define TIP_W(t) ((t) + 15)
+#define TIP_A(t) ((t) + 18)
+#define TIP_AL(t) ((t) + 21)
+
+__global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
+  extern __shared__ double qm_smem[];
+  double* S = qm_smem;
+  const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
   const double* mb = a.mb; const double* st = a.st;
   const double* xDes = a.x_des + (size_t)b * 30; const double* uDes = a.u_des + (size_t)b * 30; const double* rbd = a.rbd + (size_t)b * QM_NRBD;
   const int mode = a.mode[b]; const double time = a.time[b];
+  for (int i = l; i < WL_TOTAL; i += 64) S[i] = 0.0;
+  qm_wave_sync();
+  double* M = S + WL_M; double* nle = S + WL_NLE; double* Jf = S + WL_JF; double* Jarm = S + WL_JARM;
   WbcCtx C; C.nc = 0; for (int k = 0; k < 4; ++k) { C.fl[k] = mode_flag(mode, k); if (C.fl[k]) C.contactOf[C.nc++] = k; }
-  C.mu = st[ST_WBC_FRIC]; C.nIneq = 36 + 5 * C.nc + 3 * (4 - C.nc);
-  for (int l = 0; l < 4; ++l) for (int k = 0; k < 3; ++k) C.tauMax[3 * l + k] = mb[MB_TAUMAX + k]; for (int k = 0; k < 6; ++k) C.tauMax[12 + k] = mb[MB_TAUMAX + 12 + k];
-  // ---- updateMeasured (WbcBase.cpp:134-191) ----
-  double q[24], v[24];
-  for (int i = 0; i < 3; ++i) { q[i] = rbd[3 + i]; q[3 + i] = rbd[i]; v[i] = rbd[27 + i]; }
-  { const double sz = sin(q[3]), cz = cos(q[3]), sy = sin(q[4]), cy = cos(q[4]); const double wx = rbd[24], wy = rbd[25], wz = rbd[26]; const double tmp = cz * wx / cy + sz * wy / cy; v[3] = sy * tmp + wz; v[4] = -sz * wx + cz * wy; v[5] = tmp; }
-  for (int j = 0; j < 18; ++j) { q[6 + j] = rbd[6 + j]; v[6 + j] = rbd[30 + j]; }
-  auto ws = [&](int off) { QmSPtr r; r.p = a.scratch + (size_t)off * a.sstride + b; r.s = a.sstride; return r; };
-  QmSPtr M = ws(WS_M), Jf = ws(WS_JF), Jarm = ws(WS_JARM);
-  double nle[24]; RbdBase Bm; RbdTip fM[4], aM;
-  rbd_tree<QmSPtr, QmSPtr>(mb, q, v, Bm, M, nle, true, fM, &aM, Jf, Jarm, true, nullptr);
-  C.M = M; C.Jf = Jf; C.nle = nle;
-  // ---- updateDesired (WbcBase.cpp:193-226) ----
-  double qd[24], vd[24]; for (int i = 0; i < 24; ++i) qd[i] = xDes[6 + i];
-  double baseAcc[6]; RbdTip fD[4], aD;
+  C.mu = st[ST_WBC_FRIC]; C.nIneq = 36 + 5 * C.nc + 3 * (4 - C.nc); C.M = M; C.Jf = Jf; C.nle = nle;
+  for (int q2 = 0; q2 < 4; ++q2) for (int k = 0; k < 3; ++k) C.tauMax[3 * q2 + k] = mb[MB_TAUMAX + k]; for (int k = 0; k < 6; ++k) C.tauMax[12 + k] = mb[MB_TAUMAX + 12 + k];
+  // ---- generalized coordinates of the three passes: measured (q,v), desired (qd,vd), joint-acceleration (qd, w2) ----
+  double* q = S + WL_MISC; double* v = q + 24; double* qd = v + 24; double* vd = qd + 24; double* w2 = vd + 24; double* baseAcc = w2 + 24;
+  if (l < 3) { q[l] = rbd[3 + l]; q[3 + l] = rbd[l]; v[l] = rbd[27 + l]; }
+  if (l == 3) { const double z = rbd[0], y = rbd[1]; const double sz = sin(z), cz = cos(z), sy = sin(y), cy = cos(y); const double wx = rbd[24], wy = rbd[25], wz = rbd[26]; const double tmp = cz * wx / cy + sz * wy / cy; v[3] = sy * tmp + wz; v[4] = -sz * wx + cz * wy; v[5] = tmp; }
+  if (l >= 6 && l < 24) { q[l] = rbd[l]; v[l] = rbd[24 + l]; }
+  if (l >= 32 && l < 56) qd[l - 32] = xDes[6 + (l - 32)];
+  double Kd[KW_SIZE];                                  // SRBD quantities at the desired state (every lane: cheap, avoids a broadcast)
+  kin_base(mb, xDes, Kd);
+  if (l == 0) { double wr[3]; v3_cross(Kd + KW_OM, Kd + KW_RW, wr); for (int k = 0; k < 3; ++k) { vd[k] = xDes[k] + wr[k]; vd[3 + k] = Kd[KW_THD + k]; } }
+  if (l >= 6 && l < 24) { vd[l] = uDes[6 + l]; const double* il = a.input_last + (size_t)b * 30; w2[l] = (uDes[6 + l] - il[6 + l]) / a.period; }
+  qm_wave_sync();
+  if (l < 30) a.input_last[(size_t)b * 30 + l] = uDes[l];
+  // ---- rigid-body passes: lanes 0-5 measured, 8-13 desired, 16-21 joint-acceleration; slot 0-3 legs, 4 arm, 5 root body ----
   {
-    double K[KW_SIZE]; kin_base(mb, xDes, K);                 // SRBD: thd, omega, r_w
-    double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
-    for (int k = 0; k < 3; ++k) { vd[k] = xDes[k] + wr[k]; vd[3 + k] = K[KW_THD + k]; }
-    for (int j = 0; j < 18; ++j) vd[6 + j] = uDes[12 + j];
-    double* il = a.input_last + (size_t)b * 30; double w2[24];
-    for (int k = 0; k < 6; ++k) w2[k] = 0.0;
-    for (int j = 0; j < 18; ++j) { w2[6 + j] = (uDes[12 + j] - il[12 + j]) / a.period; }
-    for (int k = 0; k < 30; ++k) il[k] = uDes[k];
-    RbdBase Bd; RbdSums Sd, Sa;
-    double* nullp = nullptr;
-    rbd_tree<double*, double*>(mb, qd, vd, Bd, nullp, nullptr, false, fD, &aD, nullp, nullp, false, &Sd);          // Adot·v (bias momentum rate), true COM, desired frame velocities
-    RbdBase Ba; rbd_tree<double*, double*>(mb, qd, w2, Ba, nullp, nullptr, false, nullptr, nullptr, nullp, nullp, false, &Sa);   // A_j · jointAccel (full CMM joint columns)
-    const double m = mb[MB_ROBOTMASS]; const double com[3] = {Sd.mc[0] / m, Sd.mc[1] / m, Sd.mc[2] / m};
+    const int pass = l >> 3, slot = l & 7;
+    if (pass < 3 && slot < 6) {
+      const double* qq = (pass == 0) ? q : qd; const double* vv = (pass == 0) ? v : (pass == 1 ? vd : w2);
+      RbdBase Bb; rbd_base(qq, vv, Bb);
+      double cm = 0.0, ch[3] = {0, 0, 0}, cI[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[3] = {0, 0, 0}, NO[3] = {0, 0, 0};
+      RbdSums Sm; Sm.mass = 0.0; for (int i = 0; i < 3; ++i) { Sm.mc[i] = Sm.hl[i] = Sm.hO[i] = Sm.Fb[i] = Sm.NbO[i] = 0.0; }
+      RbdTip tip; const bool meas = (pass == 0);
+      if (slot < 4) {
+        const int contact = chain_to_contact(slot); double Jt[6 * QM_NQ]; if (meas) for (int i = 0; i < 6 * QM_NQ; ++i) Jt[i] = 0.0;
+        rbd_chain<3, double*, double*>(mb, 3 * slot, contact, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jt, meas);
+        if (meas) {
+          for (int r = 0; r < 3; ++r) { for (int cidx = 6 + 3 * slot; cidx < 9 + 3 * slot; ++cidx) Jf[(3 * contact + r) * QM_NQ + cidx] = Jt[r * QM_NQ + cidx]; Jf[(3 * contact + r) * QM_NQ + r] = 1.0; }
+          for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr); for (int r = 0; r < 3; ++r) Jf[(3 * contact + r) * QM_NQ + 3 + k] = cr[r]; }
+        }
+        if (pass < 2) tip_store(S + WL_TIPS + 27 * (5 * pass + contact), tip);
+      } else if (slot == 4) {
+        rbd_chain<6, double*, double*>(mb, 12, 4, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jarm, meas);
+        if (meas) {
+          for (int r = 0; r < 3; ++r) Jarm[r * QM_NQ + r] = 1.0;
+          for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr); for (int r = 0; r < 3; ++r) { Jarm[r * QM_NQ + 3 + k] = cr[r]; Jarm[(3 + r) * QM_NQ + 3 + k] = e[r]; } }
+        }
+        if (pass < 2) tip_store(S + WL_TIPS + 27 * (5 * pass + 4), tip);
+      } else {
+        const double zero3[3] = {0.0, 0.0, 0.0}; double c[3], Iw[9], vc[3], ac[3];
+        body_state(mb, 0, Bb.R, Bb.p, Bb.vlin, Bb.w, zero3, Bb.al, c, Iw, vc, ac);
+        add_body(mb[MB_MASS], c, Iw, vc, Bb.w, ac, Bb.al, cm, ch, cI, F, NO, &Sm);
+      }
+      double* acc = S + WL_ACC + (pass * 6 + slot) * 20;       // cm ch(3) cI(9) F(3) NO(3)
+      acc[0] = cm; for (int i = 0; i < 3; ++i) { acc[1 + i] = ch[i]; acc[13 + i] = F[i]; acc[16 + i] = NO[i]; } for (int i = 0; i < 9; ++i) acc[4 + i] = cI[i];
+      double* sm = S + WL_G + (pass * 6 + slot) * 16;          // momentum sums of this slot (G is free at this point)
+      sm[0] = Sm.mass; for (int i = 0; i < 3; ++i) { sm[1 + i] = Sm.mc[i]; sm[4 + i] = Sm.hl[i]; sm[7 + i] = Sm.hO[i]; sm[10 + i] = Sm.Fb[i]; sm[13 + i] = Sm.NbO[i]; }
+    }
+  }
+  qm_wave_sync();
+  RbdBase Bm; rbd_base(q, v, Bm);                        // measured root state (every lane)
+  // base block of M and base rows of nle from the whole-tree composite (lane d = base dof)
+  {
+    double cm = 0.0, ch[3] = {0, 0, 0}, cI[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[3] = {0, 0, 0}, NO[3] = {0, 0, 0};
+    for (int s2 = 0; s2 < 6; ++s2) { const double* acc = S + WL_ACC + s2 * 20; cm += acc[0]; for (int i = 0; i < 3; ++i) { ch[i] += acc[1 + i]; F[i] += acc[13 + i]; NO[i] += acc[16 + i]; } for (int i = 0; i < 9; ++i) cI[i] += acc[4 + i]; }
+    if (l < 6) {
+      double w[3], vO[3]; rbd_S_base(Bm, l, w, vO);
+      double wh[3], hv3[3], Iw_[3]; v3_cross(w, ch, wh); v3_cross(ch, vO, hv3); m3_mulv(cI, w, Iw_);
+      const double f[3] = {cm * vO[0] + wh[0], cm * vO[1] + wh[1], cm * vO[2] + wh[2]}, nO[3] = {Iw_[0] + hv3[0], Iw_[1] + hv3[1], Iw_[2] + hv3[2]};
+      for (int e = 0; e < 6; ++e) { double w2b[3], vO2[3]; rbd_S_base(Bm, e, w2b, vO2); M[e * QM_NQ + l] = w2b[0] * nO[0] + w2b[1] * nO[1] + w2b[2] * nO[2] + vO2[0] * f[0] + vO2[1] * f[1] + vO2[2] * f[2]; }
+      nle[l] = w[0] * NO[0] + w[1] * NO[1] + w[2] * NO[2] + vO[0] * F[0] + vO[1] * F[1] + vO[2] * F[2];
+    }
+  }
+  // ---- baseAccDesired (WbcBase.cpp:215-225; SURVEY.md a14 aliasing: A_b SRBD, Adot & A_j full CMM, true COM) ----
+  const double* tipsM = S + WL_TIPS; const double* tipsD = S + WL_TIPS + 27 * 5;
+  if (l == 0) {
+    double Sd[16], Sa[16]; for (int i = 0; i < 16; ++i) { Sd[i] = 0.0; Sa[i] = 0.0; }
+    for (int s2 = 0; s2 < 6; ++s2) for (int i = 0; i < 16; ++i) { Sd[i] += S[WL_G + (6 + s2) * 16 + i]; Sa[i] += S[WL_G + (12 + s2) * 16 + i]; }
+    const double m = mb[MB_ROBOTMASS]; const double com[3] = {Sd[1] / m, Sd[2] / m, Sd[3] / m};
     double rate[6] = {0.0, 0.0, -9.81 * m, 0.0, 0.0, 0.0};
-    for (int k = 0; k < 4; ++k) { const double r[3] = {fD[k].p[0] - com[0], fD[k].p[1] - com[1], fD[k].p[2] - com[2]}; double t[3]; v3_cross(r, uDes + 3 * k, t); for (int i = 0; i < 3; ++i) { rate[i] += uDes[3 * k + i]; rate[3 + i] += t[i]; } }
-    double cF[3], cH[3]; v3_cross(com, Sd.Fb, cF); v3_cross(com, Sa.hl, cH);
-    for (int i = 0; i < 3; ++i) { rate[i] -= Sd.Fb[i] + Sa.hl[i]; rate[3 + i] -= (Sd.NbO[i] - cF[i]) + (Sa.hO[i] - cH[i]); }
-    // A_b⁻¹ (SRBD) : thdd = A22inv ra ; lin = rate_lin/m − (skew(r_w) E thdd)
-    const double ra[3] = {rate[3], rate[4], rate[5]}; double wdd[3], thdd[3], t[3];
-    m3_mulv(K + KW_IINV, ra, wdd); m3_mulv(K + KW_EINV, wdd, thdd); v3_cross(K + KW_RW, wdd, t);
+    for (int k = 0; k < 4; ++k) { const double* pf = TIP_P(tipsD + 27 * k); const double r[3] = {pf[0] - com[0], pf[1] - com[1], pf[2] - com[2]}; double t[3]; v3_cross(r, uDes + 3 * k, t); for (int i = 0; i < 3; ++i) { rate[i] += uDes[3 * k + i]; rate[3 + i] += t[i]; } }
+    double cF[3], cH[3]; v3_cross(com, Sd + 10, cF); v3_cross(com, Sa + 4, cH);
+    for (int i = 0; i < 3; ++i) { rate[i] -= Sd[10 + i] + Sa[4 + i]; rate[3 + i] -= (Sd[13 + i] - cF[i]) + (Sa[7 + i] - cH[i]); }
+    const double ra3[3] = {rate[3], rate[4], rate[5]}; double wdd[3], thdd[3], t[3];
+    m3_mulv(Kd + KW_IINV, ra3, wdd); m3_mulv(Kd + KW_EINV, wdd, thdd); v3_cross(Kd + KW_RW, wdd, t);
     for (int i = 0; i < 3; ++i) { baseAcc[i] = rate[i] / m - t[i]; baseAcc[3 + i] = thdd[i]; }
   }
-  // ---- tasks ----
-  const int nc = C.nc;
-  QmSPtr A = ws(WS_A); double bb[WMAXA];          // current level's equality task
-  double f0[WMAXINEQ]; wbc_d0_f(C, f0);
-  double dJv[12]; for (int k = 0; k < 4; ++k) for (int r = 0; r < 3; ++r) dJv[3 * k + r] = fM[k].a[r];
-  // solver state
-  double x[WNV]; QmSPtr Zp = ws(WS_ZP), Zn = ws(WS_ZN); int nz = WNV;
-  for (int i = 0; i < WNV; ++i) { x[i] = 0.0; for (int j = 0; j < WNV; ++j) Zp[i * WNV + j] = (i == j) ? 1.0 : 0.0; }
-  double w0[WMAXINEQ]; for (int i = 0; i < WMAXINEQ; ++i) w0[i] = 0.0;
-  QmSPtr G0 = ws(WS_G0), Gw = ws(WS_GW), AZ = ws(WS_AZ), Vq = ws(WS_VQ), Rq = ws(WS_RQ), Erows = ws(WS_EROWS);
-  double g0[WMAXA + WNV], gw[WG_ROWS], betaq[WMAXACT], erhs[WMAXACT], lam[WMAXACT];
-  double xlev[3][WNV];
-  int status[3] = {0, 0, 0};
+  qm_wave_sync();
+  // ---- cascade ----
+  double* A = S + WL_A; double* bb = S + WL_BB; double* AZ = S + WL_AZ; double* Zp = S + WL_ZP; double* x = S + WL_X; double* z = S + WL_Z; double* zn = S + WL_ZN; double* p = S + WL_P;
+  double* f0 = S + WL_F0; double* w0 = S + WL_W0; double* fb = S + WL_FB; double* Dz = S + WL_DZ; double* Dp = S + WL_DP; double* tau = S + WL_TAU; double* g0 = S + WL_G0RHS; double* G = S + WL_G;
+  double* Zz = S + WL_ZZ; double* Zpv = S + WL_ZPV; double* lam = S + WL_LAM;
+  if (l < 18) { f0[l] = C.tauMax[l] - nle[6 + l]; f0[18 + l] = C.tauMax[l] + nle[6 + l]; }
+  for (int idx = l; idx < WNV * WNV; idx += 64) Zp[idx] = ((idx / WNV) == (idx % WNV)) ? 1.0 : 0.0;
+  qm_wave_sync();
+  int nz = WNV; int status[3] = {0, 0, 0};
   for (int level = 0; level < 3; ++level) {
-    // ---- formulate the level's equality task (rows of A, b) ----
+    // ---- the level's equality task ----
+    for (int idx = l; idx < WMAXA * WNV; idx += 64) A[idx] = 0.0;
+    qm_wave_sync();
     int ra = 0;
-    for (int i = 0; i < WMAXA * WNV; ++i) A[i] = 0.0;
-    auto setrow_scale = [&](int row, double s) { for (int k = 0; k < WNV; ++k) A[row * WNV + k] *= s; bb[row] *= s; };
     if (level == 0) {
-      for (int r = 0; r < 6; ++r) { for (int k = 0; k < 24; ++k) A[r * WNV + k] = M[r * 24 + k]; for (int k = 0; k < 12; ++k) A[r * WNV + 24 + k] = -Jf[k * 24 + r]; bb[r] = -nle[r]; }   // floating-base EoM
+      for (int idx = l; idx < 6 * 36; idx += 64) { const int r = idx / 36, k = idx - 36 * r; A[r * WNV + k] = (k < 24) ? M[r * 24 + k] : -Jf[(k - 24) * 24 + r]; }
+      if (l < 6) bb[l] = -nle[l];
       ra = 6;
-      for (int k = 0; k < 4; ++k) if (C.fl[k]) { for (int r = 0; r < 3; ++r) { for (int c2 = 0; c2 < 24; ++c2) A[(ra + r) * WNV + c2] = Jf[(3 * k + r) * 24 + c2]; bb[ra + r] = -dJv[3 * k + r]; } ra += 3; }   // no contact motion
-      for (int k = 0; k < 4; ++k) if (!C.fl[k]) { for (int r = 0; r < 3; ++r) { A[(ra + r) * WNV + 24 + 3 * k + r] = 1.0; bb[ra + r] = 0.0; } ra += 3; }   // swing: zero force
+      for (int k = 0; k < 4; ++k) if (C.fl[k]) { for (int idx = l; idx < 72; idx += 64) { const int r = idx / 24, c2 = idx - 24 * r; A[(ra + r) * WNV + c2] = Jf[(3 * k + r) * 24 + c2]; } if (l < 3) bb[ra + l] = -TIP_A(tipsM + 27 * k)[l]; ra += 3; }
+      for (int k = 0; k < 4; ++k) if (!C.fl[k]) { if (l < 3) { A[(ra + l) * WNV + 24 + 3 * k + l] = 1.0; bb[ra + l] = 0.0; } ra += 3; }
     } else if (level == 1) {
       const bool init = (a.variant == 0 && time < 10.0);
-      if (init) {   // arm joint nominal tracking
-        for (int r = 0; r < 6; ++r) { A[r * WNV + 18 + r] = 1.0; bb[r] = st[ST_KP_ARM_J + r] * (qd[18 + r] - q[18 + r]) + st[ST_KD_ARM_J + r] * (vd[18 + r] - v[18 + r]); }
-        ra = 6;
-      } else {
-        A[2] = 1.0; bb[0] = baseAcc[2] + st[ST_KP_BASE_H] * (qd[2] - q[2]) + st[ST_KD_BASE_H] * (vd[2] - v[2]); ra = 1;     // base height
-        {   // base angular
+      if (init) { if (l < 6) { A[l * WNV + 18 + l] = 1.0; bb[l] = st[ST_KP_ARM_J + l] * (qd[18 + l] - q[18 + l]) + st[ST_KD_ARM_J + l] * (vd[18 + l] - v[18 + l]); } ra = 6; }
+      else {
+        if (l == 0) { A[2] = 1.0; bb[0] = baseAcc[2] + st[ST_KP_BASE_H] * (qd[2] - q[2]) + st[ST_KD_BASE_H] * (vd[2] - v[2]); }
+        ra = 1;
+        if (l == 0) {   // base angular
           double wMeas[3], wDes[3]; const double thm[3] = {v[3], v[4], v[5]}, thdv[3] = {vd[3], vd[4], vd[5]}; m3_mulv(Bm.E, thm, wMeas); m3_mulv(Bm.E, thdv, wDes);
           double Rdes[9]; rot_zyx(qd[3], qd[4], qd[5], Rdes); double err[3]; dev_rot_error(Rdes, Bm.R, err);
-          // E(theta_meas) thdd_des + Edot(theta_meas, thd_des) thd_des
-          double acc[3]; { const double tdd[3] = {baseAcc[3], baseAcc[4], baseAcc[5]}; m3_mulv(Bm.E, tdd, acc); const double z[3] = {0.0, 0.0, 1.0}; double t0[3]; v3_cross(z, wDes, t0);
+          double acc[3]; { const double tdd[3] = {baseAcc[3], baseAcc[4], baseAcc[5]}; m3_mulv(Bm.E, tdd, acc); const double zz[3] = {0.0, 0.0, 1.0}; double t0[3]; v3_cross(zz, wDes, t0);
             const double c1[3] = {Bm.E[1], Bm.E[4], Bm.E[7]}, c2[3] = {Bm.E[2], Bm.E[5], Bm.E[8]}; double t1[3]; v3_cross(c1, c2, t1); for (int i = 0; i < 3; ++i) acc[i] += thdv[0] * t0[i] + thdv[1] * thdv[2] * t1[i]; }
           for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) A[(ra + r) * WNV + 3 + k] = Bm.E[3 * r + k]; bb[ra + r] = acc[r] + st[ST_KP_BASE_ANG] * err[r] + st[ST_KD_BASE_ANG] * (wDes[r] - wMeas[r]) - Bm.al[r]; }
-          ra += 3;
         }
+        ra += 3;
         if (a.variant == 0) {
-          for (int r = 0; r < 3; ++r) { for (int k = 0; k < 24; ++k) A[(ra + r) * WNV + k] = Jarm[r * 24 + k]; bb[ra + r] = st[ST_KP_EE_LIN + r] * (aD.p[r] - aM.p[r]) + st[ST_KD_EE_LIN + r] * (aD.v[r] - aM.v[r]) - aM.a[r]; }   // EE linear
-          ra += 3;
-          double err[3]; dev_rot_error(aD.R, aM.R, err);
-          for (int r = 0; r < 3; ++r) { for (int k = 0; k < 24; ++k) A[(ra + r) * WNV + k] = (k >= 3 && k < 6) ? 0.0 : Jarm[(3 + r) * 24 + k]; bb[ra + r] = st[ST_KP_EE_ANG + r] * err[r] + st[ST_KD_EE_ANG + r] * (-aM.w[r]) - (aM.al[r] - Bm.al[r]); }   // EE angular
-          ra += 3;
+          const double* aM = tipsM + 27 * 4; const double* aD = tipsD + 27 * 4;
+          for (int idx = l; idx < 72; idx += 64) { const int r = idx / 24, k = idx - 24 * r; A[(ra + r) * WNV + k] = Jarm[r * 24 + k]; A[(ra + 3 + r) * WNV + k] = (k >= 3 && k < 6) ? 0.0 : Jarm[(3 + r) * 24 + k]; }
+          if (l < 3) bb[ra + l] = st[ST_KP_EE_LIN + l] * (TIP_P(aD)[l] - TIP_P(aM)[l]) + st[ST_KD_EE_LIN + l] * (TIP_V(aD)[l] - TIP_V(aM)[l]) - TIP_A(aM)[l];
+          if (l == 0) { double err[3]; dev_rot_error(TIP_R(aD), TIP_R(aM), err); for (int r = 0; r < 3; ++r) bb[ra + 3 + r] = st[ST_KP_EE_ANG + r] * err[r] + st[ST_KD_EE_ANG + r] * (-TIP_W(aM)[r]) - (TIP_AL(aM)[r] - Bm.al[r]); }
+          ra += 6;
         } else {
-          for (int r = 0; r < 2; ++r) { A[(ra + r) * WNV + r] = 1.0; bb[ra + r] = baseAcc[r] + st[ST_KP_BASE_LIN] * (qd[r] - q[r]) + st[ST_KD_BASE_LIN] * (vd[r] - v[r]); }
+          if (l < 2) { A[(ra + l) * WNV + l] = 1.0; bb[ra + l] = baseAcc[l] + st[ST_KP_BASE_LIN] * (qd[l] - q[l]) + st[ST_KD_BASE_LIN] * (vd[l] - v[l]); }
           ra += 2;
         }
         for (int k = 0; k < 4; ++k) if (!C.fl[k]) {   // swing legs, x100
-          for (int r = 0; r < 3; ++r) { for (int c2 = 0; c2 < 24; ++c2) A[(ra + r) * WNV + c2] = Jf[(3 * k + r) * 24 + c2]; bb[ra + r] = st[ST_KP_SWING] * (fD[k].p[r] - fM[k].p[r]) + st[ST_KD_SWING] * (fD[k].v[r] - fM[k].v[r]) - dJv[3 * k + r]; setrow_scale(ra + r, 100.0); }
+          const double* fM = tipsM + 27 * k; const double* fD = tipsD + 27 * k;
+          for (int idx = l; idx < 72; idx += 64) { const int r = idx / 24, c2 = idx - 24 * r; A[(ra + r) * WNV + c2] = 100.0 * Jf[(3 * k + r) * 24 + c2]; }
+          if (l < 3) bb[ra + l] = 100.0 * (st[ST_KP_SWING] * (TIP_P(fD)[l] - TIP_P(fM)[l]) + st[ST_KD_SWING] * (TIP_V(fD)[l] - TIP_V(fM)[l]) - TIP_A(fM)[l]);
           ra += 3;
         }
       }
     } else {
-      for (int r = 0; r < 12; ++r) { A[r * WNV + 24 + r] = 1.0; bb[r] = uDes[r]; } ra = 12;      // contact force
-      if (a.variant == 0) { for (int r = 0; r < 2; ++r) { A[(ra + r) * WNV + r] = 1.0; bb[ra + r] = baseAcc[r] + st[ST_KP_BASE_LIN] * (qd[r] - q[r]) + st[ST_KD_BASE_LIN] * (vd[r] - v[r]); } ra += 2; }
+      if (l < 12) { A[l * WNV + 24 + l] = 1.0; bb[l] = uDes[l]; }
+      ra = 12;
+      if (a.variant == 0) { if (l < 2) { A[(ra + l) * WNV + l] = 1.0; bb[ra + l] = baseAcc[l] + st[ST_KP_BASE_LIN] * (qd[l] - q[l]) + st[ST_KD_BASE_LIN] * (vd[l] - v[l]); } ra += 2; }
     }
-    // ---- stacked LS rows G0 = [A Zp; sqrt(rho) I], g0 = [b − A xp; 0] ----
+    qm_wave_sync();
+    // ---- AZ = A Zp, g0 = [b − A xp; 0] ----
     const int n = nz;
-    for (int r = 0; r < ra; ++r) { for (int k = 0; k < n; ++k) { double s = 0.0; for (int c2 = 0; c2 < WNV; ++c2) s += A[r * WNV + c2] * Zp[c2 * n + k]; AZ[r * WNV + k] = s; G0[r * WNV + k] = s; } double s = bb[r]; for (int c2 = 0; c2 < WNV; ++c2) s -= A[r * WNV + c2] * x[c2]; g0[r] = s; }
-    for (int r = 0; r < n; ++r) { for (int k = 0; k < n; ++k) G0[(ra + r) * WNV + k] = (r == k) ? sqrt(WRHO) : 0.0; g0[ra + r] = 0.0; }
+    for (int idx = l; idx < ra * n; idx += 64) { const int r = idx / n, k = idx - r * n; double s = 0.0; for (int c2 = 0; c2 < WNV; ++c2) s += A[r * WNV + c2] * Zp[c2 * n + k]; AZ[r * WNV + k] = s; }
+    for (int r = l; r < ra + n; r += 64) { double s = 0.0; if (r < ra) { s = bb[r]; for (int c2 = 0; c2 < WNV; ++c2) s -= A[r * WNV + c2] * x[c2]; } g0[r] = s; }
+    if (l < WNV) z[l] = 0.0;
+    qm_wave_sync();
     const int rows0 = ra + n;
-    double z[WNV]; for (int k = 0; k < n; ++k) z[k] = 0.0;
-    double dx[WNV], Dx[WMAXINEQ];
     if (level == 0) {
       // own (soft) inequality rows: Newton on the active set with exact line search (phi is convex piecewise quadratic)
-      double fb[WMAXINEQ]; wbc_d0_apply(C, x, Dx); for (int i = 0; i < C.nIneq; ++i) fb[i] = f0[i] - Dx[i];
-      bool act[WMAXINEQ]; for (int i = 0; i < C.nIneq; ++i) act[i] = (0.0 - fb[i] > 0.0);
+      wv_d0_apply(C, x, tau, Dz);
+      if (l < C.nIneq) fb[l] = f0[l] - Dz[l];
+      qm_wave_sync();
+      unsigned long long actmask = 0ull; for (int i = 0; i < C.nIneq; ++i) if (0.0 - fb[i] > 0.0) actmask |= (1ull << i);
       int it = 0;
       for (; it < 100; ++it) {
+        for (int idx = l; idx < rows0 * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (k == n) ? g0[r] : (r < ra ? AZ[r * WNV + k] : ((r - ra) == k ? sqrt(WRHO) : 0.0)); }
         int na = 0;
-        for (int r = 0; r < rows0; ++r) { for (int k = 0; k < n; ++k) Gw[r * WNV + k] = G0[r * WNV + k]; gw[r] = g0[r]; }
-        for (int i = 0; i < C.nIneq && na < WMAXACT; ++i) if (act[i]) { double row[WNV]; wbc_d0_row(C, i, row); for (int k = 0; k < n; ++k) { double s = 0.0; for (int c2 = 0; c2 < WNV; ++c2) s += row[c2] * Zp[c2 * n + k]; Gw[(rows0 + na) * WNV + k] = s; } gw[rows0 + na] = fb[i]; ++na; }
-        double zn[WNV]; dev_ls_qr(Gw, WNV, rows0 + na, n, gw, zn);
-        double p[WNV]; for (int k = 0; k < n; ++k) p[k] = zn[k] - z[k];
-        // directional derivative along p: dphi(a) = (G0(z + a p) − g0)·G0 p + sum_{active at a} (d_i(z + a p) − fb_i) d_i p
-        double Zz[WNV], Zpv[WNV], Dz[WMAXINEQ], Dp[WMAXINEQ];
-        for (int r = 0; r < WNV; ++r) { double s1 = 0.0, s2 = 0.0; for (int k = 0; k < n; ++k) { s1 += Zp[r * n + k] * z[k]; s2 += Zp[r * n + k] * p[k]; } Zz[r] = s1; Zpv[r] = s2; }
-        wbc_d0_apply(C, Zz, Dz); wbc_d0_apply(C, Zpv, Dp);
-        double c0 = 0.0, c1 = 0.0;   // smooth part: derivative = c0 + a c1
-        for (int r = 0; r < rows0; ++r) { double gz = -g0[r], gp = 0.0; for (int k = 0; k < n; ++k) { gz += G0[r * WNV + k] * z[k]; gp += G0[r * WNV + k] * p[k]; } c0 += gz * gp; c1 += gp * gp; }
+        for (int i = 0; i < C.nIneq && na < WMAXACT; ++i) if ((actmask >> i) & 1ull) { wv_d0_row_Z(C, i, Zp, n, G + (rows0 + na) * WGLD); if (l == 0) G[(rows0 + na) * WGLD + n] = fb[i]; ++na; }
+        qm_wave_sync();
+        wv_ls_qr(G, WGLD, rows0 + na, n, S + WL_HV, zn);
+        if (l < n) p[l] = zn[l] - z[l];
+        qm_wave_sync();
+        wv_Z_times(Zp, n, z, Zz); wv_Z_times(Zp, n, p, Zpv);
+        wv_d0_apply(C, Zz, tau, Dz); wv_d0_apply(C, Zpv, tau, Dp);
+        double c0p = 0.0, c1p = 0.0;   // smooth part of dphi: c0 + a c1
+        for (int r = l; r < rows0; r += 64) { double gz = -g0[r], gp = 0.0; if (r < ra) { for (int k = 0; k < n; ++k) { gz += AZ[r * WNV + k] * z[k]; gp += AZ[r * WNV + k] * p[k]; } } else { gz += sqrt(WRHO) * z[r - ra]; gp = sqrt(WRHO) * p[r - ra]; } c0p += gz * gp; c1p += gp * gp; }
+        const double c0 = wv_sum(c0p), c1 = wv_sum(c1p);
         auto dphi = [&](double al) { double s = c0 + al * c1; for (int i = 0; i < C.nIneq; ++i) { const double vv = Dz[i] + al * Dp[i] - fb[i]; if (vv > 0.0) s += vv * Dp[i]; } return s; };
         double al = 1.0;
         if (dphi(1.0) > 0.0) { double lo = 0.0, hi = 1.0; for (int bi = 0; bi < 200; ++bi) { const double mid = 0.5 * (lo + hi); if (dphi(mid) > 0.0) hi = mid; else lo = mid; } al = 0.5 * (lo + hi); }
-        for (int k = 0; k < n; ++k) z[k] += al * p[k];
-        bool same = true;
-        for (int i = 0; i < C.nIneq; ++i) { const bool nai = (Dz[i] + al * Dp[i] - fb[i] > 0.0); if (nai != act[i]) same = false; act[i] = nai; }
+        const double pn = wv_max((l < n) ? fabs(al * p[l]) : 0.0);
+        if (l < n) z[l] += al * p[l];
+        unsigned long long nm = 0ull; for (int i = 0; i < C.nIneq; ++i) if (Dz[i] + al * Dp[i] - fb[i] > 0.0) nm |= (1ull << i);
+        const bool same = (nm == actmask); actmask = nm;
+        qm_wave_sync();
         if (same && al == 1.0) break;
-        double pn = 0.0, zs = 1.0; for (int k = 0; k < n; ++k) { pn = fmax(pn, fabs(al * p[k])); zs = fmax(zs, fabs(z[k])); }
-        if (pn <= 1e-12 * zs) break;                      // minimiser sits on a kink: both active sets give the same z
+        const double zs = fmax(1.0, wv_max((l < n) ? fabs(z[l]) : 0.0));
+        if (pn <= 1e-12 * zs) break;
       }
       if (it >= 100) status[0] = 1;
-      for (int r = 0; r < WNV; ++r) { double s = 0.0; for (int k = 0; k < n; ++k) s += Zp[r * n + k] * z[k]; dx[r] = s; }
-      wbc_d0_apply(C, dx, Dx); for (int i = 0; i < C.nIneq; ++i) w0[i] = fmax(0.0, Dx[i] - fb[i]);
+      wv_Z_times(Zp, n, z, Zz); wv_d0_apply(C, Zz, tau, Dz);
+      if (l < C.nIneq) w0[l] = fmax(0.0, Dz[l] - fb[l]);
+      qm_wave_sync();
     } else {
       // hard rows of level 0: primal active set (Nocedal & Wright 16.3) from the feasible z = 0
-      double fb[WMAXINEQ]; wbc_d0_apply(C, x, Dx); for (int i = 0; i < C.nIneq; ++i) fb[i] = f0[i] - Dx[i] + w0[i];
+      wv_d0_apply(C, x, tau, Dz);
+      if (l < C.nIneq) fb[l] = f0[l] - Dz[l] + w0[l];
+      qm_wave_sync();
       int W[WMAXACT]; int nw = 0; int it = 0; bool degenerate = false; double pscale = 0.0;
       for (; it < 100; ++it) {
-        for (int q2 = 0; q2 < nw; ++q2) { double row[WNV]; wbc_d0_row(C, W[q2], row); for (int k = 0; k < n; ++k) { double s = 0.0; for (int c2 = 0; c2 < WNV; ++c2) s += row[c2] * Zp[c2 * n + k]; Erows[q2 * WNV + k] = s; } erhs[q2] = fb[W[q2]]; }
-        double zn[WNV]; wbc_eq_ls(G0, g0, rows0, n, Erows, erhs, nw, Gw, gw, Vq, betaq, Rq, zn, lam);
-        double p[WNV], pn = 0.0, zs = 1.0; for (int k = 0; k < n; ++k) { p[k] = zn[k] - z[k]; pn = fmax(pn, fabs(p[k])); zs = fmax(zs, fabs(z[k])); }
+        for (int q2 = 0; q2 < nw; ++q2) { wv_d0_row_Z(C, W[q2], Zp, n, S + WL_EROWS + q2 * WNV); if (l == 0) S[WL_ERHS + q2] = fb[W[q2]]; }
+        qm_wave_sync();
+        wv_eq_ls(S, ra, n, nw, zn);
+        if (l < n) p[l] = zn[l] - z[l];
+        qm_wave_sync();
+        const double pn = wv_max((l < n) ? fabs(p[l]) : 0.0), zs = fmax(1.0, wv_max((l < n) ? fabs(z[l]) : 0.0));
         pscale = fmax(pscale, pn);
-        if (pn <= 1e-9 * fmax(zs, pscale)) {             // relative to the largest step seen: the problem's own length scale
-          // stationary on the working set: drop a row with a negative multiplier (most negative; lowest index after a degenerate step — Bland)
+        if (pn <= 1e-9 * fmax(zs, pscale)) {
           int worst = -1; double lw = 0.0, lscale = 1.0; for (int q2 = 0; q2 < nw; ++q2) lscale = fmax(lscale, fabs(lam[q2]));
           for (int q2 = 0; q2 < nw; ++q2) if (lam[q2] < -1e-9 * lscale) { if (degenerate) { if (worst < 0 || W[q2] < W[worst]) worst = q2; } else if (lam[q2] < lw) { lw = lam[q2]; worst = q2; } }
           if (worst < 0) break;
           for (int q2 = worst; q2 < nw - 1; ++q2) W[q2] = W[q2 + 1]; --nw;
         } else {
-          double Zz[WNV], Zpv[WNV], Dz[WMAXINEQ], Dp[WMAXINEQ];
-          for (int r = 0; r < WNV; ++r) { double s1 = 0.0, s2 = 0.0; for (int k = 0; k < n; ++k) { s1 += Zp[r * n + k] * z[k]; s2 += Zp[r * n + k] * p[k]; } Zz[r] = s1; Zpv[r] = s2; }
-          wbc_d0_apply(C, Zz, Dz); wbc_d0_apply(C, Zpv, Dp);
+          wv_Z_times(Zp, n, z, Zz); wv_Z_times(Zp, n, p, Zpv);
+          wv_d0_apply(C, Zz, tau, Dz); wv_d0_apply(C, Zpv, tau, Dp);
           double al = 1.0; int block = -1;
-          for (int i = 0; i < C.nIneq; ++i) { bool inW = false; for (int q2 = 0; q2 < nw; ++q2) if (W[q2] == i) inW = true; if (inW) continue; if (Dp[i] > 1e-10 * fmax(1.0, pn)) { const double aa = fmax(0.0, (fb[i] - Dz[i]) / Dp[i]); if (aa < al) { al = aa; block = i; } } }   // relative threshold: E p = 0 only to round-off
-          for (int k = 0; k < n; ++k) z[k] += al * p[k];
+          for (int i = 0; i < C.nIneq; ++i) { bool inW = false; for (int q2 = 0; q2 < nw; ++q2) if (W[q2] == i) inW = true; if (inW) continue; if (Dp[i] > 1e-10 * fmax(1.0, pn)) { const double aa = fmax(0.0, (fb[i] - Dz[i]) / Dp[i]); if (aa < al) { al = aa; block = i; } } }
+          if (l < n) z[l] += al * p[l];
+          qm_wave_sync();
           degenerate = (al <= 1e-12);
           if (block >= 0) { if (nw < n && nw < WMAXACT) W[nw++] = block; else { status[level] = 2; break; } }
         }
       }
       if (it >= 100 && status[level] == 0) status[level] = 1;
-      for (int r = 0; r < WNV; ++r) { double s = 0.0; for (int k = 0; k < n; ++k) s += Zp[r * n + k] * z[k]; dx[r] = s; }
     }
-    for (int r = 0; r < WNV; ++r) { x[r] += dx[r]; xlev[level][r] = x[r]; }
-    if (level < 2) { nz = wbc_null_space(AZ, ra, n, Zp, Zn, Gw, Gw + WMAXA * WNV); for (int i = 0; i < WNV * nz; ++i) Zp[i] = Zn[i]; }
+    wv_Z_times(Zp, n, z, Zz);
+    if (l < WNV) { x[l] += Zz[l]; S[WL_XLEV + level * WNV + l] = x[l]; }
+    qm_wave_sync();
+    if (level < 2) nz = wv_null_space(S, ra, n);
     if (level > 0 && status[level] == 0 && status[level - 1] != 0) status[level] = status[level - 1];
   }
   // ---- updateCmd (WbcBase.cpp:548-563) ----
-  double* out = a.out + (size_t)b * QM_NWBC_OUT; double tau[18]; wbc_tau_lin(C, x, tau);
-  for (int i = 0; i < WNV; ++i) out[i] = x[i];
-  for (int r = 0; r < 18; ++r) out[WNV + r] = tau[r] + nle[6 + r];
-  for (int l = 0; l < 3; ++l) a.qp_status[b * 3 + l] = status[l];
+  wv_d0_apply(C, x, tau, Dz);
+  double* out = a.out + (size_t)b * QM_NWBC_OUT;
+  if (l < WNV) out[l] = x[l];
+  if (l < 18) out[WNV + l] = tau[l] + nle[6 + l];
+  if (l < 3) a.qp_status[b * 3 + l] = status[l];
   if (a.dbg) {
-    double* d = a.dbg + (size_t)b * WBC_DBG_SIZE; int o = 0;
-    for (int i = 0; i < 24; ++i) d[o++] = q[i]; for (int i = 0; i < 24; ++i) d[o++] = v[i]; for (int i = 0; i < 24; ++i) d[o++] = qd[i]; for (int i = 0; i < 24; ++i) d[o++] = vd[i];
-    for (int i = 0; i < 6; ++i) d[o++] = baseAcc[i]; for (int i = 0; i < 24; ++i) d[o++] = nle[i];
-    for (int l = 0; l < 3; ++l) for (int i = 0; i < 36; ++i) d[o++] = xlev[l][i];
-    for (int i = 0; i < 576; ++i) d[o++] = M[i]; for (int i = 0; i < 288; ++i) d[o++] = Jf[i]; for (int i = 0; i < 12; ++i) d[o++] = dJv[i];
+    double* d = a.dbg + (size_t)b * WBC_DBG_SIZE;
+    if (l < 24) { d[l] = q[l]; d[24 + l] = v[l]; d[48 + l] = qd[l]; d[72 + l] = vd[l]; d[102 + l] = nle[l]; }
+    if (l < 6) d[96 + l] = baseAcc[l];
+    for (int idx = l; idx < 108; idx += 64) d[126 + idx] = S[WL_XLEV + idx];
+    for (int idx = l; idx < 576; idx += 64) d[234 + idx] = M[idx];
+    for (int idx = l; idx < 288; idx += 64) d[810 + idx] = Jf[idx];
+    if (l < 12) d[1098 + l] = TIP_A(tipsM + 27 * (l / 3))[l % 3];
   }
 }
