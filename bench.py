@@ -37,7 +37,7 @@ def main():
     args = ap.parse_args()
 
     import numpy as np
-    from qm_control_amd import api, scenarios
+    from qm_control_amd import api, scenarios, sharding
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -56,9 +56,7 @@ def main():
     B = args.batch
     blobs = scenarios.load_blobs()
     # C4: seed 1235, contiguous shard of the global batch for this rank
-    cfg_all = scenarios.make_config("C4", batch=B * world)
-    sl = slice(rank * B, (rank + 1) * B)
-    cfg = {k: (v[sl] if hasattr(v, "shape") and getattr(v, "ndim", 0) >= 1 and v.shape[0] == B * world else v) for k, v in cfg_all.items()}
+    cfg = sharding.shard_config(scenarios.make_config("C4", batch=B * world), rank, world)
     itf = api.QMInterface(blobs=blobs, device=local, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
     mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
     mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])     # inputs resident in HBM from here on
@@ -77,9 +75,7 @@ def main():
         step()
     itf.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist, "cuda")
 
     # per-kernel HIP-event times over the timed region (events recorded on the stream the kernels run on)
     kms = {k: itf.kernel_ms(k) for k in ("grid", "lq", "riccati", "ls_eval", "ls_misc", "policy", "wbc")}

@@ -1,0 +1,88 @@
+"""The product's device kernels, executed by the host emulator (tests/emu), against the oracle — CPU-only parity.
+Same tolerances as the GPU tests: 1e-6 relative on trajectories / torques, integers bit-exact."""
+import numpy as np
+import pytest
+from conftest import rel_err
+
+TOL = 1e-6
+
+
+def _oracle(oracle, cfg, b=0):
+    oracle.set_schedule(cfg["ev"][b], cfg["modes"][b]); oracle.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+    return oracle.mpc_step(cfg["t0"][b], cfg["t0"][b] + cfg["horizon"], cfg["x0"][b])
+
+
+@pytest.mark.parametrize("name,N", [("C1", 20), ("C2", 26), ("C5", 60)])
+def test_mpc_kernels_vs_oracle(blobs, oracle, name, N):
+    import emu_harness
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config(name, batch=1, n_intervals=N)
+    r = _oracle(oracle, cfg); n = len(r["t"])
+    e = emu_harness.Emu(blobs[0], blobs[1], 1, n + 3, 2, cfg["ev"].shape[1])
+    e.mpc_step(cfg)
+    assert e.buf("n_nodes", (1,), np.int32)[0] == n and e.buf("status", (1,), np.int32)[0] == 0
+    assert np.array_equal(e.node_arr("node_t", 1)[:n, 0], r["t"])
+    assert np.array_equal(e.node_arr("node_ev", 1, np.int32)[:n, 0], r["ev"])
+    assert np.array_equal(e.node_arr("node_mode", 1, np.int32)[:n, 0], r["mode"])
+    worst = 0.0
+    for i in range(n - 1):
+        if r["ev"][i] == 1:
+            continue
+        d = e.lqdbg(0, i); q = oracle.node_lq(i)
+        for a, b_ in ((d[0:900], q["A"]), (d[900:1800], q["B"]), (d[1800:1830], q["b"]), (d[1830:2730], q["Q"]), (d[2730:3630], q["R"]), (d[3630:3660], q["q"]), (d[3660:3690], q["r"]),
+                      (d[3690:4170], q["C"]), (d[4170:4650], q["D"]), (d[4650:4666], q["e"])):
+            worst = max(worst, np.abs(a - np.asarray(b_).ravel()).max())
+        assert int(d[4667]) == q["nc"]
+    assert worst < 1e-9                                              # analytic Jacobians / cost model vs AD, entrywise
+    dx, du = oracle.step(n)
+    assert rel_err(e.node_arr("dx", 30)[:n, 0], dx) < 1e-9 and rel_err(e.node_arr("du", 30)[:n - 1, 0], du) < 1e-9
+    assert rel_err(e.node_arr("xs", 30)[:n, 0], r["x"]) < TOL and rel_err(e.node_arr("us", 30)[:n, 0], r["u"]) < TOL
+    perf = e.buf("out_perf", (10,))
+    assert perf[8] == r["alpha"] and rel_err(perf[:8], r["perf"][:8]) < 1e-9
+
+
+def test_line_search_backtracks_like_the_oracle(blobs, oracle):
+    """tighten g_max so the first trial is rejected and the filter line-search has to halve alpha"""
+    import emu_harness, pyoracle
+    from qm_control_amd import scenarios
+    st = blobs[1].copy(); st[994] = 1e-9; st[993] = 1e-12     # g_max, deltaTol
+    o2 = pyoracle.Oracle(blobs[0], st)
+    cfg = scenarios.make_config("C3", batch=1, n_intervals=10)
+    cfg["x0"][0, 24:30] += 0.3
+    r = _oracle(o2, cfg); n = len(r["t"])
+    e = emu_harness.Emu(blobs[0], st, 1, n + 3, 2, cfg["ev"].shape[1])
+    trials = e.mpc_step(cfg)
+    perf = e.buf("out_perf", (10,))
+    assert trials == r["ls_trials"] and perf[8] == r["alpha"]
+    assert rel_err(e.node_arr("xs", 30)[:n, 0], r["x"]) < TOL
+
+
+def test_wbc_kernel_vs_oracle(blobs, oracle):
+    import emu_harness
+    from test_gpu_wbc import _random_wbc_inputs
+    e = emu_harness.Emu(blobs[0], blobs[1], 8, 8, 2, 2)
+    for variant in (0, 1):
+        cases = _random_wbc_inputs(oracle, blobs, 6, 21 + variant, 0.05)
+        arr = lambda k: np.array([c[k] for c in cases])
+        e.wbc_reset(); e.wbc_step(arr("xd"), arr("il"), arr("rbd"), arr("mode"), 0.002, arr("time"), variant)
+        out, st, dbg = e.wbc_step(arr("xd"), arr("ud"), arr("rbd"), arr("mode"), 0.002, arr("time"), variant)
+        for b, c in enumerate(cases):
+            oracle.wbc_reset(); oracle.wbc(c["xd"], c["il"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant))
+            ref, sto, d = oracle.wbc(c["xd"], c["ud"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant), debug=True)
+            assert list(sto) == [0, 0, 0] and list(st[b]) == [0, 0, 0]
+            assert rel_err(dbg[b]["M"], d["M"]) < 1e-12 and rel_err(dbg[b]["nle"], d["nle"]) < 1e-12 and rel_err(dbg[b]["J"], d["J"]) < 1e-12
+            assert rel_err(dbg[b]["dJv"], d["dJ"] @ d["vMeas"]) < 1e-11 and rel_err(dbg[b]["baseAcc"], d["baseAcc"]) < 1e-11
+            assert rel_err(out[b], ref) < TOL and rel_err(out[b, 36:], ref[36:]) < TOL
+
+
+def test_control_step_vs_oracle_and_golden(blobs):
+    import os, emu_harness, pyoracle
+    from conftest import ROOT
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config("C3", batch=4, n_intervals=40)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "C3_B4_N40.npz"))
+    e = emu_harness.Emu(blobs[0], blobs[1], 2, 56, 2, cfg["ev"].shape[1])
+    out, st, rbd = e.control_step(cfg, batch=2)
+    assert (st == 0).all()
+    for b in range(2):
+        assert rel_err(out[b], g["wbc_%d" % b]) < TOL
