@@ -78,7 +78,7 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, dist, "cuda")
 
     # per-kernel HIP-event times over the timed region (events recorded on the stream the kernels run on)
-    kms = {k: itf.kernel_ms(k) for k in ("grid", "lq", "riccati", "ls_eval", "ls_misc", "policy", "wbc")}
+    kms = {k: itf.kernel_ms(k) for k in ("grid", "lq_kin", "lq", "riccati", "ls_eval", "ls_misc", "policy", "wbc")}
     res = mpc.download(); out, qps = wbc.download(B)
     ok = bool((res["status"] == 0).all() and (qps == 0).all())
     n_intervals = int(sum(int(res["num_nodes"][b]) - 1 - int((res["event"][b, :res["num_nodes"][b]] == 1).sum()) for b in range(B)))

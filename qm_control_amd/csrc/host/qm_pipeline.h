@@ -28,7 +28,7 @@ struct QmMpcBuffers {
   int* n_nodes = nullptr; double* node_t = nullptr; double* node_ts = nullptr; double* node_dt = nullptr; int* node_ev = nullptr; int* node_mode = nullptr;
   double* zvel = nullptr; double* zpos = nullptr; double* xref = nullptr; double* eeref = nullptr; int* status = nullptr;
   // iterate, step, stage data
-  double* x = nullptr; double* u = nullptr; double* dx = nullptr; double* du = nullptr; double* stage = nullptr; double* lqdbg = nullptr;
+  double* x = nullptr; double* u = nullptr; double* dx = nullptr; double* du = nullptr; double* stage = nullptr; double* lqdbg = nullptr; double* kin = nullptr;
   double* perf = nullptr; double* base_sum = nullptr; double* perf_sum = nullptr; double* step_info = nullptr;
   double* alpha = nullptr; int* done = nullptr; double* xs = nullptr; double* us = nullptr; double* out_perf = nullptr;
 };
@@ -51,13 +51,13 @@ struct QmMpcPipeline {
     d.n_nodes = A<int>(Bmax); d.node_t = A<double>(NB); d.node_ts = A<double>(NB); d.node_dt = A<double>(NB); d.node_ev = A<int>(NB); d.node_mode = A<int>(NB);
     d.zvel = A<double>(NB * 4); d.zpos = A<double>(NB * 4); d.xref = A<double>(NB * 30); d.eeref = A<double>(NB * 7); d.status = A<int>(Bmax);
     d.x = A<double>(NB * 30); d.u = A<double>(NB * 30); d.dx = A<double>(NB * 30); d.du = A<double>(NB * 30);
-    d.stage = A<double>(NB * SR_SIZE); d.lqdbg = debug_lq ? A<double>(NB * LQ_DBG_SIZE) : nullptr;
+    d.stage = A<double>(NB * SR_SIZE); d.lqdbg = debug_lq ? A<double>(NB * LQ_DBG_SIZE) : nullptr; d.kin = A<double>(NB * KR_SIZE);
     d.perf = A<double>(NB * PF_SIZE); d.base_sum = A<double>((size_t)Bmax * 4); d.perf_sum = A<double>((size_t)Bmax * 4); d.step_info = A<double>((size_t)Bmax * 4);
     d.alpha = A<double>(Bmax); d.done = A<int>(Bmax); d.xs = A<double>(NB * 30); d.us = A<double>(NB * 30); d.out_perf = A<double>((size_t)Bmax * 10);
   }
   void release() {
     void* ps[] = {d.mb, d.st, d.t0, d.x0, d.ref_t, d.ref_x, d.ev, d.modes, d.n_nodes, d.node_t, d.node_ts, d.node_dt, d.node_ev, d.node_mode, d.zvel, d.zpos, d.xref, d.eeref, d.status,
-                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf};
+                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf};
     for (void* p : ps) if (p) bk.free(p);
     d = QmMpcBuffers();
   }
@@ -82,12 +82,14 @@ struct QmMpcPipeline {
     g.horizon = horizon; g.n_nodes = d.n_nodes; g.node_t = d.node_t; g.node_ts = d.node_ts; g.node_dt = d.node_dt; g.node_ev = d.node_ev; g.node_mode = d.node_mode;
     g.zvel = d.zvel; g.zpos = d.zpos; g.xref = d.xref; g.eeref = d.eeref; g.x = d.x; g.u = d.u; g.status = d.status;
     bk.launch(qm_grid_kernel, (B + 63) / 64, 64, 0, g);
+    bk.launch(qm_grid_nodes_kernel, (d.nmax * B + 63) / 64, 64, 0, g);
   }
   // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min)
   void sqp_iteration(int B, int max_trials = 14) {
     const int nodes_threads = d.nmax * B;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
-    q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg;
+    q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin;
+    bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, 0, q);
     bk.launch(qm_lq_kernel, B * d.nmax, QM_BLOCK, LQ_LDS_BYTES, q);
     QmLsArgs l = ls_args(B);
     { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, (B + 63) / 64, 64, 0, lb); }

@@ -25,7 +25,7 @@ struct HipBackend {
   void check(hipError_t e, const char* what) { if (e != hipSuccess && error.empty()) error = std::string(what) + ": " + hipGetErrorString(e); }
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
-    if (p == (const void*)qm_grid_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_riccati_kernel) return "riccati";
+    if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel) return "riccati";
     if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_wbc_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel) return "policy";
     return "ls_misc";
   }

@@ -83,10 +83,22 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
     if (post) { if (n >= a.nmax) { status = -1; break; } a.node_t[n * a.B + b] = nt; a.node_ev[n * a.B + b] = QM_EV_POST; ++n; }
   }
   a.n_nodes[b] = n;
+  a.status[b] = status;
+}
+
+// K0b: per (node, instance): interval start/duration, mode, swing-z references, reference interpolation, cold start
+__global__ void qm_grid_nodes_kernel(QmGridArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g / a.B, b = g - i * a.B;
+  if (i >= a.nmax) return;
+  const int n = a.n_nodes[b];
+  if (i >= n) return;
+  const double* ev = a.ev + (size_t)b * a.nev; const int* modes = a.modes + (size_t)b * (a.nev + 1);
+  int status = 0;
   const double mass = a.mb[MB_ROBOTMASS];
   const double liftV = a.st[ST_LIFTOFF_VEL], touchV = a.st[ST_TOUCHDOWN_VEL], swingH = a.st[ST_SWING_HEIGHT], tScale = a.st[ST_SWING_TIME_SCALE];
   const double* rt = a.ref_t + (size_t)b * a.nref; const double* rx = a.ref_x + (size_t)b * a.nref * QM_NREF;
-  for (int i = 0; i < n; ++i) {
+  {
     const int nb = i * a.B + b;
     const double t = a.node_t[nb]; const int e = a.node_ev[nb];
     const double ts = (e == QM_EV_POST) ? t + QM_WEAK_EPS : t;
@@ -131,5 +143,5 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
     for (int q = 0; q < 30; ++q) { a.x[nb * 30 + q] = a.x0[(size_t)b * 30 + q]; a.u[nb * 30 + q] = 0.0; }
     if (e != QM_EV_PRE && nst > 0) for (int c = 0; c < 4; ++c) if (mode_flag(mode, c)) a.u[nb * 30 + 3 * c + 2] = mass * 9.81 / nst;
   }
-  a.status[b] = status;
+  if (status != 0) a.status[b] = status;
 }
