@@ -91,6 +91,8 @@ int qmhip_synchronize(qmhip_ctx* ctx);
 int qmhip_last_ls_trials(const qmhip_ctx* ctx);
 /* debug/parity access to a device buffer by name (see QmMpcBuffers); copies `bytes` to host */
 int qmhip_debug_read(qmhip_ctx* ctx, const char* buffer, void* dst, size_t bytes);
+/* profiling-only switches (e.g. "riccati_skip" bit mask of kernel phases to skip; results are then meaningless) */
+int qmhip_debug_set(qmhip_ctx* ctx, const char* key, int value);
 /* micro-benchmarks used to anchor the FP64 roofline: returns achieved TFLOP/s */
 int qmhip_microbench_fp64(qmhip_ctx* ctx, int use_mfma, double* tflops);
 

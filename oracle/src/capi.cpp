@@ -106,6 +106,7 @@ void qmo_eval_policy(void* h, double t, double* x, double* u, int* mode) {
   std::memcpy(x, xv.data(), QM_NX * 8); std::memcpy(u, uv.data(), QM_NU * 8); *mode = m;
 }
 
+void qmo_wbc_iters(void* h, int* it3) { for (int i = 0; i < 3; ++i) it3[i] = ((Oracle*)h)->dbg.iters[i]; }
 void qmo_wbc_reset(void* h) { ((Oracle*)h)->W = WbcState(); }
 void qmo_wbc_set_input_last(void* h, const double* u) { ((Oracle*)h)->W.inputLast.assign(u, u + QM_NU); }
 // dbg (may be null): qMeas(24) vMeas(24) qDes(24) vDes(24) baseAcc(6) nle(24) x0(36) x1(36) x2(36) M(576) J(288) dJ(288)

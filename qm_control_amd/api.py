@@ -20,7 +20,7 @@ MB_SIZE, ST_SIZE = 685, 1030
 EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
            "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_download", "qmhip_policy_eval",
            "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
-           "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_microbench_fp64"]
+           "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_microbench_fp64"]
 
 
 class QmhipError(RuntimeError):
@@ -137,6 +137,9 @@ class QMInterface:
         v = C.c_double(0)
         self._check(self.lib.qmhip_microbench_fp64(self.h, int(use_mfma), C.byref(v)), "qmhip_microbench_fp64")
         return v.value
+
+    def debug_set(self, key, value):
+        self._check(self.lib.qmhip_debug_set(self.h, key.encode(), C.c_int(value)), "qmhip_debug_set")
 
     def debug_read(self, name, shape, dtype=np.float64):
         out = np.zeros(shape, dtype=dtype)

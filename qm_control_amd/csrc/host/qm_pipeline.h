@@ -37,6 +37,7 @@ template <class BK>
 struct QmMpcPipeline {
   BK& bk; QmMpcBuffers d;
   int ls_trials_run = 0;
+  int riccati_skip = 0;   // profiling only
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
   template <class T> T* A(size_t n) { T* p = (T*)bk.alloc(n * sizeof(T)); bk.zero(p, n * sizeof(T)); return p; }
@@ -93,7 +94,7 @@ struct QmMpcPipeline {
     bk.launch(qm_lq_kernel, B * d.nmax, QM_BLOCK, LQ_LDS_BYTES, q);
     QmLsArgs l = ls_args(B);
     { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, (B + 63) / 64, 64, 0, lb); }
-    QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info;
+    QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
     bk.launch(qm_riccati_kernel, B, QM_BLOCK, RC_LDS_BYTES, r);
     // line search: alpha = 1, done = 0
     std::vector<double> ones((size_t)B, 1.0); bk.to_device(d.alpha, ones.data(), (size_t)B * 8); bk.zero(d.done, (size_t)B * 4);

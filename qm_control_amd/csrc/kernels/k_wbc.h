@@ -76,8 +76,9 @@ struct QmWbcArgs {
 #define WL_LAM    (WL_ERHS + WMAXACT)
 #define WL_Y      (WL_LAM + WMAXACT)              /* [36] */
 #define WL_W36    (WL_Y + WNV)
+#define WL_WLIST  (WL_W36 + WNV)                /* [20] ints: working set */
 #define WL_ACC    (WL_G + 18 * 16)                /* chain accumulators: 3 passes x 6 slots x 20 (inside G, after the momentum sums) */
-#define WL_MISC   (WL_W36 + WNV)                  /* q v qd vd w2 (5 x 24), baseAcc(6) */
+#define WL_MISC   (WL_WLIST + 12)                 /* q v qd vd w2 (5 x 24), baseAcc(6) */
 #define WL_TIPS   (WL_MISC + 5 * 24 + 8)          /* 10 tips x 27 doubles: measured feet 0-3, arm 4, desired feet 5-8, arm 9 */
 #define WL_XLEV   (WL_TIPS + 10 * 27)             /* [3][36] */
 #define WL_TOTAL  (WL_XLEV + 3 * WNV)
@@ -96,8 +97,9 @@ __device__ __forceinline__ void dev_rot_error(const double* Rl, const double* Rr
 }
 
 // ---- wave-cooperative dense helpers (LDS, row-major) ----
-// Householder least squares: min |G[:, :n] z − G[:, n]|, rows >= n; lane j owns column j (j = n is the rhs). z -> LDS vector.
-__device__ __forceinline__ void wv_ls_qr(double* G, int ld, int rows, int n, double* hv, double* z) {
+// Householder QR in place of G (rows x (n+1), column n = rhs), rows >= n; lane j owns column j.  Leaves R in the upper
+// triangle of G[0:n, 0:n] and Qᵀ rhs in column n (entries below the diagonal are not cleared).
+__device__ __forceinline__ void wv_qr_inplace(double* G, int ld, int rows, int n, double* hv) {
   const int l = threadIdx.x & 63;
   for (int k = 0; k < n; ++k) {
     double part = 0.0; for (int i = k + l; i < rows; i += 64) part += G[i * ld + k] * G[i * ld + k];
@@ -111,14 +113,23 @@ __device__ __forceinline__ void wv_ls_qr(double* G, int ld, int rows, int n, dou
     if (l == k) G[k * ld + k] = alpha;
     qm_wave_sync();
   }
-  double zj = 0.0;
+}
+// R z = rhs with R = upper triangle of G[0:n, 0:n]; rhs is a strided vector (rhs[i * rs]); z -> LDS vector
+__device__ __forceinline__ void wv_backsub(const double* G, int ld, int n, const double* rhs, int rs, double* z) {
+  const int l = threadIdx.x & 63; double zj = 0.0;
   for (int i = n - 1; i >= 0; --i) {
     const double s = wv_sum((l > i && l < n) ? G[i * ld + l] * zj : 0.0);
-    const double zi = (G[i * ld + n] - s) / G[i * ld + i];
+    const double zi = (rhs[i * rs] - s) / G[i * ld + i];
     if (l == i) zj = zi;
   }
+  qm_wave_sync();
   if (l < n) z[l] = zj;
   qm_wave_sync();
+}
+// Householder least squares: min |G[:, :n] z − G[:, n]|
+__device__ __forceinline__ void wv_ls_qr(double* G, int ld, int rows, int n, double* hv, double* z) {
+  wv_qr_inplace(G, ld, rows, n, hv);
+  wv_backsub(G, ld, n, G + n, ld, z);
 }
 // Householder QR of Eᵀ (n x me) for E (me x n, ld = WNV): reflectors V[k][0..n) (zero above k), beta[k], R (me x me upper, ld = WMAXACT)
 __device__ __forceinline__ void wv_qr_Et(const double* E, int me, int n, double* V, double* beta, double* R) {
@@ -178,37 +189,36 @@ __device__ __forceinline__ void wv_Z_times(const double* Zp, int n, const double
   qm_wave_sync();
 }
 
-// min |G0 z − g0|² s.t. E z = e (me active rows).  G0 = [AZ; sqrt(rho) I] is rebuilt into G each call.  lam: multipliers.
-__device__ __forceinline__ void wv_eq_ls(double* S, int ra, int n, int me, double* zout) {
+// min |R z − c|² s.t. E z = e (me working-set rows in WL_EROWS / WL_ERHS), null-space method.  Rc = [R | c] (n x (n+1), ld WGLD,
+// upper triangle valid) is the once-per-level QR factor of G0 = [AZ; sqrt(rho) I | g0]; T (n x (n+1), ld WGLD) is scratch.  lam: multipliers.
+__device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* T, int n, int me, double* zout) {
   const int l = threadIdx.x & 63;
-  double* G = S + WL_G; const double* AZ = S + WL_AZ; const double* g0 = S + WL_G0RHS;
-  const int rows0 = ra + n;
-  for (int idx = l; idx < rows0 * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (k == n) ? g0[r] : (r < ra ? AZ[r * WNV + k] : ((r - ra) == k ? sqrt(WRHO) : 0.0)); }
-  qm_wave_sync();
-  if (me == 0) { wv_ls_qr(G, WGLD, rows0, n, S + WL_HV, zout); return; }
+  if (me == 0) { wv_backsub(Rc, WGLD, n, Rc + n, WGLD, zout); return; }
   double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
+  for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); T[r * WGLD + k] = (k >= r) ? Rc[r * WGLD + k] : 0.0; }
   wv_qr_Et(S + WL_EROWS, me, n, V, beta, R);
-  if (l == 0) for (int i = 0; i < me; ++i) { double s = e[i]; for (int k = 0; k < i; ++k) s -= R[k * WMAXACT + i] * y[k]; y[i] = s / R[i * WMAXACT + i]; }   // Rᵀ y1 = e
-  // G <- G Q (row-wise reflections; lane = row), rhs column untouched
-  for (int k = 0; k < me; ++k) { const double* v = V + k * WNV; for (int r = l; r < rows0; r += 64) { double* g = G + r * WGLD; double s = 0.0; for (int i = k; i < n; ++i) s += g[i] * v[i]; s *= beta[k]; for (int i = k; i < n; ++i) g[i] -= s * v[i]; } }
+  { double y1 = 0.0;                                          // R_Eᵀ y1 = e
+    for (int i = 0; i < me; ++i) { const double sacc = wv_sum((l < i) ? R[l * WMAXACT + i] * y1 : 0.0); const double v = (e[i] - sacc) / R[i * WMAXACT + i]; if (l == i) y1 = v; }
+    if (l < me) y[l] = y1; }
+  // T <- T Q (row-wise reflections; lane = row), rhs column untouched
+  if (l < n) { double* g = T + l * WGLD; for (int k = 0; k < me; ++k) { const double* v = V + k * WNV; double sacc = 0.0; for (int i = k; i < n; ++i) sacc += g[i] * v[i]; sacc *= beta[k]; for (int i = k; i < n; ++i) g[i] -= sacc * v[i]; } }
   qm_wave_sync();
-  for (int r = l; r < rows0; r += 64) { double s = 0.0; for (int k = 0; k < me; ++k) s += G[r * WGLD + k] * y[k]; G[r * WGLD + n] -= s; }
+  if (l < n) { double sacc = 0.0; for (int k = 0; k < me; ++k) sacc += T[l * WGLD + k] * y[k]; T[l * WGLD + n] -= sacc; }
   qm_wave_sync();
-  if (n - me > 0) {
-    // reduced problem on columns me..n-1; its rhs must sit right after them: move column n to column n (already there relative to G + me)
-    wv_ls_qr(G + me, WGLD, rows0, n - me, S + WL_HV, y + me);
-  }
+  if (n - me > 0) wv_ls_qr(T + me, WGLD, n, n - me, S + WL_HV, y + me);   // reduced problem on columns me..n-1 (rhs right after them)
   if (l < n) zout[l] = y[l];
   qm_wave_sync();
   wv_apply_Q(V, beta, me, n, zout);
-  // multipliers: R lam = −(Qᵀ G0ᵀ (G0 z − g0))[0:me]
+  // multipliers: R_E lam = −(Qᵀ Rᵀ (R z − c))[0:me]
   double* w = S + WL_W36; double* res = S + WL_HV;
-  for (int r = l; r < rows0; r += 64) { double s = -g0[r]; if (r < ra) { for (int k = 0; k < n; ++k) s += AZ[r * WNV + k] * zout[k]; } else s += sqrt(WRHO) * zout[r - ra]; res[r] = s; }
+  if (l < n) { double sacc = -Rc[l * WGLD + n]; for (int k = l; k < n; ++k) sacc += Rc[l * WGLD + k] * zout[k]; res[l] = sacc; }
   qm_wave_sync();
-  if (l < n) { double acc = 0.0; for (int r = 0; r < ra; ++r) acc += AZ[r * WNV + l] * res[r]; acc += sqrt(WRHO) * res[ra + l]; w[l] = acc; }
+  if (l < n) { double acc = 0.0; for (int r = 0; r <= l; ++r) acc += Rc[r * WGLD + l] * res[r]; w[l] = acc; }
   qm_wave_sync();
   wv_apply_Qt(V, beta, me, n, w);
-  if (l == 0) for (int i = me - 1; i >= 0; --i) { double s = -w[i]; for (int j = i + 1; j < me; ++j) s -= R[i * WMAXACT + j] * lam[j]; lam[i] = s / R[i * WMAXACT + i]; }
+  { double lm = 0.0;
+    for (int i = me - 1; i >= 0; --i) { const double sacc = wv_sum((l > i && l < me) ? R[i * WMAXACT + l] * lm : 0.0); const double v = (-w[i] - sacc) / R[i * WMAXACT + i]; if (l == i) lm = v; }
+    if (l < me) lam[l] = lm; }
   qm_wave_sync();
 }
 
@@ -445,33 +455,73 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       if (l < C.nIneq) w0[l] = fmax(0.0, Dz[l] - fb[l]);
       qm_wave_sync();
     } else {
-      // hard rows of level 0: primal active set (Nocedal & Wright 16.3) from the feasible z = 0
+      // hard rows of level 0: primal active set (Nocedal & Wright 16.3) from the feasible z = 0.  Factor G0 = [A Zp; sqrt(rho) I | g0]
+      // = Q [R | c] once (|G0 z − g0|² = |R z − c|² + const) and form DZ = D0 Zp once; an iteration then only touches n x n data.
       wv_d0_apply(C, x, tau, Dz);
       if (l < C.nIneq) fb[l] = f0[l] - Dz[l] + w0[l];
+      for (int idx = l; idx < rows0 * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (k == n) ? g0[r] : (r < ra ? AZ[r * WNV + k] : ((r - ra) == k ? sqrt(WRHO) : 0.0)); }
       qm_wave_sync();
-      int W[WMAXACT]; int nw = 0; int it = 0; bool degenerate = false; double pscale = 0.0;
+      wv_qr_inplace(G, WGLD, rows0, n, S + WL_HV);
+      double* Tm = S + WL_G + 20 * WGLD;                 // scratch of wv_eq_ls_R (n <= 18 rows); [R | c] stays in G rows 0..n-1
+      double* DZ = S + WL_G + 40 * WGLD;                 // DZ [nIneq][18]
+      if (l < C.nIneq) {
+        double d[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) d[k] = 0.0;
+        for (int r = 0; r < WNV; ++r) { const double e = wbc_d0_entry(C, l, r); if (e != 0.0) {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) if (k < n) d[k] += e * Zp[r * n + k]; } }
+#pragma unroll
+        for (int k = 0; k < 18; ++k) if (k < n) DZ[l * 18 + k] = d[k];
+      }
+      qm_wave_sync();
+      int* Wi = (int*)(S + WL_WLIST);                    // working-set list lives in LDS (wave-uniform reads)
+      unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false; double pscale = 0.0;
       for (; it < 100; ++it) {
-        for (int q2 = 0; q2 < nw; ++q2) { wv_d0_row_Z(C, W[q2], Zp, n, S + WL_EROWS + q2 * WNV); if (l == 0) S[WL_ERHS + q2] = fb[W[q2]]; }
+        for (int idx = l; idx < nw * n; idx += 64) { const int q2 = idx / n, k = idx - q2 * n; S[WL_EROWS + q2 * WNV + k] = DZ[Wi[q2] * 18 + k]; }
+        if (l < nw) S[WL_ERHS + l] = fb[Wi[l]];
         qm_wave_sync();
-        wv_eq_ls(S, ra, n, nw, zn);
+        wv_eq_ls_R(S, G, Tm, n, nw, zn);
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
         const double pn = wv_max((l < n) ? fabs(p[l]) : 0.0), zs = fmax(1.0, wv_max((l < n) ? fabs(z[l]) : 0.0));
         pscale = fmax(pscale, pn);
+#ifdef QM_WBC_TRACE
+        if (l == 0) { printf("L%d it %d nw %d pn %.3e zs %.3e pscale %.3e W:", level, it, nw, pn, zs, pscale); for (int q2 = 0; q2 < nw; ++q2) printf(" %d(%.2e)", Wi[q2], lam[q2]); printf("\n"); }
+#endif
         if (pn <= 1e-9 * fmax(zs, pscale)) {
-          int worst = -1; double lw = 0.0, lscale = 1.0; for (int q2 = 0; q2 < nw; ++q2) lscale = fmax(lscale, fabs(lam[q2]));
-          for (int q2 = 0; q2 < nw; ++q2) if (lam[q2] < -1e-9 * lscale) { if (degenerate) { if (worst < 0 || W[q2] < W[worst]) worst = q2; } else if (lam[q2] < lw) { lw = lam[q2]; worst = q2; } }
+          // stationary on the working set: drop a row with a negative multiplier (most negative; lowest constraint index after a degenerate step — Bland)
+          const double mylam = (l < nw) ? lam[l] : 0.0; const double lscale = fmax(1.0, wv_max(fabs(mylam)));
+          const bool cand = (l < nw) && (mylam < -1e-9 * lscale);
+          int worst;
+          if (degenerate) { int key = cand ? Wi[l] * 64 + l : (1 << 28); for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; } worst = (key == (1 << 28)) ? -1 : (key & 63); }
+          else { const double lmin = -wv_max(cand ? -mylam : -1e300); int key = (cand && mylam == lmin) ? l : 64; for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; } worst = (key == 64) ? -1 : key; }
           if (worst < 0) break;
-          for (int q2 = worst; q2 < nw - 1; ++q2) W[q2] = W[q2 + 1]; --nw;
-        } else {
-          wv_Z_times(Zp, n, z, Zz); wv_Z_times(Zp, n, p, Zpv);
-          wv_d0_apply(C, Zz, tau, Dz); wv_d0_apply(C, Zpv, tau, Dp);
-          double al = 1.0; int block = -1;
-          for (int i = 0; i < C.nIneq; ++i) { bool inW = false; for (int q2 = 0; q2 < nw; ++q2) if (W[q2] == i) inW = true; if (inW) continue; if (Dp[i] > 1e-10 * fmax(1.0, pn)) { const double aa = fmax(0.0, (fb[i] - Dz[i]) / Dp[i]); if (aa < al) { al = aa; block = i; } } }
-          if (l < n) z[l] += al * p[l];
+          wmask &= ~(1ull << Wi[worst]);
+          const int nxt = (l + 1 < nw) ? Wi[l + 1] : 0;
           qm_wave_sync();
+          if (l >= worst && l + 1 < nw) Wi[l] = nxt;
+          --nw;
+          qm_wave_sync();
+        } else {
+          double aa = 1e300;
+          if (l < C.nIneq && !((wmask >> l) & 1ull)) {
+            double dp = 0.0, dz = 0.0;
+#pragma unroll
+            for (int k = 0; k < 18; ++k) if (k < n) { const double dk = DZ[l * 18 + k]; dp += dk * p[k]; dz += dk * z[k]; }
+            if (dp > 1e-10 * fmax(1.0, pn)) aa = fmax(0.0, (fb[l] - dz) / dp);
+          }
+          const double amin = -wv_max(-aa);
+          double al = 1.0; int block = -1;
+          if (amin < 1.0) { al = amin; int key = (aa == amin) ? l : 64; for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; } block = key; }
+          qm_wave_sync();
+          if (l < n) z[l] += al * p[l];
+#ifdef QM_WBC_TRACE
+          if (l == 0) printf("   step al %.6e block %d\n", al, block);
+#endif
           degenerate = (al <= 1e-12);
-          if (block >= 0) { if (nw < n && nw < WMAXACT) W[nw++] = block; else { status[level] = 2; break; } }
+          if (block >= 0) { if (nw < n && nw < WMAXACT) { if (l == 0) Wi[nw] = block; wmask |= (1ull << block); ++nw; } else { status[level] = 2; qm_wave_sync(); break; } }
+          qm_wave_sync();
         }
       }
       if (it >= 100 && status[level] == 0) status[level] = 1;
