@@ -30,9 +30,10 @@ struct QmWbcArgs {
   double* out;                                // [B][54]
   int* qp_status;                             // [B][3]  0 ok, 1 iteration limit (nWSR=100), 2 working set overflow
   double* scratch; int sstride;               // unused by the wave kernel (kept so the pipeline ABI is stable)
+  int stop;                                   // profiling only: 1 return after the rigid-body phase, 2/3/4 after level 0/1/2 (no outputs)
   double* dbg;                                // optional [B][WBC_DBG_SIZE]: qMeas vMeas qDes vDes baseAcc nle x0 x1 x2 M J dJv
 };
-#define WBC_SCRATCH 8
+#define WBC_SCRATCH 16   /* per-instance phase cycle counters (profiling, stop < 0) */
 #define WBC_DBG_SIZE (24 * 4 + 6 + 24 + 36 * 3 + 576 + 288 + 12)
 #define WBC_BLOCK 64
 
@@ -270,6 +271,8 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   double* S = qm_smem;
   const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = (long long)__builtin_readcyclecounter();
+#define WT(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; }
   const double* mb = a.mb; const double* st = a.st;
   const double* xDes = a.x_des + (size_t)b * 30; const double* uDes = a.u_des + (size_t)b * 30; const double* rbd = a.rbd + (size_t)b * QM_NRBD;
   const int mode = a.mode[b]; const double time = a.time[b];
@@ -355,6 +358,8 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
     for (int i = 0; i < 3; ++i) { baseAcc[i] = rate[i] / m - t[i]; baseAcc[3 + i] = thdd[i]; }
   }
   qm_wave_sync();
+  if (a.stop == 1) return;
+  WT(0)
   // ---- cascade ----
   double* A = S + WL_A; double* bb = S + WL_BB; double* AZ = S + WL_AZ; double* Zp = S + WL_ZP; double* x = S + WL_X; double* z = S + WL_Z; double* zn = S + WL_ZN; double* p = S + WL_P;
   double* f0 = S + WL_F0; double* w0 = S + WL_W0; double* fb = S + WL_FB; double* Dz = S + WL_DZ; double* Dp = S + WL_DP; double* tau = S + WL_TAU; double* g0 = S + WL_G0RHS; double* G = S + WL_G;
@@ -418,6 +423,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
     if (l < WNV) z[l] = 0.0;
     qm_wave_sync();
     const int rows0 = ra + n;
+    WT(1)
     if (level == 0) {
       // own (soft) inequality rows: Newton on the active set with exact line search (phi is convex piecewise quadratic)
       wv_d0_apply(C, x, tau, Dz);
@@ -430,22 +436,30 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
         int na = 0;
         for (int i = 0; i < C.nIneq && na < WMAXACT; ++i) if ((actmask >> i) & 1ull) { wv_d0_row_Z(C, i, Zp, n, G + (rows0 + na) * WGLD); if (l == 0) G[(rows0 + na) * WGLD + n] = fb[i]; ++na; }
         qm_wave_sync();
+        WT(2)
         wv_ls_qr(G, WGLD, rows0 + na, n, S + WL_HV, zn);
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
+        WT(3)
         wv_Z_times(Zp, n, z, Zz); wv_Z_times(Zp, n, p, Zpv);
         wv_d0_apply(C, Zz, tau, Dz); wv_d0_apply(C, Zpv, tau, Dp);
         double c0p = 0.0, c1p = 0.0;   // smooth part of dphi: c0 + a c1
         for (int r = l; r < rows0; r += 64) { double gz = -g0[r], gp = 0.0; if (r < ra) { for (int k = 0; k < n; ++k) { gz += AZ[r * WNV + k] * z[k]; gp += AZ[r * WNV + k] * p[k]; } } else { gz += sqrt(WRHO) * z[r - ra]; gp = sqrt(WRHO) * p[r - ra]; } c0p += gz * gp; c1p += gp * gp; }
         const double c0 = wv_sum(c0p), c1 = wv_sum(c1p);
-        auto dphi = [&](double al) { double s = c0 + al * c1; for (int i = 0; i < C.nIneq; ++i) { const double vv = Dz[i] + al * Dp[i] - fb[i]; if (vv > 0.0) s += vv * Dp[i]; } return s; };
+        WT(4)
+        // exact line search on the convex piecewise-quadratic phi: bisection on dphi (lane i carries soft row i); the loop stops when the
+        // bracket cannot shrink any more, which leaves the same al as running all 200 halvings
+        const bool mine = (l < C.nIneq); const double myDz = mine ? Dz[l] : 0.0, myDp = mine ? Dp[l] : 0.0, myfb = mine ? fb[l] : 1.0;
+        auto dphi = [&](double al) { const double vv = myDz + al * myDp - myfb; return c0 + al * c1 + wv_sum((vv > 0.0) ? vv * myDp : 0.0); };
         double al = 1.0;
-        if (dphi(1.0) > 0.0) { double lo = 0.0, hi = 1.0; for (int bi = 0; bi < 200; ++bi) { const double mid = 0.5 * (lo + hi); if (dphi(mid) > 0.0) hi = mid; else lo = mid; } al = 0.5 * (lo + hi); }
+        if (dphi(1.0) > 0.0) { double lo = 0.0, hi = 1.0; for (int bi = 0; bi < 200; ++bi) { const double mid = 0.5 * (lo + hi); if (mid == lo || mid == hi) break; if (dphi(mid) > 0.0) hi = mid; else lo = mid; } al = 0.5 * (lo + hi); }
+        WT(5)
         const double pn = wv_max((l < n) ? fabs(al * p[l]) : 0.0);
         if (l < n) z[l] += al * p[l];
-        unsigned long long nm = 0ull; for (int i = 0; i < C.nIneq; ++i) if (Dz[i] + al * Dp[i] - fb[i] > 0.0) nm |= (1ull << i);
+        const unsigned long long nm = __ballot((l < C.nIneq) && (Dz[l] + al * Dp[l] - fb[l] > 0.0));
         const bool same = (nm == actmask); actmask = nm;
         qm_wave_sync();
+        WT(6)
         if (same && al == 1.0) break;
         const double zs = fmax(1.0, wv_max((l < n) ? fabs(z[l]) : 0.0));
         if (pn <= 1e-12 * zs) break;
@@ -475,13 +489,16 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
         for (int k = 0; k < 18; ++k) if (k < n) DZ[l * 18 + k] = d[k];
       }
       qm_wave_sync();
+      WT(8)
       int* Wi = (int*)(S + WL_WLIST);                    // working-set list lives in LDS (wave-uniform reads)
       unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false; double pscale = 0.0;
       for (; it < 100; ++it) {
         for (int idx = l; idx < nw * n; idx += 64) { const int q2 = idx / n, k = idx - q2 * n; S[WL_EROWS + q2 * WNV + k] = DZ[Wi[q2] * 18 + k]; }
         if (l < nw) S[WL_ERHS + l] = fb[Wi[l]];
         qm_wave_sync();
+        WT(10)
         wv_eq_ls_R(S, G, Tm, n, nw, zn);
+        WT(9)
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
         const double pn = wv_max((l < n) ? fabs(p[l]) : 0.0), zs = fmax(1.0, wv_max((l < n) ? fabs(z[l]) : 0.0));
@@ -529,7 +546,10 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
     wv_Z_times(Zp, n, z, Zz);
     if (l < WNV) { x[l] += Zz[l]; S[WL_XLEV + level * WNV + l] = x[l]; }
     qm_wave_sync();
+    if (a.stop == 2 + level) return;
+    WT(10)
     if (level < 2) nz = wv_null_space(S, ra, n);
+    WT(7)
     if (level > 0 && status[level] == 0 && status[level - 1] != 0) status[level] = status[level - 1];
   }
   // ---- updateCmd (WbcBase.cpp:548-563) ----
@@ -538,6 +558,9 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   if (l < WNV) out[l] = x[l];
   if (l < 18) out[WNV + l] = tau[l] + nle[6 + l];
   if (l < 3) a.qp_status[b * 3 + l] = status[l];
+  WT(11)
+  if (a.stop < 0 && l == 0) for (int k = 0; k < 12; ++k) a.scratch[(size_t)b * WBC_SCRATCH + k] = (double)tacc[k];
+#undef WT
   if (a.dbg) {
     double* d = a.dbg + (size_t)b * WBC_DBG_SIZE;
     if (l < 24) { d[l] = q[l]; d[24 + l] = v[l]; d[48 + l] = qd[l]; d[72 + l] = vd[l]; d[102 + l] = nle[l]; }

@@ -14,3 +14,20 @@ for name, mask in (("full", 0), ("no_chol_solve", 1), ("no_closed_loop", 2), ("n
     for _ in range(3): mpc.solve_resident(cfg["horizon"])
     ms, n = itf.kernel_ms("riccati"); out[name] = ms / n; itf.set_profiling(False)
 print(json.dumps(out, indent=1))
+# K4 (WBC): cumulative time up to each phase boundary
+wout = {}
+for name, stop in (("full", 0), ("rigid_body", 1), ("+level0", 2), ("+level1", 3), ("+level2 (no output stage)", 4)):
+    itf.debug_set("riccati_skip", 0); itf.debug_set("wbc_stop", stop)
+    mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
+    itf.set_profiling(True); itf.reset_kernel_ms()
+    for _ in range(3): mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+    ms, n = itf.kernel_ms("wbc"); wout[name] = ms / n; itf.set_profiling(False)
+print(json.dumps(wout, indent=1))
+# K4 in-kernel cycle counters (lane 0 of each instance), mean over instances
+itf.debug_set("wbc_stop", -1)
+mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
+import numpy as np
+cyc = itf.debug_read("wbc_scratch", (B, 16))
+names = ["init+rigid_body", "task build + AZ/g0", "L0 G build + active rows", "L0 QR solve", "L0 Z_times/d0_apply/c0c1", "L0 line search", "L0 iteration tail", "null space", "L>=1 factor + DZ", "L>=1 eq_ls_R", "L>=1 iteration rest / level tail", "output"]
+print(json.dumps({n: float(cyc[:, i].mean()) for i, n in enumerate(names)}, indent=1)); print("total cycles/instance", cyc[:, :12].sum(1).mean())
+itf.debug_set("wbc_stop", 0)
