@@ -95,7 +95,7 @@ struct QmMpcPipeline {
     QmLsArgs l = ls_args(B);
     { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, (B + 63) / 64, 64, 0, lb); }
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
-    bk.launch(qm_riccati_kernel, B, QM_BLOCK, RC_LDS_BYTES, r);
+    bk.launch(qm_riccati_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // one wavefront per instance
     // line search: alpha = 1, done = 0
     std::vector<double> ones((size_t)B, 1.0); bk.to_device(d.alpha, ones.data(), (size_t)B * 8); bk.zero(d.done, (size_t)B * 4);
     std::vector<int> done_h((size_t)B);

@@ -68,6 +68,13 @@ __device__ __forceinline__ bool mode_flag(int mode, int contact) { return (mode 
 // wave-level ordering point for LDS traffic inside ONE wavefront (no s_barrier: a wave's DS ops retire in order)
 __device__ __forceinline__ void qm_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
+// value of lane `src` (wave-uniform index) in every lane: two v_readlane_b32, the result lives in SGPRs
+__device__ __forceinline__ double qm_bcast(double v, int src) {
+  union { double d; int i[2]; } u; u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], src); u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+  return u.d;
+}
+
 // strided view of a per-instance array living in a lane-interleaved HBM workspace: element i of instance b sits at
 // base[i * stride + b], so the 64 lanes of a wave (consecutive instances) touch consecutive addresses
 struct QmSPtr {
@@ -126,8 +133,8 @@ __device__ __forceinline__ double tile_col_dot(const double* T, int col, const d
 #define SR_QPV  4674                   /* [30]                          */
 #define SR_RPV  4704                   /* [18]                          */
 #define SR_PE   4722                   /* [30]                          */
-#define SR_K    4752                   /* [18][30]  Riccati feedback (written by K3) */
-#define SR_KFF  5292                   /* [18]                          */
+#define SR_K    4752                   /* [18][30]  unused (feedback gains are not formed: the reference runs a feedforward policy) */
+#define SR_KFF  5292                   /* [18]  y = L⁻¹ hu (written by K3) */
 #define SR_SCAL 5310                   /* [0]=m (as double) [1]=cp      */
 #define SR_SIZE 5312
 

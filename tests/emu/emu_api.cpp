@@ -53,5 +53,5 @@ void emu_control_step(void* h, int B, double horizon, double period, double time
   c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time); c->wbc.step(c->mpc.d, B, period, 0);
   memcpy(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); memcpy(status, c->wbc.w.qp_status, (size_t)B * 3 * 4); if (rbd_out) memcpy(rbd_out, c->wbc.w.rbd, (size_t)B * QM_NRBD * 8);
 }
-int emu_sizes(int which) { int v[] = {SR_SIZE, LQ_DBG_SIZE, PF_SIZE, LQ_LDS_BYTES, RC_LDS_BYTES, WBC_DBG_SIZE}; return v[which]; }
+int emu_sizes(int which) { int v[] = {SR_SIZE, LQ_DBG_SIZE, PF_SIZE, LQ_LDS_BYTES, RW_LDS_BYTES, WBC_DBG_SIZE}; return v[which]; }
 }

@@ -95,13 +95,15 @@ inline double __shfl(double v, int src, int width = 64) {
 }
 inline double __shfl_xor(double v, int mask, int width = 64) { return __shfl(v, (emu::cur().lane % width) ^ mask, width); }
 inline double __shfl_down(double v, int delta, int width = 64) { const int l = emu::cur().lane % width; return __shfl(v, (l + delta < width) ? l + delta : l, width); }
+inline int __shfl(int v, int src, int width = 64);
+#define __builtin_amdgcn_readlane(v, lane) __shfl((int)(v), (int)(lane), 64)
 inline unsigned long long __ballot(int pred) {
   emu::Block* blk = emu::B; const int w = emu::cur().wave, l = emu::cur().lane;
   blk->xa[w * 64 + l] = pred ? 1.0 : 0.0; emu::wavesync();
   unsigned long long m = 0ull; for (int i = 0; i < 64; ++i) if (blk->xa[w * 64 + i] != 0.0) m |= (1ull << i);
   emu::wavesync(); return m;
 }
-inline int __shfl(int v, int src, int width = 64) { return (int)__shfl((double)v, src, width); }
+inline int __shfl(int v, int src, int width) { return (int)__shfl((double)v, src, width); }
 inline int __shfl_xor(int v, int mask, int width = 64) { return (int)__shfl_xor((double)v, mask, width); }
 
 using std::sqrt; using std::sin; using std::cos; using std::fabs; using std::fma; using std::acos; using std::log; using std::fmin; using std::fmax;
