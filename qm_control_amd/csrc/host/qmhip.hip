@@ -80,7 +80,7 @@ __global__ void qm_bench_mfma_kernel(double* out, int iters) {
 }
 
 static int create_common(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
-  if (!out || max_batch <= 0 || max_nodes < 3 || max_ref < 1 || max_ev < 1) { g_create_error = "qmhip_create: bad argument"; return QMHIP_ERR_ARG; }
+  if (!out || max_batch <= 0 || max_nodes < 3 || max_nodes > RW_MAXNODES || max_ref < 1 || max_ev < 1) { g_create_error = "qmhip_create: bad argument (max_nodes must be in [3, 512])"; return QMHIP_ERR_ARG; }
   std::string err; if (!qmio::validateModelBlob(mb, err)) { g_create_error = err; return QMHIP_ERR_MODEL; }
   int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (libqmhip has no CPU fallback)"; return QMHIP_ERR_HIP; }
   if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return QMHIP_ERR_ARG; }

@@ -32,14 +32,25 @@ struct QmRiccatiArgs {
   double* stage;                               // [B][nmax][SR_SIZE]  (L, W, y are written here)
   double* dx; double* du;                      // [nmax][B][30]
   double* step_info;                           // [B][4]: armijo, |dx|², |du|², chol status
-  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise; results are then meaningless)
+  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages; results are then meaningless)
 };
 
 #define RW_BLOCK 64
 #define RW_TLD 34                 /* transposition buffer [32][34] */
 #define RW_CLD 66                 /* Cholesky staging [18][66]: lanes 0..17 Huu columns, lanes 32..62 [Hux | hu] columns */
-#define RW_LDS_DOUBLES 1200
+/* forward staging (aliases the backward buffers): rows padded so that one-row-per-lane reads are bank-conflict free */
+#define RF_A   0                  /* [30][31] Ap */
+#define RF_B   930                /* [30][19] Bp */
+#define RF_PX  1500               /* [30][31] Px */
+#define RF_PU  2430               /* [30][19] Pu */
+#define RF_W   3000               /* [18][31] W  */
+#define RF_L   3558               /* [18][19] L (diagonal holds 1/L_jj) */
+#define RF_V   3900               /* bp(30) qp(30) rp(18) Pe(30) | y(18) */
+#define RF_LIST 4032              /* int list[RW_MAXNODES]: m | event tag << 8 per node */
+#define RW_MAXNODES 512
+#define RW_LDS_DOUBLES (RF_LIST + RW_MAXNODES / 2)
 #define RW_LDS_BYTES (RW_LDS_DOUBLES * 8)
+#define RF_NLOAD 61               /* ceil((1440 + 2304 + 108 + 18) / 64) */
 
 // P += (neg ? −1 : 1) · Zᵀ Y over k-steps [0, ksteps); Z: [KT][IT] tiles, Y: [KT][JT] tiles, P: [IT][JT] tiles (all D-layout)
 template <int KT, int IT, int JT>
@@ -79,14 +90,21 @@ __device__ __forceinline__ void rw_load(qm_d4 (&T)[IT][JT], const double* src, i
 
 // one regular stage of the backward sweep; MT = number of 16-row tiles covering the m reduced inputs
 template <int MT>
-__device__ __forceinline__ void rw_stage(double* rec, int m, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip, int& chol_fail) {
+__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, int mnext, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2],
+                                         qm_d4 (&An)[2][2], qm_d4 (&Bn)[2][2], int skip, int& chol_fail) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
   qm_d4 A[2][2], Bm[2][MT], Hux[MT][2], Huu[MT][MT], Sn[2][2];
-  rw_load<2, 2>(A, rec + SR_AP, 30, 30, 30, rec + SR_BPV);          // [Ap | bp]
-  rw_load<2, MT>(Bm, rec + SR_BP, QM_MMAX, 30, m, nullptr);
+#pragma unroll
+  for (int I = 0; I < 2; ++I) {                                      // [Ap | bp], Bp were fetched while the previous stage computed
+#pragma unroll
+    for (int J = 0; J < 2; ++J) A[I][J] = An[I][J];
+#pragma unroll
+    for (int J = 0; J < MT; ++J) Bm[I][J] = Bn[I][J];
+  }
   rw_load<MT, 2>(Hux, rec + SR_PP, 30, m, 30, rec + SR_RPV);        // [Pp | rp]
   rw_load<MT, MT>(Huu, rec + SR_RP, QM_MMAX, m, m, nullptr);
   rw_load<2, 2>(Sn, rec + SR_QP, 30, 30, 30, rec + SR_QPV);         // [Qp | qp]
+  if (nrec) { rw_load<2, 2>(An, nrec + SR_AP, 30, 30, 30, nrec + SR_BPV); rw_load<2, 2>(Bn, nrec + SR_BP, QM_MMAX, 30, mnext, nullptr); }
   qm_d4 SA[2][2], SB[2][MT];
   rw_zero<2, 2>(SA); rw_zero<2, MT>(SB);
   if (!(skip & 2)) {
@@ -123,20 +141,25 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, double* buf, qm_d4 
 #pragma unroll
       for (int i = 0; i < QM_MMAX; ++i) if (i < 16 * MT) col[i] = 0.5 * (col[i] + buf[l * RW_CLD + i]);
     }
+    double myinv = 0.0;
 #pragma unroll
     for (int j = 0; j < QM_MMAX; ++j) if (j < m) {
       const double djj = qm_bcast(col[j], j);
       if (!(djj > 0.0)) chol_fail = 1;
-      const double d = sqrt(djj), inv = 1.0 / d;
-      const double lcj = col[j] * inv;                               // L[c][j] on the Huu lanes (symmetry), (L⁻¹ rhs)[j] on the rhs lanes
+      double inv = __builtin_amdgcn_rsq(djj);                        // 1/sqrt(djj): hardware estimate + two Newton steps
+      inv = fma(0.5 * inv, fma(-djj * inv, inv, 1.0), inv);
+      inv = fma(0.5 * inv, fma(-djj * inv, inv, 1.0), inv);
+      // lanes > j: col[j] <- L[c][j] (Huu lanes, by symmetry) resp. (L⁻¹ rhs)[j] (rhs lanes); trailing update col[i] -= H[i][j] col[j] / djj
+      const double cj = col[j];
+      const double upd = (l > j) ? cj * (inv * inv) : 0.0;
 #pragma unroll
-      for (int i = j + 1; i < QM_MMAX; ++i) {
-        const double lij = qm_bcast(col[i], j) * inv;
-        col[i] = (l > j) ? col[i] - lij * lcj : ((l == j) ? lij : col[i]);
-      }
-      col[j] = (l > j) ? lcj : ((l == j) ? d : col[j]);
+      for (int i = j + 1; i < QM_MMAX; ++i) col[i] = fma(-qm_bcast(col[i], j), upd, col[i]);
+      col[j] = (l > j) ? cj * inv : ((l == j) ? inv : cj);           // the diagonal keeps 1/L_jj
+      if (l == j) myinv = inv;
     }
-    // lane j < m now holds column j of L (rows >= j); lanes 32.. hold the columns of [W | y]
+#pragma unroll
+    for (int i = 1; i < QM_MMAX; ++i) if (l < i && l < m) col[i] *= myinv;     // lane j: L[i][j] = H[i][j] / L_jj
+    // lane j < m now holds column j of L (rows > j; row j holds 1/L_jj); lanes 32.. hold the columns of [W | y]
     qm_wave_sync();
 #pragma unroll
     for (int i = 0; i < QM_MMAX; ++i) if (i < m) {
@@ -187,14 +210,34 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, double* buf, qm_d4 
       }
 }
 
+// flat, fully coalesced fetch of everything the forward rollout needs from one stage record: element e of the concatenation
+// [Ap Bp | W L Px Pu | bp qp rp Pe | y] lives at record offset rf_src(e)
+__device__ __forceinline__ int rf_src(int e) { return (e < 1440) ? e : ((e < 3744) ? e + (SR_PP - 1440) : ((e < 3852) ? e + (SR_BPV - 3744) : e + (SR_KFF - 3852))); }
+// ... and goes to this (row-padded) LDS slot
+__device__ __forceinline__ int rf_dst(int e) {
+  if (e < 900) return RF_A + (e / 30) * 31 + e % 30;
+  if (e < 1440) { const int f = e - 900; return RF_B + (f / QM_MMAX) * 19 + f % QM_MMAX; }
+  if (e < 1980) { const int f = e - 1440; return RF_W + (f / 30) * 31 + f % 30; }
+  if (e < 2304) { const int f = e - 1980; return RF_L + (f / QM_MMAX) * 19 + f % QM_MMAX; }
+  if (e < 3204) { const int f = e - 2304; return RF_PX + (f / 30) * 31 + f % 30; }
+  if (e < 3744) { const int f = e - 3204; return RF_PU + (f / QM_MMAX) * 19 + f % QM_MMAX; }
+  return RF_V + (e - 3744);
+}
+#define RF_TOTAL 3870
+
 __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   extern __shared__ double qm_smem[];
   double* buf = qm_smem;
+  int* nlist = (int*)(qm_smem + RF_LIST);
+#define mlist(k) (nlist[k] & 255)
+#define evlist(k) (nlist[k] >> 8)
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15, b = blockIdx.x;
   if (b >= a.B) return;
   const int n = a.n_nodes[b];
+  for (int k = l; k < n; k += 64) { const int ev = a.node_ev[k * a.B + b]; const int mk = (ev == QM_EV_PRE) ? 0 : (int)a.stage[((size_t)b * a.nmax + k) * SR_SIZE + SR_SCAL]; nlist[k] = (mk & 255) | (ev << 8); }
+  qm_wave_sync();
   int chol_fail = 0;
-  qm_d4 S[2][2], sv[2];
+  qm_d4 S[2][2], sv[2], An[2][2], Bn[2][2];
   {   // terminal value function
     const double* rec = a.stage + ((size_t)b * a.nmax + (n - 1)) * SR_SIZE;
     rw_load<2, 2>(S, rec + SR_QP, 30, 30, 30, nullptr);
@@ -203,9 +246,12 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; sv[I][r] = (c == 14 && row < 30) ? rec[SR_QPV + row] : 0.0; }
   }
+  rw_zero<2, 2>(An); rw_zero<2, 2>(Bn);
+  { int k0 = n - 2; while (k0 >= 0 && evlist(k0) == QM_EV_PRE) --k0;
+    if (k0 >= 0) { const double* rec = a.stage + ((size_t)b * a.nmax + k0) * SR_SIZE; rw_load<2, 2>(An, rec + SR_AP, 30, 30, 30, rec + SR_BPV); rw_load<2, 2>(Bn, rec + SR_BP, QM_MMAX, 30, mlist(k0), nullptr); } }
   for (int k = n - 2; k >= 0; --k) {
     double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
-    if (a.node_ev[k * a.B + b] == QM_EV_PRE) {
+    if (evlist(k) == QM_EV_PRE) {
       // s += S (x_k − x_{k+1}): the defect rides in column 30 of a one-tile-wide right-hand side
       qm_d4 Y[2][1], P[2][1];
 #pragma unroll
@@ -219,54 +265,63 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
       for (int I = 0; I < 2; ++I) sv[I] += P[I][0];
       continue;
     }
-    const int m = (int)rec[SR_SCAL];
-    if (m <= 16) rw_stage<1>(rec, m, buf, S, sv, a.skip, chol_fail);
-    else rw_stage<2>(rec, m, buf, S, sv, a.skip, chol_fail);
+    if (a.skip & 16) continue;
+    int kn = k - 1; while (kn >= 0 && evlist(kn) == QM_EV_PRE) --kn;      // next regular stage: its [Ap | bp], Bp are prefetched
+    const double* nrec = (kn >= 0) ? a.stage + ((size_t)b * a.nmax + kn) * SR_SIZE : nullptr; const int mnext = (kn >= 0) ? mlist(kn) : 0;
+    const int m = mlist(k);
+    if (m <= 16) rw_stage<1>(rec, m, nrec, mnext, buf, S, sv, An, Bn, a.skip, chol_fail);
+    else rw_stage<2>(rec, m, nrec, mnext, buf, S, sv, An, Bn, a.skip, chol_fail);
   }
   // L, W, y were stored by other lanes than the ones that read them back below
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-  // ---- forward rollout: lanes 0..29 own the rows of [Ap Bp bp], lanes 32..61 the rows of [Px Pu Pe]; lanes 0..m-1 also own
-  //      row i of W and column i of L; lane c carries dx[c] ----
+  // ---- forward rollout.  Each stage record is fetched flat (512 B per wave instruction) one stage ahead into registers, dropped
+  //      into row-padded LDS, and consumed one matrix row per lane: lanes 0..29 rows of [Ap Bp bp], lanes 32..61 rows of
+  //      [Px Pu Pe], lanes 0..m-1 also row i of W and column i of L; lane c carries dx[c] ----
   double dxl = (l < 30) ? a.x0[(size_t)b * 30 + l] - a.x[(0 * a.B + b) * 30 + l] : 0.0;
   double armijo = 0.0, dx2 = 0.0, du2 = 0.0;
   const int half = l >> 5, r = l & 31;
+  double pf[RF_NLOAD];
+  auto fetch = [&](int k) {
+    const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
+#pragma unroll
+    for (int t = 0; t < RF_NLOAD; ++t) { const int e = t * 64 + l; pf[t] = (e < RF_TOTAL) ? rec[rf_src(e)] : 0.0; }
+  };
+  { int k0 = 0; while (k0 < n - 1 && evlist(k0) == QM_EV_PRE) ++k0; if (k0 < n - 1 && !(a.skip & 4)) fetch(k0); }
   for (int k = 0; k < n - 1; ++k) {
     if (a.skip & 4) break;
-    const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
     const int nb = k * a.B + b;
     if (l < 30) { a.dx[nb * 30 + l] = dxl; dx2 += dxl * dxl; }
-    if (a.node_ev[nb] == QM_EV_PRE) {
+    if (evlist(k) == QM_EV_PRE) {
       if (l < 30) { a.du[nb * 30 + l] = 0.0; dxl += a.x[nb * 30 + l] - a.x[((k + 1) * a.B + b) * 30 + l]; }
       continue;
     }
-    const int m = (int)rec[SR_SCAL];
-    double ra[30], rb[QM_MMAX], wr[30], lc[QM_MMAX];
-    const double* srcA = rec + (half ? SR_PX : SR_AP) + r * 30; const double* srcB = rec + (half ? SR_PU : SR_BP) + r * QM_MMAX;
+    const int m = mlist(k);
+    qm_wave_sync();
 #pragma unroll
-    for (int q = 0; q < 30; ++q) ra[q] = (r < 30) ? srcA[q] : 0.0;
+    for (int t = 0; t < RF_NLOAD; ++t) { const int e = t * 64 + l; if (e < RF_TOTAL) buf[rf_dst(e)] = pf[t]; }
+    qm_wave_sync();
+    { int kn = k + 1; while (kn < n - 1 && evlist(kn) == QM_EV_PRE) ++kn; if (kn < n - 1) fetch(kn); }
+    const int rr = (r < 30) ? r : 29, lw = (l < m) ? l : 0;          // idle lanes read a valid row and drop the result
+    const double* rowA = buf + (half ? RF_PX : RF_A) + rr * 31; const double* rowB = buf + (half ? RF_PU : RF_B) + rr * 19;
+    const double* rowW = buf + RF_W + lw * 31; const double* vecs = buf + RF_V;
+    double acc = vecs[half ? 78 + rr : rr];
+    double t = vecs[108 + lw];
+    const double qv = (l < 30) ? vecs[30 + l] : 0.0, rp = (l < m) ? vecs[60 + l] : 0.0;
 #pragma unroll
-    for (int q = 0; q < QM_MMAX; ++q) rb[q] = (r < 30 && q < m) ? srcB[q] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 30; ++q) wr[q] = (l < m) ? rec[SR_PP + l * 30 + q] : 0.0;
-#pragma unroll
-    for (int q = 0; q < QM_MMAX; ++q) lc[q] = (l < m && q >= l && q < m) ? rec[SR_RP + q * QM_MMAX + l] : 0.0;
-    double acc = (r < 30) ? rec[(half ? SR_PE : SR_BPV) + r] : 0.0;
-    double t = (l < m) ? rec[SR_KFF + l] : 0.0;
-    const double qv = (l < 30) ? rec[SR_QPV + l] : 0.0, rp = (l < m) ? rec[SR_RPV + l] : 0.0;
-#pragma unroll
-    for (int q = 0; q < 30; ++q) { const double dq = qm_bcast(dxl, q); t += wr[q] * dq; acc += ra[q] * dq; }
+    for (int q = 0; q < 30; ++q) { const double dq = qm_bcast(dxl, q); acc += rowA[q] * dq; t += rowW[q] * dq; }
     // Lᵀ v = t (lane i keeps v_i), ut = −v
     double v = 0.0;
 #pragma unroll
     for (int q = QM_MMAX - 1; q >= 0; --q) if (q < m) {
-      const double vq = qm_bcast(t / lc[q], q);          // lane q: t_q / L[q][q]
+      const double lq = (l <= q && l < m) ? buf[RF_L + q * 19 + l] : 0.0;   // L[q][l] (row q = l: 1/L_qq)
+      const double vq = qm_bcast(t * lq, q);
       if (l == q) v = vq;
-      t -= lc[q] * vq;                                    // lanes i < q: L[q][i] v_q   (lanes >= q: their t is dead)
+      t -= lq * vq;                                       // lanes i < q: L[q][i] v_q   (lane q: its t is dead)
     }
     const double ut = -v;
     armijo += qv * dxl + rp * ut;
 #pragma unroll
-    for (int q = 0; q < QM_MMAX; ++q) if (q < m) acc += rb[q] * qm_bcast(ut, q);
+    for (int q = 0; q < QM_MMAX; ++q) if (q < m) acc += rowB[q] * qm_bcast(ut, q);
     if (half && r < 30) { a.du[nb * 30 + r] = acc; du2 += acc * acc; }
     dxl = (l < 30) ? acc : 0.0;
   }
@@ -278,3 +333,5 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   for (int off = 32; off > 0; off >>= 1) { arm += __shfl_xor(arm, off, 64); sx += __shfl_xor(sx, off, 64); su += __shfl_xor(su, off, 64); }
   if (l == 0) { a.step_info[b * 4] = arm; a.step_info[b * 4 + 1] = sx; a.step_info[b * 4 + 2] = su; a.step_info[b * 4 + 3] = (double)chol_fail; }
 }
+#undef mlist
+#undef evlist

@@ -68,6 +68,7 @@ extern double qm_smem[];
 typedef double double4v __attribute__((ext_vector_type(4)));
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_wave_barrier() emu::wavesync()
+#define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 struct double2 { double x, y; };
 inline double2 make_double2(double a, double b) { double2 r; r.x = a; r.y = b; return r; }
