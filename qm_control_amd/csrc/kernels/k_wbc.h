@@ -85,8 +85,8 @@ struct QmWbcArgs {
 #define WL_TOTAL  (WL_XLEV + 3 * WNV)
 #define WBC_LDS_BYTES (WL_TOTAL * 8)
 
-__device__ __forceinline__ double wv_sum(double v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64); return v; }
-__device__ __forceinline__ double wv_max(double v) { for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64)); return v; }
+__device__ __forceinline__ double wv_sum(double v) { return qm_wave_sum(v); }
+__device__ __forceinline__ double wv_max(double v) { return qm_wave_max(v); }
 
 // rotation error log(R_l R_rᵀ) [upstream rotationErrorInWorld]
 __device__ __forceinline__ void dev_rot_error(const double* Rl, const double* Rr, double* err) {
@@ -97,23 +97,73 @@ __device__ __forceinline__ void dev_rot_error(const double* Rl, const double* Rr
   for (int i = 0; i < 3; ++i) err[i] = s * v[i];
 }
 
-// ---- wave-cooperative dense helpers (LDS, row-major) ----
-// Householder QR in place of G (rows x (n+1), column n = rhs), rows >= n; lane j owns column j.  Leaves R in the upper
-// triangle of G[0:n, 0:n] and Qᵀ rhs in column n (entries below the diagonal are not cleared).
-__device__ __forceinline__ void wv_qr_inplace(double* G, int ld, int rows, int n, double* hv) {
+// ---- wave-cooperative dense helpers ----
+// Householder QR on REGISTER-resident columns: lane j holds column j in col[0..MR) (rows beyond the matrix are zero); lanes
+// 0..n-1 are the matrix columns, lane n is the right-hand side.  After step k the registers move up one row, so the pivot is
+// always col[0] and every index is static; the pivot column reaches the other lanes through hv (LDS broadcast reads).
+// Row k of [R | Qᵀ rhs] is written to Rout[k * ldR + l], k <= l <= n.  With Vout the reflectors are kept:
+// Vout[k * ldV + k + i] = v_k[i] (zero above the pivot), beta[k] = 2 / (v·v) (0 for a null column).
+template <int MR>
+__device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, double* hv, double* Rout, int ldR, double* Vout, int ldV, double* beta) {
+  const int l = threadIdx.x & 63;
+  for (int k = 0; k < nsteps; ++k) {
+    qm_wave_sync();
+    if (l == k) {
+#pragma unroll
+      for (int i = 0; i < MR; ++i) hv[i] = col[i];
+    }
+    qm_wave_sync();
+    // pass 1 over the pivot column: its norm and this lane's dot product with it (the pivot entry itself is patched afterwards)
+    double nrm2 = 0.0, dot = 0.0;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) { const double vi = hv[i]; nrm2 += vi * vi; if (i > 0) dot += vi * col[i]; }
+    const double gkk = hv[0], nrm = sqrt(nrm2); const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = nrm2 - gkk * gkk + vk * vk;
+    const bool ok = (nrm2 != 0.0) && (vn != 0.0);
+    const double s = ok ? (dot + vk * col[0]) * (2.0 / vn) : 0.0;
+    const double r0 = (l == k && ok) ? alpha : col[0] - s * vk;
+    if (l >= k && l <= n) Rout[k * ldR + l] = r0;
+    if (Vout && l == k) {
+#pragma unroll
+      for (int i = 0; i < MR; ++i) if (k + i < ldV) Vout[k * ldV + k + i] = ok ? (i == 0 ? vk : col[i]) : 0.0;
+      beta[k] = ok ? 2.0 / vn : 0.0;
+    }
+    // pass 2: reflect and move up one row
+#pragma unroll
+    for (int i = 1; i < MR; ++i) col[i - 1] = col[i] - s * hv[i];
+    col[MR - 1] = 0.0;
+  }
+  qm_wave_sync();
+}
+// QR of [T; D]: T (n x (n+1), upper triangular with the rhs in column n, LDS, leading dim ldT) stacked on MRD dense rows held
+// by column in registers (lane j: d[0..MRD) = column j of D, lane n = its rhs, unused rows zero).  Step k only touches row k of T
+// and the dense rows, so a least-squares matrix [sqrt(rho) I; A] costs (1 + rows(A)) per column instead of n + rows(A).
+// On return T holds [R | Qᵀ rhs].
+template <int MRD>
+__device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ldT, int n, double* hv) {
   const int l = threadIdx.x & 63;
   for (int k = 0; k < n; ++k) {
-    double part = 0.0; for (int i = k + l; i < rows; i += 64) part += G[i * ld + k] * G[i * ld + k];
-    const double nrm2 = wv_sum(part);
-    if (nrm2 == 0.0) continue;
-    const double nrm = sqrt(nrm2), gkk = G[k * ld + k]; const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = nrm2 - gkk * gkk + vk * vk;
-    if (vn == 0.0) continue;
-    for (int i = k + l; i < rows; i += 64) hv[i] = (i == k) ? vk : G[i * ld + k];
     qm_wave_sync();
-    if (l > k && l <= n) { double s = 0.0; for (int i = k; i < rows; ++i) s += hv[i] * G[i * ld + l]; s *= 2.0 / vn; for (int i = k; i < rows; ++i) G[i * ld + l] -= s * hv[i]; }
-    if (l == k) G[k * ld + k] = alpha;
+    if (l == k) {
+#pragma unroll
+      for (int i = 0; i < MRD; ++i) hv[i] = d[i];
+    }
     qm_wave_sync();
+    const double tkk = T[k * ldT + k]; const double tl = (l >= k && l <= n) ? T[k * ldT + l] : 0.0;
+    double nrm2 = tkk * tkk, dot = 0.0;
+#pragma unroll
+    for (int i = 0; i < MRD; ++i) { const double vi = hv[i]; nrm2 += vi * vi; dot += vi * d[i]; }
+    const double nrm = sqrt(nrm2); const double alpha = tkk > 0.0 ? -nrm : nrm; const double vk = tkk - alpha; const double vn = nrm2 - tkk * tkk + vk * vk;
+    const bool ok = (nrm2 != 0.0) && (vn != 0.0);
+    const double s = ok ? (dot + vk * tl) * (2.0 / vn) : 0.0;
+    if (ok && l > k && l <= n) {
+      T[k * ldT + l] = tl - s * vk;
+#pragma unroll
+      for (int i = 0; i < MRD; ++i) d[i] -= s * hv[i];
+    }
+    qm_wave_sync();                                       // every lane has read the pivot before it is replaced
+    if (ok && l == k) T[k * ldT + k] = alpha;
   }
+  qm_wave_sync();
 }
 // R z = rhs with R = upper triangle of G[0:n, 0:n]; rhs is a strided vector (rhs[i * rs]); z -> LDS vector
 __device__ __forceinline__ void wv_backsub(const double* G, int ld, int n, const double* rhs, int rs, double* z) {
@@ -128,8 +178,13 @@ __device__ __forceinline__ void wv_backsub(const double* G, int ld, int n, const
   qm_wave_sync();
 }
 // Householder least squares: min |G[:, :n] z − G[:, n]|
+template <int MR>
 __device__ __forceinline__ void wv_ls_qr(double* G, int ld, int rows, int n, double* hv, double* z) {
-  wv_qr_inplace(G, ld, rows, n, hv);
+  const int l = threadIdx.x & 63;
+  double col[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) col[i] = (i < rows && l <= n) ? G[i * ld + l] : 0.0;
+  rq_house<MR>(col, n, n, hv, G, ld, nullptr, 0, nullptr);
   wv_backsub(G, ld, n, G + n, ld, z);
 }
 // Householder QR of Eᵀ (n x me) for E (me x n, ld = WNV): reflectors V[k][0..n) (zero above k), beta[k], R (me x me upper, ld = WMAXACT)
@@ -181,6 +236,7 @@ __device__ __forceinline__ double wbc_d0_entry(const WbcCtx& c, int i, int k) { 
 // row i of D0 times Zp (36 x n)  ->  dst[0..n)  (lane k = column k)
 __device__ __forceinline__ void wv_d0_row_Z(const WbcCtx& c, int i, const double* Zp, int n, double* dst) {
   const int l = threadIdx.x & 63;
+  if (n == WNV) { if (l < n) dst[l] = wbc_d0_entry(c, i, l); return; }     // level 0: Zp = I
   if (l < n) { double s = 0.0; for (int r = 0; r < WNV; ++r) { const double d = wbc_d0_entry(c, i, r); if (d != 0.0) s += d * Zp[r * n + l]; } dst[l] = s; }
 }
 // y(36) = Zp (36 x n) z
@@ -192,35 +248,47 @@ __device__ __forceinline__ void wv_Z_times(const double* Zp, int n, const double
 
 // min |R z − c|² s.t. E z = e (me working-set rows in WL_EROWS / WL_ERHS), null-space method.  Rc = [R | c] (n x (n+1), ld WGLD,
 // upper triangle valid) is the once-per-level QR factor of G0 = [AZ; sqrt(rho) I | g0]; T (n x (n+1), ld WGLD) is scratch.  lam: multipliers.
-__device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* T, int n, int me, double* zout) {
+__device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* T, int n, int me, double* zout, long long* tf) {
   const int l = threadIdx.x & 63;
+  long long tl_ = (long long)__builtin_readcyclecounter();
+#define WF(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tf[k] += now_ - tl_; tl_ = now_; }
   if (me == 0) { wv_backsub(Rc, WGLD, n, Rc + n, WGLD, zout); return; }
   double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
   for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); T[r * WGLD + k] = (k >= r) ? Rc[r * WGLD + k] : 0.0; }
+  WF(0)
   wv_qr_Et(S + WL_EROWS, me, n, V, beta, R);
+  WF(1)
   { double y1 = 0.0;                                          // R_Eᵀ y1 = e
     for (int i = 0; i < me; ++i) { const double sacc = wv_sum((l < i) ? R[l * WMAXACT + i] * y1 : 0.0); const double v = (e[i] - sacc) / R[i * WMAXACT + i]; if (l == i) y1 = v; }
     if (l < me) y[l] = y1; }
+  WF(2)
   // T <- T Q (row-wise reflections; lane = row), rhs column untouched
   if (l < n) { double* g = T + l * WGLD; for (int k = 0; k < me; ++k) { const double* v = V + k * WNV; double sacc = 0.0; for (int i = k; i < n; ++i) sacc += g[i] * v[i]; sacc *= beta[k]; for (int i = k; i < n; ++i) g[i] -= sacc * v[i]; } }
   qm_wave_sync();
   if (l < n) { double sacc = 0.0; for (int k = 0; k < me; ++k) sacc += T[l * WGLD + k] * y[k]; T[l * WGLD + n] -= sacc; }
   qm_wave_sync();
-  if (n - me > 0) wv_ls_qr(T + me, WGLD, n, n - me, S + WL_HV, y + me);   // reduced problem on columns me..n-1 (rhs right after them)
+  WF(3)
+  if (n - me > 0) wv_ls_qr<18>(T + me, WGLD, n, n - me, S + WL_HV, y + me);
+  WF(4)   // reduced problem on columns me..n-1 (rhs right after them)
   if (l < n) zout[l] = y[l];
   qm_wave_sync();
   wv_apply_Q(V, beta, me, n, zout);
+  WF(5)
   // multipliers: R_E lam = −(Qᵀ Rᵀ (R z − c))[0:me]
   double* w = S + WL_W36; double* res = S + WL_HV;
   if (l < n) { double sacc = -Rc[l * WGLD + n]; for (int k = l; k < n; ++k) sacc += Rc[l * WGLD + k] * zout[k]; res[l] = sacc; }
   qm_wave_sync();
   if (l < n) { double acc = 0.0; for (int r = 0; r <= l; ++r) acc += Rc[r * WGLD + l] * res[r]; w[l] = acc; }
   qm_wave_sync();
+  WF(6)
   wv_apply_Qt(V, beta, me, n, w);
+  WF(7)
   { double lm = 0.0;
     for (int i = me - 1; i >= 0; --i) { const double sacc = wv_sum((l > i && l < me) ? R[i * WMAXACT + l] * lm : 0.0); const double v = (-w[i] - sacc) / R[i * WMAXACT + i]; if (l == i) lm = v; }
     if (l < me) lam[l] = lm; }
   qm_wave_sync();
+  WF(8)
+#undef WF
 }
 
 // orthonormal null space of AZ (ra x n): Zp (36 x n) <- Zp · Q[:, rank:]  (Householder QR with column pivoting of (AZ)ᵀ); returns n − rank
@@ -271,7 +339,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   double* S = qm_smem;
   const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
-  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = (long long)__builtin_readcyclecounter();
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tfine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = (long long)__builtin_readcyclecounter();
 #define WT(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; }
   const double* mb = a.mb; const double* st = a.st;
   const double* xDes = a.x_des + (size_t)b * 30; const double* uDes = a.u_des + (size_t)b * 30; const double* rbd = a.rbd + (size_t)b * QM_NRBD;
@@ -432,12 +500,25 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       unsigned long long actmask = 0ull; for (int i = 0; i < C.nIneq; ++i) if (0.0 - fb[i] > 0.0) actmask |= (1ull << i);
       int it = 0;
       for (; it < 100; ++it) {
-        for (int idx = l; idx < rows0 * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (k == n) ? g0[r] : (r < ra ? AZ[r * WNV + k] : ((r - ra) == k ? sqrt(WRHO) : 0.0)); }
-        int na = 0;
-        for (int i = 0; i < C.nIneq && na < WMAXACT; ++i) if ((actmask >> i) & 1ull) { wv_d0_row_Z(C, i, Zp, n, G + (rows0 + na) * WGLD); if (l == 0) G[(rows0 + na) * WGLD + n] = fb[i]; ++na; }
+        // least squares [sqrt(rho) I; A | b; active soft rows | fb]: the triangular part sits in G, the dense rows in registers
+        for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (r == k) ? sqrt(WRHO) : 0.0; }
+        int* alist = (int*)(S + WL_WLIST);
+        if (l == 0) { int na0 = 0; for (int i = 0; i < C.nIneq && na0 < WMAXACT; ++i) if ((actmask >> i) & 1ull) alist[na0++] = i; }
+        int na = __popcll(actmask); if (na > WMAXACT) na = WMAXACT;
         qm_wave_sync();
-        WT(2)
-        wv_ls_qr(G, WGLD, rows0 + na, n, S + WL_HV, zn);
+        {
+          double d[WMAXA + WMAXACT];
+#pragma unroll
+          for (int r = 0; r < WMAXA; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
+#pragma unroll
+          for (int q2 = 0; q2 < WMAXACT; ++q2) { double v = 0.0; if (q2 < na && l <= n) { const int i = alist[q2]; v = (l == n) ? fb[i] : wbc_d0_entry(C, i, l); } d[WMAXA + q2] = v; }
+          WT(2)
+          rq_house_tri<WMAXA + WMAXACT>(d, G, WGLD, n, S + WL_HV);
+        }
+        wv_backsub(G, WGLD, n, G + n, WGLD, zn);
+#ifdef QM_WBC_TRACE
+        if (l == 0) printf("L0 it %d na %d ra %d n %d zn %.6e %.6e %.6e  Tdiag %.3e %.3e rhs %.3e %.3e\n", it, na, ra, n, zn[0], zn[1], zn[2], G[0], G[WGLD + 1], G[n], G[WGLD + n]);
+#endif
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
         WT(3)
@@ -473,9 +554,14 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       // = Q [R | c] once (|G0 z − g0|² = |R z − c|² + const) and form DZ = D0 Zp once; an iteration then only touches n x n data.
       wv_d0_apply(C, x, tau, Dz);
       if (l < C.nIneq) fb[l] = f0[l] - Dz[l] + w0[l];
-      for (int idx = l; idx < rows0 * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (k == n) ? g0[r] : (r < ra ? AZ[r * WNV + k] : ((r - ra) == k ? sqrt(WRHO) : 0.0)); }
+      for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (r == k) ? sqrt(WRHO) : 0.0; }
       qm_wave_sync();
-      wv_qr_inplace(G, WGLD, rows0, n, S + WL_HV);
+      {
+        double d[WMAXA];
+#pragma unroll
+        for (int r = 0; r < WMAXA; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
+        rq_house_tri<WMAXA>(d, G, WGLD, n, S + WL_HV);
+      }
       double* Tm = S + WL_G + 20 * WGLD;                 // scratch of wv_eq_ls_R (n <= 18 rows); [R | c] stays in G rows 0..n-1
       double* DZ = S + WL_G + 40 * WGLD;                 // DZ [nIneq][18]
       if (l < C.nIneq) {
@@ -497,7 +583,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
         if (l < nw) S[WL_ERHS + l] = fb[Wi[l]];
         qm_wave_sync();
         WT(10)
-        wv_eq_ls_R(S, G, Tm, n, nw, zn);
+        wv_eq_ls_R(S, G, Tm, n, nw, zn, tfine);
         WT(9)
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
@@ -560,6 +646,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   if (l < 3) a.qp_status[b * 3 + l] = status[l];
   WT(11)
   if (a.stop < 0 && l == 0) for (int k = 0; k < 12; ++k) a.scratch[(size_t)b * WBC_SCRATCH + k] = (double)tacc[k];
+  if (a.stop == -2 && l == 0) for (int k = 0; k < 9; ++k) a.scratch[(size_t)b * WBC_SCRATCH + k] = (double)tfine[k];
 #undef WT
   if (a.dbg) {
     double* d = a.dbg + (size_t)b * WBC_DBG_SIZE;

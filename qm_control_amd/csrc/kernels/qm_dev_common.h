@@ -75,6 +75,28 @@ __device__ __forceinline__ double qm_bcast(double v, int src) {
   return u.d;
 }
 
+// one DPP step on a double: src taken through the dpp control (row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143);
+// lanes outside the row mask or shifted in from outside the row keep `old`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double qm_dpp(double old, double src) {
+  union { double d; int i[2]; } o, v; o.d = old; v.d = src;
+  v.i[0] = __builtin_amdgcn_update_dpp(o.i[0], v.i[0], CTRL, ROW_MASK, 0xf, false);
+  v.i[1] = __builtin_amdgcn_update_dpp(o.i[1], v.i[1], CTRL, ROW_MASK, 0xf, false);
+  return v.d;
+}
+// wave-wide sum / max, result in every lane: four row_shr steps inside the 16-lane rows, two row broadcasts, one v_readlane
+// (no LDS crossbar traffic: ds_bpermute-based butterflies cost several times more on a lone wave)
+__device__ __forceinline__ double qm_wave_sum(double v) {
+  v += qm_dpp<0x111, 0xf>(0.0, v); v += qm_dpp<0x112, 0xf>(0.0, v); v += qm_dpp<0x114, 0xf>(0.0, v); v += qm_dpp<0x118, 0xf>(0.0, v);
+  v += qm_dpp<0x142, 0xa>(0.0, v); v += qm_dpp<0x143, 0xc>(0.0, v);
+  return qm_bcast(v, 63);
+}
+__device__ __forceinline__ double qm_wave_max(double v) {
+  v = fmax(v, qm_dpp<0x111, 0xf>(v, v)); v = fmax(v, qm_dpp<0x112, 0xf>(v, v)); v = fmax(v, qm_dpp<0x114, 0xf>(v, v)); v = fmax(v, qm_dpp<0x118, 0xf>(v, v));
+  v = fmax(v, qm_dpp<0x142, 0xa>(v, v)); v = fmax(v, qm_dpp<0x143, 0xc>(v, v));
+  return qm_bcast(v, 63);
+}
+
 // strided view of a per-instance array living in a lane-interleaved HBM workspace: element i of instance b sits at
 // base[i * stride + b], so the 64 lanes of a wave (consecutive instances) touch consecutive addresses
 struct QmSPtr {

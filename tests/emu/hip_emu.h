@@ -68,6 +68,7 @@ extern double qm_smem[];
 typedef double double4v __attribute__((ext_vector_type(4)));
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_wave_barrier() emu::wavesync()
+#define __popcll(x) __builtin_popcountll(x)
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 struct double2 { double x, y; };
@@ -98,6 +99,19 @@ inline double __shfl_xor(double v, int mask, int width = 64) { return __shfl(v, 
 inline double __shfl_down(double v, int delta, int width = 64) { const int l = emu::cur().lane % width; return __shfl(v, (l + delta < width) ? l + delta : l, width); }
 inline int __shfl(int v, int src, int width = 64);
 #define __builtin_amdgcn_readlane(v, lane) __shfl((int)(v), (int)(lane), 64)
+// DPP: only the controls the kernels use (row_shr:n, row_bcast:15, row_bcast:31), bank mask 0xf
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  emu::Block* blk = emu::B; const int w = emu::cur().wave, l = emu::cur().lane;
+  blk->xa[w * 64 + l] = (double)src; emu::wavesync();
+  const int row = l >> 4, pos = l & 15; int r = old;
+  if ((row_mask >> row) & 1) {
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int sh = ctrl - 0x110; if (pos >= sh) r = (int)blk->xa[w * 64 + l - sh]; else if (bound_ctrl) r = 0; }
+    else if (ctrl == 0x142) { if (row >= 1) r = (int)blk->xa[w * 64 + 16 * row - 1]; }
+    else if (ctrl == 0x143) { if (row >= 2) r = (int)blk->xa[w * 64 + 31]; }
+    else { fprintf(stderr, "emu: unsupported dpp ctrl %x\n", ctrl); abort(); }
+  }
+  emu::wavesync(); return r;
+}
 inline unsigned long long __ballot(int pred) {
   emu::Block* blk = emu::B; const int w = emu::cur().wave, l = emu::cur().lane;
   blk->xa[w * 64 + l] = pred ? 1.0 : 0.0; emu::wavesync();
