@@ -38,6 +38,7 @@ struct QmMpcPipeline {
   BK& bk; QmMpcBuffers d;
   int ls_trials_run = 0;
   int riccati_skip = 0;   // profiling only
+  int lq_prof = 0;        // profiling only
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
   template <class T> T* A(size_t n) { T* p = (T*)bk.alloc(n * sizeof(T)); bk.zero(p, n * sizeof(T)); return p; }
@@ -89,9 +90,9 @@ struct QmMpcPipeline {
   void sqp_iteration(int B, int max_trials = 14) {
     const int nodes_threads = d.nmax * B;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
-    q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin;
+    q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof;
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, 0, q);
-    bk.launch(qm_lq_kernel, B * d.nmax, QM_BLOCK, LQ_LDS_BYTES, q);
+    bk.launch(qm_lq_kernel, B * d.nmax, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node
     QmLsArgs l = ls_args(B);
     { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, (B + 63) / 64, 64, 0, lb); }
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;

@@ -1,14 +1,17 @@
 // k_lq.h — K1: per-shooting-node linear-quadratic approximation + equality-constraint projection.
 //
-// One 256-thread workgroup (4 wavefronts) per (instance b, node i).  Restates, MI355X-first, what
+// One WAVEFRONT per (instance b, node i).  Restates, MI355X-first, what
 // [upstream ocs2_sqp multiple_shooting::setupIntermediateNode + projectTranscription] do per node for the
 // OCP of qm_interface/src/QMInterface.cpp:79-142 (SURVEY.md §8 a2–a8, a11; Appendix B.6 steps 2–3):
 //   K1a qm_lq_kin_kernel (one THREAD per node): all scalar kinematics — both Heun/RK2 stages, flow values, EE pose
 //       error — written as a 4 KB "kin record" per node (lanes = instances: no idle lanes, no barriers)
-//   K1b qm_lq_kernel (one WORKGROUP per node, 46 KB LDS -> 3 workgroups / CU):
+//   K1b qm_lq_kernel (one WAVEFRONT per node, 64-thread workgroups, 15 KB LDS): every matrix lives in the wave's registers as
+//       f64-MFMA D-fragments (qm_dev_common.h), all products are P = Zᵀ Y chains, the vectors ride in column 30 of the 32-wide
+//       tiles, and LDS is only the hand-over point between the lane-per-column analytic Jacobians and the fragments.  No
+//       workgroup barrier anywhere: the 100k nodes of a batch are independent waves.
 //   phase I   analytic Jacobian columns of the flow map, one lane per column.  df/dx and df/du only have 12 (+4 identity)
-//             non-trivial rows (SRBD), so they live in 16-row half tiles; RK2 sensitivity composition
-//             A_d = I + dt/2 (A1 + A2 + dt A2 A1), B_d likewise, on f64 MFMA over the non-zero k range only
+//             non-trivial rows (SRBD); RK2 sensitivity composition A_d = I + dt/2 (A1 + A2 + dt A2 A1) and B_dᵀ likewise
+//             (B_d is carried transposed: that is the operand form B_d Px and B_d Pu need), k restricted to the 16 live rows
 //   phase II  equality rows (zero force / zero foot velocity / swing normal velocity) and their closed-form block
 //             projection du = Pe + Px dx + Pu ut (D is block structured by construction: each row touches one foot's
 //             force triple or one leg's joint-velocity triple); projected dynamics Ap, Bp, bp streamed to HBM
@@ -36,6 +39,7 @@ struct QmLqArgs {
   double* perf;              // [nmax][B][PF_SIZE]
   double* dbg;               // optional [B][nmax][LQ_DBG_SIZE] unprojected LQ data (parity tests); may be null
   double* kin;               // [nmax][B][KR_SIZE] kin records (K1a -> K1b)
+  int prof;                  // profiling only: thread 0 leaves phase cycle stamps in the (unused) SR_K field of the record
 };
 
 // debug record (unprojected LQ): A(900) B(900) b(30) Q(900) R(900) q(30) r(30) C(16x30) D(16x30) e(16) c nc
@@ -63,59 +67,88 @@ struct QmLqArgs {
 #define KR_QEE  (KR_EEG + 6)          /* qee(4) */
 #define KR_SIZE (KR_QEE + 4 + 2)
 
-// LDS carve (doubles).  Tile pool of 4896 doubles re-used by the three phases (row-major, leading dim QM_LD):
-//   phase I : A1h[0] B1h[544] A2h[1088] B2h[1632] Th[2176] (16-row halves)  Ad[2720] Bd[3808] (32-row tiles)
-//   phase II: Px[0] (rows 12..27) PuT[544] (m<=18 rows, transposed Pu)  C[1156] D[1700] (16 rows)   Ad Bd
-//   phase III: Px PuT  RPx[1156] (rows 12..27)  RPuT[1700] (m rows, (R Pu)^T)  Q[2720] R[3808]
-#define LQ_HALF (16 * QM_LD)
-#define LQ_R18  (18 * QM_LD)
-#define LQ_P_A1 0
-#define LQ_P_B1 544
-#define LQ_P_A2 1088
-#define LQ_P_B2 1632
-#define LQ_P_T  2176
-#define LQ_P_AD 2720
-#define LQ_P_BD 3808
-#define LQ_P_PX 0
-#define LQ_P_PUT 544
-#define LQ_P_C  1156
-#define LQ_P_D  1700
-#define LQ_P_RPX 1156
-#define LQ_P_RPUT 1700
-#define LQ_P_Q  2720
-#define LQ_P_R  3808
-#define LQ_POOL 4896
-#define LQ_VEC LQ_POOL
-#define LQ_V_X    (LQ_VEC + 0)      /* x(32) */
-#define LQ_V_U    (LQ_VEC + 32)
-#define LQ_V_XN   (LQ_VEC + 64)
-#define LQ_V_X2   (LQ_VEC + 96)
-#define LQ_V_F1   (LQ_VEC + 128)
-#define LQ_V_F2   (LQ_VEC + 160)
-#define LQ_V_B    (LQ_VEC + 192)    /* b */
-#define LQ_V_Q    (LQ_VEC + 224)    /* q */
-#define LQ_V_R    (LQ_VEC + 256)    /* r */
-#define LQ_V_PE   (LQ_VEC + 288)
-#define LQ_V_RR   (LQ_VEC + 320)    /* r + R Pe */
-#define LQ_V_E    (LQ_VEC + 352)    /* e(16) */
-#define LQ_V_DU   (LQ_VEC + 368)    /* u - unom */
-#define LQ_V_RED  (LQ_VEC + 400)    /* reduction scratch (8) */
-#define LQ_V_G    (LQ_VEC + 408)    /* per contact: Ginv or g data (4 x 12) */
-#define LQ_V_EE   (LQ_VEC + 456)    /* g(6), mu(6), qee(4), ref(7) */
-#define LQ_V_K1   (LQ_VEC + 480)
-#define LQ_V_K2   (LQ_VEC + 480 + KW_SIZE)
-#define LQ_V_JEE  (LQ_VEC + 480 + 2 * KW_SIZE)    /* EE Jacobian transposed [30][6] */
-#define LQ_LDS_DOUBLES (LQ_VEC + 480 + 2 * KW_SIZE + 180)
-#define LQ_LDS_BYTES (LQ_LDS_DOUBLES * 8)
+// LDS carve (doubles) of one wave
+#define LW_BLOCK 64
+#define LW_TLD 34
+#define LW_T     0                    /* [32][34] hand-over tile (columns from lanes -> fragments) */
+#define LW_V     1088
+#define LW_V_X   (LW_V + 0)
+#define LW_V_U   (LW_V + 32)
+#define LW_V_X2  (LW_V + 64)
+#define LW_V_B   (LW_V + 96)          /* b */
+#define LW_V_E   (LW_V + 128)         /* e(16) */
+#define LW_V_PE  (LW_V + 144)         /* Pe(32) */
+#define LW_V_DU  (LW_V + 176)         /* u − unom */
+#define LW_V_G   (LW_V + 208)         /* per contact: Ginv or g data (4 x 12) */
+#define LW_V_EE  (LW_V + 256)         /* g(6) mu(6) qee(4) ref(7) */
+#define LW_V_FR  (LW_V + 280)         /* friction cone terms per contact: p2 dh dhᵀ + p1 ddh (9), p1 dh (3), ds (1) -> 4 x 16 */
+#define LW_V_RV  (LW_V + 344)         /* r */
+#define LW_V_QV  (LW_V + 376)         /* q */
+#define LW_V_RR  (LW_V + 408)         /* r + R Pe */
+#define LW_V_QD  (LW_V + 440)         /* diagonal additions of Q (32) */
+#define LW_V_RD  (LW_V + 472)         /* diagonal additions of R (32) */
+#define LW_K1    (LW_V + 504)
+#define LW_K2    (LW_K1 + KW_SIZE)
+#define LW_LDS_DOUBLES (LW_K2 + KW_SIZE)
+#define LQ_LDS_BYTES (LW_LDS_DOUBLES * 8)
 
-__device__ __forceinline__ double block_sum(double v, double* red) {   // sum over the workgroup; result to all
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[w] = v;
-  __syncthreads();
-  double s = 0.0; for (int i = 0; i < nw; ++i) s += red[i];
-  return s;
+// value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column
+__device__ __forceinline__ void lw_set_col30(qm_d4 (&F)[2][2], const double* v) {
+  const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14) F[I][1][r] = (row < 30) ? v[row] : 0.0; }
+}
+template <int IT>
+__device__ __forceinline__ void lw_get_col30(const qm_d4 (&F)[IT][2], double* v, int rows) {
+  const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+#pragma unroll
+  for (int I = 0; I < IT; ++I)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14 && row < rows) v[row] = F[I][1][r]; }
+}
+
+// projected cost + record stores; MT = tiles covering the m reduced inputs
+template <int MT>
+__device__ __forceinline__ void lw_project(double* S, double* rec, int m, const qm_d4 (&Bdt)[2][2], const qm_d4 (&PxA)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
+  const int l = threadIdx.x & 63;
+  double* T = S + LW_T;
+  // Pu (30 x m) was assembled in the hand-over tile
+  qm_d4 Pu[2][MT]; qm_frag_load<2, MT, false>(Pu, T, LW_TLD, 30, m);
+  qm_frag_store<2, MT>(Pu, rec + SR_PU, QM_MMAX, 30, m);
+  { qm_d4 Bp[2][MT]; qm_frag_zero<2, MT>(Bp); qm_gemm_tn<2, 2, MT>(Bdt, Pu, Bp, 0, 8, false); qm_frag_store<2, MT>(Bp, rec + SR_BP, QM_MMAX, 30, m); }   // Bp = Bd Pu
+  // [R Px | R Pe + r]: Px rows 12..23 (k-steps 3..5); Pe also has rows 0..11 (column 30 only -> tile column 1, k-steps 0..2)
+  qm_d4 RPx[2][2]; qm_frag_zero<2, 2>(RPx);
+  qm_gemm_tn<2, 2, 2>(Rm, PxA, RPx, 3, 6, false);
+  { qm_d4 Y1[2][1], P1[2][1];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) { Y1[I][0] = PxA[I][1]; P1[I][0] = RPx[I][1]; }
+    qm_gemm_tn<2, 2, 1>(Rm, Y1, P1, 0, 3, false);
+#pragma unroll
+    for (int I = 0; I < 2; ++I) RPx[I][1] = P1[I][0]; }
+  { const int g = l >> 4, c = l & 15;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14 && row < 30) RPx[I][1][r] += S[LW_V_RV + row]; } }
+  qm_wave_sync();
+  lw_get_col30<2>(RPx, S + LW_V_RR, 30);
+  qm_wave_sync();
+  rpe = qm_wave_sum((l < 30) ? (S[LW_V_RV + l] + 0.5 * (S[LW_V_RR + l] - S[LW_V_RV + l])) * S[LW_V_PE + l] : 0.0);
+  // [Qp | qp] = [Q | q] + Pxᵀ [R Px | rr]
+  qm_gemm_tn<2, 2, 2>(PxA, RPx, Qa, 3, 6, false);
+  qm_frag_store<2, 2>(Qa, rec + SR_QP, 30, 30, 30);
+  qm_wave_sync();
+  lw_get_col30<2>(Qa, S + LW_V_QV, 30);
+  // [Pp | rp] = Puᵀ [R Px | rr]
+  { qm_d4 Pp[MT][2]; qm_frag_zero<MT, 2>(Pp); qm_gemm_tn<2, MT, 2>(Pu, RPx, Pp, 0, 8, false); qm_frag_store<MT, 2>(Pp, rec + SR_PP, 30, m, 30); lw_get_col30<MT>(Pp, S + LW_V_RV, m); }
+  // Rp = Puᵀ R Pu
+  { qm_d4 RPu[2][MT]; qm_frag_zero<2, MT>(RPu); qm_gemm_tn<2, 2, MT>(Rm, Pu, RPu, 0, 8, false);
+    qm_d4 Rp[MT][MT]; qm_frag_zero<MT, MT>(Rp); qm_gemm_tn<2, MT, MT>(Pu, RPu, Rp, 0, 8, false); qm_frag_store<MT, MT>(Rp, rec + SR_RP, QM_MMAX, m, m); }
+  qm_wave_sync();
+  if (l < 30) rec[SR_QPV + l] = S[LW_V_QV + l];
+  if (l < m) rec[SR_RPV + l] = S[LW_V_RV + l];
 }
 
 // ---- K1a: scalar kinematics, one thread per (node, instance) ----
@@ -152,11 +185,11 @@ __global__ void qm_lq_kin_kernel(QmLqArgs a) {
   for (int q = 0; q < 30; ++q) rec[KR_F2 + q] = f2[q];
 }
 
-// ---- K1b: one workgroup per node ----
-__global__ void __launch_bounds__(QM_BLOCK) qm_lq_kernel(QmLqArgs a) {
+// ---- K1b: one wavefront per node ----
+__global__ void __launch_bounds__(LW_BLOCK) qm_lq_kernel(QmLqArgs a) {
   extern __shared__ double qm_smem[];
   double* S = qm_smem;
-  const int tid = threadIdx.x;
+  const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
   const int b = blockIdx.x / a.nmax, i = blockIdx.x - b * a.nmax;
   const int nn = a.n_nodes[b];
   if (i >= nn) return;
@@ -170,167 +203,242 @@ __global__ void __launch_bounds__(QM_BLOCK) qm_lq_kernel(QmLqArgs a) {
   const double* kr = a.kin + (size_t)nb * KR_SIZE;
   const double dt = a.node_dt[nb];
   const int mode = a.node_mode[nb];
-
-  // ---- P0: clear LDS, stage inputs and the kin record ----
-  tile_zero(S, LQ_LDS_DOUBLES);
-  __syncthreads();
-  if (tid < 30) { S[LQ_V_X + tid] = a.x[nb * 30 + tid]; S[LQ_V_U + tid] = terminal ? 0.0 : a.u[nb * 30 + tid]; S[LQ_V_XN + tid] = terminal ? 0.0 : a.x[((i + 1) * a.B + b) * 30 + tid]; }
-  if (tid >= 32 && tid < 39) S[LQ_V_EE + 16 + (tid - 32)] = a.eeref[nb * 7 + (tid - 32)];
-  if (tid >= 40 && tid < 46) S[LQ_V_EE + (tid - 40)] = kr[KR_EEG + (tid - 40)];
-  if (tid >= 48 && tid < 52) S[LQ_V_EE + 12 + (tid - 48)] = kr[KR_QEE + (tid - 48)];
-  for (int idx = tid; idx < KW_SIZE; idx += blockDim.x) { S[LQ_V_K1 + idx] = kr[KR_K1 + idx]; if (!terminal && idx < KW_ARM) S[LQ_V_K2 + idx] = kr[KR_K2 + idx]; }
-  if (!terminal && tid >= 64 && tid < 94) { const int q = tid - 64; S[LQ_V_F1 + q] = kr[KR_F1 + q]; S[LQ_V_F2 + q] = kr[KR_F2 + q]; S[LQ_V_X2 + q] = kr[KR_X2 + q]; }
-  __syncthreads();
-  double* X = S + LQ_V_X; double* U = S + LQ_V_U;
-  double* K1 = S + LQ_V_K1; double* K2 = S + LQ_V_K2;
-  double* EE = S + LQ_V_EE; double* JEE = S + LQ_V_JEE;
+  long long tp_[10]; int np_ = 0;
+#define LQT() { if (a.prof) tp_[np_] = (long long)__builtin_readcyclecounter(); ++np_; }
+  LQT()
+  // ---- P0: inputs and the kin record -> LDS ----
+  double* T = S + LW_T; double* X = S + LW_V_X; double* U = S + LW_V_U; double* K1 = S + LW_K1; double* K2 = S + LW_K2; double* EE = S + LW_V_EE;
+  for (int idx = l; idx < LW_K1 - LW_V; idx += 64) S[LW_V + idx] = 0.0;
+  qm_wave_sync();
+  double xn = 0.0, f1 = 0.0, f2 = 0.0;
+  if (l < 30) { X[l] = a.x[nb * 30 + l]; U[l] = terminal ? 0.0 : a.u[nb * 30 + l]; if (!terminal) { xn = a.x[((i + 1) * a.B + b) * 30 + l]; f1 = kr[KR_F1 + l]; f2 = kr[KR_F2 + l]; S[LW_V_X2 + l] = kr[KR_X2 + l]; } }
+  if (l >= 32 && l < 39) EE[16 + (l - 32)] = a.eeref[nb * 7 + (l - 32)];
+  if (l >= 40 && l < 46) EE[l - 40] = kr[KR_EEG + (l - 40)];
+  if (l >= 48 && l < 52) EE[12 + (l - 48)] = kr[KR_QEE + (l - 48)];
+  for (int idx = l; idx < KW_SIZE; idx += 64) { K1[idx] = kr[KR_K1 + idx]; K2[idx] = (!terminal && idx < KW_ARM) ? kr[KR_K2 + idx] : 0.0; }
+  qm_wave_sync();
 
   if (terminal) {
-    // final EE soft constraint only: Q_N = J^T mu J, q_N = J^T mu g, c_N = 1/2 g mu g
-    if (tid < 6) EE[6 + tid] = (tid < 3 ? st[ST_MU_EEF_POS] : st[ST_MU_EEF_ORI]);
-    if (tid >= 32 && tid < 62) { const int c = tid - 32; double col[6]; ee_jac_col(X, K1, EE + 12, EE + 19, c, col); for (int r = 0; r < 6; ++r) JEE[c * 6 + r] = col[r]; }
-    __syncthreads();
-    for (int idx = tid; idx < 900; idx += blockDim.x) { const int r = idx / 30, c = idx - r * 30; double s = 0.0; for (int k = 0; k < 6; ++k) s += JEE[r * 6 + k] * EE[6 + k] * JEE[c * 6 + k]; rec[SR_QP + idx] = s; }
-    if (tid < 30) { double s = 0.0; for (int k = 0; k < 6; ++k) s += JEE[tid * 6 + k] * EE[6 + k] * EE[k]; rec[SR_QPV + tid] = s; }
-    if (tid == 0) { double c = 0.0; for (int k = 0; k < 6; ++k) c += 0.5 * EE[6 + k] * EE[k] * EE[k]; rec[SR_SCAL] = 0.0; rec[SR_SCAL + 1] = c; a.perf[nb * PF_SIZE] = c; a.perf[nb * PF_SIZE + 1] = 0.0; a.perf[nb * PF_SIZE + 2] = 0.0; }
+    // final EE soft constraint only: Q_N = Jᵀ mu J, q_N = Jᵀ mu g, c_N = 1/2 g mu g
+    if (l < 6) EE[6 + l] = (l < 3 ? st[ST_MU_EEF_POS] : st[ST_MU_EEF_ORI]);
+    if (l < 30) { double col[6]; ee_jac_col(X, K1, EE + 12, EE + 19, l, col); for (int r = 0; r < 6; ++r) T[l * 6 + r] = col[r]; }
+    qm_wave_sync();
+    for (int idx = l; idx < 900; idx += 64) { const int r = idx / 30, cc = idx - r * 30; double s = 0.0; for (int k = 0; k < 6; ++k) s += T[r * 6 + k] * EE[6 + k] * T[cc * 6 + k]; rec[SR_QP + idx] = s; }
+    if (l < 30) { double s = 0.0; for (int k = 0; k < 6; ++k) s += T[l * 6 + k] * EE[6 + k] * EE[k]; rec[SR_QPV + l] = s; }
+    if (l == 0) { double cN = 0.0; for (int k = 0; k < 6; ++k) cN += 0.5 * EE[6 + k] * EE[k] * EE[k]; rec[SR_SCAL] = 0.0; rec[SR_SCAL + 1] = cN; a.perf[nb * PF_SIZE] = cN; a.perf[nb * PF_SIZE + 1] = 0.0; a.perf[nb * PF_SIZE + 2] = 0.0; }
     return;
   }
-
-  // ---- phase I: Jacobian columns (lanes 0..59 stage 1, lanes 64..123 stage 2) into 16-row half tiles ----
-  double* A1 = S + LQ_P_A1; double* B1 = S + LQ_P_B1; double* A2 = S + LQ_P_A2; double* B2 = S + LQ_P_B2; double* Th = S + LQ_P_T;
-  double* Ad = S + LQ_P_AD; double* Bd = S + LQ_P_BD;
+  LQT()
+  // ---- phase I: Jacobian columns -> fragments.  Tile rows 0..15 take [df/dx], rows 16..31 take [df/du] (rows 0..15 of each) ----
+  qm_d4 Ad[2][2], Bdt[2][2];
   {
-    const int which = tid >> 6, c = tid & 63;
-    if (which < 2 && c < 60) {
-      double col[12]; flow_jac_col(mb, which ? S + LQ_V_X2 : X, U, which ? K2 : K1, c, col);
-      double* M = (c < 30) ? (which ? A2 : A1) : (which ? B2 : B1); const int cc = (c < 30) ? c : c - 30;
-      for (int r = 0; r < 12; ++r) M[r * QM_LD + cc] = col[r];
-      if (c >= 42 && c < 46) M[(c - 30) * QM_LD + cc] = 1.0;      // d qdot_j / d u_j rows 12..15 (rows >= 16 are handled analytically)
+    qm_d4 A1[1][2], B1[1][2], B1t[2][1], A2[1][2], A2t[2][1], B2t[2][1];
+    for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
+    qm_wave_sync();
+    if (l < 60) {
+      double col[12]; flow_jac_col(mb, X, U, K1, l, col);
+      const int cc = (l < 30) ? l : l - 30, r0 = (l < 30) ? 0 : 16;
+      for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = col[r];
+      if (l >= 42 && l < 46) T[(16 + (l - 30)) * LW_TLD + cc] = 1.0;            // d qdot_j / d u_j rows 12..15 (rows >= 16 are handled analytically)
     }
+    qm_wave_sync();
+    qm_frag_load<1, 2, false>(A1, T, LW_TLD, 16, 30); qm_frag_load<1, 2, false>(B1, T + 16 * LW_TLD, LW_TLD, 16, 30); qm_frag_load<2, 1, true>(B1t, T + 16 * LW_TLD, LW_TLD, 30, 16);
+    qm_wave_sync();
+    for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
+    qm_wave_sync();
+    if (l < 60) {
+      double col[12]; flow_jac_col(mb, S + LW_V_X2, U, K2, l, col);
+      const int cc = (l < 30) ? l : l - 30, r0 = (l < 30) ? 0 : 16;
+      for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = col[r];
+      if (l >= 42 && l < 46) T[(16 + (l - 30)) * LW_TLD + cc] = 1.0;
+    }
+    qm_wave_sync();
+    qm_frag_load<1, 2, false>(A2, T, LW_TLD, 16, 30); qm_frag_load<2, 1, true>(A2t, T, LW_TLD, 30, 16); qm_frag_load<2, 1, true>(B2t, T + 16 * LW_TLD, LW_TLD, 30, 16);
+    LQT()
+    // A2 A1 (rows < 16): Z = A2ᵀ[0:16, 0:16], Y = A1
+    qm_d4 TA[1][2]; qm_frag_zero<1, 2>(TA);
+    { qm_d4 Z[1][1]; Z[0][0] = A2t[0][0]; qm_gemm_tn<1, 1, 2>(Z, A1, TA, 0, 4, false); }
+    // (A2 B1)ᵀ = B1ᵀ A2ᵀ[0:16, :] + rows >= 16 of A2ᵀ (rows >= 16 of B1 are unit rows)
+    qm_d4 TBt[2][1]; qm_frag_zero<2, 1>(TBt);
+    { qm_d4 Y[1][1]; Y[0][0] = A2t[0][0]; qm_gemm_tn<1, 2, 1>(B1, Y, TBt, 0, 4, false); }
+    TBt[1][0] += A2t[1][0];
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = g + 4 * r, col = 16 * J + c;
+        Ad[0][J][r] = (col < 30) ? 0.5 * dt * A1[0][J][r] + 0.5 * dt * (A2[0][J][r] + dt * TA[0][J][r]) + ((row == col) ? 1.0 : 0.0) : 0.0;
+        Ad[1][J][r] = (16 + row == col && col < 30) ? 1.0 : 0.0;
+      }
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r;                                    // input index; column = state row
+        Bdt[I][0][r] = (row < 30) ? 0.5 * dt * B1t[I][0][r] + 0.5 * dt * (B2t[I][0][r] + dt * TBt[I][0][r]) : 0.0;
+        Bdt[I][1][r] = (row == 16 + c && row < 30) ? dt : 0.0;
+      }
   }
-  __syncthreads();
-  // A2 A1: A1 only has rows < 16 -> k slabs 0..3
-  wg_gemm<false, false>(A2, A1, 1, 2, 0, 4, [&](int r, int c, double v) { Th[r * QM_LD + c] = v; });
-  __syncthreads();
-  for (int idx = tid; idx < 900; idx += blockDim.x) { const int r = idx / 30, c = idx - r * 30; const int o = r * QM_LD + c; Ad[o] = ((r < 16) ? 0.5 * dt * A1[o] + 0.5 * dt * (A2[o] + dt * Th[o]) : 0.0) + (r == c ? 1.0 : 0.0); }
-  __syncthreads();
-  // A2 B1 = A2[:, :16] B1h + A2[:, 16:30] (rows >= 16 of B1 are unit rows e_k)
-  wg_gemm<false, false>(A2, B1, 1, 2, 0, 4, [&](int r, int c, double v) { Th[r * QM_LD + c] = v + ((c >= 16 && c < 30) ? A2[r * QM_LD + c] : 0.0); });
-  __syncthreads();
-  for (int idx = tid; idx < 900; idx += blockDim.x) { const int r = idx / 30, c = idx - r * 30; const int o = r * QM_LD + c; Bd[o] = (r < 16) ? 0.5 * dt * B1[o] + 0.5 * dt * (B2[o] + dt * Th[o]) : ((r == c) ? dt : 0.0); }
-  if (tid < 30) S[LQ_V_B + tid] = X[tid] + 0.5 * dt * S[LQ_V_F1 + tid] + 0.5 * dt * S[LQ_V_F2 + tid] - S[LQ_V_XN + tid];
-  __syncthreads();
-  if (dbg) { tile_store(Ad, dbg + LQ_DBG_A, 30, 30, 30); tile_store(Bd, dbg + LQ_DBG_B, 30, 30, 30); if (tid < 30) dbg[LQ_DBG_b + tid] = S[LQ_V_B + tid]; }
-
+  const double bl = (l < 30) ? X[l] + 0.5 * dt * f1 + 0.5 * dt * f2 - xn : 0.0;
+  if (l < 32) S[LW_V_B + l] = bl;
+  qm_wave_sync();
+  if (dbg) {
+    qm_frag_store<2, 2>(Ad, dbg + LQ_DBG_A, 30, 30, 30);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < 30 && col < 30) dbg[LQ_DBG_B + col * 30 + row] = Bdt[I][J][r]; }
+    if (l < 30) dbg[LQ_DBG_b + l] = bl;
+  }
+  LQT()
   // ---- phase II: equality rows + closed-form block projection ----
   // rows ordered per contact i = LF,RF,LH,RH: swing -> [F_i = 0 (3)] , stance -> [v_i = 0 (3)] , swing -> [v_iz = zvel_ref (1)]
-  double* Ct = S + LQ_P_C; double* Dt = S + LQ_P_D; double* Pxs = S + LQ_P_PX; double* PuT = S + LQ_P_PUT;
-  double* Px = Pxs - 12 * QM_LD;                         // virtual base: Px[r] valid for rows 12..27
-  __syncthreads();
-  tile_zero(S, LQ_P_AD);                                 // clears the phase-I halves (Px, PuT, C, D regions)
-  __syncthreads();
+  // tile rows 0..15 = C (state part), rows 16..31 = D (input part)
+  for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
+  qm_wave_sync();
   int row0[4]; int nc = 0; for (int k = 0; k < 4; ++k) { row0[k] = nc; nc += mode_flag(mode, k) ? 3 : 4; }
   const double gain = st[ST_POS_ERR_GAIN];
-  {
-    const int k = tid >> 6, c = tid & 63;                 // one wave per contact, one lane per column of [x | u]
-    if (c < 60) {
-      const bool stance = mode_flag(mode, k);
-      double dv[3], dpz; foot_vel_jac_col(mb, X, U, K1, k, c, dv, &dpz);
-      double* M = (c < 30) ? Ct : Dt; const int cc = (c < 30) ? c : c - 30;
-      if (stance) { for (int r = 0; r < 3; ++r) M[(row0[k] + r) * QM_LD + cc] = dv[r] + ((r == 2 && gain != 0.0) ? gain * dpz : 0.0); }
+  for (int k = 0; k < 4; ++k) {
+    const bool stance = mode_flag(mode, k);
+    if (l < 60) {
+      double dv[3], dpz; foot_vel_jac_col(mb, X, U, K1, k, l, dv, &dpz);
+      double* M = (l < 30) ? T : T + 16 * LW_TLD; const int cc = (l < 30) ? l : l - 30;
+      if (stance) { for (int r = 0; r < 3; ++r) M[(row0[k] + r) * LW_TLD + cc] = dv[r] + ((r == 2 && gain != 0.0) ? gain * dpz : 0.0); }
       else {
-        M[(row0[k] + 3) * QM_LD + cc] = dv[2] + (gain != 0.0 ? gain * dpz : 0.0);
-        if (c >= 30 && c - 30 >= 3 * k && c - 30 < 3 * k + 3) M[(row0[k] + (c - 30 - 3 * k)) * QM_LD + cc] = 1.0;
+        M[(row0[k] + 3) * LW_TLD + cc] = dv[2] + (gain != 0.0 ? gain * dpz : 0.0);
+        if (l >= 30 && l - 30 >= 3 * k && l - 30 < 3 * k + 3) M[(row0[k] + (l - 30 - 3 * k)) * LW_TLD + cc] = 1.0;
       }
     }
-    if (c == 60) {
-      const bool stance = mode_flag(mode, k); double v[3]; foot_velocity(X, K1, k, v); const double pz = kin_foot(K1, k)[2];
-      if (stance) { for (int r = 0; r < 3; ++r) S[LQ_V_E + row0[k] + r] = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); }
+    if (l == 60) {
+      double v[3]; foot_velocity(X, K1, k, v); const double pz = kin_foot(K1, k)[2];
+      if (stance) { for (int r = 0; r < 3; ++r) S[LW_V_E + row0[k] + r] = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); }
       else {
-        for (int r = 0; r < 3; ++r) S[LQ_V_E + row0[k] + r] = U[3 * k + r];
+        for (int r = 0; r < 3; ++r) S[LW_V_E + row0[k] + r] = U[3 * k + r];
         double bb = -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * a.zpos[nb * 4 + k];
-        S[LQ_V_E + row0[k] + 3] = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0);
+        S[LW_V_E + row0[k] + 3] = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0);
       }
     }
   }
-  __syncthreads();
-  if (dbg) { tile_store(Ct, dbg + LQ_DBG_C, 16, 30, 30); tile_store(Dt, dbg + LQ_DBG_D, 16, 30, 30); if (tid < 16) dbg[LQ_DBG_e + tid] = S[LQ_V_E + tid]; if (tid == 0) dbg[LQ_DBG_nc] = nc; }
+  qm_wave_sync();
+  const double* Ct = T; const double* Dt = T + 16 * LW_TLD;
+  if (dbg) { for (int idx = l; idx < 480; idx += 64) { const int r = idx / 30, cc = idx - r * 30; dbg[LQ_DBG_C + idx] = Ct[r * LW_TLD + cc]; dbg[LQ_DBG_D + idx] = Dt[r * LW_TLD + cc]; } if (l < 16) dbg[LQ_DBG_e + l] = S[LW_V_E + l]; if (l == 0) dbg[LQ_DBG_nc] = nc; }
+  LQT()
   // per contact: stance -> Ginv (3x3) of the joint-velocity block; swing -> g/(g.g) and a 3x2 orthonormal complement of g
-  double* G = S + LQ_V_G;
-  if (tid < 4) {
-    const int k = tid, ch = contact_to_chain(k), jc = 12 + 3 * ch; double* g = G + 12 * k;
-    if (mode_flag(mode, k)) { double M3[9]; for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M3[3 * r + c] = Dt[(row0[k] + r) * QM_LD + jc + c]; m3_inv(M3, g); }
+  double* G = S + LW_V_G;
+  if (l < 4) {
+    const int k = l, ch = contact_to_chain(k), jc = 12 + 3 * ch; double* gg = G + 12 * k;
+    if (mode_flag(mode, k)) { double M3[9]; for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) M3[3 * r + q] = Dt[(row0[k] + r) * LW_TLD + jc + q]; m3_inv(M3, gg); }
     else {
-      const double gv[3] = {Dt[(row0[k] + 3) * QM_LD + jc], Dt[(row0[k] + 3) * QM_LD + jc + 1], Dt[(row0[k] + 3) * QM_LD + jc + 2]};
+      const double gv[3] = {Dt[(row0[k] + 3) * LW_TLD + jc], Dt[(row0[k] + 3) * LW_TLD + jc + 1], Dt[(row0[k] + 3) * LW_TLD + jc + 2]};
       const double n2 = gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2], nrm = sqrt(n2);
-      for (int r = 0; r < 3; ++r) g[r] = gv[r] / n2;
-      // Householder H = I - 2 v v^T/(v^T v), v = g - alpha e1, alpha = -sign(g0)|g| : H e1 || g, columns 2,3 of H span g-perp
+      for (int r = 0; r < 3; ++r) gg[r] = gv[r] / n2;
+      // Householder H = I - 2 v vᵀ/(vᵀ v), v = g - alpha e1, alpha = -sign(g0)|g| : H e1 || g, columns 2,3 of H span g-perp
       const double alpha = gv[0] > 0.0 ? -nrm : nrm; const double v[3] = {gv[0] - alpha, gv[1], gv[2]}; const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-      for (int r = 0; r < 3; ++r) { g[3 + r] = ((r == 1) ? 1.0 : 0.0) - 2.0 * v[r] * v[1] / vv; g[6 + r] = ((r == 2) ? 1.0 : 0.0) - 2.0 * v[r] * v[2] / vv; }
+      for (int r = 0; r < 3; ++r) { gg[3 + r] = ((r == 1) ? 1.0 : 0.0) - 2.0 * v[r] * v[1] / vv; gg[6 + r] = ((r == 2) ? 1.0 : 0.0) - 2.0 * v[r] * v[2] / vv; }
     }
   }
-  __syncthreads();
-  double* Pe = S + LQ_V_PE;
-  for (int idx = tid; idx < 12 * 31; idx += blockDim.x) {
-    const int r = idx / 31, c = idx - r * 31;             // input row 12 + r ; c == 30 -> Pe entry
-    const int ch = r / 3, jj = r - 3 * ch, k = chain_to_contact(ch); const double* g = G + 12 * k;
-    double s = 0.0;
-    if (mode_flag(mode, k)) { for (int q = 0; q < 3; ++q) s -= g[3 * jj + q] * ((c < 30) ? Ct[(row0[k] + q) * QM_LD + c] : S[LQ_V_E + row0[k] + q]); }
-    else { s = -g[jj] * ((c < 30) ? Ct[(row0[k] + 3) * QM_LD + c] : S[LQ_V_E + row0[k] + 3]); }
-    if (c < 30) Px[(12 + r) * QM_LD + c] = s; else Pe[12 + r] = s;
-  }
-  if (tid < 12) { const int k = tid / 3; Pe[tid] = mode_flag(mode, k) ? 0.0 : -U[tid]; }
-  if (tid >= 24 && tid < 30) Pe[tid] = 0.0;
-  // Pu^T (m x 30): rows = projected inputs: stance forces, swing-leg null spaces, arm
+  qm_wave_sync();
+  // [Px | Pe] straight into fragments: input rows 12..23 of Px, all rows of Pe (column 30)
+  qm_d4 PxA[2][2];
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r, col = 16 * J + c; double s = 0.0;
+        if (row >= 12 && row < 24 && col <= 30) {
+          const int rr = row - 12, ch = rr / 3, jj = rr - 3 * ch, k = chain_to_contact(ch); const double* gg = G + 12 * k;
+          if (mode_flag(mode, k)) { for (int q = 0; q < 3; ++q) s -= gg[3 * jj + q] * ((col < 30) ? Ct[(row0[k] + q) * LW_TLD + col] : S[LW_V_E + row0[k] + q]); }
+          else s = -gg[jj] * ((col < 30) ? Ct[(row0[k] + 3) * LW_TLD + col] : S[LW_V_E + row0[k] + 3]);
+        } else if (row < 12 && col == 30) s = mode_flag(mode, row / 3) ? 0.0 : -U[row];
+        PxA[I][J][r] = s;
+      }
+  qm_wave_sync();
+  lw_get_col30<2>(PxA, S + LW_V_PE, 30);
+  const double eq2 = qm_wave_sum((l < nc) ? S[LW_V_E + l] * S[LW_V_E + l] : 0.0);
+  const double b2 = qm_wave_sum(bl * bl);
+  // Pu (30 x m) in the hand-over tile: columns = stance forces, swing-leg null spaces, arm
+  qm_wave_sync();
+  for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
+  qm_wave_sync();
   int m = 0;
   {
     int col = 0;
-    for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) { if (tid < 3) PuT[(col + tid) * QM_LD + 3 * k + tid] = 1.0; col += 3; }
-    for (int k = 0; k < 4; ++k) if (!mode_flag(mode, k)) { const int jc = 12 + 3 * contact_to_chain(k); const double* g = G + 12 * k; if (tid < 6) { const int r = tid % 3, cc = tid / 3; PuT[(col + cc) * QM_LD + jc + r] = g[3 + 3 * cc + r]; } col += 2; }
-    if (tid < 6) PuT[(col + tid) * QM_LD + 24 + tid] = 1.0; col += 6;
+    for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) { if (l < 3) T[(3 * k + l) * LW_TLD + col + l] = 1.0; col += 3; }
+    for (int k = 0; k < 4; ++k) if (!mode_flag(mode, k)) { const int jc = 12 + 3 * contact_to_chain(k); const double* gg = G + 12 * k; if (l < 6) { const int r = l % 3, cc = l / 3; T[(jc + r) * LW_TLD + col + cc] = gg[3 + 3 * cc + r]; } col += 2; }
+    if (l < 6) T[(24 + l) * LW_TLD + col + l] = 1.0; col += 6;
     m = col;
   }
-  const double eq2 = block_sum((tid < nc) ? S[LQ_V_E + tid] * S[LQ_V_E + tid] : 0.0, S + LQ_V_RED);
-  const double b2 = block_sum((tid < 30) ? S[LQ_V_B + tid] * S[LQ_V_B + tid] : 0.0, S + LQ_V_RED);
-  __syncthreads();
-  const int mt_m = (m + 15) / 16;
-  // projected dynamics  Ap = Ad + Bd Px (Px rows 12..23 -> k slabs 3..5) ; Bp = Bd Pu ; bp = b + Bd Pe
-  wg_gemm<false, false>(Bd, Px, 2, 2, 3, 6, [&](int r, int c, double v) { if (r < 30 && c < 30) rec[SR_AP + r * 30 + c] = Ad[r * QM_LD + c] + v; });
-  wg_gemm<false, true>(Bd, PuT, 2, mt_m, 0, 8, [&](int r, int c, double v) { if (r < 30 && c < m) rec[SR_BP + r * QM_MMAX + c] = v; });
-  if (tid < 30) rec[SR_BPV + tid] = S[LQ_V_B + tid] + tile_row_dot(Bd, tid, Pe, 30);
-  __syncthreads();                                        // Ad, Bd, C, D dead from here
-
-  // ---- phase III: cost quadratic model (x dt): Q, R ----
-  double* Qt = S + LQ_P_Q; double* Rt = S + LQ_P_R; double* RPxs = S + LQ_P_RPX; double* RPuT = S + LQ_P_RPUT; double* RPx = RPxs - 12 * QM_LD;
-  for (int i2 = tid; i2 < LQ_POOL - LQ_P_RPX; i2 += blockDim.x) S[LQ_P_RPX + i2] = 0.0;       // RPx, RPuT, Q, R regions
-  __syncthreads();
-  tile_load(Rt, st + ST_R, 30, 30, 30);
-  double cost = 0.0;                                      // per-thread partial of the cost value
-  if (tid < 30) {
-    const double dx = X[tid] - a.xref[nb * 30 + tid]; const double qd = st[ST_Q + tid];
-    S[LQ_V_Q + tid] = qd * dx; Qt[tid * QM_LD + tid] = qd; cost += 0.5 * qd * dx * dx;
-    int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
-    double unom = 0.0; if (tid < 12 && (tid % 3) == 2 && mode_flag(mode, tid / 3) && nst > 0) unom = mb[MB_ROBOTMASS] * 9.81 / nst;
-    S[LQ_V_DU + tid] = U[tid] - unom;
+  qm_wave_sync();
+  LQT()
+  // projected dynamics  [Ap | bp] = [Ad | b] + Bd [Px | Pe]  (Z = Bdᵀ; Px rows 12..23 -> k-steps 3..5, Pe rows 0..11 -> column tile 1, k-steps 0..2)
+  {
+    qm_d4 ApA[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J) ApA[I][J] = Ad[I][J];
+    lw_set_col30(ApA, S + LW_V_B);
+    qm_gemm_tn<2, 2, 2>(Bdt, PxA, ApA, 3, 6, false);
+    { qm_d4 Y1[2][1], P1[2][1];
+#pragma unroll
+      for (int I = 0; I < 2; ++I) { Y1[I][0] = PxA[I][1]; P1[I][0] = ApA[I][1]; }
+      qm_gemm_tn<2, 2, 1>(Bdt, Y1, P1, 0, 3, false);
+#pragma unroll
+      for (int I = 0; I < 2; ++I) ApA[I][1] = P1[I][0]; }
+    qm_frag_store<2, 2>(ApA, rec + SR_AP, 30, 30, 30);
+    const int gg2 = l >> 4;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + gg2 + 4 * r; if (c == 14 && row < 30) rec[SR_BPV + row] = ApA[I][1][r]; }
   }
-  if (tid >= 32 && tid < 62) { const int c = tid - 32; double col[6]; ee_jac_col(X, K1, EE + 12, EE + 19, c, col); for (int r = 0; r < 6; ++r) JEE[c * 6 + r] = col[r]; }
-  if (tid >= 64 && tid < 70) EE[6 + (tid - 64)] = ((tid - 64) < 3 ? st[ST_MU_EE_POS] : st[ST_MU_EE_ORI]);
-  __syncthreads();
-  if (tid < 30) { const double s = tile_row_dot(Rt, tid, S + LQ_V_DU, 30); S[LQ_V_R + tid] = s; cost += 0.5 * S[LQ_V_DU + tid] * s; }
-  __syncthreads();
-  // arm soft box (a6), friction cone barrier (a7): few lanes, disjoint entries
-  if (tid < 6) {
-    const double mu = st[ST_JPOS_MU], de = st[ST_JPOS_DELTA]; const double lo = mb[MB_QLO + 12 + tid], hi = mb[MB_QHI + 12 + tid], z = X[24 + tid];
+  LQT()
+  // ---- phase III: cost quadratic model (x dt) ----
+  double cost = 0.0;
+  double* QD = S + LW_V_QD; double* RD = S + LW_V_RD; double* FR = S + LW_V_FR;
+  if (l < 30) {
+    const double dx = X[l] - a.xref[nb * 30 + l]; const double qd = st[ST_Q + l];
+    S[LW_V_QV + l] = qd * dx; QD[l] = qd; RD[l] = 0.0; cost += 0.5 * qd * dx * dx;
+    int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
+    double unom = 0.0; if (l < 12 && (l % 3) == 2 && mode_flag(mode, l / 3) && nst > 0) unom = mb[MB_ROBOTMASS] * 9.81 / nst;
+    S[LW_V_DU + l] = U[l] - unom;
+  }
+  if (l >= 32 && l < 38) EE[6 + (l - 32)] = ((l - 32) < 3 ? st[ST_MU_EE_POS] : st[ST_MU_EE_ORI]);
+  qm_wave_sync();
+  qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);
+  { // r = R0 (u − unom) through column 30
+    qm_d4 Y[2][1], P[2][1];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) { P[I][0] = qm_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; Y[I][0][r] = (c == 14 && row < 30) ? S[LW_V_DU + row] : 0.0; } }
+    qm_gemm_tn<2, 2, 1>(Rm, Y, P, 0, 8, false);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14 && row < 30) S[LW_V_RV + row] = P[I][0][r]; }
+  }
+  qm_wave_sync();
+  if (l < 30) cost += 0.5 * S[LW_V_DU + l] * S[LW_V_RV + l];
+  qm_wave_sync();
+  // arm soft box (a6), joint-velocity box, friction cone barrier (a7): few lanes, disjoint entries
+  if (l < 6) {
+    const double mu = st[ST_JPOS_MU], de = st[ST_JPOS_DELTA]; const double lo = mb[MB_QLO + 12 + l], hi = mb[MB_QHI + 12 + l], z = X[24 + l];
     cost += barrier_val(mu, de, z - lo) + barrier_val(mu, de, hi - z) - (barrier_val(mu, de, -lo) + barrier_val(mu, de, hi));
-    S[LQ_V_Q + 24 + tid] += barrier_d1(mu, de, z - lo) - barrier_d1(mu, de, hi - z);
-    Qt[(24 + tid) * QM_LD + 24 + tid] += barrier_d2(mu, de, z - lo) + barrier_d2(mu, de, hi - z);
-  } else if (tid >= 8 && tid < 14) {
-    const int k = tid - 8; const double mu = st[ST_JVEL_MU], de = st[ST_JVEL_DELTA]; const double lo = st[ST_JVEL_LO + k], hi = st[ST_JVEL_HI + k], w = U[24 + k];
+    S[LW_V_QV + 24 + l] += barrier_d1(mu, de, z - lo) - barrier_d1(mu, de, hi - z);
+    QD[24 + l] += barrier_d2(mu, de, z - lo) + barrier_d2(mu, de, hi - z);
+  } else if (l >= 8 && l < 14) {
+    const int k = l - 8; const double mu = st[ST_JVEL_MU], de = st[ST_JVEL_DELTA]; const double lo = st[ST_JVEL_LO + k], hi = st[ST_JVEL_HI + k], w = U[24 + k];
     cost += barrier_val(mu, de, w - lo) + barrier_val(mu, de, hi - w) - (barrier_val(mu, de, -lo) + barrier_val(mu, de, hi));
-    S[LQ_V_R + 24 + k] += barrier_d1(mu, de, w - lo) - barrier_d1(mu, de, hi - w);
-    Rt[(24 + k) * QM_LD + 24 + k] += barrier_d2(mu, de, w - lo) + barrier_d2(mu, de, hi - w);
-  } else if (tid >= 64 && tid < 68) {   // friction cone, one lane per contact (disjoint 3x3 blocks); Hessian shift summed below
-    const int k = tid - 64; double ds = 0.0;
+    S[LW_V_RV + 24 + k] += barrier_d1(mu, de, w - lo) - barrier_d1(mu, de, hi - w);
+    RD[24 + k] += barrier_d2(mu, de, w - lo) + barrier_d2(mu, de, hi - w);
+  } else if (l >= 16 && l < 20) {   // friction cone, one lane per contact (disjoint 3x3 blocks)
+    const int k = l - 16; double ds = 0.0; double* fr = FR + 16 * k;
+    for (int q = 0; q < 13; ++q) fr[q] = 0.0;
     if (mode_flag(mode, k)) {
       const double mu = st[ST_FRIC_MU], de = st[ST_FRIC_DELTA], muf = st[ST_FRIC_COEF], reg = st[ST_FRIC_REG], shift = st[ST_FRIC_SHIFT];
       const double Fx = U[3 * k], Fy = U[3 * k + 1], Fz = U[3 * k + 2]; const double T2 = Fx * Fx + Fy * Fy + reg, Tn = sqrt(T2), T3 = Tn * Tn * Tn;
@@ -338,35 +446,82 @@ __global__ void __launch_bounds__(QM_BLOCK) qm_lq_kernel(QmLqArgs a) {
       const double p1 = barrier_d1(mu, de, h), p2 = barrier_d2(mu, de, h);
       const double dh[3] = {-Fx / Tn, -Fy / Tn, muf};
       const double ddh[9] = {-(Fy * Fy + reg) / T3, Fx * Fy / T3, 0.0, Fx * Fy / T3, -(Fx * Fx + reg) / T3, 0.0, 0.0, 0.0, 0.0};
-      for (int r = 0; r < 3; ++r) { S[LQ_V_R + 3 * k + r] += p1 * dh[r]; for (int c = 0; c < 3; ++c) Rt[(3 * k + r) * QM_LD + 3 * k + c] += p2 * dh[r] * dh[c] + p1 * ddh[3 * r + c]; }
+      for (int r = 0; r < 3; ++r) { S[LW_V_RV + 3 * k + r] += p1 * dh[r]; for (int q = 0; q < 3; ++q) fr[3 * r + q] = p2 * dh[r] * dh[q] + p1 * ddh[3 * r + q]; }
       ds = p1 * (-shift);
     }
-    S[LQ_V_RED + 4 + k] = ds;
-  } else if (tid == 96) { for (int k = 0; k < 6; ++k) cost += 0.5 * EE[6 + k] * EE[k] * EE[k]; }
-  __syncthreads();
-  { const double dsum = S[LQ_V_RED + 4] + S[LQ_V_RED + 5] + S[LQ_V_RED + 6] + S[LQ_V_RED + 7]; if (tid < 30) { Rt[tid * QM_LD + tid] += dsum; Qt[tid * QM_LD + tid] += dsum; } }
-  __syncthreads();
-  // EE pose soft constraint (a5): Q += J^T mu J, q += J^T mu g ; then scale by dt
-  for (int idx = tid; idx < 900; idx += blockDim.x) { const int r = idx / 30, c = idx - r * 30; double s = 0.0; for (int k = 0; k < 6; ++k) s += JEE[r * 6 + k] * EE[6 + k] * JEE[c * 6 + k]; Qt[r * QM_LD + c] = (Qt[r * QM_LD + c] + s) * dt; Rt[r * QM_LD + c] *= dt; }
-  if (tid < 30) { double s = 0.0; for (int k = 0; k < 6; ++k) s += JEE[tid * 6 + k] * EE[6 + k] * EE[k]; S[LQ_V_Q + tid] = (S[LQ_V_Q + tid] + s) * dt; S[LQ_V_R + tid] *= dt; }
-  const double ctot = block_sum(cost, S + LQ_V_RED) * dt;
-  if (tid == 0) { a.perf[nb * PF_SIZE] = ctot; a.perf[nb * PF_SIZE + 1] = dt * b2; a.perf[nb * PF_SIZE + 2] = dt * eq2; }
-  if (dbg) { tile_store(Qt, dbg + LQ_DBG_Q, 30, 30, 30); tile_store(Rt, dbg + LQ_DBG_R, 30, 30, 30); if (tid < 30) { dbg[LQ_DBG_q + tid] = S[LQ_V_Q + tid]; dbg[LQ_DBG_r + tid] = S[LQ_V_R + tid]; } if (tid == 0) dbg[LQ_DBG_c] = ctot; }
-  // ---- projected cost ----
-  if (tid >= 64 && tid < 94) { const int r = tid - 64; S[LQ_V_RR + r] = S[LQ_V_R + r] + tile_row_dot(Rt, r, Pe, 30); }
-  // R Px: only rows 12..23 of R[:, 12:24] are non-zero -> 16-row result (rows 12..27), k slabs 3..5
-  wg_gemm<false, false>(Rt + 12 * QM_LD, Px, 1, 2, 3, 6, [&](int r, int c, double v) { RPxs[r * QM_LD + c] = v; });
-  // (R Pu)^T = Pu^T R  (m x 30)
-  wg_gemm<false, false>(PuT, Rt, mt_m, 2, 0, 8, [&](int r, int c, double v) { if (r < m) RPuT[r * QM_LD + c] = v; });
-  __syncthreads();
-  wg_gemm<true, false>(Px, RPx, 2, 2, 3, 6, [&](int r, int c, double v) { if (r < 30 && c < 30) rec[SR_QP + r * 30 + c] = Qt[r * QM_LD + c] + v; });
-  wg_gemm<false, false>(PuT, RPx, mt_m, 2, 3, 6, [&](int r, int c, double v) { if (r < m && c < 30) rec[SR_PP + r * 30 + c] = v; });
-  wg_gemm<false, true>(PuT, RPuT, mt_m, mt_m, 0, 8, [&](int r, int c, double v) { if (r < m && c < m) rec[SR_RP + r * QM_MMAX + c] = v; });
-  if (tid < 30) { double s = 0.0; for (int r = 12; r < 24; ++r) s += Px[r * QM_LD + tid] * S[LQ_V_RR + r]; rec[SR_QPV + tid] = S[LQ_V_Q + tid] + s; }
-  if (tid >= 64 && tid < 64 + m) rec[SR_RPV + tid - 64] = tile_row_dot(PuT, tid - 64, S + LQ_V_RR, 30);
-  if (tid >= 128 && tid < 158) rec[SR_PE + tid - 128] = Pe[tid - 128];
-  for (int idx = tid; idx < 900; idx += blockDim.x) { const int r = idx / 30, c = idx - r * 30; rec[SR_PX + idx] = (r >= 12 && r < 24) ? Px[r * QM_LD + c] : 0.0; }
-  for (int idx = tid; idx < 30 * m; idx += blockDim.x) { const int r = idx / m, c = idx - r * m; rec[SR_PU + r * QM_MMAX + c] = PuT[c * QM_LD + r]; }
-  const double rpe = block_sum((tid < 30) ? (S[LQ_V_R + tid] + 0.5 * (S[LQ_V_RR + tid] - S[LQ_V_R + tid])) * Pe[tid] : 0.0, S + LQ_V_RED);
-  if (tid == 0) { rec[SR_SCAL] = (double)m; rec[SR_SCAL + 1] = ctot + rpe; }
+    fr[12] = ds;
+  } else if (l == 24) { for (int k = 0; k < 6; ++k) cost += 0.5 * EE[6 + k] * EE[k] * EE[k]; }
+  // EE Jacobian rows into the hand-over tile: rows 0..5 = J, rows 8..13 = mu J (column 30: mu g)   [Pu was consumed? no: Pu is read by lw_project]
+  qm_wave_sync();
+  const double dsum = FR[12] + FR[28] + FR[44] + FR[60];
+  LQT()
+  // R = (R0 + diag + friction blocks + shift) dt
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r, col = 16 * J + c; double v = Rm[I][J][r];
+        if (row < 30 && col < 30) {
+          if (row == col) v += RD[row] + dsum;
+          if (row < 12 && col < 12 && row / 3 == col / 3) v += FR[16 * (row / 3) + 3 * (row % 3) + (col % 3)];
+          v *= dt;
+        } else v = 0.0;
+        Rm[I][J][r] = v;
+      }
+  if (l < 30) S[LW_V_RV + l] *= dt;
+  const double ctot = qm_wave_sum(cost) * dt;
+  if (l == 0) { a.perf[nb * PF_SIZE] = ctot; a.perf[nb * PF_SIZE + 1] = dt * b2; a.perf[nb * PF_SIZE + 2] = dt * eq2; }
+  // keep Pu safe in registers?  It stays in the tile: the EE term uses its own small staging area (K2 is dead by now)
+  double* JT = K2;                                                      // [6][32] J rows, reuse of the stage-2 kin record
+  qm_wave_sync();
+  if (l < 30) { double col[6]; ee_jac_col(X, K1, EE + 12, EE + 19, l, col); for (int r = 0; r < 6; ++r) JT[r * 32 + l] = col[r]; }
+  if (l >= 30 && l < 32) for (int r = 0; r < 6; ++r) JT[r * 32 + l] = 0.0;
+  qm_wave_sync();
+  // [Q | q] = ([diag + shift | q] + Jᵀ mu [J | g]) dt
+  qm_d4 Qa[2][2];
+  {
+    qm_d4 Jz[1][2], Jy[1][2];
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = g + 4 * r, col = 16 * J + c; const double jv = (row < 6 && col < 30) ? JT[row * 32 + col] : 0.0; Jz[0][J][r] = jv; Jy[0][J][r] = (row < 6) ? ((col < 30) ? EE[6 + row] * jv : ((col == 30) ? EE[6 + row] * EE[row] : 0.0)) : 0.0; }
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; Qa[I][J][r] = (row < 30) ? ((row == col) ? QD[row] + dsum : ((col == 30) ? S[LW_V_QV + row] : 0.0)) : 0.0; }
+    qm_gemm_tn<1, 2, 2>(Jz, Jy, Qa, 0, 2, false);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J) Qa[I][J] *= dt;
+  }
+  if (dbg) {
+    qm_frag_store<2, 2>(Qa, dbg + LQ_DBG_Q, 30, 30, 30); qm_frag_store<2, 2>(Rm, dbg + LQ_DBG_R, 30, 30, 30);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14 && row < 30) dbg[LQ_DBG_q + row] = Qa[I][1][r]; }
+    if (l < 30) dbg[LQ_DBG_r + l] = S[LW_V_RV + l]; if (l == 0) dbg[LQ_DBG_c] = ctot;
+  }
+  LQT()
+  // ---- projected cost + stores ----
+  double rpe = 0.0;
+  if (m <= 16) lw_project<1>(S, rec, m, Bdt, PxA, Rm, Qa, rpe); else lw_project<2>(S, rec, m, Bdt, PxA, Rm, Qa, rpe);
+  if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
+  {
+    qm_d4 PxO[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J) PxO[I][J] = PxA[I][J];
+    qm_frag_store<2, 2>(PxO, rec + SR_PX, 30, 30, 30);           // column 30 (Pe) is outside the 30 stored columns
+  }
+  if (l == 0) { rec[SR_SCAL] = (double)m; rec[SR_SCAL + 1] = ctot + rpe; }
+  LQT()
+  if (a.prof && l == 0) for (int k = 0; k + 1 < np_ && k < 9; ++k) rec[SR_K + k] = (double)(tp_[k + 1] - tp_[k]);
+#undef LQT
 }

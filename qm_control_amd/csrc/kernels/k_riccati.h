@@ -52,26 +52,10 @@ struct QmRiccatiArgs {
 #define RW_LDS_BYTES (RW_LDS_DOUBLES * 8)
 #define RF_NLOAD 61               /* ceil((1440 + 2304 + 108 + 18) / 64) */
 
-// P += (neg ? −1 : 1) · Zᵀ Y over k-steps [0, ksteps); Z: [KT][IT] tiles, Y: [KT][JT] tiles, P: [IT][JT] tiles (all D-layout)
 template <int KT, int IT, int JT>
-__device__ __forceinline__ void rw_gemm_tn(const qm_d4 (&Z)[KT][IT], const qm_d4 (&Y)[KT][JT], qm_d4 (&P)[IT][JT], int ksteps, bool neg) {
-#pragma unroll
-  for (int kk = 0; kk < 4 * KT; ++kk) if (kk < ksteps) {
-#pragma unroll
-    for (int I = 0; I < IT; ++I) {
-      const double av = neg ? -Z[kk >> 2][I][kk & 3] : Z[kk >> 2][I][kk & 3];
-#pragma unroll
-      for (int J = 0; J < JT; ++J) P[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Y[kk >> 2][J][kk & 3], P[I][J], 0, 0, 0);
-    }
-  }
-}
+__device__ __forceinline__ void rw_gemm_tn(const qm_d4 (&Z)[KT][IT], const qm_d4 (&Y)[KT][JT], qm_d4 (&P)[IT][JT], int ksteps, bool neg) { qm_gemm_tn<KT, IT, JT>(Z, Y, P, 0, ksteps, neg); }
 template <int IT, int JT>
-__device__ __forceinline__ void rw_zero(qm_d4 (&T)[IT][JT]) {
-#pragma unroll
-  for (int I = 0; I < IT; ++I)
-#pragma unroll
-    for (int J = 0; J < JT; ++J) T[I][J] = qm_d4{0.0, 0.0, 0.0, 0.0};
-}
+__device__ __forceinline__ void rw_zero(qm_d4 (&T)[IT][JT]) { qm_frag_zero<IT, JT>(T); }
 // D-layout load of a rows x cols row-major matrix (leading dim ld); optional vector in column 30 (rows < rows)
 template <int IT, int JT>
 __device__ __forceinline__ void rw_load(qm_d4 (&T)[IT][JT], const double* src, int ld, int rows, int cols, const double* col30) {

@@ -141,6 +141,53 @@ __device__ __forceinline__ double tile_col_dot(const double* T, int col, const d
   double s = 0.0; for (int r = 0; r < rows; ++r) s += T[r * QM_LD + col] * x[r]; return s;
 }
 
+// ---- register fragments of the f64 matrix core (one wavefront) ----
+// v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4r][col = l&15].  A matrix kept as
+// D-fragments ("D-layout": tile (I,J), register r <-> element (16I + (l>>4) + 4r, 16J + (l&15))) is directly the B operand of
+// k-step kk = 4K + r and — read as an A operand — supplies its TRANSPOSE, so products of the form P = Zᵀ Y chain from MFMA to
+// MFMA with no layout conversion.
+// P += (neg ? −1 : 1) · Zᵀ Y over k-steps [k0, k1); Z: [KT][IT] tiles, Y: [KT][JT] tiles, P: [IT][JT] tiles
+template <int KT, int IT, int JT>
+__device__ __forceinline__ void qm_gemm_tn(const qm_d4 (&Z)[KT][IT], const qm_d4 (&Y)[KT][JT], qm_d4 (&P)[IT][JT], int k0, int k1, bool neg) {
+#pragma unroll
+  for (int kk = 0; kk < 4 * KT; ++kk) if (kk >= k0 && kk < k1) {
+#pragma unroll
+    for (int I = 0; I < IT; ++I) {
+      const double av = neg ? -Z[kk >> 2][I][kk & 3] : Z[kk >> 2][I][kk & 3];
+#pragma unroll
+      for (int J = 0; J < JT; ++J) P[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Y[kk >> 2][J][kk & 3], P[I][J], 0, 0, 0);
+    }
+  }
+}
+template <int IT, int JT>
+__device__ __forceinline__ void qm_frag_zero(qm_d4 (&T)[IT][JT]) {
+#pragma unroll
+  for (int I = 0; I < IT; ++I)
+#pragma unroll
+    for (int J = 0; J < JT; ++J) T[I][J] = qm_d4{0.0, 0.0, 0.0, 0.0};
+}
+// D-layout read of a rows x cols row-major matrix (global or LDS, leading dim ld); TR: the source holds the transpose
+template <int IT, int JT, bool TR>
+__device__ __forceinline__ void qm_frag_load(qm_d4 (&T)[IT][JT], const double* src, int ld, int rows, int cols) {
+  const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+#pragma unroll
+  for (int I = 0; I < IT; ++I)
+#pragma unroll
+    for (int J = 0; J < JT; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; T[I][J][r] = (row < rows && col < cols) ? (TR ? src[col * ld + row] : src[row * ld + col]) : 0.0; }
+}
+template <int IT, int JT>
+__device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* dst, int ld, int rows, int cols) {
+  const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+#pragma unroll
+  for (int I = 0; I < IT; ++I)
+#pragma unroll
+    for (int J = 0; J < JT; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < rows && col < cols) dst[row * ld + col] = T[I][J][r]; }
+}
+
 // ---- per-node stage record written by K1 (LQ + projection) and read by K3 (Riccati); doubles ----
 // dimensions: nx = 30, projected input dim m <= 18 (stance 18, trot 16); row-major, fixed strides
 #define QM_MMAX 18

@@ -37,3 +37,12 @@ cyc = itf.debug_read("wbc_scratch", (B, 16))
 fn = ["copy T", "qr_Et", "fwd solve y1", "T Q + rhs", "reduced LS", "apply Q", "res/w", "apply Qt", "multipliers"]
 print(json.dumps({n: float(cyc[:, i].mean()) for i, n in enumerate(fn)}, indent=1))
 itf.debug_set("wbc_stop", 0)
+# K1b in-kernel stamps (thread 0 of each node's workgroup)
+itf.debug_set("lq_prof", 1)
+mpc.solve_resident(cfg["horizon"]); itf.synchronize()
+nm = 128; SR = 5312
+stage = itf.debug_read("stage", (B * nm, SR))
+rows = stage[np.arange(B)[:, None] * nm + np.arange(5, 95)[None, :]].reshape(-1, SR)[:, 4752:4761]
+ln = ["P0 stage inputs", "I jacobian columns", "I RK2 composition", "II constraint rows", "II projector", "II projected dynamics", "III cost model", "III projected cost + stores"]
+print(json.dumps({n: float(rows[:, i].mean()) for i, n in enumerate(ln)}, indent=1)); print("LQ total cycles/node", rows[:, :8].sum(1).mean())
+itf.debug_set("lq_prof", 0)
