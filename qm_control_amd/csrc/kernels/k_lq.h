@@ -186,23 +186,30 @@ __global__ void qm_lq_kin_kernel(QmLqArgs a) {
 }
 
 // ---- K1b: one wavefront per node ----
-__global__ void __launch_bounds__(LW_BLOCK) qm_lq_kernel(QmLqArgs a) {
+__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   extern __shared__ double qm_smem[];
   double* S = qm_smem;
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
   const int b = blockIdx.x / a.nmax, i = blockIdx.x - b * a.nmax;
-  const int nn = a.n_nodes[b];
-  if (i >= nn) return;
   const int nb = i * a.B + b;                       // node-major index
-  const int ev = a.node_ev[nb];
-  const bool terminal = (i == nn - 1);
-  if (!terminal && ev == QM_EV_PRE) return;         // event nodes carry no LQ data (identity jump, handled by K3)
   const double* mb = a.mb; const double* st = a.st;
   double* rec = a.stage + ((size_t)b * a.nmax + i) * SR_SIZE;
   double* dbg = a.dbg ? a.dbg + ((size_t)b * a.nmax + i) * LQ_DBG_SIZE : nullptr;
   const double* kr = a.kin + (size_t)nb * KR_SIZE;
-  const double dt = a.node_dt[nb];
-  const int mode = a.node_mode[nb];
+  // every input address depends on (b, i) only: issue all loads before looking at the node's status (one memory round trip)
+  const int nn = a.n_nodes[b]; const int ev = a.node_ev[nb];
+  const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
+  const int nxt = (i + 1 < a.nmax) ? ((i + 1) * a.B + b) : nb;
+  double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_x2 = 0.0, in_ee = 0.0, in_k[4], in_k2[4];
+  if (l < 30) { in_x = a.x[nb * 30 + l]; in_u = a.u[nb * 30 + l]; xn = a.x[nxt * 30 + l]; f1 = kr[KR_F1 + l]; f2 = kr[KR_F2 + l]; in_x2 = kr[KR_X2 + l]; }
+  if (l >= 32 && l < 39) in_ee = a.eeref[nb * 7 + (l - 32)];
+  if (l >= 40 && l < 46) in_ee = kr[KR_EEG + (l - 40)];
+  if (l >= 48 && l < 52) in_ee = kr[KR_QEE + (l - 48)];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { const int idx = l + 64 * t; in_k[t] = (idx < KW_SIZE) ? kr[KR_K1 + idx] : 0.0; in_k2[t] = (idx < KW_ARM) ? kr[KR_K2 + idx] : 0.0; }
+  if (i >= nn) return;
+  const bool terminal = (i == nn - 1);
+  if (!terminal && ev == QM_EV_PRE) return;         // event nodes carry no LQ data (identity jump, handled by K3)
   long long tp_[10]; int np_ = 0;
 #define LQT() { if (a.prof) tp_[np_] = (long long)__builtin_readcyclecounter(); ++np_; }
   LQT()
@@ -210,12 +217,13 @@ __global__ void __launch_bounds__(LW_BLOCK) qm_lq_kernel(QmLqArgs a) {
   double* T = S + LW_T; double* X = S + LW_V_X; double* U = S + LW_V_U; double* K1 = S + LW_K1; double* K2 = S + LW_K2; double* EE = S + LW_V_EE;
   for (int idx = l; idx < LW_K1 - LW_V; idx += 64) S[LW_V + idx] = 0.0;
   qm_wave_sync();
-  double xn = 0.0, f1 = 0.0, f2 = 0.0;
-  if (l < 30) { X[l] = a.x[nb * 30 + l]; U[l] = terminal ? 0.0 : a.u[nb * 30 + l]; if (!terminal) { xn = a.x[((i + 1) * a.B + b) * 30 + l]; f1 = kr[KR_F1 + l]; f2 = kr[KR_F2 + l]; S[LW_V_X2 + l] = kr[KR_X2 + l]; } }
-  if (l >= 32 && l < 39) EE[16 + (l - 32)] = a.eeref[nb * 7 + (l - 32)];
-  if (l >= 40 && l < 46) EE[l - 40] = kr[KR_EEG + (l - 40)];
-  if (l >= 48 && l < 52) EE[12 + (l - 48)] = kr[KR_QEE + (l - 48)];
-  for (int idx = l; idx < KW_SIZE; idx += 64) { K1[idx] = kr[KR_K1 + idx]; K2[idx] = (!terminal && idx < KW_ARM) ? kr[KR_K2 + idx] : 0.0; }
+  if (terminal) { in_u = 0.0; xn = 0.0; f1 = 0.0; f2 = 0.0; }
+  if (l < 30) { X[l] = in_x; U[l] = in_u; S[LW_V_X2 + l] = in_x2; }
+  if (l >= 32 && l < 39) EE[16 + (l - 32)] = in_ee;
+  if (l >= 40 && l < 46) EE[l - 40] = in_ee;
+  if (l >= 48 && l < 52) EE[12 + (l - 48)] = in_ee;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { const int idx = l + 64 * t; if (idx < KW_SIZE) { K1[idx] = in_k[t]; K2[idx] = terminal ? 0.0 : in_k2[t]; } }
   qm_wave_sync();
 
   if (terminal) {
@@ -233,25 +241,19 @@ __global__ void __launch_bounds__(LW_BLOCK) qm_lq_kernel(QmLqArgs a) {
   qm_d4 Ad[2][2], Bdt[2][2];
   {
     qm_d4 A1[1][2], B1[1][2], B1t[2][1], A2[1][2], A2t[2][1], B2t[2][1];
+    double col1[12], col2[12];
+    if (l < 60) { flow_jac_col(mb, X, U, K1, l, col1); flow_jac_col(mb, S + LW_V_X2, U, K2, l, col2); }   // two independent chains
+    const int cc = (l < 30) ? l : l - 30, r0 = (l < 30) ? 0 : 16;
     for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
     qm_wave_sync();
     if (l < 60) {
-      double col[12]; flow_jac_col(mb, X, U, K1, l, col);
-      const int cc = (l < 30) ? l : l - 30, r0 = (l < 30) ? 0 : 16;
-      for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = col[r];
+      for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = col1[r];
       if (l >= 42 && l < 46) T[(16 + (l - 30)) * LW_TLD + cc] = 1.0;            // d qdot_j / d u_j rows 12..15 (rows >= 16 are handled analytically)
     }
     qm_wave_sync();
     qm_frag_load<1, 2, false>(A1, T, LW_TLD, 16, 30); qm_frag_load<1, 2, false>(B1, T + 16 * LW_TLD, LW_TLD, 16, 30); qm_frag_load<2, 1, true>(B1t, T + 16 * LW_TLD, LW_TLD, 30, 16);
     qm_wave_sync();
-    for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
-    qm_wave_sync();
-    if (l < 60) {
-      double col[12]; flow_jac_col(mb, S + LW_V_X2, U, K2, l, col);
-      const int cc = (l < 30) ? l : l - 30, r0 = (l < 30) ? 0 : 16;
-      for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = col[r];
-      if (l >= 42 && l < 46) T[(16 + (l - 30)) * LW_TLD + cc] = 1.0;
-    }
+    if (l < 60) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = col2[r]; }      // same sparsity pattern: no re-zeroing needed
     qm_wave_sync();
     qm_frag_load<1, 2, false>(A2, T, LW_TLD, 16, 30); qm_frag_load<2, 1, true>(A2t, T, LW_TLD, 30, 16); qm_frag_load<2, 1, true>(B2t, T + 16 * LW_TLD, LW_TLD, 30, 16);
     LQT()
@@ -300,18 +302,26 @@ __global__ void __launch_bounds__(LW_BLOCK) qm_lq_kernel(QmLqArgs a) {
   qm_wave_sync();
   int row0[4]; int nc = 0; for (int k = 0; k < 4; ++k) { row0[k] = nc; nc += mode_flag(mode, k) ? 3 : 4; }
   const double gain = st[ST_POS_ERR_GAIN];
-  for (int k = 0; k < 4; ++k) {
-    const bool stance = mode_flag(mode, k);
+  {
+    double dv[4][3], dpz[4];
     if (l < 60) {
-      double dv[3], dpz; foot_vel_jac_col(mb, X, U, K1, k, l, dv, &dpz);
-      double* M = (l < 30) ? T : T + 16 * LW_TLD; const int cc = (l < 30) ? l : l - 30;
-      if (stance) { for (int r = 0; r < 3; ++r) M[(row0[k] + r) * LW_TLD + cc] = dv[r] + ((r == 2 && gain != 0.0) ? gain * dpz : 0.0); }
-      else {
-        M[(row0[k] + 3) * LW_TLD + cc] = dv[2] + (gain != 0.0 ? gain * dpz : 0.0);
-        if (l >= 30 && l - 30 >= 3 * k && l - 30 < 3 * k + 3) M[(row0[k] + (l - 30 - 3 * k)) * LW_TLD + cc] = 1.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) foot_vel_jac_col(mb, X, U, K1, k, l, dv[k], &dpz[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool stance = mode_flag(mode, k);
+      if (l < 60) {
+        double* M = (l < 30) ? T : T + 16 * LW_TLD; const int cc = (l < 30) ? l : l - 30;
+        if (stance) { for (int r = 0; r < 3; ++r) M[(row0[k] + r) * LW_TLD + cc] = dv[k][r] + ((r == 2 && gain != 0.0) ? gain * dpz[k] : 0.0); }
+        else {
+          M[(row0[k] + 3) * LW_TLD + cc] = dv[k][2] + (gain != 0.0 ? gain * dpz[k] : 0.0);
+          if (l >= 30 && l - 30 >= 3 * k && l - 30 < 3 * k + 3) M[(row0[k] + (l - 30 - 3 * k)) * LW_TLD + cc] = 1.0;
+        }
       }
     }
-    if (l == 60) {
+    if (l >= 60) {                                          // lanes 60..63: one contact each, the constraint values
+      const int k = l - 60; const bool stance = mode_flag(mode, k);
       double v[3]; foot_velocity(X, K1, k, v); const double pz = kin_foot(K1, k)[2];
       if (stance) { for (int r = 0; r < 3; ++r) S[LW_V_E + row0[k] + r] = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); }
       else {
