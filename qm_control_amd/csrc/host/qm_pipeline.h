@@ -94,24 +94,21 @@ struct QmMpcPipeline {
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, 0, q);
     bk.launch(qm_lq_kernel, B * d.nmax, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node
     QmLsArgs l = ls_args(B);
-    { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, (B + 63) / 64, 64, 0, lb); }
+    { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, B, 64, 0, lb); }   // also arms the line search: alpha = 1, done = 0
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
     bk.launch(qm_riccati_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // one wavefront per instance
-    // line search: alpha = 1, done = 0
-    std::vector<double> ones((size_t)B, 1.0); bk.to_device(d.alpha, ones.data(), (size_t)B * 8); bk.zero(d.done, (size_t)B * 4);
     std::vector<int> done_h((size_t)B);
     ls_trials_run = 0;
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;
       bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, 0, l);
-      { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, (B + 63) / 64, 64, 0, ls); }
-      bk.launch(qm_ls_accept_kernel, (B + 63) / 64, 64, 0, l);
+      { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision
       ++ls_trials_run;
       bk.to_host(done_h.data(), d.done, (size_t)B * 4);
       bool all = true; for (int b = 0; b < B; ++b) if (done_h[b] == 0) { all = false; break; }
       if (all) break;
     }
-    bk.launch(qm_ls_apply_kernel, (nodes_threads + 63) / 64, 64, 0, l);
-    bk.launch(qm_ls_commit_kernel, (nodes_threads + 63) / 64, 64, 0, l);
+    bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
+    bk.launch(qm_ls_commit_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
   }
 };

@@ -3,8 +3,8 @@
 //
 //   qm_ls_eval_kernel    one THREAD per (instance, node): value-only Heun defect, cost and equality residual of the
 //                        trial trajectory x + alpha dx, u + alpha du   (scalar kinematics: lanes = instances)
-//   qm_perf_sum_kernel   one thread per instance: ordered sum over nodes (+ initial-state defect)
-//   qm_ls_accept_kernel  one thread per instance: filter acceptance, alpha <- alpha/2 or stop
+//   qm_perf_sum_kernel   one WAVEFRONT per instance: sum over nodes (+ initial-state defect); for a trial point also the
+//                        filter acceptance: accept, alpha <- alpha/2, or stop
 //   qm_ls_apply_kernel   one thread per (instance, node): x += alpha dx, u += alpha du and the primal solution
 //                        (u at PreEvent nodes copied from the previous node, last u repeated)
 #pragma once
@@ -107,29 +107,33 @@ __global__ void qm_ls_eval_kernel(QmLsArgs a) {
   pf[0] = cost * dt; pf[1] = dt * s; pf[2] = dt * eq;
 }
 
-// ordered sum of node terms -> perf_sum[b] = {merit, cost, dynSSE, eqSSE}; with_alpha: initial defect of the trial
-__global__ void qm_perf_sum_kernel(QmLsArgs a) {
+// One WAVEFRONT per instance.  Sum of the node terms -> perf_sum[b] = {merit, cost, dynSSE, eqSSE} (lanes stride over the
+// nodes, DPP wave reduction).  with_alpha == 0: baseline of the current iterate, also arms the line search (alpha = 1, done = 0);
+// with_alpha == 1: the trial point, followed by the filter line-search decision of this instance
+// ([upstream ocs2_sqp SqpSolver::takeStep / FilterLinesearch]): accept, halve alpha, or give up.
+__global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
   const int with_alpha = a.with_alpha;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
   if (with_alpha && a.done[b] != 0) return;
   const int n = a.n_nodes[b]; double c = 0.0, d = 0.0, e = 0.0;
-  for (int i = 0; i < n; ++i) { const double* pf = a.perf + (size_t)(i * a.B + b) * PF_SIZE; c += pf[0]; d += pf[1]; e += pf[2]; }
-  const double al = with_alpha ? a.alpha[b] : 0.0; double s = 0.0;
-  for (int q = 0; q < 30; ++q) { const double dd = a.x0[(size_t)b * 30 + q] - (a.x[b * 30 + q] + al * a.dx[b * 30 + q]); s += dd * dd; }
-  d += s;
+  for (int i = l; i < n; i += 64) { const double* pf = a.perf + (size_t)(i * a.B + b) * PF_SIZE; c += pf[0]; d += pf[1]; e += pf[2]; }
+  const double al0 = with_alpha ? a.alpha[b] : 0.0;
+  if (l < 30) { const double dd = a.x0[(size_t)b * 30 + l] - (a.x[b * 30 + l] + al0 * a.dx[b * 30 + l]); d += dd * dd; }
+  c = qm_wave_sum(c); d = qm_wave_sum(d); e = qm_wave_sum(e);
+  if (l != 0) return;
   a.perf_sum[b * 4] = c; a.perf_sum[b * 4 + 1] = c; a.perf_sum[b * 4 + 2] = d; a.perf_sum[b * 4 + 3] = e;
-}
-
-__global__ void qm_ls_accept_kernel(QmLsArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
-  if (a.trial == 0) { for (int q = 0; q < 4; ++q) { a.out_perf[b * 10 + q] = a.base_sum[b * 4 + q]; a.out_perf[b * 10 + 4 + q] = a.base_sum[b * 4 + q]; } a.out_perf[b * 10 + 8] = 0.0; a.out_perf[b * 10 + 9] = a.step_info[b * 4]; }
-  if (a.done[b] != 0) return;
+  if (!with_alpha) {
+    a.alpha[b] = 1.0; a.done[b] = 0;
+    for (int q = 0; q < 4; ++q) { a.out_perf[b * 10 + q] = a.perf_sum[b * 4 + q]; a.out_perf[b * 10 + 4 + q] = a.perf_sum[b * 4 + q]; }
+    a.out_perf[b * 10 + 8] = 0.0;
+    return;
+  }
+  if (a.trial == 0) a.out_perf[b * 10 + 9] = a.step_info[b * 4];
   const double gMax = a.st[ST_G_MAX], gMin = a.st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
-  const double* bs = a.base_sum + b * 4; const double* ps = a.perf_sum + b * 4;
+  const double* bs = a.base_sum + b * 4; const double ps[4] = {c, c, d, e};
   const double theta0 = sqrt(bs[2] + bs[3]), theta = sqrt(ps[2] + ps[3]);
-  double al = a.alpha[b]; const double armijo = a.step_info[b * 4];
+  double al = al0; const double armijo = a.step_info[b * 4];
   bool acc;
   if (theta > gMax) acc = theta < (1.0 - gammaC) * theta0;
   else if (theta < gMin && theta0 < gMin && al * armijo < 0.0) acc = ps[0] < bs[0] + armijoFactor * al * armijo;
@@ -141,28 +145,29 @@ __global__ void qm_ls_accept_kernel(QmLsArgs a) {
   a.alpha[b] = al;
 }
 
+// one thread per (node, instance, component): consecutive threads touch consecutive doubles
 __global__ void qm_ls_apply_kernel(QmLsArgs a) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = g / a.B, b = g - i * a.B;
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = (int)(g / 30), q = (int)(g - (size_t)nb * 30);
+  const int i = nb / a.B, b = nb - i * a.B;
   if (i >= a.nmax) return;
   const int n = a.n_nodes[b]; if (i >= n) return;
   const double al = (a.done[b] == 1) ? a.alpha[b] : 0.0;
-  const int nb = i * a.B + b;
-  for (int q = 0; q < 30; ++q) a.xs[nb * 30 + q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
+  a.xs[nb * 30 + q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
   // input of the primal solution: own node, or the closest earlier non-event node
   int j = (i == n - 1) ? n - 2 : i;
   while (j > 0 && a.node_ev[j * a.B + b] == QM_EV_PRE) --j;
   const int jb = j * a.B + b; const bool evj = (a.node_ev[jb] == QM_EV_PRE);
-  for (int q = 0; q < 30; ++q) a.us[nb * 30 + q] = evj ? 0.0 : a.u[jb * 30 + q] + al * a.du[jb * 30 + q];
+  a.us[nb * 30 + q] = evj ? 0.0 : a.u[jb * 30 + q] + al * a.du[jb * 30 + q];
 }
 // commit the accepted step into the iterate (separate launch: apply reads neighbours' u)
 __global__ void qm_ls_commit_kernel(QmLsArgs a) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = g / a.B, b = g - i * a.B;
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = (int)(g / 30), q = (int)(g - (size_t)nb * 30);
+  const int i = nb / a.B, b = nb - i * a.B;
   if (i >= a.nmax) return;
   const int n = a.n_nodes[b]; if (i >= n) return;
   const double al = (a.done[b] == 1) ? a.alpha[b] : 0.0;
-  const int nb = i * a.B + b;
   const bool hasu = (i < n - 1) && a.node_ev[nb] != QM_EV_PRE;
-  for (int q = 0; q < 30; ++q) { a.x[nb * 30 + q] += al * a.dx[nb * 30 + q]; if (hasu) a.u[nb * 30 + q] += al * a.du[nb * 30 + q]; }
+  a.x[nb * 30 + q] += al * a.dx[nb * 30 + q]; if (hasu) a.u[nb * 30 + q] += al * a.du[nb * 30 + q];
 }
