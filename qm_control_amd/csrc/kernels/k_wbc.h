@@ -33,7 +33,7 @@ struct QmWbcArgs {
   int stop;                                   // profiling only: 1 return after the rigid-body phase, 2/3/4 after level 0/1/2 (no outputs)
   double* dbg;                                // optional [B][WBC_DBG_SIZE]: qMeas vMeas qDes vDes baseAcc nle x0 x1 x2 M J dJv
 };
-#define WBC_SCRATCH 16   /* per-instance phase cycle counters (profiling, stop < 0) */
+#define WBC_SCRATCH 432  /* per-instance HBM scratch, WS_* below */
 #define WBC_DBG_SIZE (24 * 4 + 6 + 24 + 36 * 3 + 576 + 288 + 12)
 #define WBC_BLOCK 64
 
@@ -41,21 +41,22 @@ struct QmWbcArgs {
 #define WMAXA 22        /* max equality-task rows of one level */
 #define WMAXACT 20      /* cap on simultaneously active inequality rows */
 #define WMAXINEQ 56
-#define WG_ROWS (WMAXA + WNV + WMAXACT)
-#define WGLD 38         /* leading dim of the working matrix: up to 36 columns + rhs */
 #define WRHO 1e-12
 
-// ---- LDS carve (doubles) ----
+// ---- LDS carve (doubles): 40 KB per wavefront -> four instances per CU ----
+#define WVLD 18                                   /* leading dim of the small (n <= 18) level >= 1 work arrays */
+#define WTLD 19                                   /* [R | c] and its scratch copy at levels >= 1 */
 #define WL_M      0
 #define WL_NLE    (WL_M + 576)
 #define WL_JF     (WL_NLE + 24)
-#define WL_JARM   (WL_JF + 288)
-#define WL_BB     (WL_JARM + 144)                 /* [22] */
-#define WL_AZ     (WL_BB + WMAXA)                 /* [22][36] (ld 36) */
-#define WL_G      (WL_AZ + WMAXA * WNV)           /* [78][38] working matrix (+ null-space workspace; RBD sums/accumulators before the cascade) */
-#define WL_ZP     (WL_G + WG_ROWS * WGLD)         /* [36][n] */
-#define WL_HV     (WL_ZP + WNV * WNV)             /* [80] Householder vector */
-#define WL_X      (WL_HV + 80)
+#define WL_BB     (WL_JF + 288)                   /* [22] */
+#define WL_AZ     (WL_BB + WMAXA)                 /* [22][36]: level 0 task rows (Zp = I), A Zp at levels >= 1 */
+#define WL_G      (WL_AZ + WMAXA * WNV)           /* 720: level 0 packed triangular [R | c] (702); levels >= 1 [R | c] (18 x 19) + scratch copy;
+                                                     null-space workspace (A Zp)ᵀ; RBD sums/accumulators before the cascade */
+#define WG_SIZE   720
+#define WL_ZP     (WL_G + WG_SIZE)                /* [36][n], n <= 18 (level 0 works with Zp = I implicitly) */
+#define WL_HV     (WL_ZP + WNV * WVLD)            /* [48] pivot column broadcast */
+#define WL_X      (WL_HV + 48)
 #define WL_Z      (WL_X + WNV)
 #define WL_ZN     (WL_Z + WNV)
 #define WL_P      (WL_ZN + WNV)
@@ -68,21 +69,24 @@ struct QmWbcArgs {
 #define WL_DZ     (WL_FB + WMAXINEQ)
 #define WL_DP     (WL_DZ + WMAXINEQ)
 #define WL_TAU    (WL_DP + WMAXINEQ)              /* [18] */
-#define WL_V      (WL_TAU + 24)                   /* [20][36] reflectors of the working-set QR */
-#define WL_A      WL_V                            /* [22][36] task rows: only live while AZ / g0 are formed, aliases V..EROWS */
-#define WL_BETA   (WL_V + WMAXACT * WNV)
+#define WL_V      (WL_TAU + 24)                   /* [20][18] reflectors of the working-set QR */
+#define WL_A      WL_V                            /* [22][36] task rows of levels >= 1: only live while A Zp / g0 are formed, aliases V..EROWS */
+#define WL_BETA   (WL_V + WMAXACT * WVLD)
 #define WL_R      (WL_BETA + WMAXACT)             /* [20][20] */
-#define WL_EROWS  (WL_R + WMAXACT * WMAXACT)      /* [20][36] */
-#define WL_ERHS   (WL_EROWS + WMAXACT * WNV)
+#define WL_EROWS  (WL_R + WMAXACT * WMAXACT)      /* [20][18] */
+#define WL_ERHS   (WL_EROWS + WMAXACT * WVLD)
 #define WL_LAM    (WL_ERHS + WMAXACT)
 #define WL_Y      (WL_LAM + WMAXACT)              /* [36] */
 #define WL_W36    (WL_Y + WNV)
-#define WL_WLIST  (WL_W36 + WNV)                /* [20] ints: working set */
+#define WL_WLIST  (WL_W36 + WNV)                  /* [20] ints: working set */
 #define WL_ACC    (WL_G + 18 * 16)                /* chain accumulators: 3 passes x 6 slots x 20 (inside G, after the momentum sums) */
 #define WL_MISC   (WL_WLIST + 12)                 /* q v qd vd w2 (5 x 24), baseAcc(6) */
-#define WL_TIPS   (WL_MISC + 5 * 24 + 8)          /* 10 tips x 27 doubles: measured feet 0-3, arm 4, desired feet 5-8, arm 9 */
-#define WL_XLEV   (WL_TIPS + 10 * 27)             /* [3][36] */
-#define WL_TOTAL  (WL_XLEV + 3 * WNV)
+#define WL_TOTAL  (WL_MISC + 5 * 24 + 8)
+// per-instance HBM scratch (doubles): cycle counters, arm Jacobian, the ten tip records (read a handful of times while the tasks are built)
+#define WS_TIME   0
+#define WS_JARM   16                              /* [6][24] */
+#define WS_TIPS   (WS_JARM + 144)                 /* 10 tips x 27 doubles: measured feet 0-3, arm 4, desired feet 5-8, arm 9 */
+#define WS_SIZE   (WS_TIPS + 270 + 2)
 #define WBC_LDS_BYTES (WL_TOTAL * 8)
 
 __device__ __forceinline__ double wv_sum(double v) { return qm_wave_sum(v); }
@@ -138,6 +142,8 @@ __device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, d
 // by column in registers (lane j: d[0..MRD) = column j of D, lane n = its rhs, unused rows zero).  Step k only touches row k of T
 // and the dense rows, so a least-squares matrix [sqrt(rho) I; A] costs (1 + rows(A)) per column instead of n + rows(A).
 // On return T holds [R | Qᵀ rhs].
+// ldT == 0 selects PACKED storage of the upper triangle + rhs: row k holds columns k..n at offset k (2n + 3 − k) / 2.
+__device__ __forceinline__ int wv_tidx(int k, int c, int n, int ld) { return ld ? k * ld + c : ((k * (2 * n + 3 - k)) >> 1) + (c - k); }
 template <int MRD>
 __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ldT, int n, double* hv) {
   const int l = threadIdx.x & 63;
@@ -148,7 +154,7 @@ __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ld
       for (int i = 0; i < MRD; ++i) hv[i] = d[i];
     }
     qm_wave_sync();
-    const double tkk = T[k * ldT + k]; const double tl = (l >= k && l <= n) ? T[k * ldT + l] : 0.0;
+    const double tkk = T[wv_tidx(k, k, n, ldT)]; const double tl = (l >= k && l <= n) ? T[wv_tidx(k, l, n, ldT)] : 0.0;
     double nrm2 = tkk * tkk, dot = 0.0;
 #pragma unroll
     for (int i = 0; i < MRD; ++i) { const double vi = hv[i]; nrm2 += vi * vi; dot += vi * d[i]; }
@@ -156,13 +162,25 @@ __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ld
     const bool ok = (nrm2 != 0.0) && (vn != 0.0);
     const double s = ok ? (dot + vk * tl) * (2.0 / vn) : 0.0;
     if (ok && l > k && l <= n) {
-      T[k * ldT + l] = tl - s * vk;
+      T[wv_tidx(k, l, n, ldT)] = tl - s * vk;
 #pragma unroll
       for (int i = 0; i < MRD; ++i) d[i] -= s * hv[i];
     }
     qm_wave_sync();                                       // every lane has read the pivot before it is replaced
-    if (ok && l == k) T[k * ldT + k] = alpha;
+    if (ok && l == k) T[wv_tidx(k, k, n, ldT)] = alpha;
   }
+  qm_wave_sync();
+}
+// R z = c on [R | c] held like rq_house_tri leaves it (ld == 0: packed); z -> LDS vector
+__device__ __forceinline__ void wv_backsub_tri(const double* T, int ld, int n, double* z) {
+  const int l = threadIdx.x & 63; double zj = 0.0;
+  for (int i = n - 1; i >= 0; --i) {
+    const double s = wv_sum((l > i && l < n) ? T[wv_tidx(i, l, n, ld)] * zj : 0.0);
+    const double zi = (T[wv_tidx(i, n, n, ld)] - s) / T[wv_tidx(i, i, n, ld)];
+    if (l == i) zj = zi;
+  }
+  qm_wave_sync();
+  if (l < n) z[l] = zj;
   qm_wave_sync();
 }
 // R z = rhs with R = upper triangle of G[0:n, 0:n]; rhs is a strided vector (rhs[i * rs]); z -> LDS vector
@@ -187,30 +205,30 @@ __device__ __forceinline__ void wv_ls_qr(double* G, int ld, int rows, int n, dou
   rq_house<MR>(col, n, n, hv, G, ld, nullptr, 0, nullptr);
   wv_backsub(G, ld, n, G + n, ld, z);
 }
-// Householder QR of Eᵀ (n x me) for E (me x n, ld = WNV): reflectors V[k][0..n) (zero above k), beta[k], R (me x me upper, ld = WMAXACT)
+// Householder QR of Eᵀ (n x me) for E (me x n, ld = WVLD): reflectors V[k][0..n) (zero above k), beta[k], R (me x me upper, ld = WMAXACT)
 __device__ __forceinline__ void wv_qr_Et(const double* E, int me, int n, double* V, double* beta, double* R) {
   const int l = threadIdx.x & 63;
-  for (int idx = l; idx < me * n; idx += 64) { const int c = idx / n, i = idx - c * n; V[c * WNV + i] = E[c * WNV + i]; }
+  for (int idx = l; idx < me * n; idx += 64) { const int c = idx / n, i = idx - c * n; V[c * WVLD + i] = E[c * WVLD + i]; }
   qm_wave_sync();
   for (int k = 0; k < me; ++k) {
-    double* wk = V + k * WNV;
+    double* wk = V + k * WVLD;
     const double nrm2 = wv_sum((l >= k && l < n) ? wk[l] * wk[l] : 0.0); const double nrm = sqrt(nrm2);
     const double wkk = wk[k]; const double alpha = wkk > 0.0 ? -nrm : nrm; const double vn = nrm2 - wkk * wkk + (wkk - alpha) * (wkk - alpha);
     qm_wave_sync();
     if (l < k) { R[l * WMAXACT + k] = wk[l]; wk[l] = 0.0; }
     if (l == k) { R[k * WMAXACT + k] = alpha; wk[k] = wkk - alpha; beta[k] = (vn > 0.0) ? 2.0 / vn : 0.0; }
     qm_wave_sync();
-    if (l > k && l < me) { double* wc = V + l * WNV; double s = 0.0; for (int i = k; i < n; ++i) s += wk[i] * wc[i]; s *= beta[k]; for (int i = k; i < n; ++i) wc[i] -= s * wk[i]; }
+    if (l > k && l < me) { double* wc = V + l * WVLD; double s = 0.0; for (int i = k; i < n; ++i) s += wk[i] * wc[i]; s *= beta[k]; for (int i = k; i < n; ++i) wc[i] -= s * wk[i]; }
     qm_wave_sync();
   }
 }
 __device__ __forceinline__ void wv_apply_Qt(const double* V, const double* beta, int me, int n, double* x) {   // x <- Qᵀ x
   const int l = threadIdx.x & 63;
-  for (int k = 0; k < me; ++k) { const double* v = V + k * WNV; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
+  for (int k = 0; k < me; ++k) { const double* v = V + k * WVLD; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
 }
 __device__ __forceinline__ void wv_apply_Q(const double* V, const double* beta, int me, int n, double* x) {    // x <- Q x
   const int l = threadIdx.x & 63;
-  for (int k = me - 1; k >= 0; --k) { const double* v = V + k * WNV; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
+  for (int k = me - 1; k >= 0; --k) { const double* v = V + k * WVLD; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
 }
 
 struct WbcCtx {   // everything the D0 block and the torque map need (all wave-uniform)
@@ -233,28 +251,22 @@ __device__ __forceinline__ double wbc_d0_entry(const WbcCtx& c, int i, int k) { 
     if (q == 0) return a == 2 ? -1.0 : 0.0; if (a == 2) return -c.mu; if (q == 1) return a == 0 ? 1.0 : 0.0; if (q == 2) return a == 0 ? -1.0 : 0.0; if (q == 3) return a == 1 ? 1.0 : 0.0; return a == 1 ? -1.0 : 0.0; }
   return 0.0;
 }
-// row i of D0 times Zp (36 x n)  ->  dst[0..n)  (lane k = column k)
-__device__ __forceinline__ void wv_d0_row_Z(const WbcCtx& c, int i, const double* Zp, int n, double* dst) {
-  const int l = threadIdx.x & 63;
-  if (n == WNV) { if (l < n) dst[l] = wbc_d0_entry(c, i, l); return; }     // level 0: Zp = I
-  if (l < n) { double s = 0.0; for (int r = 0; r < WNV; ++r) { const double d = wbc_d0_entry(c, i, r); if (d != 0.0) s += d * Zp[r * n + l]; } dst[l] = s; }
-}
 // y(36) = Zp (36 x n) z
 __device__ __forceinline__ void wv_Z_times(const double* Zp, int n, const double* z, double* y) {
   const int l = threadIdx.x & 63;
-  if (l < WNV) { double s = 0.0; for (int k = 0; k < n; ++k) s += Zp[l * n + k] * z[k]; y[l] = s; }
+  if (l < WNV) { double s = 0.0; if (n == WNV) s = z[l]; else for (int k = 0; k < n; ++k) s += Zp[l * n + k] * z[k]; y[l] = s; }   // level 0: Zp = I
   qm_wave_sync();
 }
 
-// min |R z − c|² s.t. E z = e (me working-set rows in WL_EROWS / WL_ERHS), null-space method.  Rc = [R | c] (n x (n+1), ld WGLD,
-// upper triangle valid) is the once-per-level QR factor of G0 = [AZ; sqrt(rho) I | g0]; T (n x (n+1), ld WGLD) is scratch.  lam: multipliers.
+// min |R z − c|² s.t. E z = e (me working-set rows in WL_EROWS / WL_ERHS), null-space method.  Rc = [R | c] (n x (n+1), ld WTLD,
+// upper triangle valid) is the once-per-level QR factor of G0 = [AZ; sqrt(rho) I | g0]; T (n x (n+1), ld WTLD) is scratch.  lam: multipliers.
 __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* T, int n, int me, double* zout, long long* tf) {
   const int l = threadIdx.x & 63;
   long long tl_ = (long long)__builtin_readcyclecounter();
 #define WF(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tf[k] += now_ - tl_; tl_ = now_; }
-  if (me == 0) { wv_backsub(Rc, WGLD, n, Rc + n, WGLD, zout); return; }
+  if (me == 0) { wv_backsub_tri(Rc, WTLD, n, zout); return; }
   double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
-  for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); T[r * WGLD + k] = (k >= r) ? Rc[r * WGLD + k] : 0.0; }
+  for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); T[r * WTLD + k] = (k >= r) ? Rc[r * WTLD + k] : 0.0; }
   WF(0)
   wv_qr_Et(S + WL_EROWS, me, n, V, beta, R);
   WF(1)
@@ -263,12 +275,12 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
     if (l < me) y[l] = y1; }
   WF(2)
   // T <- T Q (row-wise reflections; lane = row), rhs column untouched
-  if (l < n) { double* g = T + l * WGLD; for (int k = 0; k < me; ++k) { const double* v = V + k * WNV; double sacc = 0.0; for (int i = k; i < n; ++i) sacc += g[i] * v[i]; sacc *= beta[k]; for (int i = k; i < n; ++i) g[i] -= sacc * v[i]; } }
+  if (l < n) { double* g = T + l * WTLD; for (int k = 0; k < me; ++k) { const double* v = V + k * WVLD; double sacc = 0.0; for (int i = k; i < n; ++i) sacc += g[i] * v[i]; sacc *= beta[k]; for (int i = k; i < n; ++i) g[i] -= sacc * v[i]; } }
   qm_wave_sync();
-  if (l < n) { double sacc = 0.0; for (int k = 0; k < me; ++k) sacc += T[l * WGLD + k] * y[k]; T[l * WGLD + n] -= sacc; }
+  if (l < n) { double sacc = 0.0; for (int k = 0; k < me; ++k) sacc += T[l * WTLD + k] * y[k]; T[l * WTLD + n] -= sacc; }
   qm_wave_sync();
   WF(3)
-  if (n - me > 0) wv_ls_qr<18>(T + me, WGLD, n, n - me, S + WL_HV, y + me);
+  if (n - me > 0) wv_ls_qr<18>(T + me, WTLD, n, n - me, S + WL_HV, y + me);
   WF(4)   // reduced problem on columns me..n-1 (rhs right after them)
   if (l < n) zout[l] = y[l];
   qm_wave_sync();
@@ -276,9 +288,9 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
   WF(5)
   // multipliers: R_E lam = −(Qᵀ Rᵀ (R z − c))[0:me]
   double* w = S + WL_W36; double* res = S + WL_HV;
-  if (l < n) { double sacc = -Rc[l * WGLD + n]; for (int k = l; k < n; ++k) sacc += Rc[l * WGLD + k] * zout[k]; res[l] = sacc; }
+  if (l < n) { double sacc = -Rc[l * WTLD + n]; for (int k = l; k < n; ++k) sacc += Rc[l * WTLD + k] * zout[k]; res[l] = sacc; }
   qm_wave_sync();
-  if (l < n) { double acc = 0.0; for (int r = 0; r <= l; ++r) acc += Rc[r * WGLD + l] * res[r]; w[l] = acc; }
+  if (l < n) { double acc = 0.0; for (int r = 0; r <= l; ++r) acc += Rc[r * WTLD + l] * res[r]; w[l] = acc; }
   qm_wave_sync();
   WF(6)
   wv_apply_Qt(V, beta, me, n, w);
@@ -291,12 +303,14 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
 #undef WF
 }
 
-// orthonormal null space of AZ (ra x n): Zp (36 x n) <- Zp · Q[:, rank:]  (Householder QR with column pivoting of (AZ)ᵀ); returns n − rank
+// orthonormal null space of AZ (ra x n): Zp (36 x n) <- Zp · Q2, Q2 = Q[:, rank:] from the Householder QR with column pivoting of
+// (AZ)ᵀ; returns n − rank.  The reflectors stay in W below the diagonal (LAPACK style); Q2 = H_0 … H_{r-1} [0; I] is accumulated
+// backwards, straight into Zp at level 0 (Zp = I) and through a small buffer otherwise.
 __device__ __forceinline__ int wv_null_space(double* S, int ra, int n) {
   const int l = threadIdx.x & 63;
-  double* W = S + WL_G; double* ZQ = S + WL_G + WMAXA * WNV; double* Zp = S + WL_ZP; const double* AZ = S + WL_AZ; double* hv = S + WL_HV;
+  double* W = S + WL_G; double* Zp = S + WL_ZP; const double* AZ = S + WL_AZ; double* hv = S + WL_HV; double* vdiag = S + WL_R;
+  double* bet = S + WL_R + 40;                                         // [22] 2 / (v·v) per reflector
   for (int idx = l; idx < n * ra; idx += 64) { const int i = idx / ra, j = idx - i * ra; W[i * ra + j] = AZ[j * WNV + i]; }
-  for (int idx = l; idx < WNV * n; idx += 64) ZQ[idx] = Zp[idx];
   qm_wave_sync();
   int rank = 0; double maxnorm0 = 0.0; const int steps = (n < ra) ? n : ra;
   for (int k = 0; k < steps; ++k) {
@@ -313,16 +327,37 @@ __device__ __forceinline__ int wv_null_space(double* S, int ra, int n) {
     qm_wave_sync();
     const double vn = wv_sum((l >= k && l < n) ? hv[l] * hv[l] : 0.0);
     if (vn > 0.0) {
-      if (l >= k && l < ra) { double s = 0.0; for (int i = k; i < n; ++i) s += hv[i] * W[i * ra + l]; s *= 2.0 / vn; for (int i = k; i < n; ++i) W[i * ra + l] -= s * hv[i]; }
-      if (l < WNV) { double s = 0.0; for (int i = k; i < n; ++i) s += ZQ[l * n + i] * hv[i]; s *= 2.0 / vn; for (int i = k; i < n; ++i) ZQ[l * n + i] -= s * hv[i]; }
+      if (l > k && l < ra) { double s = 0.0; for (int i = k; i < n; ++i) s += hv[i] * W[i * ra + l]; s *= 2.0 / vn; for (int i = k; i < n; ++i) W[i * ra + l] -= s * hv[i]; }
     }
+    if (l == 0) { vdiag[k] = hv[k]; bet[k] = (vn > 0.0) ? 2.0 / vn : 0.0; }
     qm_wave_sync();
     ++rank;
   }
+  if (n - rank > WVLD) rank = n - WVLD;                                // the level >= 1 work arrays hold at most 18 null-space directions
   const int nn = n - rank;
+  // Q2 (n x nn) = H_0 … H_{rank-1} [0; I]; reflector k: v[k] = vdiag[k], v[i > k] = W[i][k]
+  double* Q2 = (n == WNV) ? Zp : (W + n * ra);                         // level 0: Q2 IS the new Zp
   qm_wave_sync();
-  for (int idx = l; idx < WNV * nn; idx += 64) { const int r = idx / nn, j = idx - r * nn; Zp[idx] = ZQ[r * n + rank + j]; }
+  for (int idx = l; idx < n * nn; idx += 64) { const int i = idx / nn, j = idx - i * nn; Q2[idx] = (i == rank + j) ? 1.0 : 0.0; }
   qm_wave_sync();
+  for (int k = rank - 1; k >= 0; --k) {
+    if (l < nn) { double s = vdiag[k] * Q2[k * nn + l]; for (int i = k + 1; i < n; ++i) s += W[i * ra + k] * Q2[i * nn + l]; s *= bet[k]; Q2[k * nn + l] -= s * vdiag[k]; for (int i = k + 1; i < n; ++i) Q2[i * nn + l] -= s * W[i * ra + k]; }
+    qm_wave_sync();
+  }
+  if (n != WNV) {
+    // Zp (36 x n) <- Zp Q2 (36 x nn), row by row in place (every lane holds its old row in registers before anything is written)
+    double row[WVLD];
+    if (l < WNV) {
+#pragma unroll
+      for (int i = 0; i < WVLD; ++i) row[i] = (i < n) ? Zp[l * n + i] : 0.0;
+    }
+    qm_wave_sync();
+    if (l < WNV) for (int j = 0; j < nn; ++j) { double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < WVLD; ++i) if (i < n) s += row[i] * Q2[i * nn + j];
+      Zp[l * nn + j] = s; }
+    qm_wave_sync();
+  }
   return nn;
 }
 
@@ -346,7 +381,9 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   const int mode = a.mode[b]; const double time = a.time[b];
   for (int i = l; i < WL_TOTAL; i += 64) S[i] = 0.0;
   qm_wave_sync();
-  double* M = S + WL_M; double* nle = S + WL_NLE; double* Jf = S + WL_JF; double* Jarm = S + WL_JARM;
+  double* M = S + WL_M; double* nle = S + WL_NLE; double* Jf = S + WL_JF;
+  double* gs = a.scratch + (size_t)b * WBC_SCRATCH; double* Jarm = gs + WS_JARM; double* tips = gs + WS_TIPS;
+  for (int i = l; i < 144; i += 64) Jarm[i] = 0.0;
   WbcCtx C; C.nc = 0; for (int k = 0; k < 4; ++k) { C.fl[k] = mode_flag(mode, k); if (C.fl[k]) C.contactOf[C.nc++] = k; }
   C.mu = st[ST_WBC_FRIC]; C.nIneq = 36 + 5 * C.nc + 3 * (4 - C.nc); C.M = M; C.Jf = Jf; C.nle = nle;
   for (int q2 = 0; q2 < 4; ++q2) for (int k = 0; k < 3; ++k) C.tauMax[3 * q2 + k] = mb[MB_TAUMAX + k]; for (int k = 0; k < 6; ++k) C.tauMax[12 + k] = mb[MB_TAUMAX + 12 + k];
@@ -378,14 +415,14 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
           for (int r = 0; r < 3; ++r) { for (int cidx = 6 + 3 * slot; cidx < 9 + 3 * slot; ++cidx) Jf[(3 * contact + r) * QM_NQ + cidx] = Jt[r * QM_NQ + cidx]; Jf[(3 * contact + r) * QM_NQ + r] = 1.0; }
           for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr); for (int r = 0; r < 3; ++r) Jf[(3 * contact + r) * QM_NQ + 3 + k] = cr[r]; }
         }
-        if (pass < 2) tip_store(S + WL_TIPS + 27 * (5 * pass + contact), tip);
+        if (pass < 2) tip_store(tips + 27 * (5 * pass + contact), tip);
       } else if (slot == 4) {
         rbd_chain<6, double*, double*>(mb, 12, 4, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jarm, meas);
         if (meas) {
           for (int r = 0; r < 3; ++r) Jarm[r * QM_NQ + r] = 1.0;
           for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr); for (int r = 0; r < 3; ++r) { Jarm[r * QM_NQ + 3 + k] = cr[r]; Jarm[(3 + r) * QM_NQ + 3 + k] = e[r]; } }
         }
-        if (pass < 2) tip_store(S + WL_TIPS + 27 * (5 * pass + 4), tip);
+        if (pass < 2) tip_store(tips + 27 * (5 * pass + 4), tip);
       } else {
         const double zero3[3] = {0.0, 0.0, 0.0}; double c[3], Iw[9], vc[3], ac[3];
         body_state(mb, 0, Bb.R, Bb.p, Bb.vlin, Bb.w, zero3, Bb.al, c, Iw, vc, ac);
@@ -397,6 +434,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       sm[0] = Sm.mass; for (int i = 0; i < 3; ++i) { sm[1 + i] = Sm.mc[i]; sm[4 + i] = Sm.hl[i]; sm[7 + i] = Sm.hO[i]; sm[10 + i] = Sm.Fb[i]; sm[13 + i] = Sm.NbO[i]; }
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");        // the tip records and the arm Jacobian went through HBM scratch
   qm_wave_sync();
   RbdBase Bm; rbd_base(q, v, Bm);                        // measured root state (every lane)
   // base block of M and base rows of nle from the whole-tree composite (lane d = base dof)
@@ -412,7 +450,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
     }
   }
   // ---- baseAccDesired (WbcBase.cpp:215-225; SURVEY.md a14 aliasing: A_b SRBD, Adot & A_j full CMM, true COM) ----
-  const double* tipsM = S + WL_TIPS; const double* tipsD = S + WL_TIPS + 27 * 5;
+  const double* tipsM = tips; const double* tipsD = tips + 27 * 5;
   if (l == 0) {
     double Sd[16], Sa[16]; for (int i = 0; i < 16; ++i) { Sd[i] = 0.0; Sa[i] = 0.0; }
     for (int s2 = 0; s2 < 6; ++s2) for (int i = 0; i < 16; ++i) { Sd[i] += S[WL_G + (6 + s2) * 16 + i]; Sa[i] += S[WL_G + (12 + s2) * 16 + i]; }
@@ -429,15 +467,15 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   if (a.stop == 1) return;
   WT(0)
   // ---- cascade ----
-  double* A = S + WL_A; double* bb = S + WL_BB; double* AZ = S + WL_AZ; double* Zp = S + WL_ZP; double* x = S + WL_X; double* z = S + WL_Z; double* zn = S + WL_ZN; double* p = S + WL_P;
+  double* A = S + WL_AZ; double* bb = S + WL_BB; double* AZ = S + WL_AZ; double* Zp = S + WL_ZP; double* x = S + WL_X; double* z = S + WL_Z; double* zn = S + WL_ZN; double* p = S + WL_P;
   double* f0 = S + WL_F0; double* w0 = S + WL_W0; double* fb = S + WL_FB; double* Dz = S + WL_DZ; double* Dp = S + WL_DP; double* tau = S + WL_TAU; double* g0 = S + WL_G0RHS; double* G = S + WL_G;
   double* Zz = S + WL_ZZ; double* Zpv = S + WL_ZPV; double* lam = S + WL_LAM;
   if (l < 18) { f0[l] = C.tauMax[l] - nle[6 + l]; f0[18 + l] = C.tauMax[l] + nle[6 + l]; }
-  for (int idx = l; idx < WNV * WNV; idx += 64) Zp[idx] = ((idx / WNV) == (idx % WNV)) ? 1.0 : 0.0;
   qm_wave_sync();
   int nz = WNV; int status[3] = {0, 0, 0};
   for (int level = 0; level < 3; ++level) {
     // ---- the level's equality task ----
+    A = (level == 0) ? AZ : S + WL_A;                       // level 0: Zp = I, the task rows are A Zp
     for (int idx = l; idx < WMAXA * WNV; idx += 64) A[idx] = 0.0;
     qm_wave_sync();
     int ra = 0;
@@ -486,7 +524,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
     qm_wave_sync();
     // ---- AZ = A Zp, g0 = [b − A xp; 0] ----
     const int n = nz;
-    for (int idx = l; idx < ra * n; idx += 64) { const int r = idx / n, k = idx - r * n; double s = 0.0; for (int c2 = 0; c2 < WNV; ++c2) s += A[r * WNV + c2] * Zp[c2 * n + k]; AZ[r * WNV + k] = s; }
+    if (level > 0) for (int idx = l; idx < ra * n; idx += 64) { const int r = idx / n, k = idx - r * n; double s = 0.0; for (int c2 = 0; c2 < WNV; ++c2) s += A[r * WNV + c2] * Zp[c2 * n + k]; AZ[r * WNV + k] = s; }
     for (int r = l; r < ra + n; r += 64) { double s = 0.0; if (r < ra) { s = bb[r]; for (int c2 = 0; c2 < WNV; ++c2) s -= A[r * WNV + c2] * x[c2]; } g0[r] = s; }
     if (l < WNV) z[l] = 0.0;
     qm_wave_sync();
@@ -501,7 +539,9 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       int it = 0;
       for (; it < 100; ++it) {
         // least squares [sqrt(rho) I; A | b; active soft rows | fb]: the triangular part sits in G, the dense rows in registers
-        for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (r == k) ? sqrt(WRHO) : 0.0; }
+        for (int idx = l; idx < 702; idx += 64) G[idx] = 0.0;
+        qm_wave_sync();
+        if (l < n) G[wv_tidx(l, l, n, 0)] = sqrt(WRHO);
         int* alist = (int*)(S + WL_WLIST);
         if (l == 0) { int na0 = 0; for (int i = 0; i < C.nIneq && na0 < WMAXACT; ++i) if ((actmask >> i) & 1ull) alist[na0++] = i; }
         int na = __popcll(actmask); if (na > WMAXACT) na = WMAXACT;
@@ -513,12 +553,9 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
 #pragma unroll
           for (int q2 = 0; q2 < WMAXACT; ++q2) { double v = 0.0; if (q2 < na && l <= n) { const int i = alist[q2]; v = (l == n) ? fb[i] : wbc_d0_entry(C, i, l); } d[WMAXA + q2] = v; }
           WT(2)
-          rq_house_tri<WMAXA + WMAXACT>(d, G, WGLD, n, S + WL_HV);
+          rq_house_tri<WMAXA + WMAXACT>(d, G, 0, n, S + WL_HV);
         }
-        wv_backsub(G, WGLD, n, G + n, WGLD, zn);
-#ifdef QM_WBC_TRACE
-        if (l == 0) printf("L0 it %d na %d ra %d n %d zn %.6e %.6e %.6e  Tdiag %.3e %.3e rhs %.3e %.3e\n", it, na, ra, n, zn[0], zn[1], zn[2], G[0], G[WGLD + 1], G[n], G[WGLD + n]);
-#endif
+        wv_backsub_tri(G, 0, n, zn);
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
         WT(3)
@@ -554,33 +591,33 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       // = Q [R | c] once (|G0 z − g0|² = |R z − c|² + const) and form DZ = D0 Zp once; an iteration then only touches n x n data.
       wv_d0_apply(C, x, tau, Dz);
       if (l < C.nIneq) fb[l] = f0[l] - Dz[l] + w0[l];
-      for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WGLD + k] = (r == k) ? sqrt(WRHO) : 0.0; }
+      for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); G[r * WTLD + k] = (r == k) ? sqrt(WRHO) : 0.0; }
       qm_wave_sync();
       {
         double d[WMAXA];
 #pragma unroll
         for (int r = 0; r < WMAXA; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
-        rq_house_tri<WMAXA>(d, G, WGLD, n, S + WL_HV);
+        rq_house_tri<WMAXA>(d, G, WTLD, n, S + WL_HV);
       }
-      double* Tm = S + WL_G + 20 * WGLD;                 // scratch of wv_eq_ls_R (n <= 18 rows); [R | c] stays in G rows 0..n-1
-      double* DZ = S + WL_G + 40 * WGLD;                 // DZ [nIneq][18]
-      if (l < C.nIneq) {
-        double d[18];
+      double* Tm = S + WL_G + WVLD * WTLD;               // scratch of wv_eq_ls_R; [R | c] stays in the first 18 x 19 block of G
+      double dz[WVLD];                                   // row l of D0 Zp lives in the registers of lane l
 #pragma unroll
-        for (int k = 0; k < 18; ++k) d[k] = 0.0;
+      for (int k = 0; k < WVLD; ++k) dz[k] = 0.0;
+      if (l < C.nIneq) {
         for (int r = 0; r < WNV; ++r) { const double e = wbc_d0_entry(C, l, r); if (e != 0.0) {
 #pragma unroll
-          for (int k = 0; k < 18; ++k) if (k < n) d[k] += e * Zp[r * n + k]; } }
-#pragma unroll
-        for (int k = 0; k < 18; ++k) if (k < n) DZ[l * 18 + k] = d[k];
+          for (int k = 0; k < WVLD; ++k) if (k < n) dz[k] += e * Zp[r * n + k]; } }
       }
       qm_wave_sync();
       WT(8)
       int* Wi = (int*)(S + WL_WLIST);                    // working-set list lives in LDS (wave-uniform reads)
-      unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false; double pscale = 0.0;
+      unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false; double pscale = 0.0; int myslot = -1;   // position of this lane's row in the working set
       for (; it < 100; ++it) {
-        for (int idx = l; idx < nw * n; idx += 64) { const int q2 = idx / n, k = idx - q2 * n; S[WL_EROWS + q2 * WNV + k] = DZ[Wi[q2] * 18 + k]; }
-        if (l < nw) S[WL_ERHS + l] = fb[Wi[l]];
+        if (myslot >= 0) {
+#pragma unroll
+          for (int k = 0; k < WVLD; ++k) if (k < n) S[WL_EROWS + myslot * WVLD + k] = dz[k];
+          S[WL_ERHS + myslot] = fb[l];
+        }
         qm_wave_sync();
         WT(10)
         wv_eq_ls_R(S, G, Tm, n, nw, zn, tfine);
@@ -601,6 +638,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
           else { const double lmin = -wv_max(cand ? -mylam : -1e300); int key = (cand && mylam == lmin) ? l : 64; for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; } worst = (key == 64) ? -1 : key; }
           if (worst < 0) break;
           wmask &= ~(1ull << Wi[worst]);
+          if (myslot == worst) myslot = -1; else if (myslot > worst) --myslot;
           const int nxt = (l + 1 < nw) ? Wi[l + 1] : 0;
           qm_wave_sync();
           if (l >= worst && l + 1 < nw) Wi[l] = nxt;
@@ -609,10 +647,10 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
         } else {
           double aa = 1e300;
           if (l < C.nIneq && !((wmask >> l) & 1ull)) {
-            double dp = 0.0, dz = 0.0;
+            double dp = 0.0, dzz = 0.0;
 #pragma unroll
-            for (int k = 0; k < 18; ++k) if (k < n) { const double dk = DZ[l * 18 + k]; dp += dk * p[k]; dz += dk * z[k]; }
-            if (dp > 1e-10 * fmax(1.0, pn)) aa = fmax(0.0, (fb[l] - dz) / dp);
+            for (int k = 0; k < WVLD; ++k) if (k < n) { dp += dz[k] * p[k]; dzz += dz[k] * z[k]; }
+            if (dp > 1e-10 * fmax(1.0, pn)) aa = fmax(0.0, (fb[l] - dzz) / dp);
           }
           const double amin = -wv_max(-aa);
           double al = 1.0; int block = -1;
@@ -623,14 +661,14 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
           if (l == 0) printf("   step al %.6e block %d\n", al, block);
 #endif
           degenerate = (al <= 1e-12);
-          if (block >= 0) { if (nw < n && nw < WMAXACT) { if (l == 0) Wi[nw] = block; wmask |= (1ull << block); ++nw; } else { status[level] = 2; qm_wave_sync(); break; } }
+          if (block >= 0) { if (nw < n && nw < WMAXACT) { if (l == 0) Wi[nw] = block; if (l == block) myslot = nw; wmask |= (1ull << block); ++nw; } else { status[level] = 2; qm_wave_sync(); break; } }
           qm_wave_sync();
         }
       }
       if (it >= 100 && status[level] == 0) status[level] = 1;
     }
     wv_Z_times(Zp, n, z, Zz);
-    if (l < WNV) { x[l] += Zz[l]; S[WL_XLEV + level * WNV + l] = x[l]; }
+    if (l < WNV) { x[l] += Zz[l]; if (a.dbg) a.dbg[(size_t)b * WBC_DBG_SIZE + 126 + level * WNV + l] = x[l]; }
     qm_wave_sync();
     if (a.stop == 2 + level) return;
     WT(10)
@@ -645,14 +683,13 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   if (l < 18) out[WNV + l] = tau[l] + nle[6 + l];
   if (l < 3) a.qp_status[b * 3 + l] = status[l];
   WT(11)
-  if (a.stop < 0 && l == 0) for (int k = 0; k < 12; ++k) a.scratch[(size_t)b * WBC_SCRATCH + k] = (double)tacc[k];
-  if (a.stop == -2 && l == 0) for (int k = 0; k < 9; ++k) a.scratch[(size_t)b * WBC_SCRATCH + k] = (double)tfine[k];
+  if (a.stop < 0 && l == 0) for (int k = 0; k < 12; ++k) gs[WS_TIME + k] = (double)tacc[k];
+  if (a.stop == -2 && l == 0) for (int k = 0; k < 9; ++k) gs[WS_TIME + k] = (double)tfine[k];
 #undef WT
   if (a.dbg) {
     double* d = a.dbg + (size_t)b * WBC_DBG_SIZE;
     if (l < 24) { d[l] = q[l]; d[24 + l] = v[l]; d[48 + l] = qd[l]; d[72 + l] = vd[l]; d[102 + l] = nle[l]; }
     if (l < 6) d[96 + l] = baseAcc[l];
-    for (int idx = l; idx < 108; idx += 64) d[126 + idx] = S[WL_XLEV + idx];
     for (int idx = l; idx < 576; idx += 64) d[234 + idx] = M[idx];
     for (int idx = l; idx < 288; idx += 64) d[810 + idx] = Jf[idx];
     if (l < 12) d[1098 + l] = TIP_A(tipsM + 27 * (l / 3))[l % 3];
