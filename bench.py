@@ -19,12 +19,18 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic FP64 work: flops per unit of each kernel
-FLOP_LQ_PER_NODE = 190e3 + 410e3        # K1: LQ approximation + projection, per non-event shooting interval
-FLOP_RICCATI_PER_NODE = 250e3           # K3: per non-event stage
-FLOP_LS_PER_NODE_TRIAL = 15e3           # K4
-FLOP_WBC_PER_INSTANCE = 2.0e6           # K5-K7
-FP64_MFMA_PEAK_TFLOPS = 78.6            # MI355X dense FP64 matrix peak (AMD public figure; v_mfma_f64_16x16x4 micro-benchmark: 77.7, profiles/)
+# algorithmic FP64 work and HBM bytes per unit of each kernel (DESIGN.md §5 derives every figure)
+#   unit = one non-event shooting interval (lq, riccati) or one instance (wbc)
+KERNEL_MODEL = {
+    # K1b: LQ approximation + projection. bytes: stage record written (Ap Bp Qp Pp Rp Px Pu + vectors = 4812 doubles) + kin record / inputs read (~620)
+    "lq": {"flop": 190e3 + 410e3, "bytes": (4812 + 620) * 8.0, "unit": "interval"},
+    # K3: backward sweep reads [Ap|bp] Bp [Qp|qp] [Pp|rp] Rp (3282) and writes L W y (882); forward rollout reads Ap Bp W L Px Pu + vectors (3870), x/dx/du (120)
+    "riccati": {"flop": 250e3, "bytes": (3282 + 882 + 3870 + 120) * 8.0, "unit": "interval"},
+    # K5-K7: rigid-body pass + 3-level cascade; bytes: inputs/outputs + tip/Jacobian scratch (~0.9k doubles)
+    "wbc": {"flop": 2.0e6, "bytes": 900 * 8.0, "unit": "instance"},
+}
+FP64_PEAK_TFLOPS = 78.6                 # MI355X dense FP64 matrix peak = FP64 vector peak (AMD public figure; v_mfma_f64_16x16x4 micro-benchmark: 77.7, profiles/)
+HBM_PEAK_TBS = 8.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (≈6.3 TB/s achievable)
 
 
 def main():
@@ -82,10 +88,27 @@ def main():
     res = mpc.download(); out, qps = wbc.download(B)
     ok = bool((res["status"] == 0).all() and (qps == 0).all())
     n_intervals = int(sum(int(res["num_nodes"][b]) - 1 - int((res["event"][b, :res["num_nodes"][b]] == 1).sum()) for b in range(B)))
-    dom = "lq" if kms["lq"][0] >= kms["riccati"][0] else "riccati"
-    per_node = FLOP_LQ_PER_NODE if dom == "lq" else FLOP_RICCATI_PER_NODE
-    avg_ms = kms[dom][0] / max(1, kms[dom][1])
-    achieved = per_node * n_intervals / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    # roofline of the dominant kernel (largest average launch duration among the modelled kernels), both ceilings priced
+    def roof(name):
+        ms = kms[name][0] / max(1, kms[name][1]); mdl = KERNEL_MODEL[name]; units = n_intervals if mdl["unit"] == "interval" else B
+        tf = mdl["flop"] * units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0; tb = mdl["bytes"] * units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"kernel": "qm_%s_kernel" % name, "avg_launch_ms": ms, "units_per_launch": units, "unit": mdl["unit"], "flop_per_launch": mdl["flop"] * units, "bytes_per_launch": mdl["bytes"] * units,
+                "tflops": tf, "frac_fp64": tf / FP64_PEAK_TFLOPS, "tbs": tb, "frac_hbm": tb / HBM_PEAK_TBS}
+    roofs = {k: roof(k) for k in KERNEL_MODEL}
+    dom = max(roofs, key=lambda k: roofs[k]["avg_launch_ms"]); rd = roofs[dom]
+    if rd["frac_hbm"] >= rd["frac_fp64"]:
+        roofline = {"bound": "hbm", "kernel": rd["kernel"], "achieved": rd["tbs"] * 1e3, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": rd["frac_hbm"], "traffic": None}
+    else:
+        roofline = {"bound": "mfma", "kernel": rd["kernel"], "achieved": rd["tflops"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rd["frac_fp64"], "traffic": None}
+    roofline.update({"avg_launch_ms": rd["avg_launch_ms"], "flop_per_launch": rd["flop_per_launch"], "bytes_per_launch": rd["bytes_per_launch"]})
+    # measured HBM bytes per launch of that kernel: the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
+    # summarised in profiles/hbm_traffic.json (tools/gpu_round_profile.sh; PMC collection cannot run inside the timed bench itself)
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+            roofline["traffic"] = json.load(fh)["kernels"][rd["kernel"]]["traffic_bytes"]
+            roofline["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, B=1024)"
+    except (OSError, KeyError, ValueError):
+        pass
 
     if rank == 0:
         total_steps = B * world * args.steps
@@ -95,8 +118,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3/C4: trot gait, horizon N=100 (dt 0.015), %d random initial states per GPU (seed 1235), cold start, 1 SQP iteration + policy eval + 3-level WBC" % B,
                        "instances_per_gpu": B, "parallelism": "shard%d" % world, "all_status_ok": ok, "ls_trials": int(res["ls_trials"])},
-            "roofline": {"bound": "mfma", "kernel": "qm_%s_kernel" % dom, "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "avg_launch_ms": avg_ms, "flop_per_launch": per_node * n_intervals},
+            "roofline": roofline,
+            "roofline_all": {k: {kk: v[kk] for kk in ("avg_launch_ms", "tflops", "frac_fp64", "tbs", "frac_hbm")} for k, v in roofs.items()},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kms.items()},
         }
         if not args.no_cpu_baseline:

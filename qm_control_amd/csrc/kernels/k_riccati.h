@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     else rw_stage<2>(rec, m, nrec, mnext, buf, S, sv, An, Bn, a.skip, chol_fail);
   }
   // L, W, y were stored by other lanes than the ones that read them back below
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // same wave, same CU: ordering only, no L2 write-back
   // ---- forward rollout.  Each stage record is fetched flat (512 B per wave instruction) one stage ahead into registers, dropped
   //      into row-padded LDS, and consumed one matrix row per lane: lanes 0..29 rows of [Ap Bp bp], lanes 32..61 rows of
   //      [Px Pu Pe], lanes 0..m-1 also row i of W and column i of L; lane c carries dx[c] ----

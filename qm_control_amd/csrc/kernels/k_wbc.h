@@ -118,9 +118,10 @@ __device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, d
     }
     qm_wave_sync();
     // pass 1 over the pivot column: its norm and this lane's dot product with it (the pivot entry itself is patched afterwards)
-    double nrm2 = 0.0, dot = 0.0;
+    double nq[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < MR; ++i) { const double vi = hv[i]; nrm2 += vi * vi; if (i > 0) dot += vi * col[i]; }
+    for (int i = 0; i < MR; ++i) { const double vi = hv[i]; nq[i & 3] += vi * vi; if (i > 0) dq[i & 3] += vi * col[i]; }
+    const double nrm2 = (nq[0] + nq[1]) + (nq[2] + nq[3]), dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
     const double gkk = hv[0], nrm = sqrt(nrm2); const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = nrm2 - gkk * gkk + vk * vk;
     const bool ok = (nrm2 != 0.0) && (vn != 0.0);
     const double s = ok ? (dot + vk * col[0]) * (2.0 / vn) : 0.0;
@@ -155,9 +156,10 @@ __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ld
     }
     qm_wave_sync();
     const double tkk = T[wv_tidx(k, k, n, ldT)]; const double tl = (l >= k && l <= n) ? T[wv_tidx(k, l, n, ldT)] : 0.0;
-    double nrm2 = tkk * tkk, dot = 0.0;
+    double nq[4] = {tkk * tkk, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};   // four partial sums: the dependent chain is what costs on a lone wave
 #pragma unroll
-    for (int i = 0; i < MRD; ++i) { const double vi = hv[i]; nrm2 += vi * vi; dot += vi * d[i]; }
+    for (int i = 0; i < MRD; ++i) { const double vi = hv[i]; nq[i & 3] += vi * vi; dq[i & 3] += vi * d[i]; }
+    const double nrm2 = (nq[0] + nq[1]) + (nq[2] + nq[3]), dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
     const double nrm = sqrt(nrm2); const double alpha = tkk > 0.0 ? -nrm : nrm; const double vk = tkk - alpha; const double vn = nrm2 - tkk * tkk + vk * vk;
     const bool ok = (nrm2 != 0.0) && (vn != 0.0);
     const double s = ok ? (dot + vk * tl) * (2.0 / vn) : 0.0;
@@ -382,8 +384,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   for (int i = l; i < WL_TOTAL; i += 64) S[i] = 0.0;
   qm_wave_sync();
   double* M = S + WL_M; double* nle = S + WL_NLE; double* Jf = S + WL_JF;
-  double* gs = a.scratch + (size_t)b * WBC_SCRATCH; double* Jarm = gs + WS_JARM; double* tips = gs + WS_TIPS;
-  for (int i = l; i < 144; i += 64) Jarm[i] = 0.0;
+  double* gs = a.scratch + (size_t)b * WBC_SCRATCH; double* Jarm = S + WL_ZP; double* tips = gs + WS_TIPS;   // Jarm: built in the (still unused) Zp region, parked in HBM scratch for level 1
   WbcCtx C; C.nc = 0; for (int k = 0; k < 4; ++k) { C.fl[k] = mode_flag(mode, k); if (C.fl[k]) C.contactOf[C.nc++] = k; }
   C.mu = st[ST_WBC_FRIC]; C.nIneq = 36 + 5 * C.nc + 3 * (4 - C.nc); C.M = M; C.Jf = Jf; C.nle = nle;
   for (int q2 = 0; q2 < 4; ++q2) for (int k = 0; k < 3; ++k) C.tauMax[3 * q2 + k] = mb[MB_TAUMAX + k]; for (int k = 0; k < 6; ++k) C.tauMax[12 + k] = mb[MB_TAUMAX + 12 + k];
@@ -434,7 +435,10 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       sm[0] = Sm.mass; for (int i = 0; i < 3; ++i) { sm[1 + i] = Sm.mc[i]; sm[4 + i] = Sm.hl[i]; sm[7 + i] = Sm.hO[i]; sm[10 + i] = Sm.Fb[i]; sm[13 + i] = Sm.NbO[i]; }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");        // the tip records and the arm Jacobian went through HBM scratch
+  qm_wave_sync();
+  for (int i = l; i < 144; i += 64) gs[WS_JARM + i] = Jarm[i];
+  Jarm = gs + WS_JARM;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    // the tip records and the arm Jacobian go through HBM scratch (same CU: no L2 maintenance needed)
   qm_wave_sync();
   RbdBase Bm; rbd_base(q, v, Bm);                        // measured root state (every lane)
   // base block of M and base rows of nle from the whole-tree composite (lane d = base dof)
