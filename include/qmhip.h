@@ -23,7 +23,8 @@ typedef struct qmhip_ctx qmhip_ctx;
 /* ---- construction: replaces qm::QMInterface(taskFile, urdfFile, referenceFile) + setupOptimalControlProblem
  *      (qm_interface/include/qm_interface/QMInterface.h:31-35, qm_interface/src/QMInterface.cpp:37-142) and the
  *      WBC constructor / loadTasksSetting (qm_wbc/include/qm_wbc/WbcBase.h:28-34).
- *      Missing files -> QMHIP_ERR_FILE, like the reference's std::invalid_argument (QMInterface.cpp:45,53,61). */
+ *      Missing files -> QMHIP_ERR_FILE, like the reference's std::invalid_argument (QMInterface.cpp:45,53,61).
+ *      3 <= max_nodes <= 512 (horizon nodes incl. event-split nodes; the per-instance node list lives in LDS), else QMHIP_ERR_ARG. */
 int qmhip_create(const char* urdf_file, const char* task_file, const char* reference_file,
                  int device, int max_batch, int max_nodes, int max_ref_knots, int max_events, qmhip_ctx** out);
 /* same, from the flat MODEL / SETTINGS blobs of qmhip_layout.h (no file I/O) */

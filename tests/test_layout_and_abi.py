@@ -77,3 +77,11 @@ def test_committed_blobs_are_current():
     times, modes = front.load_gait(REFERENCE + "/qm_controllers/config/gait.info", "trot")
     g = scenarios.load_gaits()["trot"]
     assert times == g["switchingTimes"] and modes == g["modeSequence"]
+
+
+def test_create_rejects_bad_sizes(blobs):
+    """argument validation happens before any device work (qmhip.h: 3 <= max_nodes <= 512)"""
+    from qm_control_amd import api
+    for bad in (2, 513):
+        with pytest.raises(api.QmhipError, match="bad argument"):
+            api.QMInterface(blobs=blobs, max_batch=1, max_nodes=bad)
