@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   const int nn = a.n_nodes[b]; const int ev = a.node_ev[nb];
   const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
   const int nxt = (i + 1 < a.nmax) ? ((i + 1) * a.B + b) : nb;
-  double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_x2 = 0.0, in_ee = 0.0, in_k[4], in_k2[4];
-  if (l < 30) { in_x = a.x[nb * 30 + l]; in_u = a.u[nb * 30 + l]; xn = a.x[nxt * 30 + l]; f1 = kr[KR_F1 + l]; f2 = kr[KR_F2 + l]; in_x2 = kr[KR_X2 + l]; }
+  double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_x2 = 0.0, in_ee = 0.0, in_k[4], in_k2[4], in_xref = 0.0, in_qd = 0.0;
+  if (l < 30) { in_xref = a.xref[nb * 30 + l]; in_qd = st[ST_Q + l]; in_x = a.x[nb * 30 + l]; in_u = a.u[nb * 30 + l]; xn = a.x[nxt * 30 + l]; f1 = kr[KR_F1 + l]; f2 = kr[KR_F2 + l]; in_x2 = kr[KR_X2 + l]; }
   if (l >= 32 && l < 39) in_ee = a.eeref[nb * 7 + (l - 32)];
   if (l >= 40 && l < 46) in_ee = kr[KR_EEG + (l - 40)];
   if (l >= 48 && l < 52) in_ee = kr[KR_QEE + (l - 48)];
@@ -241,19 +241,22 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   qm_d4 Ad[2][2], Bdt[2][2];
   {
     qm_d4 A1[1][2], B1[1][2], B1t[2][1], A2[1][2], A2t[2][1], B2t[2][1];
-    double col1[12], col2[12];
-    if (l < 60) { flow_jac_col(mb, X, U, K1, l, col1); flow_jac_col(mb, S + LW_V_X2, U, K2, l, col2); }   // two independent chains
-    const int cc = (l < 30) ? l : l - 30, r0 = (l < 30) ? 0 : 16;
+    // one (column, Heun stage) task per lane for the four non-trivial column classes of the flow Jacobian — a wave executes each
+    // divergent class body once: lanes 0-5 dθ-rate columns 3..5, 6-11 zyx columns 9..11, 12-35 leg joints 12..23, 36-59 forces 30..41
+    int fc = 0, fs = l & 1;
+    if (l < 6) fc = 3 + (l >> 1); else if (l < 12) fc = 9 + ((l - 6) >> 1); else if (l < 36) fc = 12 + ((l - 12) >> 1); else fc = 30 + ((l - 36) >> 1);
+    double colf[12];
+    if (l < 60) flow_jac_col(mb, fs ? S + LW_V_X2 : X, U, fs ? K2 : K1, fc, colf);
+    const int cc = (fc < 30) ? fc : fc - 30, r0 = (fc < 30) ? 0 : 16;
     for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
     qm_wave_sync();
-    if (l < 60) {
-      for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = col1[r];
-      if (l >= 42 && l < 46) T[(16 + (l - 30)) * LW_TLD + cc] = 1.0;            // d qdot_j / d u_j rows 12..15 (rows >= 16 are handled analytically)
-    }
+    if (l < 60 && fs == 0) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = colf[r]; }
+    if (l < 3) T[(6 + l) * LW_TLD + l] = 1.0;                                   // d rdot / d h_lin (both stages)
+    if (l >= 4 && l < 8) T[(16 + 8 + l) * LW_TLD + 8 + l] = 1.0;                // d qdot_j / d u_j rows 12..15 (rows >= 16 are handled analytically)
     qm_wave_sync();
     qm_frag_load<1, 2, false>(A1, T, LW_TLD, 16, 30); qm_frag_load<1, 2, false>(B1, T + 16 * LW_TLD, LW_TLD, 16, 30); qm_frag_load<2, 1, true>(B1t, T + 16 * LW_TLD, LW_TLD, 30, 16);
     qm_wave_sync();
-    if (l < 60) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = col2[r]; }      // same sparsity pattern: no re-zeroing needed
+    if (l < 60 && fs == 1) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = colf[r]; }      // same sparsity pattern: no re-zeroing needed
     qm_wave_sync();
     qm_frag_load<1, 2, false>(A2, T, LW_TLD, 16, 30); qm_frag_load<2, 1, true>(A2t, T, LW_TLD, 30, 16); qm_frag_load<2, 1, true>(B2t, T + 16 * LW_TLD, LW_TLD, 30, 16);
     LQT()
@@ -303,23 +306,31 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   int row0[4]; int nc = 0; for (int k = 0; k < 4; ++k) { row0[k] = nc; nc += mode_flag(mode, k) ? 3 : 4; }
   const double gain = st[ST_POS_ERR_GAIN];
   {
-    double dv[4][3], dpz[4];
-    if (l < 60) {
+    // one (column, contact) task per lane for the non-trivial classes of the foot-velocity Jacobian: lanes 0-11 columns 3..5 x 4 contacts,
+    // 12-23 columns 9..11 x 4 contacts, 24-35 the leg's own joint angles 12..23, 36-47 its own joint velocities 42..53
+    int tc = 0, tk = 0;
+    if (l < 12) { tc = 3 + (l >> 2); tk = l & 3; } else if (l < 24) { tc = 9 + ((l - 12) >> 2); tk = l & 3; }
+    else if (l < 36) { tc = 12 + (l - 24); tk = chain_to_contact((l - 24) / 3); } else if (l < 48) { tc = 42 + (l - 36); tk = chain_to_contact((l - 36) / 3); }
+    int rk = 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) foot_vel_jac_col(mb, X, U, K1, k, l, dv[k], &dpz[k]);
-    }
+    for (int j = 0; j < 4; ++j) if (j < tk) rk += mode_flag(mode, j) ? 3 : 4;
+    if (l < 48) {
+      double dv[3], dpz; foot_vel_jac_col(mb, X, U, K1, tk, tc, dv, &dpz);
+      double* M = (tc < 30) ? T : T + 16 * LW_TLD; const int cc = (tc < 30) ? tc : tc - 30;
+      if (mode_flag(mode, tk)) { for (int r = 0; r < 3; ++r) M[(rk + r) * LW_TLD + cc] = dv[r] + ((r == 2 && gain != 0.0) ? gain * dpz : 0.0); }
+      else M[(rk + 3) * LW_TLD + cc] = dv[2] + (gain != 0.0 ? gain * dpz : 0.0);
+    } else {
+      // structurally constant entries: columns 0..2 (d v / d h_lin = I), column 8 (d p_z / d z = 1), swing force rows F_k = 0
+      const int t = l - 48, k = t & 3, j = t >> 2;           // j = 0..2: column j resp. force component j ; j = 3: column 8
+      int r0k = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+      for (int q = 0; q < 4; ++q) if (q < k) r0k += mode_flag(mode, q) ? 3 : 4;
       const bool stance = mode_flag(mode, k);
-      if (l < 60) {
-        double* M = (l < 30) ? T : T + 16 * LW_TLD; const int cc = (l < 30) ? l : l - 30;
-        if (stance) { for (int r = 0; r < 3; ++r) M[(row0[k] + r) * LW_TLD + cc] = dv[k][r] + ((r == 2 && gain != 0.0) ? gain * dpz[k] : 0.0); }
-        else {
-          M[(row0[k] + 3) * LW_TLD + cc] = dv[k][2] + (gain != 0.0 ? gain * dpz[k] : 0.0);
-          if (l >= 30 && l - 30 >= 3 * k && l - 30 < 3 * k + 3) M[(row0[k] + (l - 30 - 3 * k)) * LW_TLD + cc] = 1.0;
-        }
-      }
+      if (j < 3) {
+        if (stance) T[(r0k + j) * LW_TLD + j] = 1.0; else { if (j == 2) T[(r0k + 3) * LW_TLD + 2] = 1.0; T[(16 + r0k + j) * LW_TLD + 3 * k + j] = 1.0; }
+      } else if (gain != 0.0) T[(r0k + (stance ? 2 : 3)) * LW_TLD + 8] = gain;
     }
+    qm_wave_sync();
     if (l >= 60) {                                          // lanes 60..63: one contact each, the constraint values
       const int k = l - 60; const bool stance = mode_flag(mode, k);
       double v[3]; foot_velocity(X, K1, k, v); const double pz = kin_foot(K1, k)[2];
@@ -370,6 +381,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   lw_get_col30<2>(PxA, S + LW_V_PE, 30);
   const double eq2 = qm_wave_sum((l < nc) ? S[LW_V_E + l] * S[LW_V_E + l] : 0.0);
   const double b2 = qm_wave_sum(bl * bl);
+  qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);      // input cost weights: issued here, consumed in phase III
   // Pu (30 x m) in the hand-over tile: columns = stance forces, swing-leg null spaces, arm
   qm_wave_sync();
   for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
@@ -411,7 +423,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   double cost = 0.0;
   double* QD = S + LW_V_QD; double* RD = S + LW_V_RD; double* FR = S + LW_V_FR;
   if (l < 30) {
-    const double dx = X[l] - a.xref[nb * 30 + l]; const double qd = st[ST_Q + l];
+    const double dx = X[l] - in_xref; const double qd = in_qd;
     S[LW_V_QV + l] = qd * dx; QD[l] = qd; RD[l] = 0.0; cost += 0.5 * qd * dx * dx;
     int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
     double unom = 0.0; if (l < 12 && (l % 3) == 2 && mode_flag(mode, l / 3) && nst > 0) unom = mb[MB_ROBOTMASS] * 9.81 / nst;
@@ -419,7 +431,6 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   }
   if (l >= 32 && l < 38) EE[6 + (l - 32)] = ((l - 32) < 3 ? st[ST_MU_EE_POS] : st[ST_MU_EE_ORI]);
   qm_wave_sync();
-  qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);
   { // r = R0 (u − unom) through column 30
     qm_d4 Y[2][1], P[2][1];
 #pragma unroll
@@ -436,16 +447,13 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   if (l < 30) cost += 0.5 * S[LW_V_DU + l] * S[LW_V_RV + l];
   qm_wave_sync();
   // arm soft box (a6), joint-velocity box, friction cone barrier (a7): few lanes, disjoint entries
-  if (l < 6) {
-    const double mu = st[ST_JPOS_MU], de = st[ST_JPOS_DELTA]; const double lo = mb[MB_QLO + 12 + l], hi = mb[MB_QHI + 12 + l], z = X[24 + l];
+  if (l < 12) {                                           // lanes 0..5: arm joint position box on x[24+k]; lanes 6..11: arm joint velocity box on u[24+k]
+    const int k = (l < 6) ? l : l - 6; const bool pos = (l < 6);
+    const double mu = pos ? st[ST_JPOS_MU] : st[ST_JVEL_MU], de = pos ? st[ST_JPOS_DELTA] : st[ST_JVEL_DELTA];
+    const double lo = pos ? mb[MB_QLO + 12 + k] : st[ST_JVEL_LO + k], hi = pos ? mb[MB_QHI + 12 + k] : st[ST_JVEL_HI + k], z = pos ? X[24 + k] : U[24 + k];
     cost += barrier_val(mu, de, z - lo) + barrier_val(mu, de, hi - z) - (barrier_val(mu, de, -lo) + barrier_val(mu, de, hi));
-    S[LW_V_QV + 24 + l] += barrier_d1(mu, de, z - lo) - barrier_d1(mu, de, hi - z);
-    QD[24 + l] += barrier_d2(mu, de, z - lo) + barrier_d2(mu, de, hi - z);
-  } else if (l >= 8 && l < 14) {
-    const int k = l - 8; const double mu = st[ST_JVEL_MU], de = st[ST_JVEL_DELTA]; const double lo = st[ST_JVEL_LO + k], hi = st[ST_JVEL_HI + k], w = U[24 + k];
-    cost += barrier_val(mu, de, w - lo) + barrier_val(mu, de, hi - w) - (barrier_val(mu, de, -lo) + barrier_val(mu, de, hi));
-    S[LW_V_RV + 24 + k] += barrier_d1(mu, de, w - lo) - barrier_d1(mu, de, hi - w);
-    RD[24 + k] += barrier_d2(mu, de, w - lo) + barrier_d2(mu, de, hi - w);
+    const double g1 = barrier_d1(mu, de, z - lo) - barrier_d1(mu, de, hi - z), g2 = barrier_d2(mu, de, z - lo) + barrier_d2(mu, de, hi - z);
+    if (pos) { S[LW_V_QV + 24 + k] += g1; QD[24 + k] += g2; } else { S[LW_V_RV + 24 + k] += g1; RD[24 + k] += g2; }
   } else if (l >= 16 && l < 20) {   // friction cone, one lane per contact (disjoint 3x3 blocks)
     const int k = l - 16; double ds = 0.0; double* fr = FR + 16 * k;
     for (int q = 0; q < 13; ++q) fr[q] = 0.0;
