@@ -1,0 +1,88 @@
+"""Full-size parity of the benchmark workload (BASELINE.json config 3/4: trot gait, N = 100, 1024 random initial states per GPU)
+through the C ABI.  The oracle is too slow for 1024 instances, so the full batch is checked through size-independent
+properties of the domain, and a seeded sample of it against the oracle at the stated tolerance (1e-6 relative)."""
+import numpy as np
+import pytest
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def full_run(blobs):
+    from qm_control_amd import api, scenarios
+    B = 1024
+    cfg = scenarios.make_config("C4", batch=B)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+    wbc.reset()
+    mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+    res = mpc.download(); out, qps = wbc.download(B)
+    xd, ud, mode = mpc.evaluatePolicy(cfg["t0"])
+    yield dict(cfg=cfg, res=res, out=out, qps=qps, xd=xd, ud=ud, mode=mode, itf=itf, mpc=mpc, wbc=wbc)
+    itf.close()
+
+
+def test_all_instances_solved(full_run):
+    r = full_run
+    assert (r["res"]["status"] == 0).all() and (r["qps"] == 0).all()
+    assert np.isfinite(r["out"]).all() and np.isfinite(r["res"]["x"]).all()
+
+
+def test_schedule_integers_are_consistent(full_run):
+    """node count, event tags and contact modes: every instance of the trot batch shares the gait, so the integer outputs must
+    agree with the schedule that was uploaded (bit-exact integer work)"""
+    r = full_run; res = r["res"]; cfg = r["cfg"]
+    for b in (0, 1, 511, 1023):
+        n = int(res["num_nodes"][b]); t = res["t"][b, :n]; ev = res["event"][b, :n]; md = res["mode"][b, :n]
+        assert np.all(np.diff(t) >= 0.0) and abs(t[0] - cfg["t0"][b]) < 1e-15 and abs(t[-1] - (cfg["t0"][b] + cfg["horizon"])) < 1e-12
+        # a PreEvent node carries the same time as the node after it; modes come from the uploaded schedule
+        for i in np.nonzero(ev == 1)[0]:
+            assert t[i] == t[i + 1]
+        evt = cfg["ev"][b]; modes = cfg["modes"][b]
+        for i in range(n - 1):
+            if ev[i] == 1:
+                continue
+            tm = 0.5 * (t[i] + t[i + 1]) if t[i + 1] > t[i] else t[i]
+            assert md[i] == modes[int(np.searchsorted(evt, tm, side="right"))], (b, i)
+
+
+def test_wbc_hard_constraints_hold_everywhere(full_run, blobs):
+    """torque limits, friction pyramids and zero swing forces are the hard rows of WBC levels 1-2: they must hold for every instance"""
+    mb, st = blobs; r = full_run
+    out = r["out"]; F = out[:, 24:36].reshape(-1, 4, 3); tau = out[:, 36:54]
+    taumax = np.concatenate([np.tile(mb[324:327], 4), mb[336:342]]); mu = st[997]
+    assert (np.abs(tau) <= taumax[None, :] * (1 + 1e-9) + 1e-9).all()
+    flags = np.stack([(r["mode"] >> 3) & 1, (r["mode"] >> 2) & 1, (r["mode"] >> 1) & 1, r["mode"] & 1], axis=1).astype(bool)
+    scale = max(1.0, np.abs(F).max())
+    assert (np.abs(F[~flags]) <= 1e-6 * scale).all()
+    Fs = F[flags]
+    assert (Fs[:, 2] >= -1e-9 * scale).all()
+    assert (np.abs(Fs[:, 0]) <= mu * Fs[:, 2] + 1e-9 * scale).all() and (np.abs(Fs[:, 1]) <= mu * Fs[:, 2] + 1e-9 * scale).all()
+
+
+def test_instances_are_independent(full_run, blobs):
+    """re-solving a slice of the batch on its own gives bit-identical results (no cross-instance coupling, shard-safe)"""
+    from qm_control_amd import api
+    r = full_run; cfg = r["cfg"]; sl = slice(300, 364); B = 64
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"][sl], cfg["x0"][sl], cfg["ref_t"][sl], cfg["ref_x"][sl], cfg["ev"][sl], cfg["modes"][sl])
+    wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+    res = mpc.download(); out, qps = wbc.download(B)
+    assert np.array_equal(res["x"], r["res"]["x"][sl]) and np.array_equal(res["u"], r["res"]["u"][sl]) and np.array_equal(out, r["out"][sl])
+    itf.close()
+
+
+def test_sample_matches_oracle(full_run, blobs):
+    import pyoracle
+    r = full_run; cfg = r["cfg"]
+    idx = np.array([0, 17, 255, 256, 511, 640, 901, 1023])
+    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 8, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx],
+                                         cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"])
+    assert bad == 0
+    assert rel_err(r["xd"][idx], xf) <= TOL and rel_err(r["ud"][idx], uf) <= TOL
+    for j, b in enumerate(idx):
+        assert rel_err(r["out"][b], w[j]) <= TOL and rel_err(r["out"][b, 36:], w[j, 36:]) <= TOL, b
