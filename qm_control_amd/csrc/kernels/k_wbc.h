@@ -147,6 +147,7 @@ __device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, d
 __device__ __forceinline__ int wv_tidx(int k, int c, int n, int ld) { return ld ? k * ld + c : ((k * (2 * n + 3 - k)) >> 1) + (c - k); }
 template <int MRD>
 __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ldT, int n, double* hv) {
+  // (skipping the unpopulated rows of d with per-row uniform branches was measured 2x SLOWER: the branches serialise the LDS reads)
   const int l = threadIdx.x & 63;
   for (int k = 0; k < n; ++k) {
     qm_wave_sync();
@@ -207,22 +208,15 @@ __device__ __forceinline__ void wv_ls_qr(double* G, int ld, int rows, int n, dou
   rq_house<MR>(col, n, n, hv, G, ld, nullptr, 0, nullptr);
   wv_backsub(G, ld, n, G + n, ld, z);
 }
-// Householder QR of Eᵀ (n x me) for E (me x n, ld = WVLD): reflectors V[k][0..n) (zero above k), beta[k], R (me x me upper, ld = WMAXACT)
-__device__ __forceinline__ void wv_qr_Et(const double* E, int me, int n, double* V, double* beta, double* R) {
+// Householder QR of Eᵀ (n x me) for E (me x n, ld = WVLD): reflectors V[k][0..n) (zero above k), beta[k], R (me x me upper, ld = WMAXACT).
+// Lane q holds column q of Eᵀ (= row q of E) in registers.
+__device__ __forceinline__ void wv_qr_Et(const double* E, int me, int n, double* V, double* beta, double* R, double* hv) {
   const int l = threadIdx.x & 63;
-  for (int idx = l; idx < me * n; idx += 64) { const int c = idx / n, i = idx - c * n; V[c * WVLD + i] = E[c * WVLD + i]; }
-  qm_wave_sync();
-  for (int k = 0; k < me; ++k) {
-    double* wk = V + k * WVLD;
-    const double nrm2 = wv_sum((l >= k && l < n) ? wk[l] * wk[l] : 0.0); const double nrm = sqrt(nrm2);
-    const double wkk = wk[k]; const double alpha = wkk > 0.0 ? -nrm : nrm; const double vn = nrm2 - wkk * wkk + (wkk - alpha) * (wkk - alpha);
-    qm_wave_sync();
-    if (l < k) { R[l * WMAXACT + k] = wk[l]; wk[l] = 0.0; }
-    if (l == k) { R[k * WMAXACT + k] = alpha; wk[k] = wkk - alpha; beta[k] = (vn > 0.0) ? 2.0 / vn : 0.0; }
-    qm_wave_sync();
-    if (l > k && l < me) { double* wc = V + l * WVLD; double s = 0.0; for (int i = k; i < n; ++i) s += wk[i] * wc[i]; s *= beta[k]; for (int i = k; i < n; ++i) wc[i] -= s * wk[i]; }
-    qm_wave_sync();
-  }
+  double col[WVLD];
+#pragma unroll
+  for (int i = 0; i < WVLD; ++i) col[i] = (l < me && i < n) ? E[l * WVLD + i] : 0.0;
+  for (int idx = l; idx < me * WVLD; idx += 64) V[idx] = 0.0;             // reflector entries above the pivot must read as zero
+  rq_house<WVLD>(col, me, me - 1, hv, R, WMAXACT, V, WVLD, beta);
 }
 __device__ __forceinline__ void wv_apply_Qt(const double* V, const double* beta, int me, int n, double* x) {   // x <- Qᵀ x
   const int l = threadIdx.x & 63;
@@ -268,18 +262,37 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
 #define WF(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tf[k] += now_ - tl_; tl_ = now_; }
   if (me == 0) { wv_backsub_tri(Rc, WTLD, n, zout); return; }
   double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
-  for (int idx = l; idx < n * (n + 1); idx += 64) { const int r = idx / (n + 1), k = idx - r * (n + 1); T[r * WTLD + k] = (k >= r) ? Rc[r * WTLD + k] : 0.0; }
   WF(0)
-  wv_qr_Et(S + WL_EROWS, me, n, V, beta, R);
+  wv_qr_Et(S + WL_EROWS, me, n, V, beta, R, S + WL_HV);
   WF(1)
   { double y1 = 0.0;                                          // R_Eᵀ y1 = e
     for (int i = 0; i < me; ++i) { const double sacc = wv_sum((l < i) ? R[l * WMAXACT + i] * y1 : 0.0); const double v = (e[i] - sacc) / R[i * WMAXACT + i]; if (l == i) y1 = v; }
     if (l < me) y[l] = y1; }
   WF(2)
   // T <- T Q (row-wise reflections; lane = row), rhs column untouched
-  if (l < n) { double* g = T + l * WTLD; for (int k = 0; k < me; ++k) { const double* v = V + k * WVLD; double sacc = 0.0; for (int i = k; i < n; ++i) sacc += g[i] * v[i]; sacc *= beta[k]; for (int i = k; i < n; ++i) g[i] -= sacc * v[i]; } }
   qm_wave_sync();
-  if (l < n) { double sacc = 0.0; for (int k = 0; k < me; ++k) sacc += T[l * WTLD + k] * y[k]; T[l * WTLD + n] -= sacc; }
+  {
+    double g[WVLD];                                          // row l of [R | c] in registers; V is zero above each pivot, so no index bounds are needed
+#pragma unroll
+    for (int i = 0; i < WVLD; ++i) g[i] = (l < n && i >= l && i < n) ? Rc[l * WTLD + i] : 0.0;
+    for (int k = 0; k < me; ++k) {
+      const double* v = V + k * WVLD; double sq[2] = {0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < WVLD; ++i) sq[i & 1] += g[i] * v[i];
+      const double sacc = (sq[0] + sq[1]) * beta[k];
+#pragma unroll
+      for (int i = 0; i < WVLD; ++i) g[i] -= sacc * v[i];
+    }
+    double rhs = (l < n) ? Rc[l * WTLD + n] : 0.0;
+#pragma unroll
+    for (int i = 0; i < WVLD; ++i) if (i < me) rhs -= g[i] * y[i];
+    qm_wave_sync();
+    if (l < n) {
+#pragma unroll
+      for (int i = 0; i < WVLD; ++i) if (i < n) T[l * WTLD + i] = g[i];
+      T[l * WTLD + n] = rhs;
+    }
+  }
   qm_wave_sync();
   WF(3)
   if (n - me > 0) wv_ls_qr<18>(T + me, WTLD, n, n - me, S + WL_HV, y + me);
@@ -306,60 +319,93 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
 }
 
 // orthonormal null space of AZ (ra x n): Zp (36 x n) <- Zp · Q2, Q2 = Q[:, rank:] from the Householder QR with column pivoting of
-// (AZ)ᵀ; returns n − rank.  The reflectors stay in W below the diagonal (LAPACK style); Q2 = H_0 … H_{r-1} [0; I] is accumulated
-// backwards, straight into Zp at level 0 (Zp = I) and through a small buffer otherwise.
+// (AZ)ᵀ (n x ra); returns n − rank.  Lane j holds column j of (AZ)ᵀ in registers (rows move up one slot per step, so every index
+// is static); pivoting only marks lanes — nothing is swapped, R is never needed.  The reflectors go to LDS (V[k][k..n), beta[k]) and
+// Q2 = H_0 … H_{r-1} [0; I] is accumulated backwards with one column of Q2 per lane in registers, straight into Zp at level 0
+// (Zp = I) and through a small buffer otherwise.
 __device__ __forceinline__ int wv_null_space(double* S, int ra, int n) {
   const int l = threadIdx.x & 63;
-  double* W = S + WL_G; double* Zp = S + WL_ZP; const double* AZ = S + WL_AZ; double* hv = S + WL_HV; double* vdiag = S + WL_R;
-  double* bet = S + WL_R + 40;                                         // [22] 2 / (v·v) per reflector
-  for (int idx = l; idx < n * ra; idx += 64) { const int i = idx / ra, j = idx - i * ra; W[i * ra + j] = AZ[j * WNV + i]; }
-  qm_wave_sync();
-  int rank = 0; double maxnorm0 = 0.0; const int steps = (n < ra) ? n : ra;
+  double* V = S + WL_G; double* Zp = S + WL_ZP; const double* AZ = S + WL_AZ; double* hv = S + WL_HV; double* bet = S + WL_R;   // V: [rank][n] (<= 18 x 36)
+  double col[WNV];
+#pragma unroll
+  for (int i = 0; i < WNV; ++i) col[i] = (l < ra && i < n) ? AZ[l * WNV + i] : 0.0;
+  const int steps = (n < ra) ? n : ra;
+  for (int idx = l; idx < steps * n; idx += 64) V[idx] = 0.0;
+  bool done = (l >= ra);
+  int rank = 0; double maxnorm0 = 0.0;
   for (int k = 0; k < steps; ++k) {
-    double cn = -1.0; if (l >= k && l < ra) { cn = 0.0; for (int i = k; i < n; ++i) cn += W[i * ra + l] * W[i * ra + l]; }
+    double nq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < WNV; ++i) nq[i & 3] += col[i] * col[i];
+    const double cn = done ? -1.0 : (nq[0] + nq[1]) + (nq[2] + nq[3]);
     const double bn = wv_max(cn);
-    int cand = (cn == bn && l >= k && l < ra) ? l : (1 << 20); for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(cand, off, 64); cand = (o < cand) ? o : cand; }
-    const int best = cand;
+    const unsigned long long cand = __ballot(!done && cn == bn);
+    if (cand == 0ull) break;
+    const int best = __ffsll((long long)cand) - 1;
     if (k == 0) maxnorm0 = sqrt(bn);
     if (sqrt(bn) <= 1e-9 * fmax(1.0, maxnorm0)) break;
-    if (best != k) { for (int i = l; i < n; i += 64) { const double t = W[i * ra + k]; W[i * ra + k] = W[i * ra + best]; W[i * ra + best] = t; } }
     qm_wave_sync();
-    const double nrm = sqrt(bn), wkk = W[k * ra + k]; const double alpha = wkk > 0.0 ? -nrm : nrm;
-    if (l < n) hv[l] = (l < k) ? 0.0 : ((l == k) ? wkk - alpha : W[l * ra + k]);
-    qm_wave_sync();
-    const double vn = wv_sum((l >= k && l < n) ? hv[l] * hv[l] : 0.0);
-    if (vn > 0.0) {
-      if (l > k && l < ra) { double s = 0.0; for (int i = k; i < n; ++i) s += hv[i] * W[i * ra + l]; s *= 2.0 / vn; for (int i = k; i < n; ++i) W[i * ra + l] -= s * hv[i]; }
+    if (l == best) {
+#pragma unroll
+      for (int i = 0; i < WNV; ++i) hv[i] = col[i];
     }
-    if (l == 0) { vdiag[k] = hv[k]; bet[k] = (vn > 0.0) ? 2.0 / vn : 0.0; }
     qm_wave_sync();
+    const double gkk = hv[0], nrm = sqrt(bn); const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = bn - gkk * gkk + vk * vk;
+    double dq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 1; i < WNV; ++i) dq[i & 3] += hv[i] * col[i];
+    const double s = (vn > 0.0) ? ((dq[0] + dq[1]) + (dq[2] + dq[3]) + vk * col[0]) * (2.0 / vn) : 0.0;
+    if (l == best) {
+      done = true;
+#pragma unroll
+      for (int i = 0; i < WNV; ++i) if (k + i < n) V[k * n + k + i] = (i == 0) ? vk : col[i];
+      bet[k] = (vn > 0.0) ? 2.0 / vn : 0.0;
+    }
+#pragma unroll
+    for (int i = 1; i < WNV; ++i) col[i - 1] = col[i] - s * hv[i];     // reflect and move up one row (finished lanes carry garbage, never read)
+    col[WNV - 1] = 0.0;
     ++rank;
   }
   if (n - rank > WVLD) rank = n - WVLD;                                // the level >= 1 work arrays hold at most 18 null-space directions
   const int nn = n - rank;
-  // Q2 (n x nn) = H_0 … H_{rank-1} [0; I]; reflector k: v[k] = vdiag[k], v[i > k] = W[i][k]
-  double* Q2 = (n == WNV) ? Zp : (W + n * ra);                         // level 0: Q2 IS the new Zp
   qm_wave_sync();
-  for (int idx = l; idx < n * nn; idx += 64) { const int i = idx / nn, j = idx - i * nn; Q2[idx] = (i == rank + j) ? 1.0 : 0.0; }
-  qm_wave_sync();
-  for (int k = rank - 1; k >= 0; --k) {
-    if (l < nn) { double s = vdiag[k] * Q2[k * nn + l]; for (int i = k + 1; i < n; ++i) s += W[i * ra + k] * Q2[i * nn + l]; s *= bet[k]; Q2[k * nn + l] -= s * vdiag[k]; for (int i = k + 1; i < n; ++i) Q2[i * nn + l] -= s * W[i * ra + k]; }
-    qm_wave_sync();
-  }
-  if (n != WNV) {
-    // Zp (36 x n) <- Zp Q2 (36 x nn), row by row in place (every lane holds its old row in registers before anything is written)
-    double row[WVLD];
-    if (l < WNV) {
+  // backward accumulation: lane j < nn carries column j of Q2 (n entries)
+  double q[WNV];
 #pragma unroll
-      for (int i = 0; i < WVLD; ++i) row[i] = (i < n) ? Zp[l * n + i] : 0.0;
+  for (int i = 0; i < WNV; ++i) q[i] = (i == rank + l && l < nn) ? 1.0 : 0.0;
+  for (int k = rank - 1; k >= 0; --k) {
+    const double* v = V + k * n; double sq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < WNV; ++i) if (i < n) sq[i & 3] += v[i] * q[i];
+    const double sacc = ((sq[0] + sq[1]) + (sq[2] + sq[3])) * bet[k];
+#pragma unroll
+    for (int i = 0; i < WNV; ++i) if (i < n) q[i] -= sacc * v[i];
+  }
+  if (n == WNV) {                                                      // level 0: Q2 IS the new Zp (36 x nn)
+    if (l < nn) {
+#pragma unroll
+      for (int i = 0; i < WNV; ++i) Zp[i * nn + l] = q[i];
     }
     qm_wave_sync();
-    if (l < WNV) for (int j = 0; j < nn; ++j) { double s = 0.0;
-#pragma unroll
-      for (int i = 0; i < WVLD; ++i) if (i < n) s += row[i] * Q2[i * nn + j];
-      Zp[l * nn + j] = s; }
-    qm_wave_sync();
+    return nn;
   }
+  double* Q2 = V + steps * n;                                          // [n][nn] behind the reflectors (n <= 18 here: at most 612 doubles together)
+  if (l < nn) {
+#pragma unroll
+    for (int i = 0; i < WVLD; ++i) if (i < n) Q2[i * nn + l] = q[i];
+  }
+  // Zp (36 x n) <- Zp Q2 (36 x nn), row by row in place (every lane holds its old row in registers before anything is written)
+  double row[WVLD];
+  if (l < WNV) {
+#pragma unroll
+    for (int i = 0; i < WVLD; ++i) row[i] = (i < n) ? Zp[l * n + i] : 0.0;
+  }
+  qm_wave_sync();
+  if (l < WNV) for (int j = 0; j < nn; ++j) { double sacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < WVLD; ++i) if (i < n) sacc += row[i] * Q2[i * nn + j];
+    Zp[l * nn + j] = sacc; }
+  qm_wave_sync();
   return nn;
 }
 
