@@ -122,7 +122,7 @@ def main():
             "roofline_all": {k: {kk: v[kk] for kk in ("avg_launch_ms", "tflops", "frac_fp64", "tbs", "frac_hbm")} for k, v in roofs.items()},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kms.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a property of the box: reported on the single-GPU line only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle
             cores = min(os.cpu_count() or 1, 64); S = min(B, 128)

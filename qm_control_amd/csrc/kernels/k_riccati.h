@@ -291,8 +291,10 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     double acc = vecs[half ? 78 + rr : rr];
     double t = vecs[108 + lw];
     const double qv = (l < 30) ? vecs[30 + l] : 0.0, rp = (l < m) ? vecs[60 + l] : 0.0;
+    { double ap[3] = {0.0, 0.0, 0.0}, tp[3] = {0.0, 0.0, 0.0};          // three partial sums each: a 30-long dependent FMA chain is what a lone wave waits on
 #pragma unroll
-    for (int q = 0; q < 30; ++q) { const double dq = qm_bcast(dxl, q); acc += rowA[q] * dq; t += rowW[q] * dq; }
+      for (int q = 0; q < 30; ++q) { const double dq = qm_bcast(dxl, q); ap[q % 3] += rowA[q] * dq; tp[q % 3] += rowW[q] * dq; }
+      acc += (ap[0] + ap[1]) + ap[2]; t += (tp[0] + tp[1]) + tp[2]; }
     // Lᵀ v = t (lane i keeps v_i), ut = −v
     double v = 0.0;
 #pragma unroll
@@ -304,8 +306,10 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     }
     const double ut = -v;
     armijo += qv * dxl + rp * ut;
+    { double bp[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < QM_MMAX; ++q) if (q < m) acc += rowB[q] * qm_bcast(ut, q);
+      for (int q = 0; q < QM_MMAX; ++q) if (q < m) bp[q % 3] += rowB[q] * qm_bcast(ut, q);
+      acc += (bp[0] + bp[1]) + bp[2]; }
     if (half && r < 30) { a.du[nb * 30 + r] = acc; du2 += acc * acc; }
     dxl = (l < 30) ? acc : 0.0;
   }
