@@ -64,6 +64,18 @@ int qmhip_mpc_solve_resident(qmhip_ctx* ctx, int B, double horizon);
 int qmhip_mpc_download(qmhip_ctx* ctx, int B, int32_t* out_num_nodes, double* out_t, int32_t* out_event, int32_t* out_mode,
                        double* out_x, double* out_u, double* out_perf, int32_t* status);
 
+/* ---- receding horizon: what ocs2::MPC_BASE::run does on every call after the first one
+ *      (`mpc.coldStart false`, task.info:142): the SqpSolver keeps its primal solution and the next iteration starts from its
+ *      interpolation ([upstream ocs2_sqp multiple_shooting::initializeStateInputTrajectories]; the a9 initializer only beyond it).
+ *      set_initial: new observation (t, x) per instance — MPC_MRT_Interface::setCurrentObservation (QMController.cpp:133-137); references,
+ *      schedule and the previous solution stay resident.  solve_resident_warm falls back to the cold start if there is no previous solve.
+ *      advance_resident: perfect-tracking plant for back-to-back steps without host round trips: t0 += dt, x0 <- policy state at the new t0.
+ *      closed_loop_resident: n_steps x [advance (not on the first step), warm solve, policy at t0, WBC on the state built from x0]. */
+int qmhip_mpc_set_initial(qmhip_ctx* ctx, int B, const double* t0, const double* x0 /*[B][30]*/);
+int qmhip_mpc_solve_resident_warm(qmhip_ctx* ctx, int B, double horizon);
+int qmhip_mpc_advance_resident(qmhip_ctx* ctx, int B, double dt);
+int qmhip_closed_loop_resident(qmhip_ctx* ctx, int B, int n_steps, double mpc_dt, double horizon, double period, double time0);
+
 /* ---- policy evaluation: replaces MPC_MRT_Interface::evaluatePolicy (call site QMController.cpp:139-142):
  *      linear interpolation of the last primal solution at time t[b] */
 int qmhip_policy_eval(qmhip_ctx* ctx, int B, const double* t, double* x_des /*[B][30]*/, double* u_des /*[B][30]*/, int32_t* mode /*[B]*/);

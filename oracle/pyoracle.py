@@ -110,12 +110,14 @@ class Oracle:
         return x, p, q
 
     # ---- MPC ----
-    def mpc_step(self, t0, tf, x0):
+    def mpc_step(self, t0, tf, x0, warm=False):
+        """one SQP iteration; warm=True: initial guess from this oracle's previous solution (cold start if there is none)"""
         x0 = np.ascontiguousarray(x0, float)
         n = C.c_int(0)
         nt = np.zeros(self.MAXN); ne = np.zeros(self.MAXN, np.int32); nm = np.zeros(self.MAXN, np.int32)
         xo = np.zeros((self.MAXN, 30)); uo = np.zeros((self.MAXN, 30)); perf = np.zeros(10)
-        rc = self.lib.qmo_mpc_step(self.h, C.c_double(t0), C.c_double(tf), _p(x0), C.c_int(self.MAXN), C.byref(n), _p(nt), _pi(ne), _pi(nm), _p(xo), _p(uo), _p(perf))
+        fn = self.lib.qmo_mpc_step_warm if warm else self.lib.qmo_mpc_step
+        rc = fn(self.h, C.c_double(t0), C.c_double(tf), _p(x0), C.c_int(self.MAXN), C.byref(n), _p(nt), _pi(ne), _pi(nm), _p(xo), _p(uo), _p(perf))
         if rc != 0:
             raise RuntimeError("oracle mpc_step failed rc=%d" % rc)
         k = n.value

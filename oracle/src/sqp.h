@@ -134,8 +134,15 @@ inline Performance computePerformance(const Problem& P, const std::vector<Node>&
 
 inline double trajectoryNorm(const std::vector<Vec>& v) { double s = 0; for (auto& a : v) for (double z : a) s += z * z; return std::sqrt(s); }
 
-// one SQP iteration, cold start (initializer a9) unless xInit/uInit are given
-inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, const std::vector<Vec>* xInit, const std::vector<Vec>* uInit, SqpResult& R) {
+struct SqpResult;
+inline void evaluatePolicy(const SqpResult& R, const ModeSchedule& ms, double t, Vec& x, Vec& u, int& mode);
+
+// one SQP iteration; initial guess: xInit/uInit if given, else warm start from `prev` (a previous primal solution, may be null /
+// empty -> cold start).  Warm start restates [upstream ocs2_sqp multiple_shooting::initializeStateInputTrajectories]: x_0 = x0; interval i
+// takes u_i = u_prev(intervalStart(i)) and x_{i+1} = x_prev(intervalEnd(i+1)) while the previous solution covers both times, the
+// initializer a9 (weight-compensating input, x_{i+1} = x_i) beyond it; PreEvent nodes have no input and copy their state forward.
+inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, const std::vector<Vec>* xInit, const std::vector<Vec>* uInit, SqpResult& R, const SqpResult* prev = nullptr);
+inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, const std::vector<Vec>* xInit, const std::vector<Vec>* uInit, SqpResult& R, const SqpResult* prev) {
   const Model& M = *P.M; const double* st = M.st;
   R.grid = timeDiscretizationWithEvents(t0, tf, st[ST_SQP_DT], P.ms.ev);
   const int N = (int)R.grid.size() - 1;
@@ -144,10 +151,16 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
   std::vector<Vec> x(N + 1), u(N);
   if (xInit) { x = *xInit; u = *uInit; }
   else {
+    const bool warm = prev && prev->grid.size() >= 2;
+    const double tend = warm ? prev->grid.back().t : 0.0;
     x[0] = x0;
     for (int i = 0; i < N; ++i) {
-      if (R.grid[i].ev == QM_EV_PRE) { u[i] = Vec(QM_NU, 0.0); x[i + 1] = x[i]; }
-      else { bool fl[4]; modeToFlags(P.ms.modeAt(intervalStart(R.grid[i])), fl); u[i] = weightCompensatingInput(M, fl); x[i + 1] = x[i]; }
+      if (R.grid[i].ev == QM_EV_PRE) { u[i] = Vec(QM_NU, 0.0); x[i + 1] = x[i]; continue; }
+      const double time = intervalStart(R.grid[i]), nextTime = intervalEnd(R.grid[i + 1]);
+      if (warm && !(time > tend || nextTime > tend)) {
+        Vec xa, ua, xb, ub; int md; evaluatePolicy(*prev, P.ms, time, xa, ua, md); evaluatePolicy(*prev, P.ms, nextTime, xb, ub, md);
+        u[i] = ua; x[i + 1] = xb;
+      } else { bool fl[4]; modeToFlags(P.ms.modeAt(time), fl); u[i] = weightCompensatingInput(M, fl); x[i + 1] = x[i]; }
     }
   }
   // ---- setupQuadraticSubproblem ----

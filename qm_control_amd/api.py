@@ -18,7 +18,8 @@ _ip = C.POINTER(C.c_int32)
 MB_SIZE, ST_SIZE = 685, 1030
 
 EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
-           "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_download", "qmhip_policy_eval",
+           "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_solve_resident_warm",
+           "qmhip_mpc_advance_resident", "qmhip_closed_loop_resident", "qmhip_mpc_download", "qmhip_policy_eval",
            "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
            "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_microbench_fp64"]
 
@@ -163,8 +164,24 @@ class SqpMpc:
         self.itf._check(self.lib.qmhip_mpc_upload(self.itf.h, B, _p(t0), _p(x0), ref_t.shape[1], _p(ref_t), _p(ref_x), ev.shape[1], _p(ev), _pi(modes)), "qmhip_mpc_upload")
         self.B = B
 
-    def solve_resident(self, horizon):
-        self.itf._check(self.lib.qmhip_mpc_solve_resident(self.itf.h, self.B, C.c_double(horizon)), "qmhip_mpc_solve_resident")
+    def solve_resident(self, horizon, warm=False):
+        """one SQP iteration; warm=True starts from the previous primal solution (what MPC_BASE::run does on every call after the first)"""
+        if warm:
+            self.itf._check(self.lib.qmhip_mpc_solve_resident_warm(self.itf.h, self.B, C.c_double(horizon)), "qmhip_mpc_solve_resident_warm")
+        else:
+            self.itf._check(self.lib.qmhip_mpc_solve_resident(self.itf.h, self.B, C.c_double(horizon)), "qmhip_mpc_solve_resident")
+
+    def set_initial(self, t0, x0):
+        """new observation (MPC_MRT_Interface::setCurrentObservation); references, schedule and the previous solution stay resident"""
+        t0 = _f(t0, (self.B,)); x0 = _f(x0, (self.B, 30))
+        self.itf._check(self.lib.qmhip_mpc_set_initial(self.itf.h, self.B, _p(t0), _p(x0)), "qmhip_mpc_set_initial")
+
+    def advance(self, dt):
+        """perfect-tracking plant on the device: t0 += dt, x0 <- policy state at the new t0"""
+        self.itf._check(self.lib.qmhip_mpc_advance_resident(self.itf.h, self.B, C.c_double(dt)), "qmhip_mpc_advance_resident")
+
+    def closed_loop_resident(self, n_steps, mpc_dt, horizon, period, time0):
+        self.itf._check(self.lib.qmhip_closed_loop_resident(self.itf.h, self.B, int(n_steps), C.c_double(mpc_dt), C.c_double(horizon), C.c_double(period), C.c_double(time0)), "qmhip_closed_loop_resident")
 
     def control_step_resident(self, horizon, period, time):
         self.itf._check(self.lib.qmhip_control_step_resident(self.itf.h, self.B, C.c_double(horizon), C.c_double(period), C.c_double(time)), "qmhip_control_step_resident")

@@ -31,6 +31,8 @@ struct QmMpcBuffers {
   double* x = nullptr; double* u = nullptr; double* dx = nullptr; double* du = nullptr; double* stage = nullptr; double* lqdbg = nullptr; double* kin = nullptr;
   double* perf = nullptr; double* base_sum = nullptr; double* perf_sum = nullptr; double* step_info = nullptr;
   double* alpha = nullptr; int* done = nullptr; double* xs = nullptr; double* us = nullptr; double* out_perf = nullptr;
+  // grid of the solve that produced (xs, us): the warm start of the next solve interpolates on it
+  int* prev_n = nullptr; double* prev_t = nullptr; int* prev_ev = nullptr;
 };
 
 template <class BK>
@@ -39,6 +41,7 @@ struct QmMpcPipeline {
   int ls_trials_run = 0;
   int riccati_skip = 0;   // profiling only
   int lq_prof = 0;        // profiling only
+  int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
   template <class T> T* A(size_t n) { T* p = (T*)bk.alloc(n * sizeof(T)); bk.zero(p, n * sizeof(T)); return p; }
@@ -56,10 +59,11 @@ struct QmMpcPipeline {
     d.stage = A<double>(NB * SR_SIZE); d.lqdbg = debug_lq ? A<double>(NB * LQ_DBG_SIZE) : nullptr; d.kin = A<double>(NB * KR_SIZE);
     d.perf = A<double>(NB * PF_SIZE); d.base_sum = A<double>((size_t)Bmax * 4); d.perf_sum = A<double>((size_t)Bmax * 4); d.step_info = A<double>((size_t)Bmax * 4);
     d.alpha = A<double>(Bmax); d.done = A<int>(Bmax); d.xs = A<double>(NB * 30); d.us = A<double>(NB * 30); d.out_perf = A<double>((size_t)Bmax * 10);
+    d.prev_n = A<int>(Bmax); d.prev_t = A<double>(NB); d.prev_ev = A<int>(NB);
   }
   void release() {
     void* ps[] = {d.mb, d.st, d.t0, d.x0, d.ref_t, d.ref_x, d.ev, d.modes, d.n_nodes, d.node_t, d.node_ts, d.node_dt, d.node_ev, d.node_mode, d.zvel, d.zpos, d.xref, d.eeref, d.status,
-                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf};
+                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev};
     for (void* p : ps) if (p) bk.free(p);
     d = QmMpcBuffers();
   }
@@ -78,13 +82,23 @@ struct QmMpcPipeline {
     return a;
   }
 
-  // K0: grid + references + cold start (inputs already resident on the device)
-  void grid(int B, double horizon) {
+  // K0: grid + references + initial guess (inputs already resident on the device).  warm: interpolate the previous primal solution
+  // ([upstream] SqpSolver keeps primalSolution_ between MPC calls, mpc.coldStart false, task.info:142) — falls back to cold without one.
+  void grid(int B, double horizon, bool warm = false) {
+    warm = warm && solved_B == B;
+    if (warm) { QmSaveGridArgs sg; sg.B = B; sg.nmax = d.nmax; sg.n_nodes = d.n_nodes; sg.node_t = d.node_t; sg.node_ev = d.node_ev; sg.prev_n = d.prev_n; sg.prev_t = d.prev_t; sg.prev_ev = d.prev_ev;
+                bk.launch(qm_save_grid_kernel, (d.nmax * B + 63) / 64, 64, 0, sg); }
     QmGridArgs g; g.mb = d.mb; g.st = d.st; g.B = B; g.nmax = d.nmax; g.nref = d.nref; g.nev = d.nev; g.t0 = d.t0; g.x0 = d.x0; g.ref_t = d.ref_t; g.ref_x = d.ref_x; g.ev = d.ev; g.modes = d.modes;
     g.horizon = horizon; g.n_nodes = d.n_nodes; g.node_t = d.node_t; g.node_ts = d.node_ts; g.node_dt = d.node_dt; g.node_ev = d.node_ev; g.node_mode = d.node_mode;
     g.zvel = d.zvel; g.zpos = d.zpos; g.xref = d.xref; g.eeref = d.eeref; g.x = d.x; g.u = d.u; g.status = d.status;
+    g.warm = warm ? 1 : 0; g.prev_n = d.prev_n; g.prev_t = d.prev_t; g.prev_ev = d.prev_ev; g.prev_xs = d.xs; g.prev_us = d.us;
     bk.launch(qm_grid_kernel, (B + 63) / 64, 64, 0, g);
     bk.launch(qm_grid_nodes_kernel, (d.nmax * B + 63) / 64, 64, 0, g);
+  }
+  // closed loop with a perfect-tracking plant: t0 += dt, x0 <- policy state at the new t0 (uses the grid / primal solution of the last solve)
+  void advance(int B, double dt) {
+    QmAdvanceArgs v; v.B = B; v.nmax = d.nmax; v.n_nodes = d.n_nodes; v.node_t = d.node_t; v.node_ev = d.node_ev; v.xs = d.xs; v.dt = dt; v.t0 = d.t0; v.x0 = d.x0;
+    bk.launch(qm_advance_kernel, (B + 63) / 64, 64, 0, v);
   }
   // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min)
   void sqp_iteration(int B, int max_trials = 14) {
@@ -110,5 +124,6 @@ struct QmMpcPipeline {
     }
     bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
     bk.launch(qm_ls_commit_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
+    solved_B = B;
   }
 };

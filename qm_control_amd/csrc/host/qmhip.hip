@@ -25,7 +25,7 @@ struct HipBackend {
   void check(hipError_t e, const char* what) { if (e != hipSuccess && error.empty()) error = std::string(what) + ": " + hipGetErrorString(e); }
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
-    if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel) return "riccati";
+    if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel) return "riccati";
     if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_wbc_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel) return "policy";
     return "ls_misc";
   }
@@ -129,11 +129,34 @@ int qmhip_set_setting(qmhip_ctx* c, int idx, double v) {
 int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) {
   if (!c) return QMHIP_ERR_ARG;
   if (B <= 0 || B > c->max_batch || n_ref != c->max_ref || n_ev != c->max_ev || !t0 || !x0 || !ref_t || !ref_x || !ev || !modes) { c->fail("qmhip_mpc_upload: bad argument (B <= max_batch, n_ref == max_ref_knots, n_events == max_events required)"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); c->lastB = B; c->have_solution = false; return c->hipstate();
+  hipSetDevice(c->device); c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); c->mpc.solved_B = 0; c->lastB = B; c->have_solution = false; return c->hipstate();
 }
 int qmhip_mpc_solve_resident(qmhip_ctx* c, int B, double horizon) {
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->mpc.grid(B, horizon); c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
+}
+int qmhip_mpc_set_initial(qmhip_ctx* c, int B, const double* t0, const double* x0) {
+  if (!c || B <= 0 || B > c->max_batch || !t0 || !x0) { if (c) c->fail("qmhip_mpc_set_initial: bad argument"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->bk.to_device(c->mpc.d.t0, t0, (size_t)B * 8); c->bk.to_device(c->mpc.d.x0, x0, (size_t)B * 30 * 8); return c->hipstate();
+}
+int qmhip_mpc_solve_resident_warm(qmhip_ctx* c, int B, double horizon) {
+  if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident_warm: bad argument"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
+}
+int qmhip_mpc_advance_resident(qmhip_ctx* c, int B, double dt) {
+  if (!c || B <= 0 || B > c->max_batch) { if (c) c->fail("qmhip_mpc_advance_resident: bad argument"); return QMHIP_ERR_ARG; }
+  if (!c->have_solution || c->mpc.solved_B != B) { c->fail("qmhip_mpc_advance_resident: no solution of this batch to advance along"); return QMHIP_ERR_STATE; }
+  hipSetDevice(c->device); c->mpc.advance(B, dt); return c->hipstate();
+}
+int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, double horizon, double period, double time0) {
+  if (!c || B <= 0 || B > c->max_batch || n_steps <= 0 || !(horizon > 0) || !(period > 0)) { if (c) c->fail("qmhip_closed_loop_resident: bad argument"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device);
+  for (int k = 0; k < n_steps; ++k) {
+    if (k > 0) c->mpc.advance(B, mpc_dt);
+    c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true;
+    c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time0 + k * mpc_dt); c->wbc.step(c->mpc.d, B, period, 0);
+  }
+  return c->hipstate();
 }
 int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) {
   if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG;
@@ -197,7 +220,7 @@ int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { if (!c || !key) 
 int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) {
   if (!c || !name || !dst) return QMHIP_ERR_ARG; hipSetDevice(c->device); const QmMpcBuffers& d = c->mpc.d; const void* p = nullptr;
 #define F(n) if (!strcmp(name, #n)) p = d.n;
-  F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf)
+  F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
 #undef F
   if (!p) p = c->wbc.buffer(name);
   if (!p) { c->fail(std::string("qmhip_debug_read: unknown buffer ") + name); return QMHIP_ERR_ARG; }

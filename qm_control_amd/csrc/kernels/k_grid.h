@@ -32,7 +32,9 @@ struct QmGridArgs {
   double* zvel; double* zpos;   // [nmax][B][4]
   double* xref;           // [nmax][B][30]
   double* eeref;          // [nmax][B][7]
-  double* x; double* u;   // [nmax][B][30] cold start
+  double* x; double* u;   // [nmax][B][30] initial guess (cold start, or warm start from the previous primal solution)
+  // warm start ([upstream ocs2_sqp multiple_shooting::initializeStateInputTrajectories]): previous grid + primal solution; warm == 0 -> cold
+  int warm; const int* prev_n; const double* prev_t; const int* prev_ev; const double* prev_xs; const double* prev_us;
   int* status;            // [B] 0 ok, -1 too many nodes, -2 swing phase not enclosed by stance
 };
 
@@ -84,6 +86,19 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
   }
   a.n_nodes[b] = n;
   a.status[b] = status;
+}
+
+// [upstream PrimalSolution interpolation] segment of time t on a stored node grid of instance b: PreEvent nodes nudged down, PostEvent nodes
+// nudged up by limitEpsilon (toInterpolationTime), then LinearInterpolation::timeSegment without materialising the array
+__device__ __forceinline__ void grid_policy_segment(const double* node_t, const int* node_ev, int n, int B, int b, double t, int* index, double* alpha) {
+  auto tt = [&](int i) { const int e = node_ev[i * B + b]; return node_t[i * B + b] + (e == QM_EV_POST ? QM_LIMIT_EPS : (e == QM_EV_PRE ? -QM_LIMIT_EPS : 0.0)); };
+  int part = 0; while (part < n && tt(part) < t) ++part;
+  const int interval = (part == 0 && t == tt(0)) ? 0 : part - 1; const int last = n - 1;
+  if (n <= 1) { *index = 0; *alpha = 1.0; }
+  else if (interval >= 0) {
+    if (interval < last) { const double len = tt(interval + 1) - tt(interval), till = tt(interval + 1) - t; *index = interval; *alpha = (len > 2.0 * QM_WEAK_EPS) ? till / len : ((till > 0.5 * len) ? 1.0 : 0.0); }
+    else { *index = (last - 1 > 0) ? last - 1 : 0; *alpha = 0.0; }
+  } else { *index = 0; *alpha = 1.0; }
 }
 
 // K0b: per (node, instance): interval start/duration, mode, swing-z references, reference interpolation, cold start
@@ -138,10 +153,52 @@ __global__ void qm_grid_nodes_kernel(QmGridArgs a) {
         for (int q = 0; q < 4; ++q) a.eeref[nb * 7 + 3 + q] = s0 * ql[q] + s1 * qr[q];
       }
     }
-    // cold start: x_i = x0, u_i = weight compensating input of the node's mode (QMInitializer.cpp:33-41)
+    // initial guess.  Cold start: x_i = x0, u_i = weight compensating input of the node's mode (QMInitializer.cpp:33-41).
+    // Warm start: x_0 = x0; interval j takes u_j = u_prev(start of j) and x_{j+1} = x_prev(end of j) while the previous solution covers it,
+    // the initializer (u = weight compensation, x_{j+1} = x_j) beyond; PreEvent nodes carry no input and copy their state forward.
     int nst = 0; for (int c = 0; c < 4; ++c) nst += mode_flag(mode, c);
-    for (int q = 0; q < 30; ++q) { a.x[nb * 30 + q] = a.x0[(size_t)b * 30 + q]; a.u[nb * 30 + q] = 0.0; }
-    if (e != QM_EV_PRE && nst > 0) for (int c = 0; c < 4; ++c) if (mode_flag(mode, c)) a.u[nb * 30 + 3 * c + 2] = mass * 9.81 / nst;
+    const int np = (a.warm && a.prev_n) ? a.prev_n[b] : 0;
+    const double tend = (np >= 2) ? a.prev_t[(np - 1) * a.B + b] : 0.0;
+    auto istart = [&](int j) { const double tj = a.node_t[j * a.B + b]; return (a.node_ev[j * a.B + b] == QM_EV_POST) ? tj + QM_WEAK_EPS : tj; };
+    auto iend = [&](int j) { const double tj = a.node_t[j * a.B + b]; return (a.node_ev[j * a.B + b] == QM_EV_PRE) ? tj - QM_WEAK_EPS : tj; };
+    auto covered = [&](int j) { return np >= 2 && j < n - 1 && a.node_ev[j * a.B + b] != QM_EV_PRE && !(istart(j) > tend || iend(j + 1) > tend); };
+    int j = i; while (j > 0 && !covered(j - 1)) --j;                 // x_i = x_j: the closest earlier node whose state the previous solution supplies
+    if (j == 0) { for (int q = 0; q < 30; ++q) a.x[nb * 30 + q] = a.x0[(size_t)b * 30 + q]; }
+    else {
+      int idx; double al; grid_policy_segment(a.prev_t, a.prev_ev, np, a.B, b, iend(j), &idx, &al);
+      const double* x0p = a.prev_xs + (size_t)(idx * a.B + b) * 30; const double* x1p = a.prev_xs + (size_t)((idx + 1) * a.B + b) * 30;
+      for (int q = 0; q < 30; ++q) a.x[nb * 30 + q] = al * x0p[q] + (1.0 - al) * x1p[q];
+    }
+    if (covered(i)) {
+      int idx; double al; grid_policy_segment(a.prev_t, a.prev_ev, np, a.B, b, ts, &idx, &al);
+      const double* u0p = a.prev_us + (size_t)(idx * a.B + b) * 30; const double* u1p = a.prev_us + (size_t)((idx + 1) * a.B + b) * 30;
+      for (int q = 0; q < 30; ++q) a.u[nb * 30 + q] = al * u0p[q] + (1.0 - al) * u1p[q];
+    } else {
+      for (int q = 0; q < 30; ++q) a.u[nb * 30 + q] = 0.0;
+      if (e != QM_EV_PRE && nst > 0) for (int c = 0; c < 4; ++c) if (mode_flag(mode, c)) a.u[nb * 30 + 3 * c + 2] = mass * 9.81 / nst;
+    }
   }
   if (status != 0) a.status[b] = status;
+}
+
+// keeps the grid of the solve that produced the current primal solution (xs, us) before K0 overwrites it: the warm start of the
+// next solve interpolates on it
+struct QmSaveGridArgs { int B, nmax; const int* n_nodes; const double* node_t; const int* node_ev; int* prev_n; double* prev_t; int* prev_ev; };
+__global__ void qm_save_grid_kernel(QmSaveGridArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = g / a.B, b = g - i * a.B;
+  if (i >= a.nmax) return;
+  if (i == 0) a.prev_n[b] = a.n_nodes[b];
+  if (i < a.n_nodes[b]) { a.prev_t[g] = a.node_t[g]; a.prev_ev[g] = a.node_ev[g]; }
+}
+// closed-loop advance (perfect-tracking plant): t0 += dt and x0 <- the policy state at the new t0
+struct QmAdvanceArgs { int B, nmax; const int* n_nodes; const double* node_t; const int* node_ev; const double* xs; double dt; double* t0; double* x0; };
+__global__ void qm_advance_kernel(QmAdvanceArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const double t = a.t0[b] + a.dt;
+  int idx; double al; grid_policy_segment(a.node_t, a.node_ev, a.n_nodes[b], a.B, b, t, &idx, &al);
+  const int i1 = (a.n_nodes[b] > 1) ? idx + 1 : idx;
+  for (int q = 0; q < 30; ++q) a.x0[(size_t)b * 30 + q] = al * a.xs[(size_t)(idx * a.B + b) * 30 + q] + (1.0 - al) * a.xs[(size_t)(i1 * a.B + b) * 30 + q];
+  a.t0[b] = t;
 }

@@ -209,7 +209,11 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   for (int t = 0; t < 4; ++t) { const int idx = l + 64 * t; in_k[t] = (idx < KW_SIZE) ? kr[KR_K1 + idx] : 0.0; in_k2[t] = (idx < KW_ARM) ? kr[KR_K2 + idx] : 0.0; }
   if (i >= nn) return;
   const bool terminal = (i == nn - 1);
-  if (!terminal && ev == QM_EV_PRE) return;         // event nodes carry no LQ data (identity jump, handled by K3)
+  if (!terminal && ev == QM_EV_PRE) {                 // event nodes carry no LQ data (identity jump, handled by K3): only clear their merit terms
+    const double jd = (l < 30) ? in_x - xn : 0.0; const double s2 = qm_wave_sum(jd * jd);   // jump defect x_i − x_{i+1} (identity jump map), unweighted
+    if (l < 3) a.perf[nb * PF_SIZE + l] = (l == 1) ? s2 : 0.0;   // (the node index of an event moves between receding-horizon solves)
+    return;
+  }
   long long tp_[10]; int np_ = 0;
 #define LQT() { if (a.prof) tp_[np_] = (long long)__builtin_readcyclecounter(); ++np_; }
   LQT()

@@ -19,17 +19,7 @@ __global__ void qm_policy_kernel(QmPolicyArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const int n = a.n_nodes[b]; const double t = a.t[b];
-  // interpolation times: PreEvent nodes nudged down, PostEvent nodes nudged up by limitEpsilon ([upstream] toInterpolationTime)
-  // timeSegment over the node times without materialising the array
-  auto tt = [&](int i) { const int e = a.node_ev[i * a.B + b]; return a.node_t[i * a.B + b] + (e == QM_EV_POST ? QM_LIMIT_EPS : (e == QM_EV_PRE ? -QM_LIMIT_EPS : 0.0)); };
-  int part = 0; while (part < n && tt(part) < t) ++part;
-  const int interval = (part == 0 && t == tt(0)) ? 0 : part - 1; const int last = n - 1;
-  int idx; double al;
-  if (n <= 1) { idx = 0; al = 1.0; }
-  else if (interval >= 0) {
-    if (interval < last) { const double len = tt(interval + 1) - tt(interval), till = tt(interval + 1) - t; idx = interval; al = (len > 2.0 * QM_WEAK_EPS) ? till / len : ((till > 0.5 * len) ? 1.0 : 0.0); }
-    else { idx = (last - 1 > 0) ? last - 1 : 0; al = 0.0; }
-  } else { idx = 0; al = 1.0; }
+  int idx; double al; grid_policy_segment(a.node_t, a.node_ev, n, a.B, b, t, &idx, &al);
   const int i0 = idx * a.B + b, i1 = ((n > 1 ? idx + 1 : idx)) * a.B + b;
   for (int q = 0; q < 30; ++q) { a.x_des[(size_t)b * 30 + q] = al * a.xs[i0 * 30 + q] + (1.0 - al) * a.xs[i1 * 30 + q]; a.u_des[(size_t)b * 30 + q] = al * a.us[i0 * 30 + q] + (1.0 - al) * a.us[i1 * 30 + q]; }
   a.mode[b] = a.modes[(size_t)b * (a.nev + 1) + grid_find_index(a.ev + (size_t)b * a.nev, a.nev, t)];

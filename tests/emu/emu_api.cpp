@@ -28,13 +28,20 @@ int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const doubl
   c->mpc.sqp_iteration(B, max_trials);
   return c->mpc.ls_trials_run;
 }
+// receding horizon: new observation + warm-started iteration / perfect-tracking advance (same calls as the qmhip_* entry points)
+int emu_mpc_step_warm(void* h, int B, const double* t0, const double* x0, double horizon, int max_trials) {
+  EmuCtx* c = (EmuCtx*)h; QmMpcBuffers& d = c->mpc.d;
+  if (t0) memcpy(d.t0, t0, (size_t)B * 8); if (x0) memcpy(d.x0, x0, (size_t)B * 30 * 8);
+  c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B, max_trials); return c->mpc.ls_trials_run;
+}
+void emu_advance(void* h, int B, double dt) { ((EmuCtx*)h)->mpc.advance(B, dt); }
 void emu_upload(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes) { ((EmuCtx*)h)->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); }
 // raw buffer access for parity tests: name -> pointer
 void* emu_buffer(void* h, const char* name) {
   QmMpcBuffers& d = ((EmuCtx*)h)->mpc.d;
 #define F(n) if (!strcmp(name, #n)) return (void*)d.n;
   F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(lqdbg) F(perf) F(base_sum)
-  F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf)
+  F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
 #undef F
   return nullptr;
 }

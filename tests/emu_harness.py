@@ -51,6 +51,14 @@ class Emu:
         assert rt.shape[1] == self.nref and ev.shape[1] == self.nev
         return self.lib.emu_mpc_step(self.h, C.c_int(B), _p(t0), _p(x0), _p(rt), _p(rx), _p(ev), _pi(mo), C.c_double(cfg["horizon"]), C.c_int(max_trials))
 
+    def mpc_step_warm(self, t0, x0, horizon, max_trials=14):
+        """new observation + warm-started SQP iteration (inputs / schedule of the last mpc_step stay resident)"""
+        t0 = np.ascontiguousarray(t0, float); x0 = np.ascontiguousarray(x0, float)
+        return self.lib.emu_mpc_step_warm(self.h, C.c_int(self.B), _p(t0), _p(x0), C.c_double(horizon), C.c_int(max_trials))
+
+    def advance(self, dt):
+        self.lib.emu_advance(self.h, C.c_int(self.B), C.c_double(dt))
+
     def buf(self, name, shape, dtype=np.float64):
         ptr = self.lib.emu_buffer(self.h, name.encode())
         assert ptr, name

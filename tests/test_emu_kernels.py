@@ -86,3 +86,29 @@ def test_control_step_vs_oracle_and_golden(blobs):
     assert (st == 0).all()
     for b in range(2):
         assert rel_err(out[b], g["wbc_%d" % b]) < TOL
+
+
+def test_receding_horizon_warm_start_vs_oracle(blobs, oracle):
+    """three MPC calls in a row, each started from the previous primal solution, the observation moved along
+    the policy (perfect-tracking plant).  Device kernels (host emulator) vs the oracle: integers bit-exact, trajectories 1e-9."""
+    from qm_control_amd import scenarios
+    import emu_harness
+    B, steps, dt_mpc = 2, 3, 0.03
+    cfg = scenarios.make_config("C3", batch=B, n_intervals=20)
+    e = emu_harness.Emu(blobs[0], blobs[1], B, 64, cfg["ref_t"].shape[1], cfg["ev"].shape[1])
+    e.mpc_step(cfg)
+    snaps = []
+    for k in range(1, steps):
+        e.advance(dt_mpc); e.mpc_step_warm(e.buf("t0", (B,)), e.buf("x0", (B, 30)), cfg["horizon"])
+        snaps.append(dict(n=e.buf("n_nodes", (B,), np.int32), t=e.node_arr("node_t", 1), ev=e.node_arr("node_ev", 1, np.int32), xs=e.node_arr("xs", 30), us=e.node_arr("us", 30),
+                          x0=e.buf("x0", (B, 30)), t0=e.buf("t0", (B,)), perf=e.buf("out_perf", (B, 10))))
+    for b in range(B):
+        oracle.set_schedule(cfg["ev"][b], cfg["modes"][b]); oracle.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+        t0 = float(cfg["t0"][b]); r = oracle.mpc_step(t0, t0 + cfg["horizon"], cfg["x0"][b])
+        for s in snaps:
+            t0 += dt_mpc; x0, _, _ = oracle.eval_policy(t0)
+            r = oracle.mpc_step(t0, t0 + cfg["horizon"], x0, warm=True); n = len(r["t"])
+            assert s["n"][b] == n and np.array_equal(s["t"][:n, b], r["t"]) and np.array_equal(s["ev"][:n, b], r["ev"])
+            assert abs(s["t0"][b] - t0) < 1e-15 and rel_err(s["x0"][b], x0) < 1e-12
+            assert rel_err(s["xs"][:n, b], r["x"]) < 1e-9 and rel_err(s["us"][:n, b], r["u"]) < 1e-9, b
+            assert rel_err(s["perf"][b, :8], r["perf"][:8]) < 1e-8 and s["perf"][b, 8] == r["alpha"]

@@ -72,3 +72,33 @@ def test_node_buffer_too_small_is_reported(blobs):
     itf, mpc, res = _gpu_solve(blobs, cfg, 1, 32)
     assert res["status"][0] == -1
     itf.close()
+
+
+def test_receding_horizon_closed_loop(blobs, oracle):
+    """SURVEY.md §8(f) rank 1 through the C ABI: warm-started MPC calls chained on the device (advance along the policy), against the
+    oracle doing the same thing; and qmhip_closed_loop_resident == the same calls issued one by one."""
+    from qm_control_amd import api, scenarios
+    B, steps, dt_mpc = 4, 4, 0.02
+    cfg = scenarios.make_config("C3", batch=B, n_intervals=40)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=80, max_ref_knots=cfg["ref_t"].shape[1], max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+    mpc.solve_resident(cfg["horizon"]); got = [mpc.download()]
+    for k in range(1, steps):
+        mpc.advance(dt_mpc); mpc.solve_resident(cfg["horizon"], warm=True); got.append(mpc.download())
+    for b in range(B):
+        oracle.set_schedule(cfg["ev"][b], cfg["modes"][b]); oracle.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+        t0 = float(cfg["t0"][b]); x0 = cfg["x0"][b]
+        for k in range(steps):
+            if k > 0:
+                t0 += dt_mpc; x0, _, _ = oracle.eval_policy(t0)
+            r = oracle.mpc_step(t0, t0 + cfg["horizon"], x0, warm=(k > 0)); n = len(r["t"]); g = got[k]
+            assert g["status"][b] == 0 and g["num_nodes"][b] == n
+            assert np.array_equal(g["t"][b, :n], r["t"]) and np.array_equal(g["event"][b, :n], r["ev"]) and np.array_equal(g["mode"][b, :n], r["mode"])
+            assert rel_err(g["x"][b, :n], r["x"]) <= TOL and rel_err(g["u"][b, :n], r["u"]) <= TOL, (b, k)
+    # the fused closed loop (MPC + policy + WBC per step) reproduces the step-by-step sequence bit for bit
+    wbc.reset(); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+    mpc.closed_loop_resident(steps, dt_mpc, cfg["horizon"], cfg["period"], cfg["time"])
+    last = mpc.download(); out, qps = wbc.download(B)
+    assert np.array_equal(last["x"], got[-1]["x"]) and np.array_equal(last["u"], got[-1]["u"]) and (qps == 0).all() and np.isfinite(out).all()
+    itf.close()
