@@ -1,6 +1,6 @@
 // k_riccati.h — K3: discrete-time Riccati backward sweep + forward rollout of the projected QP.
 //
-// ONE WAVEFRONT per MPC instance (64-thread workgroups, ~10 KB LDS): the sweep is a serial chain of small dense products, so
+// ONE WAVEFRONT per MPC instance (64-thread workgroups, 38 KB LDS -> four per CU): the sweep is a serial chain of small dense products, so
 // the whole stage lives in the registers of one wave as f64-MFMA fragments and no workgroup barrier is ever needed.  With every
 // equality constraint projected out and no inequality rows the QP sub-problem the reference hands to HPIPM is solved exactly by
 // one Riccati factorise+solve ([upstream ocs2_sqp SqpSolver::getOCPSolution -> hpipm]):
@@ -17,6 +17,8 @@
 // tiles: A|b, (S A | S b + s), (P | r), (Q | q), (W | y) — the mat-vecs cost nothing extra.
 // Only two steps leave the registers (wave-local LDS round trips): the Cholesky + forward substitution of [Huu | Hux hu]
 // (lane = column, column in registers, pivots broadcast with v_readlane) and the symmetrisation of S'.
+// The operands of the NEXT stage are copied global -> LDS asynchronously (global_load_lds_dwordx4, 1 KB per wave instruction, no
+// VGPRs) while the current stage computes; a stage starts by pulling its fragments out of that buffer.
 //
 // The backward sweep leaves L (in SR_RP), W (in SR_PP) and y (in SR_KFF) in the stage record; the forward rollout
 //   ut = −L⁻ᵀ (W dx + y),  dx+ = Ap dx + Bp ut + bp,  du = Px dx + Pu ut + Pe,  Armijo metric += qp·dx + rp·ut
@@ -46,7 +48,12 @@ struct QmRiccatiArgs {
 #define RF_W   3000               /* [18][31] W  */
 #define RF_L   3558               /* [18][19] L (diagonal holds 1/L_jj) */
 #define RF_V   3900               /* bp(30) qp(30) rp(18) Pe(30) | y(18) */
-#define RF_LIST 4032              /* int list[RW_MAXNODES]: m | event tag << 8 per node */
+/* backward prefetch buffer (global_load_lds): a flat copy of record fields [0, 3204) = Ap Bp Qp Pp Rp and [4644, 4722) = bp qp rp of the
+   NEXT regular stage, landing while the current stage computes; lives behind the 1200-double Cholesky / transposition buffer */
+#define RP_REC   1200
+#define RP_VEC   (RP_REC + 3204)
+#define RP_END   (RP_VEC + 80)
+#define RF_LIST  4496             /* int list[RW_MAXNODES]: m | event tag << 8 per node (behind both the prefetch buffer and the forward staging) */
 #define RW_MAXNODES 512
 #define RW_LDS_DOUBLES (RF_LIST + RW_MAXNODES / 2)
 #define RW_LDS_BYTES (RW_LDS_DOUBLES * 8)
@@ -72,23 +79,31 @@ __device__ __forceinline__ void rw_load(qm_d4 (&T)[IT][JT], const double* src, i
       }
 }
 
+// asynchronous copy of the backward operands of one stage record into the LDS prefetch buffer
+__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds) {
+  // 3204 doubles = 1602 sixteen-byte units + 39 units of vectors, 1 KB per wave instruction
+  const int l = threadIdx.x & 63;
+#pragma unroll
+  for (int t = 0; t < 26; ++t) { const int unit = t * 64 + l; if (unit < 1602) qm_dma16(rec + 2 * unit, lds + RP_REC + 128 * t); }
+  if (l < 39) qm_dma16(rec + SR_BPV + 2 * l, lds + RP_VEC);
+}
 // one regular stage of the backward sweep; MT = number of 16-row tiles covering the m reduced inputs
 template <int MT>
-__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, int mnext, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2],
-                                         qm_d4 (&An)[2][2], qm_d4 (&Bn)[2][2], int skip, int& chol_fail) {
+__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip, int& chol_fail) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
   qm_d4 A[2][2], Bm[2][MT], Hux[MT][2], Huu[MT][MT], Sn[2][2];
-#pragma unroll
-  for (int I = 0; I < 2; ++I) {                                      // [Ap | bp], Bp were fetched while the previous stage computed
-#pragma unroll
-    for (int J = 0; J < 2; ++J) A[I][J] = An[I][J];
-#pragma unroll
-    for (int J = 0; J < MT; ++J) Bm[I][J] = Bn[I][J];
+  {
+    // this stage's operands were copied into LDS (asynchronously, global_load_lds) while the previous stage computed
+    const double* P = buf + RP_REC; const double* PV = buf + RP_VEC;
+    qm_dma_wait();
+    rw_load<2, 2>(A, P + SR_AP, 30, 30, 30, PV);                    // [Ap | bp]
+    rw_load<2, MT>(Bm, P + SR_BP, QM_MMAX, 30, m, nullptr);
+    rw_load<MT, 2>(Hux, P + SR_PP, 30, m, 30, PV + 60);             // [Pp | rp]
+    rw_load<MT, MT>(Huu, P + SR_RP, QM_MMAX, m, m, nullptr);
+    rw_load<2, 2>(Sn, P + SR_QP, 30, 30, 30, PV + 30);              // [Qp | qp]
+    qm_lds_drain();
+    if (nrec) rw_prefetch(nrec, buf);                               // next regular stage: flies during this stage's products and Cholesky
   }
-  rw_load<MT, 2>(Hux, rec + SR_PP, 30, m, 30, rec + SR_RPV);        // [Pp | rp]
-  rw_load<MT, MT>(Huu, rec + SR_RP, QM_MMAX, m, m, nullptr);
-  rw_load<2, 2>(Sn, rec + SR_QP, 30, 30, 30, rec + SR_QPV);         // [Qp | qp]
-  if (nrec) { rw_load<2, 2>(An, nrec + SR_AP, 30, 30, 30, nrec + SR_BPV); rw_load<2, 2>(Bn, nrec + SR_BP, QM_MMAX, 30, mnext, nullptr); }
   qm_d4 SA[2][2], SB[2][MT];
   rw_zero<2, 2>(SA); rw_zero<2, MT>(SB);
   if (!(skip & 2)) {
@@ -221,7 +236,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   for (int k = l; k < n; k += 64) { const int ev = a.node_ev[k * a.B + b]; const int mk = (ev == QM_EV_PRE) ? 0 : (int)a.stage[((size_t)b * a.nmax + k) * SR_SIZE + SR_SCAL]; nlist[k] = (mk & 255) | (ev << 8); }
   qm_wave_sync();
   int chol_fail = 0;
-  qm_d4 S[2][2], sv[2], An[2][2], Bn[2][2];
+  qm_d4 S[2][2], sv[2];
   {   // terminal value function
     const double* rec = a.stage + ((size_t)b * a.nmax + (n - 1)) * SR_SIZE;
     rw_load<2, 2>(S, rec + SR_QP, 30, 30, 30, nullptr);
@@ -230,9 +245,8 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; sv[I][r] = (c == 14 && row < 30) ? rec[SR_QPV + row] : 0.0; }
   }
-  rw_zero<2, 2>(An); rw_zero<2, 2>(Bn);
   { int k0 = n - 2; while (k0 >= 0 && evlist(k0) == QM_EV_PRE) --k0;
-    if (k0 >= 0) { const double* rec = a.stage + ((size_t)b * a.nmax + k0) * SR_SIZE; rw_load<2, 2>(An, rec + SR_AP, 30, 30, 30, rec + SR_BPV); rw_load<2, 2>(Bn, rec + SR_BP, QM_MMAX, 30, mlist(k0), nullptr); } }
+    if (k0 >= 0 && !(a.skip & 16)) rw_prefetch(a.stage + ((size_t)b * a.nmax + k0) * SR_SIZE, buf); }
   for (int k = n - 2; k >= 0; --k) {
     double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
     if (evlist(k) == QM_EV_PRE) {
@@ -250,11 +264,11 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
       continue;
     }
     if (a.skip & 16) continue;
-    int kn = k - 1; while (kn >= 0 && evlist(kn) == QM_EV_PRE) --kn;      // next regular stage: its [Ap | bp], Bp are prefetched
-    const double* nrec = (kn >= 0) ? a.stage + ((size_t)b * a.nmax + kn) * SR_SIZE : nullptr; const int mnext = (kn >= 0) ? mlist(kn) : 0;
+    int kn = k - 1; while (kn >= 0 && evlist(kn) == QM_EV_PRE) --kn;      // next regular stage: its operands are prefetched into LDS
+    const double* nrec = (kn >= 0) ? a.stage + ((size_t)b * a.nmax + kn) * SR_SIZE : nullptr;
     const int m = mlist(k);
-    if (m <= 16) rw_stage<1>(rec, m, nrec, mnext, buf, S, sv, An, Bn, a.skip, chol_fail);
-    else rw_stage<2>(rec, m, nrec, mnext, buf, S, sv, An, Bn, a.skip, chol_fail);
+    if (m <= 16) rw_stage<1>(rec, m, nrec, buf, S, sv, a.skip, chol_fail);
+    else rw_stage<2>(rec, m, nrec, buf, S, sv, a.skip, chol_fail);
   }
   // L, W, y were stored by other lanes than the ones that read them back below
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // same wave, same CU: ordering only, no L2 write-back

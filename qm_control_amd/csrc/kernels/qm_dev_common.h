@@ -97,6 +97,12 @@ __device__ __forceinline__ double qm_wave_max(double v) {
   return qm_bcast(v, 63);
 }
 
+// asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): lane l's 16 bytes land at lds_chunk + 16 l, no VGPR
+// is touched; completion is tracked by vmcnt (qm_dma_wait), the data becomes visible to ds_read after that
+__device__ __forceinline__ void qm_dma16(const double* g, double* lds_chunk) { __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0); }
+__device__ __forceinline__ void qm_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }      // vmcnt(0)
+__device__ __forceinline__ void qm_lds_drain() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }     // lgkmcnt(0): every ds_read has returned
+
 // strided view of a per-instance array living in a lane-interleaved HBM workspace: element i of instance b sits at
 // base[i * stride + b], so the 64 lanes of a wave (consecutive instances) touch consecutive addresses
 struct QmSPtr {

@@ -69,6 +69,9 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_wave_barrier() emu::wavesync()
 #define __popcll(x) __builtin_popcountll(x)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+// global_load_lds: lane l's `size` bytes land at lds_base + size * l
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char*)(l) + (size) * emu::cur().lane, (const char*)(g), (size))
 #define __ffsll(x) __builtin_ffsll(x)
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
