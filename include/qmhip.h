@@ -41,7 +41,7 @@ int qmhip_set_setting(qmhip_ctx* ctx, int settings_index, double value);   /* e.
 
 /* ---- MPC: replaces ocs2::MPC_BASE::run(t, x) on the SqpMpc the reference installs
  *      (qm_controllers/src/QMController.cpp:287-288,315-323) for B independent instances: one multiple-shooting
- *      SQP iteration (task.info:75-92) from a cold start.
+ *      SQP iteration (task.info:75-92; `sqp.sqpIteration` of them, shipped 1 — settable through qmhip_set_setting(ST_SQP_ITER)) from a cold start.
  *      Inputs per instance: initial time/state, target trajectory knots (37-dim, QmTargetTrajectoriesPublisher_node.cpp:44-68),
  *      contact-mode schedule (event times + mode ids, modes has n_events+1 entries).
  *      Outputs (any may be NULL): node count, node times / event tags / modes (int, bit-exact), optimal state and

@@ -111,12 +111,13 @@ class Oracle:
 
     # ---- MPC ----
     def mpc_step(self, t0, tf, x0, warm=False):
-        """one SQP iteration; warm=True: initial guess from this oracle's previous solution (cold start if there is none)"""
+        """one SQP iteration; warm=True: initial guess from this oracle's previous solution (cold start if there is none);
+        warm="iterate": one more iteration on the iterate of the last call (sqp.sqpIteration > 1)"""
         x0 = np.ascontiguousarray(x0, float)
         n = C.c_int(0)
         nt = np.zeros(self.MAXN); ne = np.zeros(self.MAXN, np.int32); nm = np.zeros(self.MAXN, np.int32)
         xo = np.zeros((self.MAXN, 30)); uo = np.zeros((self.MAXN, 30)); perf = np.zeros(10)
-        fn = self.lib.qmo_mpc_step_warm if warm else self.lib.qmo_mpc_step
+        fn = self.lib.qmo_mpc_iterate if warm == "iterate" else (self.lib.qmo_mpc_step_warm if warm else self.lib.qmo_mpc_step)
         rc = fn(self.h, C.c_double(t0), C.c_double(tf), _p(x0), C.c_int(self.MAXN), C.byref(n), _p(nt), _pi(ne), _pi(nm), _p(xo), _p(uo), _p(perf))
         if rc != 0:
             raise RuntimeError("oracle mpc_step failed rc=%d" % rc)

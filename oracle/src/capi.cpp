@@ -101,6 +101,22 @@ int qmo_get_step(void* h, double* dx, double* du) {
   return n;
 }
 int qmo_ls_trials(void* h) { return ((Oracle*)h)->R.lsTrials; }
+// one more SQP iteration on the iterate the last call left (sqp.sqpIteration > 1, [upstream SqpSolver::runImpl loop]); same outputs as qmo_mpc_step
+int qmo_mpc_iterate(void* h, double t0, double tf, const double* x0, int maxn, int* n_nodes, double* node_t, int* node_ev, int* node_mode, double* xs, double* us, double* perf) {
+  Oracle* o = (Oracle*)h; Vec x0v(x0, x0 + QM_NX);
+  if (o->R.grid.size() < 2) return -3;
+  std::vector<Vec> xi = o->R.x, ui(o->R.u.begin(), o->R.u.end() - 1);
+  for (size_t i = 0; i < ui.size(); ++i) if (o->R.grid[i].ev == QM_EV_PRE) ui[i] = Vec(QM_NU, 0.0);
+  o->R = SqpResult();
+  try { sqpIteration(o->P, t0, tf, x0v, &xi, &ui, o->R); } catch (const std::exception&) { return -2; }
+  const SqpResult& R = o->R; const int n = (int)R.grid.size(); if (n > maxn) return -1;
+  *n_nodes = n;
+  for (int i = 0; i < n; ++i) { node_t[i] = R.grid[i].t; node_ev[i] = R.grid[i].ev; node_mode[i] = R.mode[i]; std::memcpy(xs + QM_NX * i, R.x[i].data(), QM_NX * 8); std::memcpy(us + QM_NU * i, R.u[i].data(), QM_NU * 8); }
+  const Performance* pf[2] = {&R.baseline, &R.after};
+  for (int k = 0; k < 2; ++k) { perf[4 * k] = pf[k]->merit; perf[4 * k + 1] = pf[k]->cost; perf[4 * k + 2] = pf[k]->dynSSE; perf[4 * k + 3] = pf[k]->eqSSE; }
+  perf[8] = R.alpha; perf[9] = R.armijo;
+  return 0;
+}
 // warm-started iteration: the previous solution of this oracle is the initial guess (cold start if there is none)
 int qmo_mpc_step_warm(void* h, double t0, double tf, const double* x0, int maxn, int* n_nodes, double* node_t, int* node_ev, int* node_mode, double* xs, double* us, double* perf) {
   Oracle* o = (Oracle*)h; Vec x0v(x0, x0 + QM_NX);

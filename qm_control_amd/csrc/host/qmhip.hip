@@ -61,6 +61,9 @@ struct qmhip_ctx {
   std::string error; int lastB = 0; bool have_solution = false;
   qmhip_ctx() : mpc(bk), wbc(bk) {}
   void fail(const std::string& m) { error = m; }
+  // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
+  // them (an instance whose line search finds no step just keeps its iterate)
+  int sqp_iterations() const { const int n = (int)st[ST_SQP_ITER]; return n < 1 ? 1 : (n > 50 ? 50 : n); }
   int hipstate() { if (!bk.error.empty()) { error = bk.error; bk.error.clear(); return QMHIP_ERR_HIP; } return QMHIP_OK; }
 };
 
@@ -133,7 +136,7 @@ int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, in
 }
 int qmhip_mpc_solve_resident(qmhip_ctx* c, int B, double horizon) {
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident: bad argument"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->mpc.grid(B, horizon); c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
+  hipSetDevice(c->device); c->mpc.grid(B, horizon); for (int it = 0; it < c->sqp_iterations(); ++it) c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
 }
 int qmhip_mpc_set_initial(qmhip_ctx* c, int B, const double* t0, const double* x0) {
   if (!c || B <= 0 || B > c->max_batch || !t0 || !x0) { if (c) c->fail("qmhip_mpc_set_initial: bad argument"); return QMHIP_ERR_ARG; }
@@ -141,7 +144,7 @@ int qmhip_mpc_set_initial(qmhip_ctx* c, int B, const double* t0, const double* x
 }
 int qmhip_mpc_solve_resident_warm(qmhip_ctx* c, int B, double horizon) {
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident_warm: bad argument"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
+  hipSetDevice(c->device); c->mpc.grid(B, horizon, true); for (int it = 0; it < c->sqp_iterations(); ++it) c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
 }
 int qmhip_mpc_advance_resident(qmhip_ctx* c, int B, double dt) {
   if (!c || B <= 0 || B > c->max_batch) { if (c) c->fail("qmhip_mpc_advance_resident: bad argument"); return QMHIP_ERR_ARG; }
@@ -153,7 +156,7 @@ int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, 
   hipSetDevice(c->device);
   for (int k = 0; k < n_steps; ++k) {
     if (k > 0) c->mpc.advance(B, mpc_dt);
-    c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true;
+    c->mpc.grid(B, horizon, true); for (int it = 0; it < c->sqp_iterations(); ++it) c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true;
     c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time0 + k * mpc_dt); c->wbc.step(c->mpc.d, B, period, 0);
   }
   return c->hipstate();

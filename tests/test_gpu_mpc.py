@@ -102,3 +102,24 @@ def test_receding_horizon_closed_loop(blobs, oracle):
     last = mpc.download(); out, qps = wbc.download(B)
     assert np.array_equal(last["x"], got[-1]["x"]) and np.array_equal(last["u"], got[-1]["u"]) and (qps == 0).all() and np.isfinite(out).all()
     itf.close()
+
+
+def test_multiple_sqp_iterations(blobs, oracle):
+    """sqp.sqpIteration = 3 through qmhip_set_setting: three SQP iterations per MPC call, against the oracle iterating on its own iterate"""
+    from qm_control_amd import api, scenarios
+    B = 2
+    cfg = scenarios.make_config("C3", batch=B, n_intervals=40)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=80, max_ref_knots=cfg["ref_t"].shape[1], max_events=cfg["ev"].shape[1])
+    itf.set_setting(992, 3.0)                                   # ST_SQP_ITER
+    mpc = api.SqpMpc(itf)
+    got = mpc.run(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"])
+    for b in range(B):
+        oracle.set_schedule(cfg["ev"][b], cfg["modes"][b]); oracle.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+        t0 = float(cfg["t0"][b]); r = oracle.mpc_step(t0, t0 + cfg["horizon"], cfg["x0"][b])
+        for _ in range(2):
+            r = oracle.mpc_step(t0, t0 + cfg["horizon"], cfg["x0"][b], warm="iterate")
+        n = len(r["t"])
+        assert got["status"][b] == 0 and got["num_nodes"][b] == n
+        assert rel_err(got["x"][b, :n], r["x"]) <= TOL and rel_err(got["u"][b, :n], r["u"]) <= TOL, b
+        assert rel_err(got["perf"][b, :8], r["perf"][:8]) <= 1e-5
+    itf.close()
