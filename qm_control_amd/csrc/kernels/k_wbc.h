@@ -104,25 +104,22 @@ __device__ __forceinline__ void dev_rot_error(const double* Rl, const double* Rr
 // ---- wave-cooperative dense helpers ----
 // Householder QR on REGISTER-resident columns: lane j holds column j in col[0..MR) (rows beyond the matrix are zero); lanes
 // 0..n-1 are the matrix columns, lane n is the right-hand side.  After step k the registers move up one row, so the pivot is
-// always col[0] and every index is static; the pivot column reaches the other lanes through hv (LDS broadcast reads).
+// always col[0] and every index is static; the pivot column reaches the other lanes through v_readlane (hv is unused, kept for symmetry).
 // Row k of [R | Qᵀ rhs] is written to Rout[k * ldR + l], k <= l <= n.  With Vout the reflectors are kept:
 // Vout[k * ldV + k + i] = v_k[i] (zero above the pivot), beta[k] = 2 / (v·v) (0 for a null column).
 template <int MR>
 __device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, double* hv, double* Rout, int ldR, double* Vout, int ldV, double* beta) {
   const int l = threadIdx.x & 63;
   for (int k = 0; k < nsteps; ++k) {
-    qm_wave_sync();
-    if (l == k) {
+    // the pivot column reaches every lane through v_readlane (MR <= 18 values fit the scalar registers): no LDS round trip in the chain
+    double v[MR];
 #pragma unroll
-      for (int i = 0; i < MR; ++i) hv[i] = col[i];
-    }
-    qm_wave_sync();
-    // pass 1 over the pivot column: its norm and this lane's dot product with it (the pivot entry itself is patched afterwards)
+    for (int i = 0; i < MR; ++i) v[i] = qm_bcast(col[i], k);
     double nq[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < MR; ++i) { const double vi = hv[i]; nq[i & 3] += vi * vi; if (i > 0) dq[i & 3] += vi * col[i]; }
+    for (int i = 0; i < MR; ++i) { nq[i & 3] += v[i] * v[i]; if (i > 0) dq[i & 3] += v[i] * col[i]; }
     const double nrm2 = (nq[0] + nq[1]) + (nq[2] + nq[3]), dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
-    const double gkk = hv[0], nrm = sqrt(nrm2); const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = nrm2 - gkk * gkk + vk * vk;
+    const double gkk = v[0], nrm = sqrt(nrm2); const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = nrm2 - gkk * gkk + vk * vk;
     const bool ok = (nrm2 != 0.0) && (vn != 0.0);
     const double s = ok ? (dot + vk * col[0]) * (2.0 / vn) : 0.0;
     const double r0 = (l == k && ok) ? alpha : col[0] - s * vk;
@@ -132,9 +129,9 @@ __device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, d
       for (int i = 0; i < MR; ++i) if (k + i < ldV) Vout[k * ldV + k + i] = ok ? (i == 0 ? vk : col[i]) : 0.0;
       beta[k] = ok ? 2.0 / vn : 0.0;
     }
-    // pass 2: reflect and move up one row
+    // reflect and move up one row
 #pragma unroll
-    for (int i = 1; i < MR; ++i) col[i - 1] = col[i] - s * hv[i];
+    for (int i = 1; i < MR; ++i) col[i - 1] = col[i] - s * v[i];
     col[MR - 1] = 0.0;
   }
   qm_wave_sync();
