@@ -147,16 +147,24 @@ __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ld
   // (skipping the unpopulated rows of d with per-row uniform branches was measured 2x SLOWER: the branches serialise the LDS reads)
   const int l = threadIdx.x & 63;
   for (int k = 0; k < n; ++k) {
-    qm_wave_sync();
-    if (l == k) {
+    // pivot column to every lane: through v_readlane when it fits the scalar registers (MRD <= 24), through LDS otherwise
+    double pv[MRD <= 24 ? MRD : 1];
+    if (MRD <= 24) {
 #pragma unroll
-      for (int i = 0; i < MRD; ++i) hv[i] = d[i];
+      for (int i = 0; i < (MRD <= 24 ? MRD : 1); ++i) pv[i] = qm_bcast(d[i], k);
+    } else {
+      qm_wave_sync();
+      if (l == k) {
+#pragma unroll
+        for (int i = 0; i < MRD; ++i) hv[i] = d[i];
+      }
+      qm_wave_sync();
     }
-    qm_wave_sync();
+#define RQ_V(i) (MRD <= 24 ? pv[(MRD <= 24) ? (i) : 0] : hv[i])
     const double tkk = T[wv_tidx(k, k, n, ldT)]; const double tl = (l >= k && l <= n) ? T[wv_tidx(k, l, n, ldT)] : 0.0;
     double nq[4] = {tkk * tkk, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};   // four partial sums: the dependent chain is what costs on a lone wave
 #pragma unroll
-    for (int i = 0; i < MRD; ++i) { const double vi = hv[i]; nq[i & 3] += vi * vi; dq[i & 3] += vi * d[i]; }
+    for (int i = 0; i < MRD; ++i) { const double vi = RQ_V(i); nq[i & 3] += vi * vi; dq[i & 3] += vi * d[i]; }
     const double nrm2 = (nq[0] + nq[1]) + (nq[2] + nq[3]), dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
     const double nrm = sqrt(nrm2); const double alpha = tkk > 0.0 ? -nrm : nrm; const double vk = tkk - alpha; const double vn = nrm2 - tkk * tkk + vk * vk;
     const bool ok = (nrm2 != 0.0) && (vn != 0.0);
@@ -164,12 +172,13 @@ __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ld
     if (ok && l > k && l <= n) {
       T[wv_tidx(k, l, n, ldT)] = tl - s * vk;
 #pragma unroll
-      for (int i = 0; i < MRD; ++i) d[i] -= s * hv[i];
+      for (int i = 0; i < MRD; ++i) d[i] -= s * RQ_V(i);
     }
     qm_wave_sync();                                       // every lane has read the pivot before it is replaced
     if (ok && l == k) T[wv_tidx(k, k, n, ldT)] = alpha;
   }
   qm_wave_sync();
+#undef RQ_V
 }
 // R z = c on [R | c] held like rq_house_tri leaves it (ld == 0: packed); z -> LDS vector
 __device__ __forceinline__ void wv_backsub_tri(const double* T, int ld, int n, double* z) {
