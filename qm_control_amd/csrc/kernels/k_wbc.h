@@ -180,28 +180,48 @@ __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ld
   qm_wave_sync();
 #undef RQ_V
 }
+// Triangular solves without a wave reduction in the dependency chain: lane j keeps ROW j of the triangular matrix in registers, its
+// own right-hand side and 1 / diagonal; the unknowns are resolved one by one (z_i = r_i / R_ii on lane i), broadcast with v_readlane,
+// and every other lane folds R[j][i] z_i into its r_j.  `at(j, i)` reads element (j, i) of the matrix (LDS); returns lane l's z_l.
+// upper: R z = r, i = n-1 .. 0, row j holds i > j.
+template <int MAXN, class At>
+__device__ __forceinline__ double wv_solve_upper(At at, int n, double rj) {
+  const int l = threadIdx.x & 63;
+  double row[MAXN];
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) row[i] = (l < n && i > l && i < n) ? at(l, i) : 0.0;
+  const double rinv = (l < n) ? 1.0 / at(l, l) : 0.0; double z = 0.0;
+#pragma unroll
+  for (int i = MAXN - 1; i >= 0; --i) if (i < n) { const double zi = qm_bcast(rj * rinv, i); if (l == i) z = zi; rj -= row[i] * zi; }
+  return z;
+}
+// lower: L y = r with L = Rᵀ (at(j, i) must return R[i][j]), i = 0 .. n-1, row j holds i < j.
+template <int MAXN, class At>
+__device__ __forceinline__ double wv_solve_lower(At at, int n, double rj) {
+  const int l = threadIdx.x & 63;
+  double row[MAXN];
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) row[i] = (l < n && i < l) ? at(l, i) : 0.0;
+  const double rinv = (l < n) ? 1.0 / at(l, l) : 0.0; double z = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) if (i < n) { const double zi = qm_bcast(rj * rinv, i); if (l == i) z = zi; rj -= row[i] * zi; }
+  return z;
+}
 // R z = c on [R | c] held like rq_house_tri leaves it (ld == 0: packed); z -> LDS vector
+template <int MAXN>
 __device__ __forceinline__ void wv_backsub_tri(const double* T, int ld, int n, double* z) {
-  const int l = threadIdx.x & 63; double zj = 0.0;
-  for (int i = n - 1; i >= 0; --i) {
-    const double s = wv_sum((l > i && l < n) ? T[wv_tidx(i, l, n, ld)] * zj : 0.0);
-    const double zi = (T[wv_tidx(i, n, n, ld)] - s) / T[wv_tidx(i, i, n, ld)];
-    if (l == i) zj = zi;
-  }
+  const int l = threadIdx.x & 63;
+  const double zl = wv_solve_upper<MAXN>([&](int j, int i) { return T[wv_tidx(j, i, n, ld)]; }, n, (l < n) ? T[wv_tidx(l, n, n, ld)] : 0.0);
   qm_wave_sync();
-  if (l < n) z[l] = zj;
+  if (l < n) z[l] = zl;
   qm_wave_sync();
 }
-// R z = rhs with R = upper triangle of G[0:n, 0:n]; rhs is a strided vector (rhs[i * rs]); z -> LDS vector
+// R z = rhs with R = upper triangle of G[0:n, 0:n] (n <= 18); rhs is a strided vector (rhs[i * rs]); z -> LDS vector
 __device__ __forceinline__ void wv_backsub(const double* G, int ld, int n, const double* rhs, int rs, double* z) {
-  const int l = threadIdx.x & 63; double zj = 0.0;
-  for (int i = n - 1; i >= 0; --i) {
-    const double s = wv_sum((l > i && l < n) ? G[i * ld + l] * zj : 0.0);
-    const double zi = (rhs[i * rs] - s) / G[i * ld + i];
-    if (l == i) zj = zi;
-  }
+  const int l = threadIdx.x & 63;
+  const double zl = wv_solve_upper<WVLD>([&](int j, int i) { return G[j * ld + i]; }, n, (l < n) ? rhs[l * rs] : 0.0);
   qm_wave_sync();
-  if (l < n) z[l] = zj;
+  if (l < n) z[l] = zl;
   qm_wave_sync();
 }
 // Householder least squares: min |G[:, :n] z − G[:, n]|
@@ -266,13 +286,12 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
   const int l = threadIdx.x & 63;
   long long tl_ = (long long)__builtin_readcyclecounter();
 #define WF(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tf[k] += now_ - tl_; tl_ = now_; }
-  if (me == 0) { wv_backsub_tri(Rc, WTLD, n, zout); return; }
+  if (me == 0) { wv_backsub_tri<WVLD>(Rc, WTLD, n, zout); return; }
   double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
   WF(0)
   wv_qr_Et(S + WL_EROWS, me, n, V, beta, R, S + WL_HV);
   WF(1)
-  { double y1 = 0.0;                                          // R_Eᵀ y1 = e
-    for (int i = 0; i < me; ++i) { const double sacc = wv_sum((l < i) ? R[l * WMAXACT + i] * y1 : 0.0); const double v = (e[i] - sacc) / R[i * WMAXACT + i]; if (l == i) y1 = v; }
+  { const double y1 = wv_solve_lower<WVLD>([&](int j, int i) { return R[i * WMAXACT + j]; }, me, (l < me) ? e[l] : 0.0);   // R_Eᵀ y1 = e
     if (l < me) y[l] = y1; }
   WF(2)
   // T <- T Q (row-wise reflections; lane = row), rhs column untouched
@@ -316,8 +335,7 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
   WF(6)
   wv_apply_Qt(V, beta, me, n, w);
   WF(7)
-  { double lm = 0.0;
-    for (int i = me - 1; i >= 0; --i) { const double sacc = wv_sum((l > i && l < me) ? R[i * WMAXACT + l] * lm : 0.0); const double v = (-w[i] - sacc) / R[i * WMAXACT + i]; if (l == i) lm = v; }
+  { const double lm = wv_solve_upper<WVLD>([&](int j, int i) { return R[j * WMAXACT + i]; }, me, (l < me) ? -w[l] : 0.0);          // R_E lam = −(Qᵀ ∇)[0:me]
     if (l < me) lam[l] = lm; }
   qm_wave_sync();
   WF(8)
@@ -611,7 +629,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
           WT(2)
           rq_house_tri<WMAXA + WMAXACT>(d, G, 0, n, S + WL_HV);
         }
-        wv_backsub_tri(G, 0, n, zn);
+        wv_backsub_tri<WNV>(G, 0, n, zn);
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
         WT(3)
