@@ -620,7 +620,16 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
         if (l == 0) { int na0 = 0; for (int i = 0; i < C.nIneq && na0 < WMAXACT; ++i) if ((actmask >> i) & 1ull) alist[na0++] = i; }
         int na = __popcll(actmask); if (na > WMAXACT) na = WMAXACT;
         qm_wave_sync();
-        {
+        if (ra <= 18 && na <= 6) {
+          // the usual case (18 task rows, a handful of active soft rows): 24 dense rows, pivot column broadcast by v_readlane
+          double d[24];
+#pragma unroll
+          for (int r = 0; r < 18; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
+#pragma unroll
+          for (int q2 = 0; q2 < 6; ++q2) { double v = 0.0; if (q2 < na && l <= n) { const int i = alist[q2]; v = (l == n) ? fb[i] : wbc_d0_entry(C, i, l); } d[18 + q2] = v; }
+          WT(2)
+          rq_house_tri<24>(d, G, 0, n, S + WL_HV);
+        } else {
           double d[WMAXA + WMAXACT];
 #pragma unroll
           for (int r = 0; r < WMAXA; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
