@@ -686,10 +686,42 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       double dz[WVLD];                                   // row l of D0 Zp lives in the registers of lane l
 #pragma unroll
       for (int k = 0; k < WVLD; ++k) dz[k] = 0.0;
-      if (l < C.nIneq) {
-        for (int r = 0; r < WNV; ++r) { const double e = wbc_d0_entry(C, l, r); if (e != 0.0) {
+      {
+        // torque rows (+/- the same 18 x 36 block [M_j | −J_jᵀ]) times Zp on the matrix core: P = Zᵀ Y, Z[k][i] = D0[i][k], Y = Zp
+        const int g4 = l >> 4, c4 = l & 15;
+        qm_d4 Zt[3][2], Yz[3][2], Pz[2][2];
 #pragma unroll
-          for (int k = 0; k < WVLD; ++k) if (k < n) dz[k] += e * Zp[r * n + k]; } }
+        for (int K = 0; K < 3; ++K)
+#pragma unroll
+          for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = 16 * K + g4 + 4 * r, i = 16 * J + c4;
+              Zt[K][J][r] = (k < WNV && i < 18) ? ((k < 24) ? M[(6 + i) * 24 + k] : -Jf[(k - 24) * 24 + 6 + i]) : 0.0;
+              Yz[K][J][r] = (k < WNV && i < n) ? Zp[k * n + i] : 0.0;
+            }
+        qm_frag_zero<2, 2>(Pz);
+        qm_gemm_tn<3, 2, 2>(Zt, Yz, Pz, 0, 9, false);
+        double* tmp = S + WL_EROWS;                       // [18][18] hand-over: fragments -> one row per lane
+        qm_wave_sync();
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+          for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int row = 16 * I + g4 + 4 * r, col = 16 * J + c4; if (row < 18 && col < WVLD) tmp[row * WVLD + col] = Pz[I][J][r]; }
+        qm_wave_sync();
+        if (l < 36) {
+          const int rr = (l < 18) ? l : l - 18; const double sg = (l < 18) ? 1.0 : -1.0;
+#pragma unroll
+          for (int k = 0; k < WVLD; ++k) dz[k] = (k < n) ? sg * tmp[rr * WVLD + k] : 0.0;
+        } else if (l < 36 + 5 * C.nc) {                   // friction pyramid rows touch one force triple
+          const int k0 = 24 + 3 * C.contactOf[(l - 36) / 5];
+          for (int a3 = 0; a3 < 3; ++a3) { const double e = wbc_d0_entry(C, l, k0 + a3); if (e != 0.0) {
+#pragma unroll
+            for (int k = 0; k < WVLD; ++k) if (k < n) dz[k] += e * Zp[(k0 + a3) * n + k]; } }
+        }
+        qm_wave_sync();
       }
       qm_wave_sync();
       WT(8)
