@@ -35,6 +35,8 @@ int emu_mpc_step_warm(void* h, int B, const double* t0, const double* x0, double
   c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B, max_trials); return c->mpc.ls_trials_run;
 }
 void emu_advance(void* h, int B, double dt) { ((EmuCtx*)h)->mpc.advance(B, dt); }
+// K0 only: grid, modes, references, initial guess of the uploaded problem
+void emu_grid(void* h, int B, double horizon) { ((EmuCtx*)h)->mpc.grid(B, horizon); }
 void emu_upload(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes) { ((EmuCtx*)h)->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); }
 // raw buffer access for parity tests: name -> pointer
 void* emu_buffer(void* h, const char* name) {

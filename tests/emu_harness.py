@@ -51,6 +51,14 @@ class Emu:
         assert rt.shape[1] == self.nref and ev.shape[1] == self.nev
         return self.lib.emu_mpc_step(self.h, C.c_int(B), _p(t0), _p(x0), _p(rt), _p(rx), _p(ev), _pi(mo), C.c_double(cfg["horizon"]), C.c_int(max_trials))
 
+    def grid_only(self, cfg, batch=None):
+        """upload + K0 (time discretisation, modes, references, initial guess) without the SQP iteration"""
+        B = cfg["B"] if batch is None else batch
+        self.B = B
+        a = lambda k, t=float: np.ascontiguousarray(cfg[k][:B], t)
+        self.lib.emu_upload(self.h, C.c_int(B), _p(a("t0")), _p(a("x0")), _p(a("ref_t")), _p(a("ref_x")), _p(a("ev")), _pi(a("modes", np.int32)))
+        self.lib.emu_grid(self.h, C.c_int(B), C.c_double(cfg["horizon"]))
+
     def mpc_step_warm(self, t0, x0, horizon, max_trials=14):
         """new observation + warm-started SQP iteration (inputs / schedule of the last mpc_step stay resident)"""
         t0 = np.ascontiguousarray(t0, float); x0 = np.ascontiguousarray(x0, float)
