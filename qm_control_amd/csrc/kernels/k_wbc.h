@@ -343,80 +343,102 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
 }
 
 // orthonormal null space of AZ (ra x n): Zp (36 x n) <- Zp · Q2, Q2 = Q[:, rank:] from the Householder QR with column pivoting of
-// (AZ)ᵀ (n x ra); returns n − rank.  Lane j holds column j of (AZ)ᵀ in registers (rows move up one slot per step, so every index
-// is static); pivoting only marks lanes — nothing is swapped, R is never needed.  The reflectors go to LDS (V[k][k..n), beta[k]) and
-// Q2 = H_0 … H_{r-1} [0; I] is accumulated backwards with one column of Q2 per lane in registers, straight into Zp at level 0
-// (Zp = I) and through a small buffer otherwise.
-__device__ __forceinline__ int wv_null_space(double* S, int ra, int n) {
+// (AZ)ᵀ (n x ra); returns n − rank.  MAXN = 36 at level 0 (n == 36, Zp = I), 18 afterwards.  Lane j holds column j of (AZ)ᵀ in
+// registers; rows move up one slot per step so every register index is static, and pivoting only marks lanes — nothing is swapped,
+// R is never needed.  Reflector k is stored SHIFTED (Vs[k][i] = v_k[k + i], zero padded to MAXN), so neither sweep needs an index
+// bound: Q2 = H_0 … H_{r-1} [0; I] is accumulated backwards with one column of Q2 per lane in a register window that moves down one
+// row per reflector (the row that enters is a zero of [0; I]).
+template <int MAXN>
+__device__ __forceinline__ int wv_null_space(double* S, int ra, int n, long long* tn) {
   const int l = threadIdx.x & 63;
-  double* V = S + WL_G; double* Zp = S + WL_ZP; const double* AZ = S + WL_AZ; double* hv = S + WL_HV; double* bet = S + WL_R;   // V: [rank][n] (<= 18 x 36)
-  double col[WNV];
+  long long tl_ = (long long)__builtin_readcyclecounter();
+#define WN(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tn[k] += now_ - tl_; tl_ = now_; }
+  double* Vs = S + WL_G; double* Zp = S + WL_ZP; const double* AZ = S + WL_AZ; double* bet = S + WL_R; double* vd = S + WL_R + 40;   // Vs: [rank][MAXN] (<= 18 x 36); bet, vd: 2 / (v·v) and the pivot entry of each reflector
+  double col[MAXN];
 #pragma unroll
-  for (int i = 0; i < WNV; ++i) col[i] = (l < ra && i < n) ? AZ[l * WNV + i] : 0.0;
+  for (int i = 0; i < MAXN; ++i) col[i] = (l < ra && i < n) ? AZ[l * WNV + i] : 0.0;
   const int steps = (n < ra) ? n : ra;
-  for (int idx = l; idx < steps * n; idx += 64) V[idx] = 0.0;
   bool done = (l >= ra);
   int rank = 0; double maxnorm0 = 0.0;
+  WN(0)
   for (int k = 0; k < steps; ++k) {
     double nq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < WNV; ++i) nq[i & 3] += col[i] * col[i];
+    for (int i = 0; i < MAXN; ++i) nq[i & 3] += col[i] * col[i];
     const double cn = done ? -1.0 : (nq[0] + nq[1]) + (nq[2] + nq[3]);
     const double bn = wv_max(cn);
     const unsigned long long cand = __ballot(!done && cn == bn);
     if (cand == 0ull) break;
     const int best = __ffsll((long long)cand) - 1;
-    if (k == 0) maxnorm0 = sqrt(bn);
-    if (sqrt(bn) <= 1e-9 * fmax(1.0, maxnorm0)) break;
-    qm_wave_sync();
-    if (l == best) {
+    const double nrm = sqrt(bn);
+    if (k == 0) maxnorm0 = nrm;
+    if (nrm <= 1e-9 * fmax(1.0, maxnorm0)) break;
+    // pivot column to every lane: v_readlane when it fits the scalar registers, else through its (final) place in Vs
+    double v[MAXN];
+    if (MAXN <= 18) {
 #pragma unroll
-      for (int i = 0; i < WNV; ++i) hv[i] = col[i];
+      for (int i = 0; i < MAXN; ++i) v[i] = qm_bcast(col[i], best);
+    } else {
+      qm_wave_sync();
+      if (l == best) {
+#pragma unroll
+        for (int i = 0; i < MAXN; ++i) Vs[k * MAXN + i] = col[i];
+      }
+      qm_wave_sync();
+#pragma unroll
+      for (int i = 0; i < MAXN; ++i) v[i] = Vs[k * MAXN + i];
     }
-    qm_wave_sync();
-    const double gkk = hv[0], nrm = sqrt(bn); const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = bn - gkk * gkk + vk * vk;
+    const double gkk = v[0]; const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = bn - gkk * gkk + vk * vk;
+    const double b2 = (vn > 0.0) ? 2.0 / vn : 0.0;
     double dq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 1; i < WNV; ++i) dq[i & 3] += hv[i] * col[i];
-    const double s = (vn > 0.0) ? ((dq[0] + dq[1]) + (dq[2] + dq[3]) + vk * col[0]) * (2.0 / vn) : 0.0;
+    for (int i = 1; i < MAXN; ++i) dq[i & 3] += v[i] * col[i];
+    const double s = ((dq[0] + dq[1]) + (dq[2] + dq[3]) + vk * col[0]) * b2;
     if (l == best) {
-      done = true;
+      done = true; bet[k] = b2; vd[k] = vk;               // (the pivot slot Vs[k][0] still holds the unreflected value other lanes are reading)
+      if (MAXN <= 18) {
 #pragma unroll
-      for (int i = 0; i < WNV; ++i) if (k + i < n) V[k * n + k + i] = (i == 0) ? vk : col[i];
-      bet[k] = (vn > 0.0) ? 2.0 / vn : 0.0;
+        for (int i = 1; i < MAXN; ++i) Vs[k * MAXN + i] = col[i];
+      }
     }
 #pragma unroll
-    for (int i = 1; i < WNV; ++i) col[i - 1] = col[i] - s * hv[i];     // reflect and move up one row (finished lanes carry garbage, never read)
-    col[WNV - 1] = 0.0;
+    for (int i = 1; i < MAXN; ++i) col[i - 1] = col[i] - s * v[i];      // reflect and move up one row (finished lanes carry garbage, never read)
+    col[MAXN - 1] = 0.0;
     ++rank;
   }
+  WN(1)
   if (n - rank > WVLD) rank = n - WVLD;                                // the level >= 1 work arrays hold at most 18 null-space directions
   const int nn = n - rank;
   qm_wave_sync();
-  // backward accumulation: lane j < nn carries column j of Q2 (n entries)
-  double q[WNV];
+  // backward accumulation: lane j < nn carries column j of Q2 in a window w[i] = Q2[k + i][j] that starts at k = rank
+  double w[MAXN];
 #pragma unroll
-  for (int i = 0; i < WNV; ++i) q[i] = (i == rank + l && l < nn) ? 1.0 : 0.0;
+  for (int i = 0; i < MAXN; ++i) w[i] = (i == l && l < nn) ? 1.0 : 0.0;
   for (int k = rank - 1; k >= 0; --k) {
-    const double* v = V + k * n; double sq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < WNV; ++i) if (i < n) sq[i & 3] += v[i] * q[i];
+    for (int i = MAXN - 1; i > 0; --i) w[i] = w[i - 1];
+    w[0] = 0.0;
+    const double* vs = Vs + k * MAXN; double sq[4] = {0.0, 0.0, 0.0, 0.0}; double vv[MAXN];
+#pragma unroll
+    for (int i = 0; i < MAXN; ++i) { vv[i] = (i == 0) ? vd[k] : vs[i]; sq[i & 3] += vv[i] * w[i]; }
     const double sacc = ((sq[0] + sq[1]) + (sq[2] + sq[3])) * bet[k];
 #pragma unroll
-    for (int i = 0; i < WNV; ++i) if (i < n) q[i] -= sacc * v[i];
+    for (int i = 0; i < MAXN; ++i) w[i] -= sacc * vv[i];
   }
-  if (n == WNV) {                                                      // level 0: Q2 IS the new Zp (36 x nn)
+  WN(2)
+  if (MAXN == WNV) {                                                   // level 0: Q2 IS the new Zp (36 x nn)
     if (l < nn) {
 #pragma unroll
-      for (int i = 0; i < WNV; ++i) Zp[i * nn + l] = q[i];
+      for (int i = 0; i < MAXN; ++i) Zp[i * nn + l] = w[i];
     }
     qm_wave_sync();
+    WN(3)
     return nn;
   }
-  double* Q2 = V + steps * n;                                          // [n][nn] behind the reflectors (n <= 18 here: at most 612 doubles together)
+  double* Q2 = Vs + steps * MAXN;                                      // [n][nn] behind the reflectors (n <= 18 here: at most 612 doubles together)
   if (l < nn) {
 #pragma unroll
-    for (int i = 0; i < WVLD; ++i) if (i < n) Q2[i * nn + l] = q[i];
+    for (int i = 0; i < (MAXN <= WVLD ? MAXN : WVLD); ++i) if (i < n) Q2[i * nn + l] = w[i];
   }
   // Zp (36 x n) <- Zp Q2 (36 x nn), row by row in place (every lane holds its old row in registers before anything is written)
   double row[WVLD];
@@ -430,6 +452,8 @@ __device__ __forceinline__ int wv_null_space(double* S, int ra, int n) {
     for (int i = 0; i < WVLD; ++i) if (i < n) sacc += row[i] * Q2[i * nn + j];
     Zp[l * nn + j] = sacc; }
   qm_wave_sync();
+  WN(4)
+#undef WN
   return nn;
 }
 
@@ -446,7 +470,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   double* S = qm_smem;
   const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
-  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tfine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = (long long)__builtin_readcyclecounter();
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tfine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tnull[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = (long long)__builtin_readcyclecounter();
 #define WT(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; }
   const double* mb = a.mb; const double* st = a.st;
   const double* xDes = a.x_des + (size_t)b * 30; const double* uDes = a.u_des + (size_t)b * 30; const double* rbd = a.rbd + (size_t)b * QM_NRBD;
@@ -787,7 +811,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
     qm_wave_sync();
     if (a.stop == 2 + level) return;
     WT(10)
-    if (level < 2) nz = wv_null_space(S, ra, n);
+    if (level < 2) nz = (level == 0) ? wv_null_space<WNV>(S, ra, n, tnull) : wv_null_space<WVLD>(S, ra, n, tnull + 5);
     WT(7)
     if (level > 0 && status[level] == 0 && status[level - 1] != 0) status[level] = status[level - 1];
   }
@@ -800,6 +824,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   WT(11)
   if (a.stop < 0 && l == 0) for (int k = 0; k < 12; ++k) gs[WS_TIME + k] = (double)tacc[k];
   if (a.stop == -2 && l == 0) for (int k = 0; k < 9; ++k) gs[WS_TIME + k] = (double)tfine[k];
+  if (a.stop == -3 && l == 0) for (int k = 0; k < 10; ++k) gs[WS_TIME + k] = (double)tnull[k];
 #undef WT
   if (a.dbg) {
     double* d = a.dbg + (size_t)b * WBC_DBG_SIZE;

@@ -46,3 +46,9 @@ rows = stage[np.arange(B)[:, None] * nm + np.arange(5, 95)[None, :]].reshape(-1,
 ln = ["P0 stage inputs", "I jacobian columns", "I RK2 composition", "II constraint rows", "II projector", "II projected dynamics", "III cost model", "III projected cost + stores"]
 print(json.dumps({n: float(rows[:, i].mean()) for i, n in enumerate(ln)}, indent=1)); print("LQ total cycles/node", rows[:, :8].sum(1).mean())
 itf.debug_set("lq_prof", 0)
+itf.debug_set("wbc_stop", -3)
+mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
+cyc = itf.debug_read("wbc_scratch", (B, 432))
+nn_ = ["L0 load", "L0 pivoted QR", "L0 backward accumulation", "L0 write Zp", "-", "L1 load", "L1 pivoted QR", "L1 backward accumulation", "-", "L1 Zp <- Zp Q2"]
+print(json.dumps({n: float(cyc[:, i].mean()) for i, n in enumerate(nn_)}, indent=1))
+itf.debug_set("wbc_stop", 0)
