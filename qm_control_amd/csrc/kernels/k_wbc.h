@@ -126,7 +126,7 @@ __device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, d
     if (l >= k && l <= n) Rout[k * ldR + l] = r0;
     if (Vout && l == k) {
 #pragma unroll
-      for (int i = 0; i < MR; ++i) if (k + i < ldV) Vout[k * ldV + k + i] = ok ? (i == 0 ? vk : col[i]) : 0.0;
+      for (int i = 0; i < MR; ++i) Vout[k * ldV + k + i] = ok ? (i == 0 ? vk : col[i]) : 0.0;   // entries past the row end are zeros that land above the NEXT row's pivot (Vout must have MR spare slots)
       beta[k] = ok ? 2.0 / vn : 0.0;
     }
     // reflect and move up one row
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       for (; it < 100; ++it) {
         if (myslot >= 0) {
 #pragma unroll
-          for (int k = 0; k < WVLD; ++k) if (k < n) S[WL_EROWS + myslot * WVLD + k] = dz[k];
+          for (int k = 0; k < WVLD; ++k) S[WL_EROWS + myslot * WVLD + k] = dz[k];      // dz is zero beyond n: no per-index bound (uniform branches would serialise the LDS traffic)
           S[WL_ERHS + myslot] = fb[l];
         }
         qm_wave_sync();
@@ -788,7 +788,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
           if (l < C.nIneq && !((wmask >> l) & 1ull)) {
             double dp = 0.0, dzz = 0.0;
 #pragma unroll
-            for (int k = 0; k < WVLD; ++k) if (k < n) { dp += dz[k] * p[k]; dzz += dz[k] * z[k]; }
+            for (int k = 0; k < WVLD; ++k) { dp += dz[k] * p[k]; dzz += dz[k] * z[k]; }            // dz[k >= n] == 0, p / z hold finite leftovers there
             if (dp > 1e-10 * fmax(1.0, pn)) aa = fmax(0.0, (fb[l] - dzz) / dp);
           }
           const double amin = -wv_max(-aa);
