@@ -312,8 +312,8 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     // Lᵀ v = t (lane i keeps v_i), ut = −v
     double v = 0.0;
 #pragma unroll
-    for (int q = QM_MMAX - 1; q >= 0; --q) if (q < m) {
-      const double lq = (l <= q && l < m) ? buf[RF_L + q * 19 + l] : 0.0;   // L[q][l] (row q = l: 1/L_qq)
+    for (int q = QM_MMAX - 1; q >= 0; --q) {                     // steps q >= m are no-ops (lane q carries lq == 0): no uniform branch in the chain
+      const double lq = (l <= q && l < m && q < m) ? buf[RF_L + q * 19 + l] : 0.0;   // L[q][l] (row q = l: 1/L_qq)
       const double vq = qm_bcast(t * lq, q);
       if (l == q) v = vq;
       t -= lq * vq;                                       // lanes i < q: L[q][i] v_q   (lane q: its t is dead)
@@ -322,7 +322,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     armijo += qv * dxl + rp * ut;
     { double bp[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < QM_MMAX; ++q) if (q < m) bp[q % 3] += rowB[q] * qm_bcast(ut, q);
+      for (int q = 0; q < QM_MMAX; ++q) bp[q % 3] += rowB[q] * qm_bcast(ut, q);          // ut == 0 on lanes >= m: no bound needed
       acc += (bp[0] + bp[1]) + bp[2]; }
     if (half && r < 30) { a.du[nb * 30 + r] = acc; du2 += acc * acc; }
     dxl = (l < 30) ? acc : 0.0;

@@ -438,7 +438,7 @@ __device__ __forceinline__ int wv_null_space(double* S, int ra, int n, long long
   double* Q2 = Vs + steps * MAXN;                                      // [n][nn] behind the reflectors (n <= 18 here: at most 612 doubles together)
   if (l < nn) {
 #pragma unroll
-    for (int i = 0; i < (MAXN <= WVLD ? MAXN : WVLD); ++i) if (i < n) Q2[i * nn + l] = w[i];
+    for (int i = 0; i < (MAXN <= WVLD ? MAXN : WVLD); ++i) Q2[i * nn + l] = w[i];          // rows >= n are zeros that stay inside the workspace
   }
   // Zp (36 x n) <- Zp Q2 (36 x nn), row by row in place (every lane holds its old row in registers before anything is written)
   double row[WVLD];
@@ -449,7 +449,7 @@ __device__ __forceinline__ int wv_null_space(double* S, int ra, int n, long long
   qm_wave_sync();
   if (l < WNV) for (int j = 0; j < nn; ++j) { double sacc = 0.0;
 #pragma unroll
-    for (int i = 0; i < WVLD; ++i) if (i < n) sacc += row[i] * Q2[i * nn + j];
+    for (int i = 0; i < WVLD; ++i) sacc += row[i] * Q2[i * nn + j];                            // row[i >= n] == 0
     Zp[l * nn + j] = sacc; }
   qm_wave_sync();
   WN(4)
