@@ -101,6 +101,21 @@ __device__ __forceinline__ void dev_rot_error(const double* Rl, const double* Rr
   for (int i = 0; i < 3; ++i) err[i] = s * v[i];
 }
 
+// Householder scalars of a pivot column with squared norm nrm2 and pivot entry g: alpha = −sign(g)|x|, vk = g − alpha, b2 = 2 / (v·v).
+// v·v = 2 |x| (|x| + |g|), so one reciprocal square root and one reciprocal (hardware estimates + two Newton steps each) replace
+// the sqrt and the division of the dependency chain; ok = false for a null column.
+__device__ __forceinline__ bool qm_house_scalars(double nrm2, double g, double& alpha, double& vk, double& b2) {
+  const bool ok = nrm2 > 0.0;
+  const double x = ok ? nrm2 : 1.0;
+  double r = __builtin_amdgcn_rsq(x);
+  r = fma(0.5 * r, fma(-x * r, r, 1.0), r); r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
+  const double nrm = x * r, den = nrm + fabs(g);
+  double q = __builtin_amdgcn_rcp(den);
+  q = fma(q, fma(-den, q, 1.0), q); q = fma(q, fma(-den, q, 1.0), q);
+  alpha = g > 0.0 ? -nrm : nrm; vk = g - alpha; b2 = ok ? r * q : 0.0;
+  return ok;
+}
+
 // ---- wave-cooperative dense helpers ----
 // Householder QR on REGISTER-resident columns: lane j holds column j in col[0..MR) (rows beyond the matrix are zero); lanes
 // 0..n-1 are the matrix columns, lane n is the right-hand side.  After step k the registers move up one row, so the pivot is
@@ -119,15 +134,14 @@ __device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, d
 #pragma unroll
     for (int i = 0; i < MR; ++i) { nq[i & 3] += v[i] * v[i]; if (i > 0) dq[i & 3] += v[i] * col[i]; }
     const double nrm2 = (nq[0] + nq[1]) + (nq[2] + nq[3]), dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
-    const double gkk = v[0], nrm = sqrt(nrm2); const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = nrm2 - gkk * gkk + vk * vk;
-    const bool ok = (nrm2 != 0.0) && (vn != 0.0);
-    const double s = ok ? (dot + vk * col[0]) * (2.0 / vn) : 0.0;
+    double alpha, vk, b2; const bool ok = qm_house_scalars(nrm2, v[0], alpha, vk, b2);
+    const double s = (dot + vk * col[0]) * b2;
     const double r0 = (l == k && ok) ? alpha : col[0] - s * vk;
     if (l >= k && l <= n) Rout[k * ldR + l] = r0;
     if (Vout && l == k) {
 #pragma unroll
       for (int i = 0; i < MR; ++i) Vout[k * ldV + k + i] = ok ? (i == 0 ? vk : col[i]) : 0.0;   // entries past the row end are zeros that land above the NEXT row's pivot (Vout must have MR spare slots)
-      beta[k] = ok ? 2.0 / vn : 0.0;
+      beta[k] = b2;
     }
     // reflect and move up one row
 #pragma unroll
@@ -166,9 +180,8 @@ __device__ __forceinline__ void rq_house_tri(double (&d)[MRD], double* T, int ld
 #pragma unroll
     for (int i = 0; i < MRD; ++i) { const double vi = RQ_V(i); nq[i & 3] += vi * vi; dq[i & 3] += vi * d[i]; }
     const double nrm2 = (nq[0] + nq[1]) + (nq[2] + nq[3]), dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
-    const double nrm = sqrt(nrm2); const double alpha = tkk > 0.0 ? -nrm : nrm; const double vk = tkk - alpha; const double vn = nrm2 - tkk * tkk + vk * vk;
-    const bool ok = (nrm2 != 0.0) && (vn != 0.0);
-    const double s = ok ? (dot + vk * tl) * (2.0 / vn) : 0.0;
+    double alpha, vk, b2; const bool ok = qm_house_scalars(nrm2, tkk, alpha, vk, b2);
+    const double s = (dot + vk * tl) * b2;
     if (ok && l > k && l <= n) {
       T[wv_tidx(k, l, n, ldT)] = tl - s * vk;
 #pragma unroll
@@ -328,9 +341,20 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
   WF(5)
   // multipliers: R_E lam = −(Qᵀ Rᵀ (R z − c))[0:me]
   double* w = S + WL_W36; double* res = S + WL_HV;
-  if (l < n) { double sacc = -Rc[l * WTLD + n]; for (int k = l; k < n; ++k) sacc += Rc[l * WTLD + k] * zout[k]; res[l] = sacc; }
+  // (entries of [R | c] below the diagonal are zeros, z and res are zero padded to 18: static loops, no bounds, two partial sums)
+  if (l >= n && l < WVLD) zout[l] = 0.0;
   qm_wave_sync();
-  if (l < n) { double acc = 0.0; for (int r = 0; r <= l; ++r) acc += Rc[r * WTLD + l] * res[r]; w[l] = acc; }
+  { double sp[2] = {(l < n) ? -Rc[l * WTLD + n] : 0.0, 0.0};
+    const int lr = (l < n) ? l : 0;
+#pragma unroll
+    for (int k = 0; k < WVLD; ++k) sp[k & 1] += Rc[lr * WTLD + k] * zout[k];
+    if (l < WVLD) res[l] = (l < n) ? sp[0] + sp[1] : 0.0; }
+  qm_wave_sync();
+  { double sp[2] = {0.0, 0.0};
+    const int lc = (l < n) ? l : 0;
+#pragma unroll
+    for (int r = 0; r < WVLD; ++r) sp[r & 1] += Rc[r * WTLD + lc] * res[r];
+    if (l < n) w[l] = sp[0] + sp[1]; }
   qm_wave_sync();
   WF(6)
   wv_apply_Qt(V, beta, me, n, w);
@@ -370,9 +394,8 @@ __device__ __forceinline__ int wv_null_space(double* S, int ra, int n, long long
     const unsigned long long cand = __ballot(!done && cn == bn);
     if (cand == 0ull) break;
     const int best = __ffsll((long long)cand) - 1;
-    const double nrm = sqrt(bn);
-    if (k == 0) maxnorm0 = nrm;
-    if (nrm <= 1e-9 * fmax(1.0, maxnorm0)) break;
+    if (k == 0) maxnorm0 = bn;                                           // squared norms throughout: |x| <= 1e-9 max(1, |x0|)  <=>  |x|² <= 1e-18 max(1, |x0|²)
+    if (bn <= 1e-18 * fmax(1.0, maxnorm0)) break;
     // pivot column to every lane: v_readlane when it fits the scalar registers, else through its (final) place in Vs
     double v[MAXN];
     if (MAXN <= 18) {
@@ -388,8 +411,7 @@ __device__ __forceinline__ int wv_null_space(double* S, int ra, int n, long long
 #pragma unroll
       for (int i = 0; i < MAXN; ++i) v[i] = Vs[k * MAXN + i];
     }
-    const double gkk = v[0]; const double alpha = gkk > 0.0 ? -nrm : nrm; const double vk = gkk - alpha; const double vn = bn - gkk * gkk + vk * vk;
-    const double b2 = (vn > 0.0) ? 2.0 / vn : 0.0;
+    double alpha, vk, b2; qm_house_scalars(bn, v[0], alpha, vk, b2);
     double dq[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 1; i < MAXN; ++i) dq[i & 3] += v[i] * col[i];

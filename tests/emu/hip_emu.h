@@ -74,6 +74,7 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char*)(l) + (size) * emu::cur().lane, (const char*)(g), (size))
 #define __ffsll(x) __builtin_ffsll(x)
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
+#define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 struct double2 { double x, y; };
 inline double2 make_double2(double a, double b) { double2 r; r.x = a; r.y = b; return r; }
