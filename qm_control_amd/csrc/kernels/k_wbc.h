@@ -516,6 +516,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   if (l >= 6 && l < 24) { vd[l] = uDes[6 + l]; const double* il = a.input_last + (size_t)b * 30; w2[l] = (uDes[6 + l] - il[6 + l]) / a.period; }
   qm_wave_sync();
   if (l < 30) a.input_last[(size_t)b * 30 + l] = uDes[l];
+  { const long long now_ = (long long)__builtin_readcyclecounter(); tnull[4] = now_ - tlast; }
   // ---- rigid-body passes: lanes 0-5 measured, 8-13 desired, 16-21 joint-acceleration; slot 0-3 legs, 4 arm, 5 root body ----
   {
     const int pass = l >> 3, slot = l & 7;
@@ -526,10 +527,10 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       RbdSums Sm; Sm.mass = 0.0; for (int i = 0; i < 3; ++i) { Sm.mc[i] = Sm.hl[i] = Sm.hO[i] = Sm.Fb[i] = Sm.NbO[i] = 0.0; }
       RbdTip tip; const bool meas = (pass == 0);
       if (slot < 4) {
-        const int contact = chain_to_contact(slot); double Jt[6 * QM_NQ]; if (meas) for (int i = 0; i < 6 * QM_NQ; ++i) Jt[i] = 0.0;
-        rbd_chain<3, double*, double*>(mb, 3 * slot, contact, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jt, meas);
+        const int contact = chain_to_contact(slot); RbdJlin3 Jt; Jt.rows = Jf + 3 * contact * QM_NQ; Jt.dummy = 0.0;   // the leg's columns land in the foot's Jf rows directly (Jf was cleared with the rest of the LDS)
+        rbd_chain<3, double*, RbdJlin3>(mb, 3 * slot, contact, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jt, meas);
         if (meas) {
-          for (int r = 0; r < 3; ++r) { for (int cidx = 6 + 3 * slot; cidx < 9 + 3 * slot; ++cidx) Jf[(3 * contact + r) * QM_NQ + cidx] = Jt[r * QM_NQ + cidx]; Jf[(3 * contact + r) * QM_NQ + r] = 1.0; }
+          for (int r = 0; r < 3; ++r) Jf[(3 * contact + r) * QM_NQ + r] = 1.0;
           for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr); for (int r = 0; r < 3; ++r) Jf[(3 * contact + r) * QM_NQ + 3 + k] = cr[r]; }
         }
         if (pass < 2) tip_store(tips + 27 * (5 * pass + contact), tip);
@@ -556,6 +557,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   Jarm = gs + WS_JARM;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    // the tip records and the arm Jacobian go through HBM scratch (same CU: no L2 maintenance needed)
   qm_wave_sync();
+  { const long long now_ = (long long)__builtin_readcyclecounter(); tnull[8] = now_ - tlast; }
   RbdBase Bm; rbd_base(q, v, Bm);                        // measured root state (every lane)
   // base block of M and base rows of nle from the whole-tree composite (lane d = base dof)
   {

@@ -64,6 +64,9 @@ __device__ __forceinline__ void body_state(const double* mb, int body, const dou
 //  M, nle (may be null): fills entries of the chain's dofs against themselves and the base dofs (both triangles)
 //  cm/ch/cI/F/NO: composite + bias wrench of the whole chain added to the caller's accumulators (for the base block)
 //  Jt (may be null): 6x24 tip Jacobian [lin; ang] columns of this chain's joints (base columns are the caller's job)
+// tip-Jacobian sink that keeps only the three linear rows (feet): index i * QM_NQ + col -> rows[i][col] for i < 3, a dummy otherwise
+struct RbdJlin3 { double* rows; double dummy; __device__ __forceinline__ double& operator[](int idx) { return (idx < 3 * QM_NQ) ? rows[idx] : dummy; } };
+
 template <int NJ, class PM, class PJ>
 __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, const double* q, const double* v, const RbdBase& B,
                                           PM M /*[24][24]*/, double* nle /*[24]*/, bool wantM, double& cm, double* ch, double* cI, double* F, double* NO, RbdSums* S,
@@ -73,7 +76,8 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
   double Rp[9], op[3], vp[3], wp[3], ap[3], alp[3];
   for (int i = 0; i < 9; ++i) Rp[i] = B.R[i];
   for (int i = 0; i < 3; ++i) { op[i] = B.p[i]; vp[i] = B.vlin[i]; wp[i] = B.w[i]; ap[i] = 0.0; alp[i] = B.al[i]; }
-  for (int jj = 0; jj < NJ; ++jj) {
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {                 // fully unrolled: the per-joint arrays must stay in registers, not in the private segment
     const int j = j0 + jj; const double qd = v[6 + j];
     double r[3]; m3_mulv(Rp, mb + MB_JP + 3 * j, r);
     double wr[3], wwr[3], alr[3]; v3_cross(wp, r, wr); v3_cross(wp, wr, wwr); v3_cross(alp, r, alr);
@@ -95,14 +99,19 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
     double wr[3], wwr[3], alr[3]; v3_cross(wp, r, wr); v3_cross(wp, wr, wwr); v3_cross(alp, r, alr);
     for (int i = 0; i < 3; ++i) { tip.p[i] = op[i] + r[i]; tip.v[i] = vp[i] + wr[i]; tip.w[i] = wp[i]; tip.a[i] = ap[i] + alr[i] + wwr[i]; tip.al[i] = alp[i]; }
   }
-  if (wantJ) for (int jj = 0; jj < NJ; ++jj) {
+  if (wantJ) {
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
     const double d[3] = {tip.p[0] - o[jj][0], tip.p[1] - o[jj][1], tip.p[2] - o[jj][2]}; double l[3]; v3_cross(a[jj], d, l);
     for (int i = 0; i < 3; ++i) { Jt[i * QM_NQ + 6 + j0 + jj] = l[i]; Jt[(3 + i) * QM_NQ + 6 + j0 + jj] = a[jj][i]; }
   }
+  }
   // tip -> root accumulation
+#pragma unroll
   for (int jj = NJ - 2; jj >= 0; --jj) { bm[jj] += bm[jj + 1]; for (int i = 0; i < 3; ++i) { bh[jj][i] += bh[jj + 1][i]; bF[jj][i] += bF[jj + 1][i]; bN[jj][i] += bN[jj + 1][i]; } for (int i = 0; i < 9; ++i) bI[jj][i] += bI[jj + 1][i]; }
   cm += bm[0]; for (int i = 0; i < 3; ++i) { ch[i] += bh[0][i]; F[i] += bF[0][i]; NO[i] += bN[0][i]; } for (int i = 0; i < 9; ++i) cI[i] += bI[0][i];
   if (wantM) {
+#pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       const int dj = 6 + j0 + jj;
       // S_j = (a_j, o_j × a_j);  momentum of the subtree composite: f = m vO + w × h ; nO = I_O w + h × vO
@@ -110,7 +119,8 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
       double wh[3], hv[3], Iw_[3]; v3_cross(a[jj], bh[jj], wh); v3_cross(bh[jj], vO, hv); m3_mulv(bI[jj], a[jj], Iw_);
       const double f[3] = {bm[jj] * vO[0] + wh[0], bm[jj] * vO[1] + wh[1], bm[jj] * vO[2] + wh[2]};
       const double nO[3] = {Iw_[0] + hv[0], Iw_[1] + hv[1], Iw_[2] + hv[2]};
-      for (int ii = 0; ii <= jj; ++ii) {   // chain ancestors (incl. itself)
+#pragma unroll
+      for (int ii = 0; ii < NJ; ++ii) if (ii <= jj) {   // chain ancestors (incl. itself)
         double vOi[3]; v3_cross(o[ii], a[ii], vOi);
         const double val = a[ii][0] * nO[0] + a[ii][1] * nO[1] + a[ii][2] * nO[2] + vOi[0] * f[0] + vOi[1] * f[1] + vOi[2] * f[2];
         M[(6 + j0 + ii) * QM_NQ + dj] = val; M[dj * QM_NQ + 6 + j0 + ii] = val;

@@ -49,6 +49,6 @@ itf.debug_set("lq_prof", 0)
 itf.debug_set("wbc_stop", -3)
 mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
 cyc = itf.debug_read("wbc_scratch", (B, 432))
-nn_ = ["L0 load", "L0 pivoted QR", "L0 backward accumulation", "L0 write Zp", "-", "L1 load", "L1 pivoted QR", "L1 backward accumulation", "-", "L1 Zp <- Zp Q2"]
+nn_ = ["L0 load", "L0 pivoted QR", "L0 backward accumulation", "L0 write Zp", "(start -> rigid-body passes)", "L1 load", "L1 pivoted QR", "L1 backward accumulation", "(start -> end of rigid-body passes)", "L1 Zp <- Zp Q2"]
 print(json.dumps({n: float(cyc[:, i].mean()) for i, n in enumerate(nn_)}, indent=1))
 itf.debug_set("wbc_stop", 0)
