@@ -526,21 +526,18 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       double cm = 0.0, ch[3] = {0, 0, 0}, cI[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[3] = {0, 0, 0}, NO[3] = {0, 0, 0};
       RbdSums Sm; Sm.mass = 0.0; for (int i = 0; i < 3; ++i) { Sm.mc[i] = Sm.hl[i] = Sm.hO[i] = Sm.Fb[i] = Sm.NbO[i] = 0.0; }
       RbdTip tip; const bool meas = (pass == 0);
-      if (slot < 4) {
-        const int contact = chain_to_contact(slot); RbdJlin3 Jt; Jt.rows = Jf + 3 * contact * QM_NQ; Jt.dummy = 0.0;   // the leg's columns land in the foot's Jf rows directly (Jf was cleared with the rest of the LDS)
-        rbd_chain<3, double*, RbdJlin3>(mb, 3 * slot, contact, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jt, meas);
+      if (slot < 5) {
+        // legs (3 joints) and the arm (6 joints) share one instruction stream: slot 4 runs all six joint slots, the legs mask the last three
+        const bool leg = slot < 4; const int contact = leg ? chain_to_contact(slot) : 4;
+        RbdJsink Jt; Jt.rows = leg ? Jf + 3 * contact * QM_NQ : Jarm; Jt.nrows = leg ? 3 : 6; Jt.dummy = 0.0;   // Jacobian columns land in place (LDS was cleared at the start)
+        rbd_chain<6, double*, RbdJsink>(mb, leg ? 3 * slot : 12, contact, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jt, meas, leg ? 3 : 6);
         if (meas) {
-          for (int r = 0; r < 3; ++r) Jf[(3 * contact + r) * QM_NQ + r] = 1.0;
-          for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr); for (int r = 0; r < 3; ++r) Jf[(3 * contact + r) * QM_NQ + 3 + k] = cr[r]; }
+          double* Jr = Jt.rows;
+          for (int r = 0; r < 3; ++r) Jr[r * QM_NQ + r] = 1.0;
+          for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr);
+            for (int r = 0; r < 3; ++r) { Jr[r * QM_NQ + 3 + k] = cr[r]; if (!leg) Jr[(3 + r) * QM_NQ + 3 + k] = e[r]; } }
         }
         if (pass < 2) tip_store(tips + 27 * (5 * pass + contact), tip);
-      } else if (slot == 4) {
-        rbd_chain<6, double*, double*>(mb, 12, 4, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jarm, meas);
-        if (meas) {
-          for (int r = 0; r < 3; ++r) Jarm[r * QM_NQ + r] = 1.0;
-          for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr); for (int r = 0; r < 3; ++r) { Jarm[r * QM_NQ + 3 + k] = cr[r]; Jarm[(3 + r) * QM_NQ + 3 + k] = e[r]; } }
-        }
-        if (pass < 2) tip_store(tips + 27 * (5 * pass + 4), tip);
       } else {
         const double zero3[3] = {0.0, 0.0, 0.0}; double c[3], Iw[9], vc[3], ac[3];
         body_state(mb, 0, Bb.R, Bb.p, Bb.vlin, Bb.w, zero3, Bb.al, c, Iw, vc, ac);

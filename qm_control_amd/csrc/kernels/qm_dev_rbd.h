@@ -64,13 +64,15 @@ __device__ __forceinline__ void body_state(const double* mb, int body, const dou
 //  M, nle (may be null): fills entries of the chain's dofs against themselves and the base dofs (both triangles)
 //  cm/ch/cI/F/NO: composite + bias wrench of the whole chain added to the caller's accumulators (for the base block)
 //  Jt (may be null): 6x24 tip Jacobian [lin; ang] columns of this chain's joints (base columns are the caller's job)
-// tip-Jacobian sink that keeps only the three linear rows (feet): index i * QM_NQ + col -> rows[i][col] for i < 3, a dummy otherwise
-struct RbdJlin3 { double* rows; double dummy; __device__ __forceinline__ double& operator[](int idx) { return (idx < 3 * QM_NQ) ? rows[idx] : dummy; } };
+// tip-Jacobian sink that keeps the first nrows rows (3: linear rows of a foot, 6: the arm): index i * QM_NQ + col -> rows[i][col], a dummy otherwise
+struct RbdJsink { double* rows; int nrows; double dummy; __device__ __forceinline__ double& operator[](int idx) { return (idx < nrows * QM_NQ) ? rows[idx] : dummy; } };
 
 template <int NJ, class PM, class PJ>
 __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, const double* q, const double* v, const RbdBase& B,
                                           PM M /*[24][24]*/, double* nle /*[24]*/, bool wantM, double& cm, double* ch, double* cI, double* F, double* NO, RbdSums* S,
-                                          RbdTip& tip, PJ Jt /*[6][24]*/, bool wantJ) {
+                                          RbdTip& tip, PJ Jt /*[6][24]*/, bool wantJ, int nj = NJ) {
+  // nj <= NJ joints are live (lane-dependent): chains of different length run through the SAME instruction stream side by side
+  // (a wave executes divergent template instances one after the other); the dead joints are masked out, their arrays stay zero
   double a[NJ][3], o[NJ][3];                        // world axes / joint origins
   double bm[NJ], bh[NJ][3], bI[NJ][9], bF[NJ][3], bN[NJ][3];   // per-joint subtree composites (accumulated tip->root)
   double Rp[9], op[3], vp[3], wp[3], ap[3], alp[3];
@@ -78,11 +80,12 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
   for (int i = 0; i < 3; ++i) { op[i] = B.p[i]; vp[i] = B.vlin[i]; wp[i] = B.w[i]; ap[i] = 0.0; alp[i] = B.al[i]; }
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {                 // fully unrolled: the per-joint arrays must stay in registers, not in the private segment
-    const int j = j0 + jj; const double qd = v[6 + j];
+    const bool live = jj < nj; const int j = live ? j0 + jj : j0; const double qd = v[6 + j];
     double r[3]; m3_mulv(Rp, mb + MB_JP + 3 * j, r);
     double wr[3], wwr[3], alr[3]; v3_cross(wp, r, wr); v3_cross(wp, wr, wwr); v3_cross(alp, r, alr);
     double vo[3], ao[3];
     for (int i = 0; i < 3; ++i) { o[jj][i] = op[i] + r[i]; vo[i] = vp[i] + wr[i]; ao[i] = ap[i] + alr[i] + wwr[i]; }
+    if (!live) { for (int i = 0; i < 3; ++i) { a[jj][i] = 0.0; o[jj][i] = 0.0; } bm[jj] = 0.0; for (int i = 0; i < 3; ++i) { bh[jj][i] = 0.0; bF[jj][i] = 0.0; bN[jj][i] = 0.0; } for (int i = 0; i < 9; ++i) bI[jj][i] = 0.0; continue; }
     double Rj[9], Rq[9], Rc[9]; m3_mul(Rp, mb + MB_JR + 9 * j, Rj); m3_mulv(Rj, mb + MB_AXIS + 3 * j, a[jj]);
     rot_axis_angle(mb + MB_AXIS + 3 * j, q[6 + j], Rq); m3_mul(Rj, Rq, Rc);
     double wa[3]; v3_cross(wp, a[jj], wa);
@@ -101,7 +104,7 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
   }
   if (wantJ) {
 #pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
+  for (int jj = 0; jj < NJ; ++jj) if (jj < nj) {
     const double d[3] = {tip.p[0] - o[jj][0], tip.p[1] - o[jj][1], tip.p[2] - o[jj][2]}; double l[3]; v3_cross(a[jj], d, l);
     for (int i = 0; i < 3; ++i) { Jt[i * QM_NQ + 6 + j0 + jj] = l[i]; Jt[(3 + i) * QM_NQ + 6 + j0 + jj] = a[jj][i]; }
   }
@@ -112,7 +115,7 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
   cm += bm[0]; for (int i = 0; i < 3; ++i) { ch[i] += bh[0][i]; F[i] += bF[0][i]; NO[i] += bN[0][i]; } for (int i = 0; i < 9; ++i) cI[i] += bI[0][i];
   if (wantM) {
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
+    for (int jj = 0; jj < NJ; ++jj) if (jj < nj) {
       const int dj = 6 + j0 + jj;
       // S_j = (a_j, o_j × a_j);  momentum of the subtree composite: f = m vO + w × h ; nO = I_O w + h × vO
       double vO[3]; v3_cross(o[jj], a[jj], vO);
