@@ -111,11 +111,13 @@ __device__ __forceinline__ void lw_get_col30(const qm_d4 (&F)[IT][2], double* v,
 
 // projected cost + record stores; MT = tiles covering the m reduced inputs
 template <int MT>
-__device__ __forceinline__ void lw_project(double* S, double* rec, int m, const qm_d4 (&Bdt)[2][2], const qm_d4 (&PxA)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
+__device__ __forceinline__ void lw_project(double* S, double* rec, int m, const qm_d4 (&Bdt)[2][2], const qm_d4 (&PxA)[2][2], const qm_d4 (&PuF)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
   const int l = threadIdx.x & 63;
-  double* T = S + LW_T;
-  // Pu (30 x m) was assembled in the hand-over tile
-  qm_d4 Pu[2][MT]; qm_frag_load<2, MT, false>(Pu, T, LW_TLD, 30, m);
+  qm_d4 Pu[2][MT];
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < MT; ++J) Pu[I][J] = PuF[I][J];
   qm_frag_store<2, MT>(Pu, rec + SR_PU, QM_MMAX, 30, m);
   { qm_d4 Bp[2][MT]; qm_frag_zero<2, MT>(Bp); qm_gemm_tn<2, 2, MT>(Bdt, Pu, Bp, 0, 8, false); qm_frag_store<2, MT>(Bp, rec + SR_BP, QM_MMAX, 30, m); }   // Bp = Bd Pu
   // [R Px | R Pe + r]: Px rows 12..23 (k-steps 3..5); Pe also has rows 0..11 (column 30 only -> tile column 1, k-steps 0..2)
@@ -344,6 +346,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
         double bb = -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * a.zpos[nb * 4 + k];
         S[LW_V_E + row0[k] + 3] = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0);
       }
+      for (int r = 0; r < (stance ? 3 : 4); ++r) T[(row0[k] + r) * LW_TLD + 30] = S[LW_V_E + row0[k] + r];   // e rides in column 30 of the C rows: [C | e]
     }
   }
   qm_wave_sync();
@@ -365,40 +368,64 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     }
   }
   qm_wave_sync();
-  // [Px | Pe] straight into fragments: input rows 12..23 of Px, all rows of Pe (column 30)
-  qm_d4 PxA[2][2];
+  // [Px | Pe] straight into fragments: input rows 12..23 of Px, all rows of Pe (column 30).  One code path for stance and swing legs:
+  // row 12 + 3 ch + jj of Px is −(c0 Crow(i0) + c1 Crow(i1) + c2 Crow(i2)) with (c, i) = (Ginv row jj, the leg's 3 velocity rows) for a
+  // stance leg and (g_jj / g·g, 0, 0; the normal-velocity row) for a swing leg; [C | e] carries e in column 30.
+  qm_d4 PxA[2][2]; qm_frag_zero<2, 2>(PxA);
+  auto px_entry = [&](int row, int col) {
+    const int rr = row - 12, ch = rr / 3, jj = rr - 3 * ch, k = chain_to_contact(ch); const double* gg = G + 12 * k;
+    int r0k = 0;
 #pragma unroll
-  for (int I = 0; I < 2; ++I)
+    for (int q = 0; q < 4; ++q) if (q < k) r0k += mode_flag(mode, q) ? 3 : 4;
+    const bool stance = mode_flag(mode, k);
+    const double c0 = stance ? gg[3 * jj] : gg[jj], c1 = stance ? gg[3 * jj + 1] : 0.0, c2 = stance ? gg[3 * jj + 2] : 0.0;
+    const int i0 = stance ? r0k : r0k + 3, i1 = stance ? r0k + 1 : r0k + 3, i2 = stance ? r0k + 2 : r0k + 3;
+    return -(c0 * Ct[i0 * LW_TLD + col] + c1 * Ct[i1 * LW_TLD + col] + c2 * Ct[i2 * LW_TLD + col]);
+  };
 #pragma unroll
-    for (int J = 0; J < 2; ++J)
+  for (int J = 0; J < 2; ++J) {
+    const int col = 16 * J + c;                               // column 31 of [C | e] is zero
+    PxA[0][J][3] = px_entry(12 + g, col); PxA[1][J][0] = px_entry(16 + g, col); PxA[1][J][1] = px_entry(20 + g, col);
+  }
+  if (c == 14) {                                              // Pe rows 0..11: −F of a swing foot
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + g + 4 * r, col = 16 * J + c; double s = 0.0;
-        if (row >= 12 && row < 24 && col <= 30) {
-          const int rr = row - 12, ch = rr / 3, jj = rr - 3 * ch, k = chain_to_contact(ch); const double* gg = G + 12 * k;
-          if (mode_flag(mode, k)) { for (int q = 0; q < 3; ++q) s -= gg[3 * jj + q] * ((col < 30) ? Ct[(row0[k] + q) * LW_TLD + col] : S[LW_V_E + row0[k] + q]); }
-          else s = -gg[jj] * ((col < 30) ? Ct[(row0[k] + 3) * LW_TLD + col] : S[LW_V_E + row0[k] + 3]);
-        } else if (row < 12 && col == 30) s = mode_flag(mode, row / 3) ? 0.0 : -U[row];
-        PxA[I][J][r] = s;
-      }
+    for (int r = 0; r < 3; ++r) { const int row = g + 4 * r; PxA[0][1][r] = mode_flag(mode, row / 3) ? 0.0 : -U[row]; }
+  }
   qm_wave_sync();
   lw_get_col30<2>(PxA, S + LW_V_PE, 30);
   const double eq2 = qm_wave_sum((l < nc) ? S[LW_V_E + l] * S[LW_V_E + l] : 0.0);
   const double b2 = qm_wave_sum(bl * bl);
   qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);      // input cost weights: issued here, consumed in phase III
-  // Pu (30 x m) in the hand-over tile: columns = stance forces, swing-leg null spaces, arm
-  qm_wave_sync();
-  for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
-  qm_wave_sync();
-  int m = 0;
-  {
-    int col = 0;
-    for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) { if (l < 3) T[(3 * k + l) * LW_TLD + col + l] = 1.0; col += 3; }
-    for (int k = 0; k < 4; ++k) if (!mode_flag(mode, k)) { const int jc = 12 + 3 * contact_to_chain(k); const double* gg = G + 12 * k; if (l < 6) { const int r = l % 3, cc = l / 3; T[(jc + r) * LW_TLD + col + cc] = gg[3 + 3 * cc + r]; } col += 2; }
-    if (l < 6) T[(24 + l) * LW_TLD + col + l] = 1.0; col += 6;
-    m = col;
+  // Pu (30 x m) straight into fragments: columns = stance forces (identity triples), swing-leg null spaces (3 x 2 blocks), arm (identity)
+  int nst = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
+  const int m = 3 * nst + 2 * (4 - nst) + 6;
+  qm_d4 PuF[2][2];
+#pragma unroll
+  for (int J = 0; J < 2; ++J) {
+    const int j = 16 * J + c;
+    // which block does column j belong to?  type 0: stance contact kk, component t; 1: swing contact kk, null-space column t; 2: arm joint t; 3: none
+    int type = 3, kk = 0, t = 0;
+    if (j < 3 * nst) { type = 0; t = j % 3; int cnt = j / 3;
+#pragma unroll
+      for (int k = 3; k >= 0; --k) { int before = 0; for (int q = 0; q < 4; ++q) if (q < k && mode_flag(mode, q)) ++before; if (mode_flag(mode, k) && before == cnt) kk = k; } }
+    else if (j < 3 * nst + 2 * (4 - nst)) { type = 1; const int jj2 = j - 3 * nst; t = jj2 & 1; const int cnt = jj2 >> 1;
+#pragma unroll
+      for (int k = 3; k >= 0; --k) { int before = 0; for (int q = 0; q < 4; ++q) if (q < k && !mode_flag(mode, q)) ++before; if (!mode_flag(mode, k) && before == cnt) kk = k; } }
+    else if (j < m) { type = 2; t = j - (3 * nst + 2 * (4 - nst)); }
+    const int jc = 12 + 3 * contact_to_chain(kk); const double* gg = G + 12 * kk;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r; double v = 0.0;
+        if (type == 0) v = (row == 3 * kk + t) ? 1.0 : 0.0;
+        else if (type == 1) v = (row >= jc && row < jc + 3) ? gg[3 + 3 * t + (row - jc)] : 0.0;
+        else if (type == 2) v = (row == 24 + t) ? 1.0 : 0.0;
+        PuF[I][J][r] = v;
+      }
   }
-  qm_wave_sync();
   LQT()
   // projected dynamics  [Ap | bp] = [Ad | b] + Bd [Px | Pe]  (Z = Bdᵀ; Px rows 12..23 -> k-steps 3..5, Pe rows 0..11 -> column tile 1, k-steps 0..2)
   {
@@ -473,7 +500,6 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     }
     fr[12] = ds;
   } else if (l == 24) { for (int k = 0; k < 6; ++k) cost += 0.5 * EE[6 + k] * EE[k] * EE[k]; }
-  // EE Jacobian rows into the hand-over tile: rows 0..5 = J, rows 8..13 = mu J (column 30: mu g)   [Pu was consumed? no: Pu is read by lw_project]
   qm_wave_sync();
   const double dsum = FR[12] + FR[28] + FR[44] + FR[60];
   LQT()
@@ -532,7 +558,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   LQT()
   // ---- projected cost + stores ----
   double rpe = 0.0;
-  if (m <= 16) lw_project<1>(S, rec, m, Bdt, PxA, Rm, Qa, rpe); else lw_project<2>(S, rec, m, Bdt, PxA, Rm, Qa, rpe);
+  if (m <= 16) lw_project<1>(S, rec, m, Bdt, PxA, PuF, Rm, Qa, rpe); else lw_project<2>(S, rec, m, Bdt, PxA, PuF, Rm, Qa, rpe);
   if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
   {
     qm_d4 PxO[2][2];
