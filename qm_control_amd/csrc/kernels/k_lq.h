@@ -154,7 +154,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, int m, const 
 }
 
 // ---- K1a: scalar kinematics, one thread per (node, instance) ----
-__global__ void qm_lq_kin_kernel(QmLqArgs a) {
+__global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = g / a.B, b = g - i * a.B;
   if (i >= a.nmax) return;
@@ -164,27 +164,27 @@ __global__ void qm_lq_kin_kernel(QmLqArgs a) {
   if (!terminal && a.node_ev[nb] == QM_EV_PRE) return;
   double* rec = a.kin + (size_t)nb * KR_SIZE;
   double x[30], u[30], K[KW_SIZE];
-  for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q];
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q];
   const double* ee = a.eeref + nb * 7;
   if (terminal) {
     kin_base(a.mb, x, K); kin_arm(a.mb, x, K);
-    for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
+    _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
     double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq);
-    for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q];
+    _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q];
     return;
   }
-  for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q];
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q];
   const double dt = a.node_dt[nb];
-  kin_base(a.mb, x, K); for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x, u, K); kin_arm(a.mb, x, K);
-  for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
-  { double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq); for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q]; }
+  kin_base(a.mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x, u, K); kin_arm(a.mb, x, K);
+  _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
+  { double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq); _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q]; }
   double f1[30], x2[30], f2[30];
   flow_from_kin(a.mb, x, u, K, f1);
-  for (int q = 0; q < 30; ++q) { x2[q] = x[q] + dt * f1[q]; rec[KR_F1 + q] = f1[q]; rec[KR_X2 + q] = x2[q]; }
-  kin_base(a.mb, x2, K); for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x2, u, K);
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) { x2[q] = x[q] + dt * f1[q]; rec[KR_F1 + q] = f1[q]; rec[KR_X2 + q] = x2[q]; }
+  kin_base(a.mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x2, u, K);
   flow_from_kin(a.mb, x2, u, K, f2);
-  for (int q = 0; q < KW_ARM; ++q) rec[KR_K2 + q] = K[q];
-  for (int q = 0; q < 30; ++q) rec[KR_F2 + q] = f2[q];
+  _Pragma("unroll") for (int q = 0; q < KW_ARM; ++q) rec[KR_K2 + q] = K[q];
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) rec[KR_F2 + q] = f2[q];
 }
 
 // ---- K1b: one wavefront per node ----

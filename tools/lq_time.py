@@ -8,4 +8,4 @@ mpc = api.SqpMpc(itf); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["
 mpc.solve_resident(cfg["horizon"]); itf.synchronize()
 itf.set_profiling(True); itf.reset_kernel_ms()
 for _ in range(5): mpc.solve_resident(cfg["horizon"])
-print({k: round(itf.kernel_ms(k)[0] / max(1, itf.kernel_ms(k)[1]), 3) for k in ("lq_kin", "lq", "riccati")})
+print({k: round(itf.kernel_ms(k)[0] / max(1, itf.kernel_ms(k)[1]), 3) for k in ("lq_kin", "lq", "riccati", "ls_eval", "ls_misc")})
