@@ -162,12 +162,12 @@ __global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
   if (i >= nn) return;
   const int nb = i * a.B + b; const bool terminal = (i == nn - 1);
   if (!terminal && a.node_ev[nb] == QM_EV_PRE) return;
-  double* rec = a.kin + (size_t)nb * KR_SIZE;
+  double* rec = a.kin + (size_t)nb * KR_SIZE; const double* mb = qm_table(a.mb);
   double x[30], u[30], K[KW_SIZE];
   _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q];
   const double* ee = a.eeref + nb * 7;
   if (terminal) {
-    kin_base(a.mb, x, K); kin_arm(a.mb, x, K);
+    kin_base(mb, x, K); kin_arm(mb, x, K);
     _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
     double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq);
     _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q];
@@ -175,14 +175,14 @@ __global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
   }
   _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q];
   const double dt = a.node_dt[nb];
-  kin_base(a.mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x, u, K); kin_arm(a.mb, x, K);
+  kin_base(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x, u, K); kin_arm(mb, x, K);
   _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
   { double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq); _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q]; }
   double f1[30], x2[30], f2[30];
-  flow_from_kin(a.mb, x, u, K, f1);
+  flow_from_kin(mb, x, u, K, f1);
   _Pragma("unroll") for (int q = 0; q < 30; ++q) { x2[q] = x[q] + dt * f1[q]; rec[KR_F1 + q] = f1[q]; rec[KR_X2 + q] = x2[q]; }
-  kin_base(a.mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x2, u, K);
-  flow_from_kin(a.mb, x2, u, K, f2);
+  kin_base(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x2, u, K);
+  flow_from_kin(mb, x2, u, K, f2);
   _Pragma("unroll") for (int q = 0; q < KW_ARM; ++q) rec[KR_K2 + q] = K[q];
   _Pragma("unroll") for (int q = 0; q < 30; ++q) rec[KR_F2 + q] = f2[q];
 }
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
   const int b = blockIdx.x / a.nmax, i = blockIdx.x - b * a.nmax;
   const int nb = i * a.B + b;                       // node-major index
-  const double* mb = a.mb; const double* st = a.st;
+  const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   double* rec = a.stage + ((size_t)b * a.nmax + i) * SR_SIZE;
   double* dbg = a.dbg ? a.dbg + ((size_t)b * a.nmax + i) * LQ_DBG_SIZE : nullptr;
   const double* kr = a.kin + (size_t)nb * KR_SIZE;

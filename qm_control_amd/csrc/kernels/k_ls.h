@@ -78,13 +78,14 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   const int n = a.n_nodes[b];
   if (i >= n || a.done[b] != 0) return;
   const int nb = i * a.B + b; const double al = a.alpha[b];
+  const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   double x[30], u[30], K[KW_SIZE];
   _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
   double* pf = a.perf + (size_t)nb * PF_SIZE;
   const int ev = a.node_ev[nb];
   if (i == n - 1) {
-    kin_base(a.mb, x, K); kin_arm(a.mb, x, K);
-    pf[0] = node_cost_value(a.mb, a.st, x, nullptr, K, 0, nullptr, a.eeref + nb * 7, a.st[ST_MU_EEF_POS], a.st[ST_MU_EEF_ORI], false); pf[1] = 0.0; pf[2] = 0.0;
+    kin_base(mb, x, K); kin_arm(mb, x, K);
+    pf[0] = node_cost_value(mb, st, x, nullptr, K, 0, nullptr, a.eeref + nb * 7, st[ST_MU_EEF_POS], st[ST_MU_EEF_ORI], false); pf[1] = 0.0; pf[2] = 0.0;
     return;
   }
   const int nbn = (i + 1) * a.B + b;
@@ -94,14 +95,14 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   }
   _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q] + al * a.du[nb * 30 + q];
   const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
-  kin_base(a.mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x, u, K); kin_arm(a.mb, x, K);
-  const double cost = node_cost_value(a.mb, a.st, x, u, K, mode, a.xref + nb * 30, a.eeref + nb * 7, a.st[ST_MU_EE_POS], a.st[ST_MU_EE_ORI], true);
+  kin_base(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x, u, K); kin_arm(mb, x, K);
+  const double cost = node_cost_value(mb, st, x, u, K, mode, a.xref + nb * 30, a.eeref + nb * 7, st[ST_MU_EE_POS], st[ST_MU_EE_ORI], true);
   const double eq = node_eq_sse(a.st, x, u, K, mode, a.zvel + nb * 4, a.zpos + nb * 4);
   double f1[30], x2[30], f2[30];
-  flow_from_kin(a.mb, x, u, K, f1);
+  flow_from_kin(mb, x, u, K, f1);
   _Pragma("unroll") for (int q = 0; q < 30; ++q) x2[q] = x[q] + dt * f1[q];
-  kin_base(a.mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(a.mb, c, x2, u, K);
-  flow_from_kin(a.mb, x2, u, K, f2);
+  kin_base(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x2, u, K);
+  flow_from_kin(mb, x2, u, K, f2);
   double s = 0.0;
   _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double d = x[q] + 0.5 * dt * f1[q] + 0.5 * dt * f2[q] - (a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]); s += d * d; }
   pf[0] = cost * dt; pf[1] = dt * s; pf[2] = dt * eq;

@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   if (b >= a.B) return;
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tfine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tnull[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = (long long)__builtin_readcyclecounter();
 #define WT(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; }
-  const double* mb = a.mb; const double* st = a.st;
+  const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   const double* xDes = a.x_des + (size_t)b * 30; const double* uDes = a.u_des + (size_t)b * 30; const double* rbd = a.rbd + (size_t)b * QM_NRBD;
   const int mode = a.mode[b]; const double time = a.time[b];
   for (int i = l; i < WL_TOTAL; i += 64) S[i] = 0.0;

@@ -19,6 +19,14 @@
 
 typedef double qm_d4 __attribute__((ext_vector_type(4)));
 
+// Read-only parameter tables (model blob `mb`, settings `st`) are read through the CONSTANT address space: their loads become
+// scalar (s_load into SGPRs, one copy per wave) instead of 64-lane vector loads into VGPR pairs.  No kernel writes these tables.
+typedef const double __attribute__((address_space(4)))* qm_ctab;
+#ifndef QM_TABLE_OPAQUE                 /* keeps the compiler from folding the two casts back into a plain global pointer */
+#define QM_TABLE_OPAQUE(p) asm volatile("" : "+s"(p))
+#endif
+__device__ __forceinline__ const double* qm_table(const double* p) { qm_ctab c = (qm_ctab)(p); QM_TABLE_OPAQUE(c); return (const double*)c; }
+
 // ---- 3-vector helpers (pointer based so operands may live in LDS, registers or global) ----
 __device__ __forceinline__ void v3_cross(const double* a, const double* b, double* c) {
   const double c0 = a[1] * b[2] - a[2] * b[1], c1 = a[2] * b[0] - a[0] * b[2], c2 = a[0] * b[1] - a[1] * b[0];
@@ -67,6 +75,27 @@ __device__ __forceinline__ bool mode_flag(int mode, int contact) { return (mode 
 
 // wave-level ordering point for LDS traffic inside ONE wavefront (no s_barrier: a wave's DS ops retire in order)
 __device__ __forceinline__ void qm_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// One-thread-per-row kernels: 64 consecutive rows of W doubles, row r of the block <-> lane r.  The global side is accessed
+// coalesced (lanes run over consecutive elements) and transposed through LDS [64][W+1]; per-lane arrays keep static indices.
+#define QM_ROWS_LDS(W) (64 * ((W) + 1))
+template <int W, class F> __device__ __forceinline__ void qm_rows_gather(double* lds, size_t row0, size_t nrows, int l, double* out, F elem) {
+#pragma unroll
+  for (int t = 0; t < W; ++t) { const int e = t * 64 + l; const int r = e / W, c = e - r * W; lds[r * (W + 1) + c] = (row0 + r < nrows) ? elem(row0 + r, c) : 0.0; }
+  qm_wave_sync();
+#pragma unroll
+  for (int q = 0; q < W; ++q) out[q] = lds[l * (W + 1) + q];
+  qm_wave_sync();
+}
+// rows whose bit in `rowmask` is clear are not written
+template <int W> __device__ __forceinline__ void qm_rows_scatter(double* lds, double* dst, size_t stride, size_t row0, unsigned long long rowmask, int l, const double* v) {
+#pragma unroll
+  for (int q = 0; q < W; ++q) lds[l * (W + 1) + q] = v[q];
+  qm_wave_sync();
+#pragma unroll
+  for (int t = 0; t < W; ++t) { const int e = t * 64 + l; const int r = e / W, c = e - r * W; if ((rowmask >> r) & 1ull) dst[(row0 + r) * stride + c] = lds[r * (W + 1) + c]; }
+  qm_wave_sync();
+}
 
 // value of lane `src` (wave-uniform index) in every lane: two v_readlane_b32, the result lives in SGPRs
 __device__ __forceinline__ double qm_bcast(double v, int src) {

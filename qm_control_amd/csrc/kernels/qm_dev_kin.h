@@ -95,6 +95,32 @@ __device__ __forceinline__ void flow_from_kin(const double* mb, const double* x,
   for (int k = 0; k < 3; ++k) { f[k] = lin[k] * im; f[3 + k] = ang[k] * im; f[6 + k] = x[k] + wr[k]; f[9 + k] = K[KW_THD + k]; }
   for (int j = 0; j < QM_NJ; ++j) f[12 + j] = u[12 + j];
 }
+// One Heun stage of one node on thread-private data with the legs in a ROLLED loop (small code, few live registers, so that
+// several waves fit a SIMD): x and u may point to global memory.  Kb[KW_LEG] receives the base block, leg(c, L) is called with
+// every leg block L[KW_LEGSZ] = {a, o, p, s}, f[30] is the flow-map value (same terms as flow_from_kin).
+template <class LegFn> __device__ __forceinline__ void kin_stage(const double* mb, const double* x, const double* u, double* Kb, double* f, LegFn leg) {
+  kin_base(mb, x, Kb);
+  const double m = mb[MB_ROBOTMASS], im = 1.0 / m;
+  double lin[3] = {0.0, 0.0, -9.81 * m}, ang[3] = {0.0, 0.0, 0.0};
+#pragma nounroll
+  for (int c = 0; c < 4; ++c) {
+    double L[KW_LEGSZ];
+    const int contact = chain_to_contact(c);
+    kin_chain(mb, 3 * c, 3, contact, x, u, Kb, L, L + 9, L + 18, L + 21, nullptr);
+    leg(c, L);
+    const double F[3] = {u[3 * contact], u[3 * contact + 1], u[3 * contact + 2]};
+    const double d[3] = {L[18] - Kb[KW_COM], L[19] - Kb[KW_COM + 1], L[20] - Kb[KW_COM + 2]};
+    double t[3]; v3_cross(d, F, t);
+    for (int k = 0; k < 3; ++k) { lin[k] += F[k]; ang[k] += t[k]; }
+  }
+  double wr[3]; v3_cross(Kb + KW_OM, Kb + KW_RW, wr);
+  for (int k = 0; k < 3; ++k) { f[k] = lin[k] * im; f[3 + k] = ang[k] * im; f[6 + k] = x[k] + wr[k]; f[9 + k] = Kb[KW_THD + k]; }
+  for (int j = 0; j < QM_NJ; ++j) f[12 + j] = u[12 + j];
+}
+// arm block A[KW_SIZE - KW_ARM] = {a[6][3], o[6][3], p, R} from the base block
+__device__ __forceinline__ void kin_arm_block(const double* mb, const double* x, const double* Kb, double* A) {
+  kin_chain(mb, 12, 6, 4, x, nullptr, Kb, A, A + 18, A + 36, nullptr, A + 39);
+}
 // foot velocity v_i = h_lin + ω × d_i + s_i   (LOCAL_WORLD_ALIGNED linear velocity of the foot frame under the SRBD map)
 __device__ __forceinline__ void foot_velocity(const double* x, const double* K, int contact, double* v) {
   const double* L = K + KW_LEG + KW_LEGSZ * contact_to_chain(contact);
@@ -207,13 +233,13 @@ __device__ __forceinline__ void mat_to_quat(const double* R, double* q) {
   for (int i = 0; i < 4; ++i) q[i] *= s;
 }
 // a5: EE pose error g(6) (EndEffectorConstraint.cpp:36-80) from the arm part of the workspace
-__device__ __forceinline__ void ee_error(const double* K, const double* pref, const double* qref, double* qee, double* g) {
-  const double* A = K + KW_ARM;
+__device__ __forceinline__ void ee_error_arm(const double* A, const double* pref, const double* qref, double* qee, double* g) {
   for (int i = 0; i < 3; ++i) g[i] = A[36 + i] - pref[i];
   mat_to_quat(A + 39, qee);
   double c[3]; v3_cross(qee, qref, c);
   for (int i = 0; i < 3; ++i) g[3 + i] = qee[3] * qref[i] - qref[3] * qee[i] + c[i];
 }
+__device__ __forceinline__ void ee_error(const double* K, const double* pref, const double* qref, double* qee, double* g) { ee_error_arm(K + KW_ARM, pref, qref, qee, g); }
 // column of the 6x30 EE error Jacobian wrt x_c; returns false for structurally zero columns.
 // c in 6..8: base position, 9..11: zyx, 24..29: arm joints
 __device__ __forceinline__ bool ee_jac_col(const double* x, const double* K, const double* qee, const double* qref, int c, double* col6) {
