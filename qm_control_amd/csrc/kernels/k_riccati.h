@@ -15,12 +15,13 @@
 //   S A = Sᵀ A,  S B = Sᵀ B,  Hux = Bᵀ (S A),  Huu = Bᵀ (S B),  Aᵀ (S A),  Wᵀ W
 // so results chain from MFMA to MFMA without any layout conversion.  The vectors ride in the padding column 30 of the 32-wide
 // tiles: A|b, (S A | S b + s), (P | r), (Q | q), (W | y) — the mat-vecs cost nothing extra.
-// Only two steps leave the registers (wave-local LDS round trips): the Cholesky + forward substitution of [Huu | Hux hu]
-// (lane = column, column in registers, pivots broadcast with v_readlane) and the symmetrisation of S'.
+// The Cholesky factorisation of Huu and the forward substitution of [Hux | hu] stay in fragment layout as well: the rank-1 update of
+// one elimination step is an MFMA with a single live k-slot (see rw_stage).  Only the symmetrisation of S' takes a wave-local LDS
+// round trip.  (On gfx950 f64 MFMA and f64 VALU share one rate and do not overlap: the MFMA buys the data movement, not flops.)
 // The operands of the NEXT stage are copied global -> LDS asynchronously (global_load_lds_dwordx4, 1 KB per wave instruction, no
 // VGPRs) while the current stage computes; a stage starts by pulling its fragments out of that buffer.
 //
-// The backward sweep leaves L (in SR_RP), W (in SR_PP) and y (in SR_KFF) in the stage record; the forward rollout
+// The backward sweep leaves Lᵀ (in SR_RP; upper triangle, diagonal = 1/L_jj), W (in SR_PP) and y (in SR_KFF) in the stage record; the forward rollout
 //   ut = −L⁻ᵀ (W dx + y),  dx+ = Ap dx + Bp ut + bp,  du = Px dx + Pu ut + Pe,  Armijo metric += qp·dx + rp·ut
 // streams the records once more with one matrix row per lane.
 #pragma once
@@ -34,12 +35,12 @@ struct QmRiccatiArgs {
   double* stage;                               // [B][nmax][SR_SIZE]  (L, W, y are written here)
   double* dx; double* du;                      // [nmax][B][30]
   double* step_info;                           // [B][4]: armijo, |dx|², |du|², chol status
-  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages; results are then meaningless)
+  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages: results are then
+                                               // meaningless; 32: results intact, per-phase cycle counts are written to SR_K of each instance's first stage record)
 };
 
 #define RW_BLOCK 64
 #define RW_TLD 34                 /* transposition buffer [32][34] */
-#define RW_CLD 66                 /* Cholesky staging [18][66]: lanes 0..17 Huu columns, lanes 32..62 [Hux | hu] columns */
 /* forward staging (aliases the backward buffers): rows padded so that one-row-per-lane reads are bank-conflict free */
 #define RF_A   0                  /* [30][31] Ap */
 #define RF_B   930                /* [30][19] Bp */
@@ -89,8 +90,10 @@ __device__ __forceinline__ void rw_prefetch(const double* rec, double* lds) {
 }
 // one regular stage of the backward sweep; MT = number of 16-row tiles covering the m reduced inputs
 template <int MT>
-__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip, int& chol_fail) {
+__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip, int& chol_fail, long long (&tacc)[8]) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
+  const bool prof = (skip & 32) != 0; long long tq_ = prof ? (long long)__builtin_readcyclecounter() : 0;
+#define RWT(i) { if (prof) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[i] += t_ - tq_; tq_ = t_; } }
   qm_d4 A[2][2], Bm[2][MT], Hux[MT][2], Huu[MT][MT], Sn[2][2];
   {
     // this stage's operands were copied into LDS (asynchronously, global_load_lds) while the previous stage computed
@@ -104,6 +107,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
     qm_lds_drain();
     if (nrec) rw_prefetch(nrec, buf);                               // next regular stage: flies during this stage's products and Cholesky
   }
+  RWT(0)
   qm_d4 SA[2][2], SB[2][MT];
   rw_zero<2, 2>(SA); rw_zero<2, MT>(SB);
   if (!(skip & 2)) {
@@ -115,67 +119,95 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
     rw_gemm_tn<2, MT, MT>(Bm, SB, Huu, 8, false);                    // Huu
     rw_gemm_tn<2, 2, 2>(A, SA, Sn, 8, false);                        // [Q + Aᵀ S A | q + Aᵀ (S b + s)]  (row 30 is garbage, masked below)
   }
-  // ---- Cholesky of Huu and forward substitution of [Hux | hu]: lane = column, column in registers ----
+  RWT(1)
+  // ---- Cholesky of Huu and forward substitution of [Hux | hu] IN FRAGMENT LAYOUT (right-looking, one pivot per step).
+  // Row j of a D-layout matrix is register (j&15)>>2 of lane group g = j&3, i.e. it already is k-slot j&3 of an MFMA B operand, and
+  // — Huu being symmetric — the same register read as an A operand supplies column j.  The rank-1 update of the trailing rows of
+  // [Huu | Hux hu] is therefore one MFMA per 16x16 tile with a single live k-slot: no LDS staging and no layout change, and
+  // W = L⁻¹[Hux | hu] comes out as fragments, ready for Wᵀ W.  Only the upper triangle of Huu is ever read (pivot row, columns > j);
+  // rows <= j are masked out of the update, so at the end row j still holds its value at elimination time: L_jj · (row j of Lᵀ resp. W).
   qm_d4 W[MT][2];
   if (!(skip & 1)) {
-    qm_wave_sync();
+    double dsel[MT][4];                                              // pivot d_row of this lane's rows (1 on padding rows)
+#pragma unroll
+    for (int I = 0; I < MT; ++I)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsel[I][r] = 1.0;
+    RWT(2)
+    // The pivots run one step AHEAD of the matrix cores: d_{j+1} = H[j+1][j+1] − H[j][j+1]² / d_j is formed from two entries of the
+    // not-yet-updated fragments, so its reciprocal chain overlaps the MFMAs of step j instead of waiting for their result.
+    double djj = qm_bcast(Huu[0][0][0], 0);
+    double rd = __builtin_amdgcn_rcp(djj);                           // 1/d_j: hardware estimate + two Newton steps
+    rd = fma(fma(-djj, rd, 1.0), rd, rd); rd = fma(fma(-djj, rd, 1.0), rd, rd);
+#pragma unroll
+    for (int j = 0; j < QM_MMAX; ++j) if (j < 16 * MT && j < m) {
+      const int I = j >> 4, r = (j & 15) >> 2, gj = j & 3;
+      if (!(djj > 0.0)) chol_fail = 1;
+      double hd = 1.0, hj = 0.0;
+      if (j + 1 < 16 * MT) {
+        const int I1 = (j + 1) >> 4, r1 = ((j + 1) & 15) >> 2, g1 = (j + 1) & 3;
+        hd = qm_bcast(Huu[I1][I1][r1], 16 * g1 + ((j + 1) & 15)); hj = qm_bcast(Huu[I][I1][r], 16 * gj + ((j + 1) & 15));
+      }
+      if (g == gj) dsel[I][r] = djj;
+      // program order pinned by hand: the reciprocal chain of the NEXT pivot (≈ 7 dependent f64 ops) is cut into three pieces that
+      // issue right behind one MFMA each, i.e. while the matrix core is busy with it
+      double av[MT];
+#pragma unroll
+      for (int Ip = I; Ip < MT; ++Ip) av[Ip] = (g == gj && 16 * Ip + c > j) ? -rd * Huu[I][Ip][r] : 0.0;     // −H[j][row] / d_j for rows > j
+      const double rcur = rd;
+      __builtin_amdgcn_sched_barrier(0);
+      Huu[I][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], Huu[I][I][r], Huu[I][I], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      djj = fma(-rcur * hj, hj, hd);
+      double r0 = __builtin_amdgcn_rcp(djj);
+      __builtin_amdgcn_sched_barrier(0);
+      Hux[I][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], Hux[I][0][r], Hux[I][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      double e0 = fma(-djj, r0, 1.0); r0 = fma(e0, r0, r0); e0 = fma(-djj, r0, 1.0);
+      __builtin_amdgcn_sched_barrier(0);
+      Hux[I][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], Hux[I][1][r], Hux[I][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rd = fma(e0, r0, r0);
+      if (MT == 2) {                                                 // 17/18 inputs: the remaining tiles (second tile row / column)
+        if (I == 0) {
+          Huu[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], Huu[0][1][r], Huu[0][1], 0, 0, 0);
+          Huu[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], Huu[0][1][r], Huu[1][1], 0, 0, 0);
+          Hux[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], Hux[0][0][r], Hux[1][0], 0, 0, 0);
+          Hux[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], Hux[0][1][r], Hux[1][1], 0, 0, 0);
+        }
+      }
+    }
+    double invr[MT][4];                                              // 1/L_jj = d_j^(-1/2) for this lane's rows: four independent chains
 #pragma unroll
     for (int I = 0; I < MT; ++I)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + g + 4 * r;
-        if (row < QM_MMAX) {
-#pragma unroll
-          for (int J = 0; J < MT; ++J) buf[row * RW_CLD + 16 * J + c] = Huu[I][J][r];
-#pragma unroll
-          for (int J = 0; J < 2; ++J) buf[row * RW_CLD + 32 + 16 * J + c] = Hux[I][J][r];
-        }
+        const double d = dsel[I][r]; double inv = __builtin_amdgcn_rsq(d);
+        inv = fma(0.5 * inv, fma(-d * inv, inv, 1.0), inv); inv = fma(0.5 * inv, fma(-d * inv, inv, 1.0), inv);
+        invr[I][r] = inv;
       }
-    qm_wave_sync();
-    const bool live = (l < 16 * MT) || (l >= 32);
-    double col[QM_MMAX];
-#pragma unroll
-    for (int i = 0; i < QM_MMAX; ++i) col[i] = (i < 16 * MT && live) ? buf[i * RW_CLD + l] : 0.0;
-    if (l < QM_MMAX && l < 16 * MT) {                                // symmetrise Huu
-#pragma unroll
-      for (int i = 0; i < QM_MMAX; ++i) if (i < 16 * MT) col[i] = 0.5 * (col[i] + buf[l * RW_CLD + i]);
-    }
-    double myinv = 0.0;
-#pragma unroll
-    for (int j = 0; j < QM_MMAX; ++j) if (j < m) {
-      const double djj = qm_bcast(col[j], j);
-      if (!(djj > 0.0)) chol_fail = 1;
-      double inv = __builtin_amdgcn_rsq(djj);                        // 1/sqrt(djj): hardware estimate + two Newton steps
-      inv = fma(0.5 * inv, fma(-djj * inv, inv, 1.0), inv);
-      inv = fma(0.5 * inv, fma(-djj * inv, inv, 1.0), inv);
-      // lanes > j: col[j] <- L[c][j] (Huu lanes, by symmetry) resp. (L⁻¹ rhs)[j] (rhs lanes); trailing update col[i] -= H[i][j] col[j] / djj
-      const double cj = col[j];
-      const double upd = (l > j) ? cj * (inv * inv) : 0.0;
-#pragma unroll
-      for (int i = j + 1; i < QM_MMAX; ++i) col[i] = fma(-qm_bcast(col[i], j), upd, col[i]);
-      col[j] = (l > j) ? cj * inv : ((l == j) ? inv : cj);           // the diagonal keeps 1/L_jj
-      if (l == j) myinv = inv;
-    }
-#pragma unroll
-    for (int i = 1; i < QM_MMAX; ++i) if (l < i && l < m) col[i] *= myinv;     // lane j: L[i][j] = H[i][j] / L_jj
-    // lane j < m now holds column j of L (rows > j; row j holds 1/L_jj); lanes 32.. hold the columns of [W | y]
-    qm_wave_sync();
-#pragma unroll
-    for (int i = 0; i < QM_MMAX; ++i) if (i < m) {
-      if (l < m && i >= l) rec[SR_RP + i * QM_MMAX + l] = col[i];
-      if (l >= 32 && l < 62) rec[SR_PP + i * 30 + (l - 32)] = col[i];
-      if (l == 62) rec[SR_KFF + i] = col[i];
-      if (l >= 32) buf[i * RW_CLD + l] = col[i];
-    }
-    qm_wave_sync();
+    RWT(3)
+    // Lᵀ (upper triangle, the diagonal keeps 1/L_jj), W and y go to the stage record for the forward rollout
 #pragma unroll
     for (int I = 0; I < MT; ++I)
 #pragma unroll
-      for (int J = 0; J < 2; ++J)
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r; const double sc = invr[I][r];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; W[I][J][r] = (row < m) ? buf[row * RW_CLD + 32 + 16 * J + c] : 0.0; }
+        for (int J = 0; J < 2; ++J) {
+          const int col = 16 * J + c; const double w = Hux[I][J][r] * sc; W[I][J][r] = w;
+          if (row < m) { if (col < 30) rec[SR_PP + row * 30 + col] = w; else if (col == 30) rec[SR_KFF + row] = w; }
+        }
+#pragma unroll
+        for (int J = I; J < MT; ++J) {
+          const int col = 16 * J + c;
+          if (row < m && col >= row && col < m) rec[SR_RP + row * QM_MMAX + col] = (col == row) ? sc : Huu[I][J][r] * sc;
+        }
+      }
   } else rw_zero<MT, 2>(W);
+  RWT(4)
   if (!(skip & 2)) rw_gemm_tn<MT, 2, 2>(W, W, Sn, (m + 3) >> 2, true);   // −[Wᵀ W | Wᵀ y]
+  RWT(5)
   // ---- S' <- sym(Sn[0:30, 0:30]), s' <- Sn[0:30, 30] ----
 #pragma unroll
   for (int I = 0; I < 2; ++I)
@@ -207,6 +239,8 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
         const int row = 16 * I + g + 4 * r, cc = 16 * J + c;
         S[I][J][r] = (row < 30 && cc < 30) ? 0.5 * (Sn[I][J][r] + buf[cc * RW_TLD + row]) : 0.0;
       }
+  RWT(6)
+#undef RWT
 }
 
 // flat, fully coalesced fetch of everything the forward rollout needs from one stage record: element e of the concatenation
@@ -217,7 +251,7 @@ __device__ __forceinline__ int rf_dst(int e) {
   if (e < 900) return RF_A + (e / 30) * 31 + e % 30;
   if (e < 1440) { const int f = e - 900; return RF_B + (f / QM_MMAX) * 19 + f % QM_MMAX; }
   if (e < 1980) { const int f = e - 1440; return RF_W + (f / 30) * 31 + f % 30; }
-  if (e < 2304) { const int f = e - 1980; return RF_L + (f / QM_MMAX) * 19 + f % QM_MMAX; }
+  if (e < 2304) { const int f = e - 1980; return RF_L + (f % QM_MMAX) * 19 + f / QM_MMAX; }     // the record holds Lᵀ
   if (e < 3204) { const int f = e - 2304; return RF_PX + (f / 30) * 31 + f % 30; }
   if (e < 3744) { const int f = e - 3204; return RF_PU + (f / QM_MMAX) * 19 + f % QM_MMAX; }
   return RF_V + (e - 3744);
@@ -236,6 +270,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   for (int k = l; k < n; k += 64) { const int ev = a.node_ev[k * a.B + b]; const int mk = (ev == QM_EV_PRE) ? 0 : (int)a.stage[((size_t)b * a.nmax + k) * SR_SIZE + SR_SCAL]; nlist[k] = (mk & 255) | (ev << 8); }
   qm_wave_sync();
   int chol_fail = 0;
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long tstart = (long long)__builtin_readcyclecounter();
   qm_d4 S[2][2], sv[2];
   {   // terminal value function
     const double* rec = a.stage + ((size_t)b * a.nmax + (n - 1)) * SR_SIZE;
@@ -267,9 +302,10 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     int kn = k - 1; while (kn >= 0 && evlist(kn) == QM_EV_PRE) --kn;      // next regular stage: its operands are prefetched into LDS
     const double* nrec = (kn >= 0) ? a.stage + ((size_t)b * a.nmax + kn) * SR_SIZE : nullptr;
     const int m = mlist(k);
-    if (m <= 16) rw_stage<1>(rec, m, nrec, buf, S, sv, a.skip, chol_fail);
-    else rw_stage<2>(rec, m, nrec, buf, S, sv, a.skip, chol_fail);
+    if (m <= 16) rw_stage<1>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc);
+    else rw_stage<2>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc);
   }
+  const long long tback = (long long)__builtin_readcyclecounter();
   // L, W, y were stored by other lanes than the ones that read them back below
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // same wave, same CU: ordering only, no L2 write-back
   // ---- forward rollout.  Each stage record is fetched flat (512 B per wave instruction) one stage ahead into registers, dropped
@@ -333,6 +369,11 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   }
   double arm = armijo, sx = dx2, su = du2;
   for (int off = 32; off > 0; off >>= 1) { arm += __shfl_xor(arm, off, 64); sx += __shfl_xor(sx, off, 64); su += __shfl_xor(su, off, 64); }
+  if ((a.skip & 32) && l == 0) {                      // profiling: cycles per backward phase, whole sweeps
+    double* r0 = a.stage + (size_t)b * a.nmax * SR_SIZE + SR_K;
+    for (int i = 0; i < 7; ++i) r0[i] = (double)tacc[i];
+    r0[7] = (double)(tback - tstart); r0[8] = (double)((long long)__builtin_readcyclecounter() - tback);
+  }
   if (l == 0) { a.step_info[b * 4] = arm; a.step_info[b * 4 + 1] = sx; a.step_info[b * 4 + 2] = su; a.step_info[b * 4 + 3] = (double)chol_fail; }
 }
 #undef mlist

@@ -24,6 +24,7 @@
 #define __shared__
 #define __restrict__
 #define __launch_bounds__(...)
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)   /* instruction-scheduling fence: no meaning on the host */
 #define QM_TABLE_OPAQUE(p)            /* device-only register constraint */
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
