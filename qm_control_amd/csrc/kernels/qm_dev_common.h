@@ -63,8 +63,24 @@ __device__ __forceinline__ void euler_E(double z, double y, double* E) {
   const double sz = sin(z), cz = cos(z), sy = sin(y), cy = cos(y);
   E[0] = 0.0; E[1] = -sz; E[2] = cy * cz; E[3] = 0.0; E[4] = cz; E[5] = cy * sz; E[6] = 1.0; E[7] = 0.0; E[8] = -sy;
 }
-// relaxed log barrier (task.info:290-314 -> [upstream RelaxedBarrierPenalty])
-__device__ __forceinline__ double barrier_val(double mu, double delta, double h) { if (h > delta) return -mu * log(h); const double t = (h - 2.0 * delta) / delta; return mu * (-log(delta) + 0.5 * t * t - 0.5); }
+// natural logarithm for the barrier values: frexp + atanh series in s = (m − 1)/(m + 1), |s| <= 0.172, error < 1e-15 relative.
+// (≈ 30 instructions; the library's double-double log costs ≈ 200 and a one-thread-per-node kernel evaluates 52 barriers per node)
+__device__ __forceinline__ double qm_log(double h) {
+  int e; double m = frexp(h, &e);                                   // h = m 2^e, m in [0.5, 1)
+  if (m < 0.70710678118654752) { m *= 2.0; e -= 1; }                // m in [1/sqrt 2, sqrt 2)
+  const double den = m + 1.0; double r = __builtin_amdgcn_rcp(den);
+  r = fma(fma(-den, r, 1.0), r, r); r = fma(fma(-den, r, 1.0), r, r);
+  const double s = (m - 1.0) * r, z = s * s;
+  double p = 1.0 / 19.0;
+  p = fma(p, z, 1.0 / 17.0); p = fma(p, z, 1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, 1.0 / 3.0); p = fma(p, z, 1.0);
+  return fma((double)e, 0.69314718055994531, 2.0 * s * p);
+}
+// relaxed log barrier (task.info:290-314 -> [upstream RelaxedBarrierPenalty]); one logarithm, no divergent branch
+__device__ __forceinline__ double barrier_val(double mu, double delta, double h) {
+  const bool in = h > delta; const double L = qm_log(in ? h : delta), t = (h - 2.0 * delta) * (1.0 / delta);   // 1/delta: one division per distinct delta after CSE
+  return in ? -mu * L : mu * (-L + 0.5 * t * t - 0.5);
+}
 __device__ __forceinline__ double barrier_d1(double mu, double delta, double h) { return (h > delta) ? -mu / h : mu * (h - 2.0 * delta) / (delta * delta); }
 __device__ __forceinline__ double barrier_d2(double mu, double delta, double h) { return (h > delta) ? mu / (h * h) : mu / (delta * delta); }
 
