@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     int fc = 0, fs = l & 1;
     if (l < 6) fc = 3 + (l >> 1); else if (l < 12) fc = 9 + ((l - 6) >> 1); else if (l < 36) fc = 12 + ((l - 12) >> 1); else fc = 30 + ((l - 36) >> 1);
     double colf[12];
-    if (l < 60) flow_jac_col(mb, fs ? S + LW_V_X2 : X, U, fs ? K2 : K1, fc, colf);
+    flow_jac_col_wave(mb, U, fs ? K2 : K1, fc, colf);        // lanes 60..63 repeat a force column and drop it
     const int cc = (fc < 30) ? fc : fc - 30, r0 = (fc < 30) ? 0 : 16;
     for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
     qm_wave_sync();
@@ -314,18 +314,19 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   {
     // one (column, contact) task per lane for the non-trivial classes of the foot-velocity Jacobian: lanes 0-11 columns 3..5 x 4 contacts,
     // 12-23 columns 9..11 x 4 contacts, 24-35 the leg's own joint angles 12..23, 36-47 its own joint velocities 42..53
-    int tc = 0, tk = 0;
+    int tc = 3, tk = 0;
     if (l < 12) { tc = 3 + (l >> 2); tk = l & 3; } else if (l < 24) { tc = 9 + ((l - 12) >> 2); tk = l & 3; }
     else if (l < 36) { tc = 12 + (l - 24); tk = chain_to_contact((l - 24) / 3); } else if (l < 48) { tc = 42 + (l - 36); tk = chain_to_contact((l - 36) / 3); }
     int rk = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (j < tk) rk += mode_flag(mode, j) ? 3 : 4;
+    if (l >= 60) tk = l - 60;                              // lanes 60..63: one contact each, the constraint values
+    double dv[3], dpz, vk[3], pzk; foot_vel_jac_col_wave(mb, X, U, K1, tk, tc, dv, &dpz, vk, &pzk);   // branch-free over the column classes
     if (l < 48) {
-      double dv[3], dpz; foot_vel_jac_col(mb, X, U, K1, tk, tc, dv, &dpz);
       double* M = (tc < 30) ? T : T + 16 * LW_TLD; const int cc = (tc < 30) ? tc : tc - 30;
       if (mode_flag(mode, tk)) { for (int r = 0; r < 3; ++r) M[(rk + r) * LW_TLD + cc] = dv[r] + ((r == 2 && gain != 0.0) ? gain * dpz : 0.0); }
       else M[(rk + 3) * LW_TLD + cc] = dv[2] + (gain != 0.0 ? gain * dpz : 0.0);
-    } else {
+    } else if (l < 60) {
       // structurally constant entries: columns 0..2 (d v / d h_lin = I), column 8 (d p_z / d z = 1), swing force rows F_k = 0
       const int t = l - 48, k = t & 3, j = t >> 2;           // j = 0..2: column j resp. force component j ; j = 3: column 8
       int r0k = 0;
@@ -335,18 +336,14 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
       if (j < 3) {
         if (stance) T[(r0k + j) * LW_TLD + j] = 1.0; else { if (j == 2) T[(r0k + 3) * LW_TLD + 2] = 1.0; T[(16 + r0k + j) * LW_TLD + 3 * k + j] = 1.0; }
       } else if (gain != 0.0) T[(r0k + (stance ? 2 : 3)) * LW_TLD + 8] = gain;
-    }
-    qm_wave_sync();
-    if (l >= 60) {                                          // lanes 60..63: one contact each, the constraint values
-      const int k = l - 60; const bool stance = mode_flag(mode, k);
-      double v[3]; foot_velocity(X, K1, k, v); const double pz = kin_foot(K1, k)[2];
-      if (stance) { for (int r = 0; r < 3; ++r) S[LW_V_E + row0[k] + r] = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); }
-      else {
-        for (int r = 0; r < 3; ++r) S[LW_V_E + row0[k] + r] = U[3 * k + r];
-        double bb = -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * a.zpos[nb * 4 + k];
-        S[LW_V_E + row0[k] + 3] = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0);
-      }
-      for (int r = 0; r < (stance ? 3 : 4); ++r) T[(row0[k] + r) * LW_TLD + 30] = S[LW_V_E + row0[k] + r];   // e rides in column 30 of the C rows: [C | e]
+    } else {
+      const int k = tk; const bool stance = mode_flag(mode, k); const int rr = row0[k];
+      const double gz = (gain != 0.0) ? gain * pzk : 0.0;
+      double bb = -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * a.zpos[nb * 4 + k];
+      const double e0 = stance ? vk[0] : U[3 * k], e1 = stance ? vk[1] : U[3 * k + 1], e2 = stance ? vk[2] + gz : U[3 * k + 2], e3 = bb + vk[2] + gz;
+      // e also rides in column 30 of the C rows: [C | e]
+      S[LW_V_E + rr] = e0; T[rr * LW_TLD + 30] = e0; S[LW_V_E + rr + 1] = e1; T[(rr + 1) * LW_TLD + 30] = e1; S[LW_V_E + rr + 2] = e2; T[(rr + 2) * LW_TLD + 30] = e2;
+      if (!stance) { S[LW_V_E + rr + 3] = e3; T[(rr + 3) * LW_TLD + 30] = e3; }
     }
   }
   qm_wave_sync();

@@ -179,6 +179,55 @@ __device__ __forceinline__ void flow_jac_col(const double* mb, const double* x, 
   }
 }
 
+// flow_jac_col for a wave that holds one column per lane: the four non-trivial column classes (3..5, 9..11, 12..23, 30..41) are all
+// evaluated by every lane with clamped indices and the lane's class selects the result — one basic block of four independent chains
+// (interleaved by the scheduler) instead of four divergent bodies executed one after the other.  Same arithmetic per class.
+__device__ __forceinline__ void flow_jac_col_wave(const double* mb, const double* u, const double* K, int c, double* col12) {
+  const double m = mb[MB_ROBOTMASS], im = 1.0 / m;
+  const int cls = (c < 6) ? 0 : (c < 12) ? 1 : (c < 24) ? 2 : 3;
+  const int k3 = (cls == 0) ? c - 3 : (cls == 1) ? c - 9 : 0;
+  // class 0: d/d(h_ang)_k
+  double a6[3], a9[3];
+  { const double w[3] = {K[KW_IINV + k3] * m, K[KW_IINV + 3 + k3] * m, K[KW_IINV + 6 + k3] * m}; v3_cross(w, K + KW_RW, a6); m3_mulv(K + KW_EINV, w, a9); }
+  // class 1: d/d(zyx)_k
+  double b3[3] = {0.0, 0.0, 0.0}, b6[3], b9[3];
+  { double ek[3], dw[3]; d_omega_dtheta(K, k3, ek, dw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double* p = kin_foot(K, i); const double d[3] = {p[0] - K[KW_COM], p[1] - K[KW_COM + 1], p[2] - K[KW_COM + 2]};
+      double t[3], t2[3]; v3_cross(ek, d, t); v3_cross(t, u + 3 * i, t2);
+      b3[0] += t2[0] * im; b3[1] += t2[1] * im; b3[2] += t2[2] * im;
+    }
+    double t1[3], t2[3], t3[3]; v3_cross(dw, K + KW_RW, t1); v3_cross(ek, K + KW_RW, t2); v3_cross(K + KW_OM, t2, t3);
+    for (int r = 0; r < 3; ++r) b6[r] = t1[r] + t3[r];
+    // (dE/dθ_k) θdot: k = 0: e_z × ω, k = 1: (E[:,1] × E[:,2]) θdot_2, k = 2: 0
+    const double c1[3] = {K[KW_E + 1], K[KW_E + 4], K[KW_E + 7]}, c2[3] = {K[KW_E + 2], K[KW_E + 5], K[KW_E + 8]}; double cx[3]; v3_cross(c1, c2, cx);
+    const double th2 = K[KW_THD + 2];
+    const double de[3] = {(k3 == 0) ? -K[KW_OM + 1] : (k3 == 1) ? cx[0] * th2 : 0.0, (k3 == 0) ? K[KW_OM] : (k3 == 1) ? cx[1] * th2 : 0.0, (k3 == 1) ? cx[2] * th2 : 0.0};
+    const double rhs[3] = {dw[0] - de[0], dw[1] - de[1], dw[2] - de[2]};
+    m3_mulv(K + KW_EINV, rhs, b9); }
+  // class 2: d/d(q_j), leg joints
+  double c3[3];
+  { const int j = (cls == 2) ? c - 12 : 0, chain = j / 3, jj = j - 3 * chain, contact = chain_to_contact(chain);
+    const double* L = K + KW_LEG + KW_LEGSZ * chain;
+    const double d[3] = {L[18] - L[9 + 3 * jj], L[19] - L[10 + 3 * jj], L[20] - L[11 + 3 * jj]};
+    double t[3], t2[3]; v3_cross(L + 3 * jj, d, t); v3_cross(t, u + 3 * contact, t2);
+    for (int r = 0; r < 3; ++r) c3[r] = t2[r] * im; }
+  // class 3: d/d(F_i)_k
+  double d0[3], d3[3];
+  { const int q = (cls == 3) ? c - 30 : 0, i = q / 3, k = q - 3 * i;
+    const double* p = kin_foot(K, i); const double d[3] = {p[0] - K[KW_COM], p[1] - K[KW_COM + 1], p[2] - K[KW_COM + 2]};
+    for (int r = 0; r < 3; ++r) d0[r] = (r == k) ? im : 0.0;
+    d3[0] = ((k == 1) ? -d[2] : (k == 2) ? d[1] : 0.0) * im; d3[1] = ((k == 0) ? d[2] : (k == 2) ? -d[0] : 0.0) * im; d3[2] = ((k == 0) ? -d[1] : (k == 1) ? d[0] : 0.0) * im; }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    col12[r] = (cls == 3) ? d0[r] : 0.0;
+    col12[3 + r] = (cls == 1) ? b3[r] : (cls == 2) ? c3[r] : (cls == 3) ? d3[r] : 0.0;
+    col12[6 + r] = (cls == 0) ? a6[r] : (cls == 1) ? b6[r] : 0.0;
+    col12[9 + r] = (cls == 0) ? a9[r] : (cls == 1) ? b9[r] : 0.0;
+  }
+}
+
 // a8: derivative of foot `contact`'s velocity (and z-position, for positionErrorGain) wrt column c of [x | u] -> dv[3], dpz
 __device__ __forceinline__ void foot_vel_jac_col(const double* mb, const double* x, const double* u, const double* K, int contact, int c, double* dv, double* dpz) {
   const double m = mb[MB_ROBOTMASS];
@@ -217,6 +266,47 @@ __device__ __forceinline__ void foot_vel_jac_col(const double* mb, const double*
     const int jj = j - 3 * chain; const double dj[3] = {p[0] - L[9 + 3 * jj], p[1] - L[10 + 3 * jj], p[2] - L[11 + 3 * jj]};
     v3_cross(L + 3 * jj, dj, dv);
   }
+}
+
+// foot_vel_jac_col for a wave that holds one (column, contact) task per lane: the four non-trivial classes (columns 3..5, 9..11, the
+// leg's own joint angles 12..23 and joint velocities 42..53) evaluated by every lane with clamped indices, selected by the lane's
+// class (see flow_jac_col_wave).  Also returns the foot velocity v and height pz of the contact (the constraint values need them).
+__device__ __forceinline__ void foot_vel_jac_col_wave(const double* mb, const double* x, const double* u, const double* K, int contact, int c,
+                                                       double* dv, double* dpz, double* v, double* pz) {
+  const double m = mb[MB_ROBOTMASS];
+  const int chain = contact_to_chain(contact);
+  const double* L = K + KW_LEG + KW_LEGSZ * chain;
+  const double p[3] = {L[18], L[19], L[20]};
+  const double d[3] = {p[0] - K[KW_COM], p[1] - K[KW_COM + 1], p[2] - K[KW_COM + 2]};
+  const double om[3] = {K[KW_OM], K[KW_OM + 1], K[KW_OM + 2]};
+  { double cv[3]; v3_cross(om, d, cv); for (int r = 0; r < 3; ++r) v[r] = x[r] + cv[r] + L[21 + r]; *pz = p[2]; }
+  const int cls = (c < 6) ? 0 : (c < 12) ? 1 : (c < 24) ? 2 : 3;
+  const int k3 = (cls == 0) ? c - 3 : (cls == 1) ? c - 9 : 0;
+  // class 0: d/d(h_ang)_k
+  double a[3];
+  { const double w[3] = {K[KW_IINV + k3] * m, K[KW_IINV + 3 + k3] * m, K[KW_IINV + 6 + k3] * m}; v3_cross(w, d, a); }
+  // class 1: d/d(zyx)_k
+  double b[3], bz;
+  { double ek[3], dw[3]; d_omega_dtheta(K, k3, ek, dw);
+    double t1[3], t2[3], t3[3], t4[3]; v3_cross(dw, d, t1); v3_cross(ek, d, t2); v3_cross(om, t2, t3); v3_cross(ek, L + 21, t4);
+    for (int r = 0; r < 3; ++r) b[r] = t1[r] + t3[r] + t4[r];
+    const double pb[3] = {p[0] - x[6], p[1] - x[7], p[2] - x[8]}; double t5[3]; v3_cross(ek, pb, t5); bz = t5[2]; }
+  // classes 2, 3: the leg's own joint l (angle resp. velocity)
+  const int l = (cls == 2) ? c - 12 - 3 * chain : (cls == 3) ? c - 42 - 3 * chain : 0;
+  const double al[3] = {L[3 * l], L[3 * l + 1], L[3 * l + 2]};
+  const double dl[3] = {p[0] - L[9 + 3 * l], p[1] - L[10 + 3 * l], p[2] - L[11 + 3 * l]};
+  double dp[3]; v3_cross(al, dl, dp);                  // ∂p/∂q_l  (= class 3's answer)
+  double acc[3]; v3_cross(om, dp, acc);                // ω × ∂d/∂q_l
+#pragma unroll
+  for (int jj = 0; jj < 3; ++jj) {
+    const double qd = u[12 + 3 * chain + jj]; const double* aj = L + 3 * jj;
+    const double dj[3] = {p[0] - L[9 + 3 * jj], p[1] - L[10 + 3 * jj], p[2] - L[11 + 3 * jj]};
+    double t1[3], t2[3], t3[3], t4[3], t0[3];
+    v3_cross(al, aj, t1); v3_cross(t1, dj, t2); v3_cross(al, dj, t3); v3_cross(aj, t3, t4); v3_cross(aj, dp, t0);
+    for (int r = 0; r < 3; ++r) acc[r] += qd * ((jj > l) ? t2[r] + t4[r] : t0[r]);
+  }
+  for (int r = 0; r < 3; ++r) dv[r] = (cls == 0) ? a[r] : (cls == 1) ? b[r] : (cls == 2) ? acc[r] : dp[r];
+  *dpz = (cls == 1) ? bz : (cls == 2) ? dp[2] : 0.0;
 }
 
 // rotation matrix -> quaternion xyzw ([upstream] ocs2 matrixToQuaternion branches)
