@@ -474,29 +474,35 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   qm_wave_sync();
   if (l < 30) cost += 0.5 * S[LW_V_DU + l] * S[LW_V_RV + l];
   qm_wave_sync();
-  // arm soft box (a6), joint-velocity box, friction cone barrier (a7): few lanes, disjoint entries
-  if (l < 12) {                                           // lanes 0..5: arm joint position box on x[24+k]; lanes 6..11: arm joint velocity box on u[24+k]
-    const int k = (l < 6) ? l : l - 6; const bool pos = (l < 6);
-    const double mu = pos ? st[ST_JPOS_MU] : st[ST_JVEL_MU], de = pos ? st[ST_JPOS_DELTA] : st[ST_JVEL_DELTA];
+  // arm soft box (a6), joint-velocity box, friction cone barrier (a7).  All three are "relaxed barrier of h" evaluations: ONE branch-free
+  // body serves lanes 0..11 (variable part of the boxes: lane < 6 position of arm joint l, else velocity), lanes 32..43 (the boxes' constant
+  // offsets b(−lo) + b(hi): same code, other arguments) and lanes 16..19 (friction cone of contact l − 16); idle lanes evaluate h = 1.
+  {
+    const bool boxv = l < 12, boxc = (l >= 32 && l < 44), fric = (l >= 16 && l < 20);
+    const int kb = boxv ? l : (boxc ? l - 32 : 0); const bool pos = kb < 6; const int k = pos ? kb : kb - 6;
+    const int kf = fric ? l - 16 : 0; const bool fon = fric && mode_flag(mode, kf);
+    const double muf = st[ST_FRIC_COEF], reg = st[ST_FRIC_REG];
+    const double Fx = U[3 * kf], Fy = U[3 * kf + 1], Fz = U[3 * kf + 2]; const double T2 = Fx * Fx + Fy * Fy + reg, Tn = sqrt(T2);
+    const double mu = fric ? st[ST_FRIC_MU] : (pos ? st[ST_JPOS_MU] : st[ST_JVEL_MU]), de = fric ? st[ST_FRIC_DELTA] : (pos ? st[ST_JPOS_DELTA] : st[ST_JVEL_DELTA]);
     const double lo = pos ? mb[MB_QLO + 12 + k] : st[ST_JVEL_LO + k], hi = pos ? mb[MB_QHI + 12 + k] : st[ST_JVEL_HI + k], z = pos ? X[24 + k] : U[24 + k];
-    cost += barrier_val(mu, de, z - lo) + barrier_val(mu, de, hi - z) - (barrier_val(mu, de, -lo) + barrier_val(mu, de, hi));
-    const double g1 = barrier_d1(mu, de, z - lo) - barrier_d1(mu, de, hi - z), g2 = barrier_d2(mu, de, z - lo) + barrier_d2(mu, de, hi - z);
-    if (pos) { S[LW_V_QV + 24 + k] += g1; QD[24 + k] += g2; } else { S[LW_V_RV + 24 + k] += g1; RD[24 + k] += g2; }
-  } else if (l >= 16 && l < 20) {   // friction cone, one lane per contact (disjoint 3x3 blocks)
-    const int k = l - 16; double ds = 0.0; double* fr = FR + 16 * k;
-    for (int q = 0; q < 13; ++q) fr[q] = 0.0;
-    if (mode_flag(mode, k)) {
-      const double mu = st[ST_FRIC_MU], de = st[ST_FRIC_DELTA], muf = st[ST_FRIC_COEF], reg = st[ST_FRIC_REG], shift = st[ST_FRIC_SHIFT];
-      const double Fx = U[3 * k], Fy = U[3 * k + 1], Fz = U[3 * k + 2]; const double T2 = Fx * Fx + Fy * Fy + reg, Tn = sqrt(T2), T3 = Tn * Tn * Tn;
-      const double h = muf * Fz - Tn; cost += barrier_val(mu, de, h);
-      const double p1 = barrier_d1(mu, de, h), p2 = barrier_d2(mu, de, h);
-      const double dh[3] = {-Fx / Tn, -Fy / Tn, muf};
-      const double ddh[9] = {-(Fy * Fy + reg) / T3, Fx * Fy / T3, 0.0, Fx * Fy / T3, -(Fx * Fx + reg) / T3, 0.0, 0.0, 0.0, 0.0};
-      for (int r = 0; r < 3; ++r) { S[LW_V_RV + 3 * k + r] += p1 * dh[r]; for (int q = 0; q < 3; ++q) fr[3 * r + q] = p2 * dh[r] * dh[q] + p1 * ddh[3 * r + q]; }
-      ds = p1 * (-shift);
-    }
-    fr[12] = ds;
-  } else if (l == 24) { for (int k = 0; k < 6; ++k) cost += 0.5 * EE[6 + k] * EE[k] * EE[k]; }
+    const double h1 = boxv ? z - lo : (boxc ? -lo : (fon ? muf * Fz - Tn : 1.0)), h2 = boxv ? hi - z : (boxc ? hi : 1.0);
+    const double v1 = barrier_val(mu, de, h1), v2 = barrier_val(mu, de, h2);
+    const double p1 = barrier_d1(mu, de, h1), q1 = barrier_d1(mu, de, h2), p2 = barrier_d2(mu, de, h1), q2 = barrier_d2(mu, de, h2);
+    cost += boxv ? v1 + v2 : (boxc ? -(v1 + v2) : (fon ? v1 : 0.0));
+    if (boxv) { const double g1 = p1 - q1, g2 = p2 + q2; if (pos) { S[LW_V_QV + 24 + k] += g1; QD[24 + k] += g2; } else { S[LW_V_RV + 24 + k] += g1; RD[24 + k] += g2; } }
+    else if (fric) {                                                     // one lane per contact (disjoint 3x3 blocks)
+      double* fr = FR + 16 * kf; double ds = 0.0;
+      for (int q = 0; q < 13; ++q) fr[q] = 0.0;
+      if (fon) {
+        const double shift = st[ST_FRIC_SHIFT], T3 = Tn * Tn * Tn;
+        const double dh[3] = {-Fx / Tn, -Fy / Tn, muf};
+        const double ddh[9] = {-(Fy * Fy + reg) / T3, Fx * Fy / T3, 0.0, Fx * Fy / T3, -(Fx * Fx + reg) / T3, 0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < 3; ++r) { S[LW_V_RV + 3 * kf + r] += p1 * dh[r]; for (int q = 0; q < 3; ++q) fr[3 * r + q] = p2 * dh[r] * dh[q] + p1 * ddh[3 * r + q]; }
+        ds = p1 * (-shift);
+      }
+      fr[12] = ds;
+    } else if (l == 24) { for (int q = 0; q < 6; ++q) cost += 0.5 * EE[6 + q] * EE[q] * EE[q]; }
+  }
   qm_wave_sync();
   const double dsum = FR[12] + FR[28] + FR[44] + FR[60];
   LQT()
