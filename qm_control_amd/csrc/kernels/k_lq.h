@@ -260,11 +260,11 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     if (l < 3) T[(6 + l) * LW_TLD + l] = 1.0;                                   // d rdot / d h_lin (both stages)
     if (l >= 4 && l < 8) T[(16 + 8 + l) * LW_TLD + 8 + l] = 1.0;                // d qdot_j / d u_j rows 12..15 (rows >= 16 are handled analytically)
     qm_wave_sync();
-    qm_frag_load<1, 2, false>(A1, T, LW_TLD, 16, 30); qm_frag_load<1, 2, false>(B1, T + 16 * LW_TLD, LW_TLD, 16, 30); qm_frag_load<2, 1, true>(B1t, T + 16 * LW_TLD, LW_TLD, 30, 16);
+    qm_frag_load_tile<1, 2, false>(A1, T, LW_TLD); qm_frag_load_tile<1, 2, false>(B1, T + 16 * LW_TLD, LW_TLD); qm_frag_load_tile<2, 1, true>(B1t, T + 16 * LW_TLD, LW_TLD);   // columns 30, 31 of the tile are zero
     qm_wave_sync();
     if (l < 60 && fs == 1) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = colf[r]; }      // same sparsity pattern: no re-zeroing needed
     qm_wave_sync();
-    qm_frag_load<1, 2, false>(A2, T, LW_TLD, 16, 30); qm_frag_load<2, 1, true>(A2t, T, LW_TLD, 30, 16); qm_frag_load<2, 1, true>(B2t, T + 16 * LW_TLD, LW_TLD, 30, 16);
+    qm_frag_load_tile<1, 2, false>(A2, T, LW_TLD); qm_frag_load_tile<2, 1, true>(A2t, T, LW_TLD); qm_frag_load_tile<2, 1, true>(B2t, T + 16 * LW_TLD, LW_TLD);
     LQT()
     // A2 A1 (rows < 16): Z = A2ᵀ[0:16, 0:16], Y = A1
     qm_d4 TA[1][2]; qm_frag_zero<1, 2>(TA);

@@ -228,6 +228,17 @@ __device__ __forceinline__ void qm_frag_load(qm_d4 (&T)[IT][JT], const double* s
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; T[I][J][r] = (row < rows && col < cols) ? (TR ? src[col * ld + row] : src[row * ld + col]) : 0.0; }
 }
+// the same for a source that is a fully populated, zero-padded 32 x ld LDS tile: no bounds, hence no exec-mask juggling per element
+template <int IT, int JT, bool TR>
+__device__ __forceinline__ void qm_frag_load_tile(qm_d4 (&T)[IT][JT], const double* src, int ld) {
+  const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+#pragma unroll
+  for (int I = 0; I < IT; ++I)
+#pragma unroll
+    for (int J = 0; J < JT; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; T[I][J][r] = TR ? src[col * ld + row] : src[row * ld + col]; }
+}
 template <int IT, int JT>
 __device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* dst, int ld, int rows, int cols) {
   const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
