@@ -87,6 +87,39 @@ def trot_stance_trot_schedule(ts1, ts2, t_until):
     return np.array(ev), np.array(modes, dtype=np.int32)
 
 
+def gait_schedule(name, t_until):
+    """Any template of gait.info tiled from t = 0 until t_until (initial and final STANCE as the reference's schedule has them)."""
+    g = load_gaits()[name]
+    return tile_gait(g["switchingTimes"], g["modeSequence"], 0.0, t_until)
+
+
+def gait_config(gait, batch=4, n_intervals=30, seed=7):
+    """C3-style random instances walking `gait` (all 12 templates of qm_controllers/config/gait.info:1-255): same dict as make_config."""
+    mb, st = load_blobs()
+    xbar = st[ST_XINIT:ST_XINIT + 30].copy()
+    qnom = mb[MB_QNOM:MB_QNOM + 18].copy()
+    horizon = n_intervals * st[ST_SQP_DT]
+    g = load_gaits()[gait]
+    rng = np.random.default_rng(seed)
+    d = np.zeros((batch, 30))
+    d[:, 0:6] = rng.uniform(-0.05, 0.05, (batch, 6)); d[:, 6:9] = rng.uniform(-0.02, 0.02, (batch, 3)); d[:, 9:12] = rng.uniform(-0.03, 0.03, (batch, 3))
+    d[:, 12:24] = rng.uniform(-0.05, 0.05, (batch, 12)); d[:, 24:30] = rng.uniform(-0.1, 0.1, (batch, 6))
+    x0 = np.tile(xbar, (batch, 1)) + d
+    t0 = rng.uniform(0.0, g["switchingTimes"][-1], batch)
+    ee_nom = np.concatenate([EE_NOMINAL_POS, EE_NOMINAL_QUAT])
+    evs, mos = [], []
+    ref_t = np.zeros((batch, 2)); ref_x = np.zeros((batch, 2, 37))
+    for b in range(batch):
+        e, m = gait_schedule(gait, g["switchingTimes"][-1] + 3.0 * horizon)
+        goal = x0[b, 6:12].copy(); goal[0] += 0.1; goal[2] = COM_HEIGHT; goal[4] = 0.0; goal[5] = 0.0
+        now = x0[b, 6:12].copy(); now[2] = COM_HEIGHT; now[4] = 0.0; now[5] = 0.0
+        ref_t[b], ref_x[b] = make_target(t0[b], horizon, now, goal, qnom, ee_nom, ee_nom)
+        evs.append(e); mos.append(m)
+    ev, modes = _pad_schedules(evs, mos)
+    return dict(name="gait:" + gait, B=batch, n_intervals=n_intervals, horizon=horizon, t0=t0, x0=x0, ref_t=ref_t, ref_x=ref_x, ev=ev, modes=modes,
+                period=0.002, time=20.0)
+
+
 def make_target(t0, horizon, base_now, base_goal, q_nom, ee_now, ee_goal):
     """targetPoseToTargetTrajectories: 2 knots of [0_6, base pose(6), defaultJointState(18), EE pose(7)]."""
     ref_t = np.array([t0, t0 + horizon])

@@ -57,6 +57,20 @@ def test_batch_random_trot(blobs, oracle):
     itf.close()
 
 
+ALL_GAITS = ["stance", "trot", "standing_trot", "flying_trot", "pace", "standing_pace", "dynamic_walk", "static_walk", "amble", "lindyhop", "skipping", "pawup"]
+
+
+@pytest.mark.parametrize("gait", ALL_GAITS)
+def test_every_gait_template(blobs, oracle, gait):
+    """All 12 templates of gait.info: 1-, 2-, 3-leg support and flight phases (nc = 12..16, m = 14..18)."""
+    from qm_control_amd import scenarios
+    cfg = scenarios.gait_config(gait, batch=4, n_intervals=30)
+    itf, mpc, res = _gpu_solve(blobs, cfg, 4, 96)
+    for b in range(4):
+        _compare(res, b, _oracle_solve(oracle, cfg, b))
+    itf.close()
+
+
 def test_ee_tracking_schedule_switch(blobs, oracle):
     from qm_control_amd import scenarios
     cfg = scenarios.make_config("C5", batch=16, n_intervals=150)

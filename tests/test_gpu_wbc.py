@@ -72,3 +72,25 @@ def test_control_step_vs_oracle(blobs, oracle, name, B, N):
         assert rel_err(out[b], w[b]) <= TOL, b
         assert rel_err(out[b, 36:], w[b, 36:]) <= TOL, b
     itf.close()
+
+
+@pytest.mark.parametrize("gait", ["flying_trot", "pace", "dynamic_walk", "static_walk", "amble", "skipping", "pawup"])
+def test_control_step_other_gaits(blobs, oracle, gait):
+    """whole control step on the gaits the benchmark does not walk: 0-, 1-, 2- (lateral) and 3-leg support in the WBC's contact tasks"""
+    import pyoracle
+    from qm_control_amd import api, scenarios
+    B, N = 8, 30
+    cfg = scenarios.gait_config(gait, batch=B, n_intervals=N, seed=11)
+    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 8, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
+    assert bad == 0
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=96, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+    wbc.reset()
+    mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+    out, st = wbc.download(B)
+    assert (st == 0).all()
+    for b in range(B):
+        assert rel_err(out[b], w[b]) <= TOL, b
+        assert rel_err(out[b, 36:], w[b, 36:]) <= TOL, b
+    itf.close()
