@@ -70,11 +70,56 @@ int qmhip_mpc_download(qmhip_ctx* ctx, int B, int32_t* out_num_nodes, double* ou
  *      set_initial: new observation (t, x) per instance — MPC_MRT_Interface::setCurrentObservation (QMController.cpp:133-137); references,
  *      schedule and the previous solution stay resident.  solve_resident_warm falls back to the cold start if there is no previous solve.
  *      advance_resident: perfect-tracking plant for back-to-back steps without host round trips: t0 += dt, x0 <- policy state at the new t0.
- *      closed_loop_resident: n_steps x [advance (not on the first step), warm solve, policy at t0, WBC on the state built from x0]. */
+ *      closed_loop_resident: n_steps x [advance (not on the first step), warm solve, policy at t0, WBC on the state built from x0]; when the gait
+ *      front-end below has been reset for this batch, every step first refreshes the mode schedule (qmhip_gait_update_resident). */
 int qmhip_mpc_set_initial(qmhip_ctx* ctx, int B, const double* t0, const double* x0 /*[B][30]*/);
 int qmhip_mpc_solve_resident_warm(qmhip_ctx* ctx, int B, double horizon);
 int qmhip_mpc_advance_resident(qmhip_ctx* ctx, int B, double dt);
 int qmhip_closed_loop_resident(qmhip_ctx* ctx, int B, int n_steps, double mpc_dt, double horizon, double period, double time0);
+
+/* ---- reference / gait front-end, batched and device resident.
+ *      Gait side — replaces, per instance, the reference's GaitSchedule object (constructed at qm_interface/src/QMInterface.cpp:455-480 from
+ *      reference.info:28-52 with phaseTransitionStanceTime, task.info:11) and the two calls made on it around every MPC iteration
+ *      ([upstream ocs2_legged_robot] GaitReceiver::preSolverRun -> GaitSchedule::insertModeSequenceTemplate(template, finalTime, timeHorizon);
+ *      SwitchedModelReferenceManager::modifyReferences -> GaitSchedule::getModeSchedule(initTime - T, finalTime + T)), fed by the templates
+ *      GaitJoyPublisher loads from gait.info (qm_controllers/src/GaitJoyPublisher.cpp:17-33).
+ *      set_templates: the table of mode-sequence templates, n_phases[g] <= QMHIP_GAIT_MAX_PHASES, switching_times[g][QMHIP_GAIT_MAX_PHASES + 1],
+ *                     mode_sequence[g][QMHIP_GAIT_MAX_PHASES] (mode id = 8 LF + 4 RF + 2 LH + RH).
+ *      reset:         every instance starts from the initial mode schedule (event_times[n_events], mode_sequence[n_events + 1]) and template
+ *                     `default_template`; B is the batch size of all later gait calls.
+ *      insert_template: insertModeSequenceTemplate for the instances with template_id[b] >= 0 (host arrays [B]).
+ *      update_resident: getModeSchedule(t0 - T, t0 + 2T) on every instance (t0 = the resident observation time, T = horizon); the result
+ *                     becomes the solver's mode schedule (same buffers qmhip_mpc_upload fills; needs n_events <= max_events, else status -3).
+ *                     Event times are produced by the reference's additions in the reference's order: bit-exact.
+ *      download / schedule_download: test access to the per-instance GaitSchedule state ([B][QMHIP_GAIT_EVENT_SLOTS], [B][.. + 1]) and to
+ *                     the solver's schedule buffers ([B][max_events], [B][max_events + 1]). */
+#define QMHIP_GAIT_MAX_PHASES 16
+#define QMHIP_GAIT_EVENT_SLOTS 256
+int qmhip_gait_set_templates(qmhip_ctx* ctx, int n_gaits, const int32_t* n_phases, const double* switching_times, const int32_t* mode_sequence);
+int qmhip_gait_reset(qmhip_ctx* ctx, int B, int n_events, const double* event_times, const int32_t* mode_sequence, int default_template);
+int qmhip_gait_insert_template(qmhip_ctx* ctx, int B, const int32_t* template_id, const double* start_time, const double* final_time);
+int qmhip_gait_update_resident(qmhip_ctx* ctx, int B, double horizon);
+int qmhip_gait_download(qmhip_ctx* ctx, int B, int32_t* n_events, double* event_times, int32_t* mode_sequence, int32_t* template_id, int32_t* status);
+int qmhip_schedule_download(qmhip_ctx* ctx, int B, double* event_times /*[B][max_events]*/, int32_t* modes /*[B][max_events + 1]*/);
+
+/*      Target side — replaces the three command callbacks of QmTargetTrajectoriesInteractiveMarker
+ *      (qm_controllers/include/qm_controllers/QmTargetTrajectoriesPublisher.h:75-112, QmTargetTrajectoriesPublisher.cpp:94-109) and the
+ *      conversion functions of qm_controllers/src/QmTargetTrajectoriesPublisher_node.cpp: kind 1 cmdVelToTargetTrajectories (:71-116),
+ *      2 EeCmdVelToTargetTrajectories (:121-165), 3 EEgoalPoseToTargetTrajectories (:172-208), all through targetPoseToTargetTrajectories
+ *      (:44-68); kind 0 leaves the instance's target untouched.  The observation is the resident (t0, x0); ee_state[B][7] (position, quaternion
+ *      xyzw) may be null: forward kinematics of x0.  ee_through_float != 0 rounds the EE state to float like the qm_msgs::ee_state message does
+ *      (QMController.cpp:246-256).  The 2 knots are written into the solver's target buffers (spare knots of max_ref_knots hold the last one);
+ *      lastEeTarget_ (QmTargetTrajectoriesPublisher.h:52-54) is per-instance device state, set by target_reset. */
+typedef struct qmhip_target_params {
+  double time_to_target;                 /* mpc.timeHorizon, task.info:140 (TIME_TO_TARGET, _node.cpp:226) */
+  double target_displacement_velocity;   /* reference.info:1 */
+  double target_rotation_velocity;       /* reference.info:2 */
+  double com_height;                     /* reference.info:4 */
+} qmhip_target_params;
+int qmhip_target_reset(qmhip_ctx* ctx, int B, const double* last_ee_target /*[7]*/);
+int qmhip_target_from_command(qmhip_ctx* ctx, int B, const int32_t* kind /*[B]*/, const double* cmd /*[B][7]*/, const double* ee_state /*[B][7] or NULL*/,
+                              int ee_through_float, const qmhip_target_params* params);
+int qmhip_target_download(qmhip_ctx* ctx, int B, double* ref_t /*[B][max_ref_knots]*/, double* ref_x /*[B][max_ref_knots][37]*/, double* last_ee_target /*[B][7]*/);
 
 /* ---- policy evaluation: replaces MPC_MRT_Interface::evaluatePolicy (call site QMController.cpp:139-142):
  *      linear interpolation of the last primal solution at time t[b] */

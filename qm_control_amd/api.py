@@ -21,7 +21,9 @@ EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_la
            "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_solve_resident_warm",
            "qmhip_mpc_advance_resident", "qmhip_closed_loop_resident", "qmhip_mpc_download", "qmhip_policy_eval",
            "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
-           "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_microbench_fp64"]
+           "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_microbench_fp64",
+           "qmhip_gait_set_templates", "qmhip_gait_reset", "qmhip_gait_insert_template", "qmhip_gait_update_resident", "qmhip_gait_download", "qmhip_schedule_download",
+           "qmhip_target_reset", "qmhip_target_from_command", "qmhip_target_download"]
 
 
 class QmhipError(RuntimeError):
@@ -227,3 +229,88 @@ class HierarchicalWbc:
         out = np.zeros((B, 54)); st = np.zeros((B, 3), np.int32)
         self.itf._check(self.lib.qmhip_wbc_download(self.itf.h, B, _p(out), _pi(st)), "qmhip_wbc_download")
         return out, st
+
+
+GAIT_MAX_PHASES, GAIT_EVENT_SLOTS = 16, 256
+CMD_NONE, CMD_VEL, CMD_EE_VEL, CMD_EE_GOAL = 0, 1, 2, 3
+
+
+class _TargetParams(C.Structure):
+    _fields_ = [("time_to_target", C.c_double), ("target_displacement_velocity", C.c_double), ("target_rotation_velocity", C.c_double), ("com_height", C.c_double)]
+
+
+class GaitSchedule:
+    """B device-resident copies of the reference's GaitSchedule ([upstream ocs2_legged_robot]; built at QMInterface.cpp:455-480) plus the
+    template table GaitJoyPublisher loads from gait.info (GaitJoyPublisher.cpp:17-33).  Method names follow the upstream class."""
+
+    def __init__(self, interface, gaits, batch, initial_event_times=(0.5,), initial_mode_sequence=(15, 15), default_gait="stance"):
+        """gaits: {name: {"modeSequence": [...], "switchingTimes": [...]}} (scenarios.load_gaits()); initial schedule = reference.info:28-39."""
+        self.itf = interface; self.lib = interface.lib; self.B = batch
+        self.names = list(gaits.keys())
+        G = len(self.names)
+        n_ph = np.zeros(G, dtype=np.int32); times = np.zeros((G, GAIT_MAX_PHASES + 1)); modes = np.zeros((G, GAIT_MAX_PHASES), dtype=np.int32)
+        for g, name in enumerate(self.names):
+            seq, sw = gaits[name]["modeSequence"], gaits[name]["switchingTimes"]
+            if len(seq) > GAIT_MAX_PHASES or len(sw) != len(seq) + 1:
+                raise ValueError("gait template %r: at most %d phases, switchingTimes one longer than modeSequence" % (name, GAIT_MAX_PHASES))
+            n_ph[g] = len(seq); times[g, :len(sw)] = sw; modes[g, :len(seq)] = seq
+        self.itf._check(self.lib.qmhip_gait_set_templates(self.itf.h, G, _pi(n_ph), _p(times), _pi(modes)), "qmhip_gait_set_templates")
+        ev = _f(initial_event_times); mo = np.ascontiguousarray(initial_mode_sequence, dtype=np.int32)
+        self.itf._check(self.lib.qmhip_gait_reset(self.itf.h, batch, len(ev), _p(ev), _pi(mo), self.names.index(default_gait)), "qmhip_gait_reset")
+
+    def insertModeSequenceTemplate(self, gait, start_time, final_time):
+        """gait: one name for every instance, or a list of names / None per instance."""
+        B = self.B
+        req = [gait] * B if (gait is None or isinstance(gait, str)) else list(gait)
+        ids = np.array([-1 if g is None else self.names.index(g) for g in req], dtype=np.int32)
+        st = _f(np.broadcast_to(np.asarray(start_time, dtype=float), (B,)).copy()); fi = _f(np.broadcast_to(np.asarray(final_time, dtype=float), (B,)).copy())
+        self.itf._check(self.lib.qmhip_gait_insert_template(self.itf.h, B, _pi(ids), _p(st), _p(fi)), "qmhip_gait_insert_template")
+
+    def preSolverRun(self, gait, init_time, horizon):
+        """GaitReceiver::preSolverRun [upstream]: a received template is inserted at the end of the current horizon; the upstream call passes the
+        horizon LENGTH as the tiling bound (insertModeSequenceTemplate(template, finalTime, finalTime − initTime))."""
+        init_time = np.broadcast_to(np.asarray(init_time, dtype=float), (self.B,))
+        final = init_time + horizon
+        self.insertModeSequenceTemplate(gait, final, final - init_time)
+
+    def updateSolverSchedule(self, horizon):
+        """SwitchedModelReferenceManager::modifyReferences [upstream]: getModeSchedule(t0 − T, t0 + 2T) for the resident observation times;
+        the result becomes the mode schedule of the next MPC iteration."""
+        self.itf._check(self.lib.qmhip_gait_update_resident(self.itf.h, self.B, C.c_double(horizon)), "qmhip_gait_update_resident")
+
+    def download(self):
+        B = self.B
+        n = np.zeros(B, dtype=np.int32); ev = np.zeros((B, GAIT_EVENT_SLOTS)); mo = np.zeros((B, GAIT_EVENT_SLOTS + 1), dtype=np.int32); tp = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+        self.itf._check(self.lib.qmhip_gait_download(self.itf.h, B, _pi(n), _p(ev), _pi(mo), _pi(tp), _pi(st)), "qmhip_gait_download")
+        return dict(n=n, event_times=ev, mode_sequence=mo, template=tp, status=st)
+
+    def solver_schedule(self):
+        B, ne = self.B, self.itf.max_events
+        ev = np.zeros((B, ne)); mo = np.zeros((B, ne + 1), dtype=np.int32)
+        self.itf._check(self.lib.qmhip_schedule_download(self.itf.h, B, _p(ev), _pi(mo)), "qmhip_schedule_download")
+        return ev, mo
+
+
+class TargetTrajectoriesPublisher:
+    """The command callbacks of QmTargetTrajectoriesInteractiveMarker for B robots (QmTargetTrajectoriesPublisher.h:75-112,
+    QmTargetTrajectoriesPublisher_node.cpp:44-208): commands in, the solver's resident 2-knot TargetTrajectories out."""
+
+    def __init__(self, interface, batch, time_to_target=None, target_displacement_velocity=0.3, target_rotation_velocity=0.1, com_height=0.4,
+                 last_ee_target=(0.52, 0.09, 0.44, 0.5, -0.5, 0.5, -0.5)):
+        self.itf = interface; self.lib = interface.lib; self.B = batch
+        T = interface.settings_blob[996] if time_to_target is None else time_to_target       # mpc.timeHorizon
+        self.params = _TargetParams(T, target_displacement_velocity, target_rotation_velocity, com_height)
+        self.itf._check(self.lib.qmhip_target_reset(self.itf.h, batch, _p(_f(last_ee_target, (7,)))), "qmhip_target_reset")
+
+    def publish(self, kind, cmd, ee_state=None, ee_through_float=False):
+        """kind[B] in {CMD_NONE, CMD_VEL, CMD_EE_VEL, CMD_EE_GOAL}; cmd[B][7]; ee_state[B][7] (None: forward kinematics of the resident x0)."""
+        B = self.B
+        kd = np.ascontiguousarray(np.broadcast_to(np.asarray(kind, dtype=np.int32), (B,)), dtype=np.int32)
+        cm = _f(cmd, (B, 7)); ee = None if ee_state is None else _f(ee_state, (B, 7))
+        self.itf._check(self.lib.qmhip_target_from_command(self.itf.h, B, _pi(kd), _p(cm), _p(ee), int(bool(ee_through_float)), C.byref(self.params)), "qmhip_target_from_command")
+
+    def download(self):
+        B, nr = self.B, self.itf.max_ref_knots
+        rt = np.zeros((B, nr)); rx = np.zeros((B, nr, 37)); le = np.zeros((B, 7))
+        self.itf._check(self.lib.qmhip_target_download(self.itf.h, B, _p(rt), _p(rx), _p(le)), "qmhip_target_download")
+        return rt, rx, le

@@ -10,6 +10,7 @@
 #include "qm_model_io.h"
 #include "qm_pipeline.h"
 #include "qm_wbc_pipeline.h"
+#include "qm_front_pipeline.h"
 
 static std::string g_create_error;
 
@@ -57,9 +58,9 @@ struct HipBackend {
 struct qmhip_ctx {
   int device = 0, max_batch = 0, max_nodes = 0, max_ref = 0, max_ev = 0;
   double mb[MB_SIZE], st[ST_SIZE];
-  HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc;
-  std::string error; int lastB = 0; bool have_solution = false;
-  qmhip_ctx() : mpc(bk), wbc(bk) {}
+  HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc; QmFrontPipeline<HipBackend> front;
+  std::string error; int lastB = 0; bool have_solution = false; int front_B = 0;
+  qmhip_ctx() : mpc(bk), wbc(bk), front(bk) {}
   void fail(const std::string& m) { error = m; }
   // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
   // them (an instance whose line search finds no step just keeps its iterate)
@@ -93,8 +94,9 @@ static int create_common(const double* mb, const double* st, int device, int max
   if (hipStreamCreate(&c->bk.stream) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
   c->mpc.allocate(c->mb, c->st, max_batch, max_nodes, max_ref, max_ev, false);
   c->wbc.allocate(max_batch);
+  c->front.allocate(max_batch);
   c->bk.sync();
-  if (!c->bk.error.empty()) { g_create_error = c->bk.error; c->mpc.release(); c->wbc.release(); hipStreamDestroy(c->bk.stream); delete c; return QMHIP_ERR_HIP; }
+  if (!c->bk.error.empty()) { g_create_error = c->bk.error; c->mpc.release(); c->wbc.release(); c->front.release(); hipStreamDestroy(c->bk.stream); delete c; return QMHIP_ERR_HIP; }
   *out = c; return QMHIP_OK;
 }
 
@@ -120,7 +122,7 @@ int qmhip_create_from_blobs(const double* mb, const double* st, int device, int 
   return create_common(mb, st, device, max_batch, max_nodes, max_ref, max_ev, out);
 }
 void qmhip_destroy(qmhip_ctx* c) {
-  if (!c) return; hipSetDevice(c->device); c->bk.sync(); c->mpc.release(); c->wbc.release();
+  if (!c) return; hipSetDevice(c->device); c->bk.sync(); c->mpc.release(); c->wbc.release(); c->front.release();
   for (auto e : c->bk.pool) hipEventDestroy(e); hipStreamDestroy(c->bk.stream); delete c;
 }
 const char* qmhip_last_error(const qmhip_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
@@ -156,9 +158,57 @@ int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, 
   hipSetDevice(c->device);
   for (int k = 0; k < n_steps; ++k) {
     if (k > 0) c->mpc.advance(B, mpc_dt);
+    if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon);     // device-resident GaitSchedule active: modifyReferences before every MPC call
     c->mpc.grid(B, horizon, true); for (int it = 0; it < c->sqp_iterations(); ++it) c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true;
     c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time0 + k * mpc_dt); c->wbc.step(c->mpc.d, B, period, 0);
   }
+  return c->hipstate();
+}
+// ---- reference / gait front-end ----
+int qmhip_gait_set_templates(qmhip_ctx* c, int n_gaits, const int32_t* n_phases, const double* switching_times, const int32_t* mode_sequence) {
+  if (!c || n_gaits <= 0 || !n_phases || !switching_times || !mode_sequence) { if (c) c->fail("qmhip_gait_set_templates: bad argument"); return QMHIP_ERR_ARG; }
+  for (int g = 0; g < n_gaits; ++g) if (n_phases[g] < 0 || n_phases[g] > QM_GAIT_MAX_PHASES) { c->fail("qmhip_gait_set_templates: a template has more than QMHIP_GAIT_MAX_PHASES phases"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->front.set_templates(n_gaits, n_phases, switching_times, mode_sequence); return c->hipstate();
+}
+int qmhip_gait_reset(qmhip_ctx* c, int B, int n_events, const double* event_times, const int32_t* mode_sequence, int default_template) {
+  if (!c || B <= 0 || B > c->max_batch || n_events < 1 || n_events > QM_GAIT_EVENT_SLOTS || !event_times || !mode_sequence || default_template < 0 || default_template >= c->front.f.n_gaits) {
+    if (c) c->fail("qmhip_gait_reset: bad argument (templates must be set first; the initial schedule needs at least one event)"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->front.phase_transition_stance_time = c->st[ST_PHASE_TRANS_STANCE];
+  c->front.gait_reset(B, n_events, event_times, mode_sequence, default_template); c->front_B = B; return c->hipstate();
+}
+int qmhip_gait_insert_template(qmhip_ctx* c, int B, const int32_t* template_id, const double* start_time, const double* final_time) {
+  if (!c || B <= 0 || B != c->front_B || !template_id || !start_time || !final_time) { if (c) c->fail("qmhip_gait_insert_template: bad argument (B must be the batch of qmhip_gait_reset)"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->front.gait_insert(B, template_id, start_time, final_time); return c->hipstate();
+}
+int qmhip_gait_update_resident(qmhip_ctx* c, int B, double horizon) {
+  if (!c || B <= 0 || B != c->front_B || !(horizon > 0)) { if (c) c->fail("qmhip_gait_update_resident: bad argument (B must be the batch of qmhip_gait_reset)"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->front.gait_schedule(c->mpc.d, B, horizon); return c->hipstate();
+}
+int qmhip_gait_download(qmhip_ctx* c, int B, int32_t* n_events, double* event_times, int32_t* mode_sequence, int32_t* template_id, int32_t* status) {
+  if (!c || B <= 0 || B != c->front_B || !n_events || !event_times || !mode_sequence || !template_id || !status) return QMHIP_ERR_ARG;
+  hipSetDevice(c->device); c->front.gait_download(B, n_events, event_times, mode_sequence, template_id, status); return c->hipstate();
+}
+int qmhip_schedule_download(qmhip_ctx* c, int B, double* ev, int32_t* modes) {
+  if (!c || B <= 0 || B > c->max_batch || !ev || !modes) return QMHIP_ERR_ARG;
+  hipSetDevice(c->device); c->bk.to_host(ev, c->mpc.d.ev, (size_t)B * c->max_ev * 8); c->bk.to_host(modes, c->mpc.d.modes, (size_t)B * (c->max_ev + 1) * 4); return c->hipstate();
+}
+int qmhip_target_reset(qmhip_ctx* c, int B, const double* last_ee_target) {
+  if (!c || B <= 0 || B > c->max_batch || !last_ee_target) return QMHIP_ERR_ARG;
+  hipSetDevice(c->device); c->front.target_reset(B, last_ee_target); return c->hipstate();
+}
+int qmhip_target_from_command(qmhip_ctx* c, int B, const int32_t* kind, const double* cmd, const double* ee_state, int ee_through_float, const qmhip_target_params* p) {
+  if (!c || B <= 0 || B > c->max_batch || !kind || !cmd || !p || !(p->target_displacement_velocity > 0) || !(p->target_rotation_velocity > 0) || c->max_ref < 2) {
+    if (c) c->fail("qmhip_target_from_command: bad argument (max_ref_knots >= 2 required)"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device);
+  c->front.target_from_command(c->mpc.d, B, kind, cmd, ee_state, ee_through_float, p->time_to_target, p->target_displacement_velocity, p->target_rotation_velocity, p->com_height);
+  return c->hipstate();
+}
+int qmhip_target_download(qmhip_ctx* c, int B, double* ref_t, double* ref_x, double* last_ee_target) {
+  if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG;
+  hipSetDevice(c->device);
+  if (ref_t) c->bk.to_host(ref_t, c->mpc.d.ref_t, (size_t)B * c->max_ref * 8);
+  if (ref_x) c->bk.to_host(ref_x, c->mpc.d.ref_x, (size_t)B * c->max_ref * QM_NREF * 8);
+  if (last_ee_target) c->bk.to_host(last_ee_target, c->front.f.last_ee, (size_t)B * 7 * 8);
   return c->hipstate();
 }
 int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) {

@@ -3,6 +3,7 @@
 #include "hip_emu.h"
 #include "../../qm_control_amd/csrc/host/qm_pipeline.h"
 #include "../../qm_control_amd/csrc/host/qm_wbc_pipeline.h"
+#include "../../qm_control_amd/csrc/host/qm_front_pipeline.h"
 
 struct EmuBackend {
   template <class K, class A> void launch(K kernel, int grid, int block, size_t, const A& args) { emu::launch(dim3(grid), dim3(block), [&]() { kernel(args); }); }
@@ -14,13 +15,13 @@ struct EmuBackend {
   void sync() {}
 };
 
-struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; EmuCtx() : mpc(bk), wbc(bk) {} };
+struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; EmuCtx() : mpc(bk), wbc(bk), front(bk) {} };
 
 extern "C" {
 void* emu_create(const double* mb, const double* st, int Bmax, int nmax, int nref, int nev) {
-  EmuCtx* c = new EmuCtx(); c->mpc.allocate(mb, st, Bmax, nmax, nref, nev, true); c->wbc.allocate(Bmax, true); return c;
+  EmuCtx* c = new EmuCtx(); c->mpc.allocate(mb, st, Bmax, nmax, nref, nev, true); c->wbc.allocate(Bmax, true); c->front.allocate(Bmax); c->front.phase_transition_stance_time = st[ST_PHASE_TRANS_STANCE]; return c;
 }
-void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; c->mpc.release(); c->wbc.release(); delete c; }
+void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; c->mpc.release(); c->wbc.release(); c->front.release(); delete c; }
 int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes, double horizon, int max_trials) {
   EmuCtx* c = (EmuCtx*)h;
   c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes);
@@ -61,6 +62,21 @@ void emu_control_step(void* h, int B, double horizon, double period, double time
   EmuCtx* c = (EmuCtx*)h; c->mpc.grid(B, horizon); c->mpc.sqp_iteration(B);
   c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time); c->wbc.step(c->mpc.d, B, period, 0);
   memcpy(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); memcpy(status, c->wbc.w.qp_status, (size_t)B * 3 * 4); if (rbd_out) memcpy(rbd_out, c->wbc.w.rbd, (size_t)B * QM_NRBD * 8);
+}
+// reference / gait front-end (same calls as the qmhip_gait_* / qmhip_target_* entry points)
+void emu_gait_set_templates(void* h, int G, const int* n_phases, const double* times, const int* modes) { ((EmuCtx*)h)->front.set_templates(G, n_phases, times, modes); }
+void emu_gait_reset(void* h, int B, int n0, const double* ev0, const int* mode0, int tpl0) { ((EmuCtx*)h)->front.gait_reset(B, n0, ev0, mode0, tpl0); }
+void emu_gait_insert(void* h, int B, const int* tpl, const double* start, const double* final_t) { ((EmuCtx*)h)->front.gait_insert(B, tpl, start, final_t); }
+void emu_gait_update(void* h, int B, const double* t0, double horizon) { EmuCtx* c = (EmuCtx*)h; memcpy(c->mpc.d.t0, t0, (size_t)B * 8); c->front.gait_schedule(c->mpc.d, B, horizon); }
+void emu_gait_download(void* h, int B, int* n, double* ev, int* mode, int* tpl, int* status) { ((EmuCtx*)h)->front.gait_download(B, n, ev, mode, tpl, status); }
+void emu_schedule_download(void* h, int B, double* ev, int* modes) { EmuCtx* c = (EmuCtx*)h; memcpy(ev, c->mpc.d.ev, (size_t)B * c->mpc.d.nev * 8); memcpy(modes, c->mpc.d.modes, (size_t)B * (c->mpc.d.nev + 1) * 4); }
+void emu_target_reset(void* h, int B, const double* last7) { ((EmuCtx*)h)->front.target_reset(B, last7); }
+void emu_target_from_command(void* h, int B, const double* t0, const double* x0, const int* kind, const double* cmd, const double* ee, int thru_float, double T, double vd, double vr, double ch) {
+  EmuCtx* c = (EmuCtx*)h; memcpy(c->mpc.d.t0, t0, (size_t)B * 8); memcpy(c->mpc.d.x0, x0, (size_t)B * 30 * 8);
+  c->front.target_from_command(c->mpc.d, B, kind, cmd, ee, thru_float, T, vd, vr, ch);
+}
+void emu_target_download(void* h, int B, double* rt, double* rx, double* last) {
+  EmuCtx* c = (EmuCtx*)h; memcpy(rt, c->mpc.d.ref_t, (size_t)B * c->mpc.d.nref * 8); memcpy(rx, c->mpc.d.ref_x, (size_t)B * c->mpc.d.nref * QM_NREF * 8); memcpy(last, c->front.f.last_ee, (size_t)B * 7 * 8);
 }
 int emu_sizes(int which) { int v[] = {SR_SIZE, LQ_DBG_SIZE, PF_SIZE, LQ_LDS_BYTES, RW_LDS_BYTES, WBC_DBG_SIZE}; return v[which]; }
 }

@@ -67,6 +67,52 @@ class Emu:
     def advance(self, dt):
         self.lib.emu_advance(self.h, C.c_int(self.B), C.c_double(dt))
 
+    # ---- reference / gait front-end ----
+    def gait_setup(self, gaits, B, ev0=(0.5,), mode0=(15, 15), default="stance"):
+        self.gait_names = list(gaits.keys()); self.B = B
+        G = len(self.gait_names)
+        n_ph = np.zeros(G, np.int32); times = np.zeros((G, 17)); modes = np.zeros((G, 16), np.int32)
+        for g, name in enumerate(self.gait_names):
+            seq, sw = gaits[name]["modeSequence"], gaits[name]["switchingTimes"]
+            n_ph[g] = len(seq); times[g, :len(sw)] = sw; modes[g, :len(seq)] = seq
+        self.lib.emu_gait_set_templates(self.h, G, _pi(n_ph), _p(times), _pi(modes))
+        ev = np.ascontiguousarray(ev0, float); mo = np.ascontiguousarray(mode0, np.int32)
+        self.lib.emu_gait_reset(self.h, B, len(ev), _p(ev), _pi(mo), self.gait_names.index(default))
+
+    def gait_insert(self, names, start, final):
+        B = self.B
+        ids = np.array([-1 if g is None else self.gait_names.index(g) for g in names], np.int32)
+        st = np.ascontiguousarray(np.broadcast_to(np.asarray(start, float), (B,))); fi = np.ascontiguousarray(np.broadcast_to(np.asarray(final, float), (B,)))
+        self.lib.emu_gait_insert(self.h, B, _pi(ids), _p(st), _p(fi))
+
+    def gait_update(self, t0, horizon):
+        t0 = np.ascontiguousarray(t0, float)
+        self.lib.emu_gait_update(self.h, self.B, _p(t0), C.c_double(horizon))
+
+    def gait_download(self):
+        B = self.B
+        n = np.zeros(B, np.int32); ev = np.zeros((B, 256)); mo = np.zeros((B, 257), np.int32); tp = np.zeros(B, np.int32); st = np.zeros(B, np.int32)
+        self.lib.emu_gait_download(self.h, B, _pi(n), _p(ev), _pi(mo), _pi(tp), _pi(st))
+        return dict(n=n, event_times=ev, mode_sequence=mo, template=tp, status=st)
+
+    def schedule_download(self):
+        ev = np.zeros((self.B, self.nev)); mo = np.zeros((self.B, self.nev + 1), np.int32)
+        self.lib.emu_schedule_download(self.h, self.B, _p(ev), _pi(mo))
+        return ev, mo
+
+    def target_reset(self, B, last7):
+        self.B = B
+        self.lib.emu_target_reset(self.h, B, _p(np.ascontiguousarray(last7, float)))
+
+    def target_from_command(self, t0, x0, kind, cmd, ee, thru_float, T, vd, vr, ch):
+        B = self.B
+        a = lambda v, t=float: np.ascontiguousarray(v, t)
+        self.lib.emu_target_from_command(self.h, B, _p(a(t0)), _p(a(x0)), _pi(a(kind, np.int32)), _p(a(cmd)), None if ee is None else _p(a(ee)), int(thru_float),
+                                         C.c_double(T), C.c_double(vd), C.c_double(vr), C.c_double(ch))
+        rt = np.zeros((B, self.nref)); rx = np.zeros((B, self.nref, 37)); last = np.zeros((B, 7))
+        self.lib.emu_target_download(self.h, B, _p(rt), _p(rx), _p(last))
+        return rt, rx, last
+
     def buf(self, name, shape, dtype=np.float64):
         ptr = self.lib.emu_buffer(self.h, name.encode())
         assert ptr, name
