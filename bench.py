@@ -47,7 +47,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("QM_BENCH_FORCE_DIST"):      # (the env switch exercises the RCCL path on a single GPU)
         import torch
         import torch.distributed as dist_mod
         torch.cuda.set_device(local)
