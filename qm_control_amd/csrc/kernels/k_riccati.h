@@ -64,7 +64,20 @@ template <int KT, int IT, int JT>
 __device__ __forceinline__ void rw_gemm_tn(const qm_d4 (&Z)[KT][IT], const qm_d4 (&Y)[KT][JT], qm_d4 (&P)[IT][JT], int ksteps, bool neg) { qm_gemm_tn<KT, IT, JT>(Z, Y, P, 0, ksteps, neg); }
 template <int IT, int JT>
 __device__ __forceinline__ void rw_zero(qm_d4 (&T)[IT][JT]) { qm_frag_zero<IT, JT>(T); }
+// P += (−) Zᵀ Y for a SYMMETRIC 2x2-tile result: only the tiles (0,0), (0,1), (1,1) are formed — the lower-left tile is the mirror image
+// of (0,1) and is restored by the symmetrisation at the end of the stage (12 MFMAs less per stage)
+template <int KT>
+__device__ __forceinline__ void rw_gemm_tn_upper(const qm_d4 (&Z)[KT][2], const qm_d4 (&Y)[KT][2], qm_d4 (&P)[2][2], int ksteps, bool neg) {
+  qm_d4 Z0[KT][1], Z1[KT][1], Y1[KT][1], P0[1][2], P1[1][1];
+#pragma unroll
+  for (int K = 0; K < KT; ++K) { Z0[K][0] = Z[K][0]; Z1[K][0] = Z[K][1]; Y1[K][0] = Y[K][1]; }
+  P0[0][0] = P[0][0]; P0[0][1] = P[0][1]; P1[0][0] = P[1][1];
+  qm_gemm_tn<KT, 1, 2>(Z0, Y, P0, 0, ksteps, neg);
+  qm_gemm_tn<KT, 1, 1>(Z1, Y1, P1, 0, ksteps, neg);
+  P[0][0] = P0[0][0]; P[0][1] = P0[0][1]; P[1][1] = P1[0][0];
+}
 // D-layout load of a rows x cols row-major matrix (leading dim ld); optional vector in column 30 (rows < rows)
+// (measured: exec-masked conditional loads are faster here than unconditional clamped loads + selects)
 template <int IT, int JT>
 __device__ __forceinline__ void rw_load(qm_d4 (&T)[IT][JT], const double* src, int ld, int rows, int cols, const double* col30) {
   const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
@@ -117,7 +130,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
     rw_gemm_tn<2, 2, MT>(S, Bm, SB, 8, false);                       // S B
     rw_gemm_tn<2, MT, 2>(Bm, SA, Hux, 8, false);                     // [Hux | hu]
     rw_gemm_tn<2, MT, MT>(Bm, SB, Huu, 8, false);                    // Huu
-    rw_gemm_tn<2, 2, 2>(A, SA, Sn, 8, false);                        // [Q + Aᵀ S A | q + Aᵀ (S b + s)]  (row 30 is garbage, masked below)
+    rw_gemm_tn_upper<2>(A, SA, Sn, 8, false);                        // [Q + Aᵀ S A | q + Aᵀ (S b + s)], upper tiles  (row 30 is garbage, masked below)
   }
   RWT(1)
   // ---- Cholesky of Huu and forward substitution of [Hux | hu] IN FRAGMENT LAYOUT (right-looking, one pivot per step).
@@ -206,7 +219,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
       }
   } else rw_zero<MT, 2>(W);
   RWT(4)
-  if (!(skip & 2)) rw_gemm_tn<MT, 2, 2>(W, W, Sn, (m + 3) >> 2, true);   // −[Wᵀ W | Wᵀ y]
+  if (!(skip & 2)) rw_gemm_tn_upper<MT>(W, W, Sn, (m + 3) >> 2, true);   // −[Wᵀ W | Wᵀ y], upper tiles
   RWT(5)
   // ---- S' <- sym(Sn[0:30, 0:30]), s' <- Sn[0:30, 30] ----
 #pragma unroll
@@ -222,11 +235,12 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
         for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, cc = 16 * J + c; S[I][J][r] = (row < 30 && cc < 30) ? Sn[I][J][r] : 0.0; }
     return;
   }
+  // the diagonal tiles are averaged with their transposes, the lower-left tile is the transpose of the upper-right one (never computed)
   qm_wave_sync();
 #pragma unroll
   for (int I = 0; I < 2; ++I)
 #pragma unroll
-    for (int J = 0; J < 2; ++J)
+    for (int J = I; J < 2; ++J)
 #pragma unroll
       for (int r = 0; r < 4; ++r) buf[(16 * I + g + 4 * r) * RW_TLD + 16 * J + c] = Sn[I][J][r];
   qm_wave_sync();
@@ -236,8 +250,9 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
     for (int J = 0; J < 2; ++J)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + g + 4 * r, cc = 16 * J + c;
-        S[I][J][r] = (row < 30 && cc < 30) ? 0.5 * (Sn[I][J][r] + buf[cc * RW_TLD + row]) : 0.0;
+        const int row = 16 * I + g + 4 * r, cc = 16 * J + c; const double tr = buf[cc * RW_TLD + row];
+        const double v = (I == J) ? 0.5 * (Sn[I][J][r] + tr) : ((I < J) ? Sn[I][J][r] : tr);
+        S[I][J][r] = (row < 30 && cc < 30) ? v : 0.0;
       }
   RWT(6)
 #undef RWT
