@@ -150,8 +150,8 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
     // The pivots run one step AHEAD of the matrix cores: d_{j+1} = H[j+1][j+1] − H[j][j+1]² / d_j is formed from two entries of the
     // not-yet-updated fragments, so its reciprocal chain overlaps the MFMAs of step j instead of waiting for their result.
     double djj = qm_bcast(Huu[0][0][0], 0);
-    double rd = __builtin_amdgcn_rcp(djj);                           // 1/d_j: hardware estimate + two Newton steps
-    rd = fma(fma(-djj, rd, 1.0), rd, rd); rd = fma(fma(-djj, rd, 1.0), rd, rd);
+    double rd = __builtin_amdgcn_rcp(djj);                           // 1/d_j: hardware estimate (2^-24) + one third-order correction
+    { const double e = fma(-djj, rd, 1.0); rd = fma(fma(e, e, e), rd, rd); }
 #pragma unroll
     for (int j = 0; j < QM_MMAX; ++j) if (j < 16 * MT && j < m) {
       const int I = j >> 4, r = (j & 15) >> 2, gj = j & 3;
@@ -176,7 +176,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
       __builtin_amdgcn_sched_barrier(0);
       Hux[I][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], Hux[I][0][r], Hux[I][0], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      double e0 = fma(-djj, r0, 1.0); r0 = fma(e0, r0, r0); e0 = fma(-djj, r0, 1.0);
+      double e0 = fma(-djj, r0, 1.0); e0 = fma(e0, e0, e0);         // r0 (1 + e + e²): the 2^-24 hardware estimate to ≈ 1 ulp in one third-order step
       __builtin_amdgcn_sched_barrier(0);
       Hux[I][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], Hux[I][1][r], Hux[I][1], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);

@@ -102,16 +102,20 @@ __device__ __forceinline__ void dev_rot_error(const double* Rl, const double* Rr
 }
 
 // Householder scalars of a pivot column with squared norm nrm2 and pivot entry g: alpha = −sign(g)|x|, vk = g − alpha, b2 = 2 / (v·v).
-// v·v = 2 |x| (|x| + |g|), so one reciprocal square root and one reciprocal (hardware estimates + two Newton steps each) replace
-// the sqrt and the division of the dependency chain; ok = false for a null column.
+// v·v = 2 |x| (|x| + |g|), so b2 = (1/|x|) · 1/(|x| + |g|): one reciprocal square root and one reciprocal instead of a sqrt and a division.
+// This sits on the critical path of every Householder step of a lone wave (≈ 16 cycles per dependent f64 op), so the chain is kept short:
+// the hardware estimates (v_rsq_f64 / v_rcp_f64, 2^-24 on gfx950, measured) get ONE third-order correction each (error e³ ≈ 2^-70), and the
+// reciprocal's estimate is started from the ESTIMATED norm so that it overlaps the refinement of the rsqrt.  ok = false for a null column.
 __device__ __forceinline__ bool qm_house_scalars(double nrm2, double g, double& alpha, double& vk, double& b2) {
   const bool ok = nrm2 > 0.0;
-  const double x = ok ? nrm2 : 1.0;
-  double r = __builtin_amdgcn_rsq(x);
-  r = fma(0.5 * r, fma(-x * r, r, 1.0), r); r = fma(0.5 * r, fma(-x * r, r, 1.0), r);
-  const double nrm = x * r, den = nrm + fabs(g);
-  double q = __builtin_amdgcn_rcp(den);
-  q = fma(q, fma(-den, q, 1.0), q); q = fma(q, fma(-den, q, 1.0), q);
+  const double x = ok ? nrm2 : 1.0, ag = fabs(g);
+  const double y0 = __builtin_amdgcn_rsq(x);                        // 1/|x| (2^-24)
+  const double h = x * y0;                                          // |x| (2^-24)
+  const double q0 = __builtin_amdgcn_rcp(h + ag);                   // 1/(|x| + |g|) from the estimated norm: off the rsqrt's chain
+  const double e = fma(-h, y0, 1.0), t = fma(0.375, e, 0.5);        // 1/sqrt(x) = y0 (1 + e/2 + 3 e²/8 + O(e³)),  e = 1 − x y0²
+  const double r = fma(y0 * e, t, y0), nrm = fma(h * e, t, h);      // 1/|x| and |x| = x / |x|, both to ≈ 1 ulp
+  const double den = nrm + ag, e2 = fma(-den, q0, 1.0);
+  const double q = fma(fma(e2, e2, e2), q0, q0);                    // q0 (1 + e2 + e2²): 1/den to ≈ 1 ulp
   alpha = g > 0.0 ? -nrm : nrm; vk = g - alpha; b2 = ok ? r * q : 0.0;
   return ok;
 }
