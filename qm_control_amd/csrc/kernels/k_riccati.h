@@ -44,7 +44,7 @@ struct QmRiccatiArgs {
 /* forward staging (aliases the backward buffers): rows padded so that one-row-per-lane reads are bank-conflict free */
 #define RF_A   0                  /* [30][31] Ap */
 #define RF_B   930                /* [30][19] Bp */
-#define RF_PX  1500               /* [30][31] Px */
+#define RF_PX  1500               /* [12][31] Px rows 12..23 (the only non-zero ones: leg joint velocities) + one zero row */
 #define RF_PU  2430               /* [30][19] Pu */
 #define RF_W   3000               /* [18][31] W  */
 #define RF_L   3558               /* [18][19] L (diagonal holds 1/L_jj) */
@@ -58,7 +58,7 @@ struct QmRiccatiArgs {
 #define RW_MAXNODES 512
 #define RW_LDS_DOUBLES (RF_LIST + RW_MAXNODES / 2)
 #define RW_LDS_BYTES (RW_LDS_DOUBLES * 8)
-#define RF_NLOAD 61               /* ceil((1440 + 2304 + 108 + 18) / 64) */
+#define RF_NLOAD 53               /* ceil((1440 + 864 + 360 + 540 + 108 + 18) / 64) */
 
 template <int KT, int IT, int JT>
 __device__ __forceinline__ void rw_gemm_tn(const qm_d4 (&Z)[KT][IT], const qm_d4 (&Y)[KT][JT], qm_d4 (&P)[IT][JT], int ksteps, bool neg) { qm_gemm_tn<KT, IT, JT>(Z, Y, P, 0, ksteps, neg); }
@@ -259,19 +259,22 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 }
 
 // flat, fully coalesced fetch of everything the forward rollout needs from one stage record: element e of the concatenation
-// [Ap Bp | W L Px Pu | bp qp rp Pe | y] lives at record offset rf_src(e)
-__device__ __forceinline__ int rf_src(int e) { return (e < 1440) ? e : ((e < 3744) ? e + (SR_PP - 1440) : ((e < 3852) ? e + (SR_BPV - 3744) : e + (SR_KFF - 3852))); }
+// [Ap Bp | W L | Px rows 12..23 | Pu | bp qp rp Pe | y] lives at record offset rf_src(e).  (Px has no other non-zero rows: contact forces
+// and arm joint velocities are free or constant inputs, only the leg joint velocities depend on dx through the constraints.)
+__device__ __forceinline__ int rf_src(int e) {
+  return (e < 1440) ? e : ((e < 2304) ? e + (SR_PP - 1440) : ((e < 2664) ? e + (SR_PX + 360 - 2304) : ((e < 3204) ? e + (SR_PU - 2664) : ((e < 3312) ? e + (SR_BPV - 3204) : e + (SR_KFF - 3312)))));
+}
 // ... and goes to this (row-padded) LDS slot
 __device__ __forceinline__ int rf_dst(int e) {
   if (e < 900) return RF_A + (e / 30) * 31 + e % 30;
   if (e < 1440) { const int f = e - 900; return RF_B + (f / QM_MMAX) * 19 + f % QM_MMAX; }
   if (e < 1980) { const int f = e - 1440; return RF_W + (f / 30) * 31 + f % 30; }
   if (e < 2304) { const int f = e - 1980; return RF_L + (f % QM_MMAX) * 19 + f / QM_MMAX; }     // the record holds Lᵀ
-  if (e < 3204) { const int f = e - 2304; return RF_PX + (f / 30) * 31 + f % 30; }
-  if (e < 3744) { const int f = e - 3204; return RF_PU + (f / QM_MMAX) * 19 + f % QM_MMAX; }
-  return RF_V + (e - 3744);
+  if (e < 2664) { const int f = e - 2304; return RF_PX + (f / 30) * 31 + f % 30; }
+  if (e < 3204) { const int f = e - 2664; return RF_PU + (f / QM_MMAX) * 19 + f % QM_MMAX; }
+  return RF_V + (e - 3204);
 }
-#define RF_TOTAL 3870
+#define RF_TOTAL 3330
 
 __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   extern __shared__ double qm_smem[];
@@ -325,10 +328,11 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // same wave, same CU: ordering only, no L2 write-back
   // ---- forward rollout.  Each stage record is fetched flat (512 B per wave instruction) one stage ahead into registers, dropped
   //      into row-padded LDS, and consumed one matrix row per lane: lanes 0..29 rows of [Ap Bp bp], lanes 32..61 rows of
-  //      [Px Pu Pe], lanes 0..m-1 also row i of W and column i of L; lane c carries dx[c] ----
+  //      [Px Pu Pe] (only rows 12..23 of Px exist), lanes 0..m-1 also row i of W and column i of L; lane c carries dx[c] ----
   double dxl = (l < 30) ? a.x0[(size_t)b * 30 + l] - a.x[(0 * a.B + b) * 30 + l] : 0.0;
   double armijo = 0.0, dx2 = 0.0, du2 = 0.0;
   const int half = l >> 5, r = l & 31;
+  if (l < 31) buf[RF_PX + 12 * 31 + l] = 0.0;              // the zero row of the Px block (no stage writes it; a wave sync precedes its first use)
   double pf[RF_NLOAD];
   auto fetch = [&](int k) {
     const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
@@ -351,7 +355,8 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     qm_wave_sync();
     { int kn = k + 1; while (kn < n - 1 && evlist(kn) == QM_EV_PRE) ++kn; if (kn < n - 1) fetch(kn); }
     const int rr = (r < 30) ? r : 29, lw = (l < m) ? l : 0;          // idle lanes read a valid row and drop the result
-    const double* rowA = buf + (half ? RF_PX : RF_A) + rr * 31; const double* rowB = buf + (half ? RF_PU : RF_B) + rr * 19;
+    const double* rowA = half ? buf + RF_PX + ((rr >= 12 && rr < 24) ? rr - 12 : 12) * 31 : buf + RF_A + rr * 31;      // row 12 of the Px block: zeros
+    const double* rowB = buf + (half ? RF_PU : RF_B) + rr * 19;
     const double* rowW = buf + RF_W + lw * 31; const double* vecs = buf + RF_V;
     double acc = vecs[half ? 78 + rr : rr];
     double t = vecs[108 + lw];
