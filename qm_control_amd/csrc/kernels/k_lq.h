@@ -111,14 +111,14 @@ __device__ __forceinline__ void lw_get_col30(const qm_d4 (&F)[IT][2], double* v,
 
 // projected cost + record stores; MT = tiles covering the m reduced inputs
 template <int MT>
-__device__ __forceinline__ void lw_project(double* S, double* rec, int m, const qm_d4 (&Bdt)[2][2], const qm_d4 (&PxA)[2][2], const qm_d4 (&PuF)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
+__device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu, int m, const qm_d4 (&Bdt)[2][2], const qm_d4 (&PxA)[2][2], const qm_d4 (&PuF)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
   const int l = threadIdx.x & 63;
   qm_d4 Pu[2][MT];
 #pragma unroll
   for (int I = 0; I < 2; ++I)
 #pragma unroll
     for (int J = 0; J < MT; ++J) Pu[I][J] = PuF[I][J];
-  qm_frag_store<2, MT>(Pu, rec + SR_PU, QM_MMAX, 30, m);
+  if (store_pu) qm_frag_store<2, MT>(Pu, rec + SR_PU, QM_MMAX, 30, m);
   { qm_d4 Bp[2][MT]; qm_frag_zero<2, MT>(Bp); qm_gemm_tn<2, 2, MT>(Bdt, Pu, Bp, 0, 8, false); qm_frag_store<2, MT>(Bp, rec + SR_BP, QM_MMAX, 30, m); }   // Bp = Bd Pu
   // [R Px | R Pe + r]: Px rows 12..23 (k-steps 3..5); Pe also has rows 0..11 (column 30 only -> tile column 1, k-steps 0..2)
   qm_d4 RPx[2][2]; qm_frag_zero<2, 2>(RPx);
@@ -561,7 +561,10 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   LQT()
   // ---- projected cost + stores ----
   double rpe = 0.0;
-  if (m <= 16) lw_project<1>(S, rec, m, Bdt, PxA, PuF, Rm, Qa, rpe); else lw_project<2>(S, rec, m, Bdt, PxA, PuF, Rm, Qa, rpe);
+  if (m <= 16) lw_project<1>(S, rec, dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe); else lw_project<2>(S, rec, dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe);
+  // what K3's forward rollout needs to apply Pu without reading it: the swing legs' null-space blocks and the contact mode
+  if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
+  if (l == 24) rec[SR_MODEF] = (double)mode;
   if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
   {
     qm_d4 PxO[2][2];

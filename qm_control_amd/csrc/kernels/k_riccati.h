@@ -45,10 +45,10 @@ struct QmRiccatiArgs {
 #define RF_A   0                  /* [30][31] Ap */
 #define RF_B   930                /* [30][19] Bp */
 #define RF_PX  1500               /* [12][31] Px rows 12..23 (the only non-zero ones: leg joint velocities) + one zero row */
-#define RF_PU  2430               /* [30][19] Pu */
+#define RF_PU  2430               /* [19] zeros (Pu itself is not fetched: identity columns and the swing blocks of RF_V) */
 #define RF_W   3000               /* [18][31] W  */
 #define RF_L   3558               /* [18][19] L (diagonal holds 1/L_jj) */
-#define RF_V   3900               /* bp(30) qp(30) rp(18) Pe(30) | y(18) */
+#define RF_V   3900               /* bp(30) qp(30) rp(18) Pe(30) | y(18) | pad(2) swing blocks [4][6] (128..151) mode (152) */
 /* backward prefetch buffer (global_load_lds): a flat copy of record fields [0, 3204) = Ap Bp Qp Pp Rp and [4644, 4722) = bp qp rp of the
    NEXT regular stage, landing while the current stage computes; lives behind the 1200-double Cholesky / transposition buffer */
 #define RP_REC   1200
@@ -58,7 +58,7 @@ struct QmRiccatiArgs {
 #define RW_MAXNODES 512
 #define RW_LDS_DOUBLES (RF_LIST + RW_MAXNODES / 2)
 #define RW_LDS_BYTES (RW_LDS_DOUBLES * 8)
-#define RF_NLOAD 53               /* ceil((1440 + 864 + 360 + 540 + 108 + 18) / 64) */
+#define RF_NLOAD 44               /* ceil((1440 + 864 + 360 + 108 + 18 + 24 + 1) / 64) */
 
 template <int KT, int IT, int JT>
 __device__ __forceinline__ void rw_gemm_tn(const qm_d4 (&Z)[KT][IT], const qm_d4 (&Y)[KT][JT], qm_d4 (&P)[IT][JT], int ksteps, bool neg) { qm_gemm_tn<KT, IT, JT>(Z, Y, P, 0, ksteps, neg); }
@@ -259,10 +259,12 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 }
 
 // flat, fully coalesced fetch of everything the forward rollout needs from one stage record: element e of the concatenation
-// [Ap Bp | W L | Px rows 12..23 | Pu | bp qp rp Pe | y] lives at record offset rf_src(e).  (Px has no other non-zero rows: contact forces
-// and arm joint velocities are free or constant inputs, only the leg joint velocities depend on dx through the constraints.)
+// [Ap Bp | W L | Px rows 12..23 | bp qp rp Pe | y | swing blocks | mode] lives at record offset rf_src(e).  (Px has no other non-zero rows:
+// contact forces and arm joint velocities are free or constant inputs, only the leg joint velocities depend on dx through the constraints.
+// Pu is not read at all: its columns are unit vectors — stance force components, arm joint velocities — and one 3x2 block per swing leg.)
 __device__ __forceinline__ int rf_src(int e) {
-  return (e < 1440) ? e : ((e < 2304) ? e + (SR_PP - 1440) : ((e < 2664) ? e + (SR_PX + 360 - 2304) : ((e < 3204) ? e + (SR_PU - 2664) : ((e < 3312) ? e + (SR_BPV - 3204) : e + (SR_KFF - 3312)))));
+  return (e < 1440) ? e : ((e < 2304) ? e + (SR_PP - 1440) : ((e < 2664) ? e + (SR_PX + 360 - 2304) : ((e < 2772) ? e + (SR_BPV - 2664) : ((e < 2790) ? e + (SR_KFF - 2772) :
+         ((e < 2814) ? e + (SR_SWG - 2790) : SR_MODEF)))));
 }
 // ... and goes to this (row-padded) LDS slot
 __device__ __forceinline__ int rf_dst(int e) {
@@ -271,10 +273,10 @@ __device__ __forceinline__ int rf_dst(int e) {
   if (e < 1980) { const int f = e - 1440; return RF_W + (f / 30) * 31 + f % 30; }
   if (e < 2304) { const int f = e - 1980; return RF_L + (f % QM_MMAX) * 19 + f / QM_MMAX; }     // the record holds Lᵀ
   if (e < 2664) { const int f = e - 2304; return RF_PX + (f / 30) * 31 + f % 30; }
-  if (e < 3204) { const int f = e - 2664; return RF_PU + (f / QM_MMAX) * 19 + f % QM_MMAX; }
-  return RF_V + (e - 3204);
+  if (e < 2790) return RF_V + (e - 2664);
+  return RF_V + 128 + (e - 2790);
 }
-#define RF_TOTAL 3330
+#define RF_TOTAL 2815
 
 __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   extern __shared__ double qm_smem[];
@@ -333,6 +335,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   double armijo = 0.0, dx2 = 0.0, du2 = 0.0;
   const int half = l >> 5, r = l & 31;
   if (l < 31) buf[RF_PX + 12 * 31 + l] = 0.0;              // the zero row of the Px block (no stage writes it; a wave sync precedes its first use)
+  if (l < 19) buf[RF_PU + l] = 0.0;
   double pf[RF_NLOAD];
   auto fetch = [&](int k) {
     const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     { int kn = k + 1; while (kn < n - 1 && evlist(kn) == QM_EV_PRE) ++kn; if (kn < n - 1) fetch(kn); }
     const int rr = (r < 30) ? r : 29, lw = (l < m) ? l : 0;          // idle lanes read a valid row and drop the result
     const double* rowA = half ? buf + RF_PX + ((rr >= 12 && rr < 24) ? rr - 12 : 12) * 31 : buf + RF_A + rr * 31;      // row 12 of the Px block: zeros
-    const double* rowB = buf + (half ? RF_PU : RF_B) + rr * 19;
+    const double* rowB = half ? buf + RF_PU : buf + RF_B + rr * 19;                 // input-space rows: a row of zeros, Pu ut is assembled below
     const double* rowW = buf + RF_W + lw * 31; const double* vecs = buf + RF_V;
     double acc = vecs[half ? 78 + rr : rr];
     double t = vecs[108 + lw];
@@ -375,11 +378,29 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
       t -= lq * vq;                                       // lanes i < q: L[q][i] v_q   (lane q: its t is dead)
     }
     const double ut = -v;
+    // (Pu ut)[row] for the lanes that hold a row of du: a stance force component or an arm joint velocity IS one entry of ut, a swing leg's
+    // joint velocity combines the two null-space coordinates of its leg, swing forces get nothing (Pe carries −F)
+    double puut;
+    { const int md = (int)vecs[152];
+      int nst = 0;
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) nst += mode_flag(md, kq);
+      const int row = half ? rr : 0;
+      const int kk = (row < 12) ? row / 3 : ((row < 24) ? chain_to_contact((row - 12) / 3) : 0), r3 = (row < 12) ? row % 3 : ((row < 24) ? (row - 12) % 3 : row - 24);
+      int before_st = 0, before_sw = 0;
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq) if (kq < kk) { before_st += mode_flag(md, kq); before_sw += !mode_flag(md, kq); }
+      const bool st = mode_flag(md, kk);
+      const int col = (row < 12) ? 3 * before_st + r3 : ((row < 24) ? 3 * nst + 2 * before_sw : 3 * nst + 2 * (4 - nst) + r3);
+      const double c1 = (row < 12) ? (st ? 1.0 : 0.0) : ((row < 24) ? (st ? 0.0 : vecs[128 + 6 * kk + r3]) : 1.0);
+      const double c2 = (row >= 12 && row < 24 && !st) ? vecs[128 + 6 * kk + 3 + r3] : 0.0;
+      const double u1 = __shfl(ut, col & 63, 64), u2 = __shfl(ut, (col + 1) & 63, 64);
+      puut = (half && r < 30) ? c1 * u1 + c2 * u2 : 0.0; }
     armijo += qv * dxl + rp * ut;
     { double bp[3] = {0.0, 0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < QM_MMAX; ++q) bp[q % 3] += rowB[q] * qm_bcast(ut, q);          // ut == 0 on lanes >= m: no bound needed
-      acc += (bp[0] + bp[1]) + bp[2]; }
+      acc += ((bp[0] + bp[1]) + bp[2]) + puut; }
     if (half && r < 30) { a.du[nb * 30 + r] = acc; du2 += acc * acc; }
     dxl = (l < 30) ? acc : 0.0;
   }

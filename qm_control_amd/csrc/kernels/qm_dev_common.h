@@ -259,12 +259,14 @@ __device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* 
 #define SR_PP   2340                   /* [18][30]  Puᵀ(P + R Px)       */
 #define SR_RP   2880                   /* [18][18]  Puᵀ R Pu            */
 #define SR_PX   3204                   /* [30][30]  du = Pe + Px dx + Pu ut */
-#define SR_PU   4104                   /* [30][18]                      */
+#define SR_PU   4104                   /* [30][18]  (written only with the debug records: K3 rebuilds Pu ut from SR_SWG / SR_MODEF) */
 #define SR_BPV  4644                   /* [30]      b + B Pe            */
 #define SR_QPV  4674                   /* [30]                          */
 #define SR_RPV  4704                   /* [18]                          */
 #define SR_PE   4722                   /* [30]                          */
-#define SR_K    4752                   /* [18][30]  unused (feedback gains are not formed: the reference runs a feedforward policy) */
+#define SR_K    4752                   /* [18][30]  free (feedback gains are not formed: the reference runs a feedforward policy); profiling stamps use [0, 16) */
+#define SR_SWG   (SR_K + 32)            /* [4][6]    per contact: the 3x2 null-space block of a swing leg's joint velocities (columns of Pu) */
+#define SR_MODEF (SR_K + 56)            /* contact mode of the interval (as double): Pu = {identity columns, SR_SWG blocks} is rebuilt from it */
 #define SR_KFF  5292                   /* [18]  y = L⁻¹ hu (written by K3) */
 #define SR_SCAL 5310                   /* [0]=m (as double) [1]=cp      */
 #define SR_SIZE 5312
