@@ -566,13 +566,12 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
   if (l == 24) rec[SR_MODEF] = (double)mode;
   if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
-  {
-    qm_d4 PxO[2][2];
+  // Px: only rows 12..23 (leg joint velocities) are non-zero and only they are stored / read back by K3 (register (I = 0, r = 3), (1, 0), (1, 1))
 #pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-      for (int J = 0; J < 2; ++J) PxO[I][J] = PxA[I][J];
-    qm_frag_store<2, 2>(PxO, rec + SR_PX, 30, 30, 30);           // column 30 (Pe) is outside the 30 stored columns
+  for (int J = 0; J < 2; ++J) {
+    const int col = 16 * J + c;
+    if (col < 30) { rec[SR_PX + (12 + g) * 30 + col] = PxA[0][J][3]; rec[SR_PX + (16 + g) * 30 + col] = PxA[1][J][0]; rec[SR_PX + (20 + g) * 30 + col] = PxA[1][J][1]; }
+    if (dbg && col < 30) { for (int r = 0; r < 3; ++r) rec[SR_PX + (g + 4 * r) * 30 + col] = 0.0; rec[SR_PX + (24 + g) * 30 + col] = 0.0; if (g < 2) rec[SR_PX + (28 + g) * 30 + col] = 0.0; }
   }
   if (l == 0) { rec[SR_SCAL] = (double)m; rec[SR_SCAL + 1] = ctot + rpe; }
   LQT()
