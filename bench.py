@@ -22,8 +22,8 @@ sys.path.insert(0, ROOT)
 # algorithmic FP64 work and HBM bytes per unit of each kernel (DESIGN.md §5 derives every figure)
 #   unit = one non-event shooting interval (lq, riccati) or one instance (wbc)
 KERNEL_MODEL = {
-    # K1b: LQ approximation + projection. bytes: stage record written (Ap Bp Qp Pp Rp, the 12 non-zero rows of Px, vectors, swing blocks = 3757 doubles; Pu is not stored) + kin record / inputs read (~620)
-    "lq": {"flop": 190e3 + 410e3, "bytes": (3757 + 620) * 8.0, "unit": "interval"},
+    # K1b: LQ approximation + projection. bytes: stage record written (Ap Bp, the upper tiles of Qp, Pp Rp, the 12 non-zero rows of Px, vectors, swing blocks = 3533 doubles; Pu is not stored) + kin record / inputs read (~620)
+    "lq": {"flop": 190e3 + 410e3, "bytes": (3533 + 620) * 8.0, "unit": "interval"},
     # K3: backward sweep reads [Ap|bp] Bp [Qp|qp] [Pp|rp] Rp (3282) and writes L W y (882); forward rollout reads Ap Bp W L, the 12 non-zero rows of Px, vectors and
     #     the swing blocks (2815; Pu is rebuilt from the contact mode), x/dx/du (120)
     "riccati": {"flop": 250e3, "bytes": (3282 + 882 + 2815 + 120) * 8.0, "unit": "interval"},

@@ -140,7 +140,14 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
   rpe = qm_wave_sum((l < 30) ? (S[LW_V_RV + l] + 0.5 * (S[LW_V_RR + l] - S[LW_V_RV + l])) * S[LW_V_PE + l] : 0.0);
   // [Qp | qp] = [Q | q] + Pxᵀ [R Px | rr]
   qm_gemm_tn<2, 2, 2>(PxA, RPx, Qa, 3, 6, false);
-  qm_frag_store<2, 2>(Qa, rec + SR_QP, 30, 30, 30);
+  { // Qp is symmetric and K3 forms only the upper tiles of the value function: the lower-left tile (rows 16.., columns < 16) is not stored
+    const int g = l >> 4, c = l & 15;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = I; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < 30 && col < 30) rec[SR_QP + row * 30 + col] = Qa[I][J][r]; } }
   qm_wave_sync();
   lw_get_col30<2>(Qa, S + LW_V_QV, 30);
   // [Pp | rp] = Puᵀ [R Px | rr]
