@@ -157,3 +157,41 @@ def test_emulated_targets_vs_oracle(emu):
     rt, rx, last = e.target_from_command(t0, x0, np.full(B, 2, np.int32), np.zeros((B, 7)), None, 0, T, vd, vr, ch)
     assert np.all(np.isfinite(rx)) and np.allclose(np.linalg.norm(rx[:, 0, 33:37], axis=1), 1.0, atol=1e-12)
     assert np.allclose(rx[:, 0, 30:32], rx[:, 1, 30:32])    # zero EE velocity command: target x, y = current x, y
+
+
+# ---------------- committed golden fixture (tools/gen_golden_frontend.py) ----------------
+def _golden():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_golden_frontend as gg
+    return gg, np.load(os.path.join(ROOT, "tests", "golden", "frontend_stream.npz"))
+
+
+def test_oracle_reproduces_the_golden_stream():
+    gg, G = _golden()
+    names, ts, reqs = gg.stream()
+    orc = [_fresh() for _ in range(gg.B)]
+    for s in range(gg.STEPS):
+        for b in range(gg.B):
+            if reqs[s, b] >= 0:
+                g = GAITS[names[reqs[s, b]]]; orc[b].pre_solver_run_insert(g["switchingTimes"], g["modeSequence"], ts[s, b], ts[s, b] + gg.HORIZON)
+            e, m = orc[b].modify_references(ts[s, b], gg.HORIZON)
+            n = G["n"][s, b]
+            assert n == len(e) and np.array_equal(G["ev"][s, b, :n], np.array(e)) and np.array_equal(G["mo"][s, b, :n + 1], np.array(m))
+
+
+def test_emulated_front_end_reproduces_the_golden_stream(emu):
+    e, mb, st = emu
+    gg, G = _golden()
+    names, ts, reqs = gg.stream()
+    e.gait_setup(GAITS, gg.B)
+    for s in range(gg.STEPS):
+        req = [None if r < 0 else names[r] for r in reqs[s]]
+        e.gait_insert(req, ts[s] + gg.HORIZON, (ts[s] + gg.HORIZON) - ts[s])
+        e.gait_update(ts[s], gg.HORIZON)
+        ev, mo = e.schedule_download()
+        for b in range(gg.B):
+            n = G["n"][s, b]
+            assert np.array_equal(ev[b, :n], G["ev"][s, b, :n]) and np.array_equal(mo[b, :n + 1], G["mo"][s, b, :n + 1]) and (mo[b, n + 1:] == 15).all()
+    e.target_reset(6, np.array([0.52, 0.09, 0.44, 0.5, -0.5, 0.5, -0.5]))
+    rt, rx, last = e.target_from_command(G["tgt_t0"], G["tgt_x0"], G["tgt_kind"], G["tgt_cmd"], G["tgt_ee"], 0, 1.0, 0.3, 0.1, 0.4)
+    assert np.allclose(rt[:, :2], G["tgt_rt"], rtol=1e-13, atol=0) and np.allclose(rx[:, :2], G["tgt_rx"], rtol=1e-12, atol=1e-13) and np.allclose(last, G["tgt_last"], rtol=1e-13, atol=0)

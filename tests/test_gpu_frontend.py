@@ -195,3 +195,33 @@ def test_fused_closed_loop_refreshes_the_schedule(blobs):
     assert np.array_equal(s0[0], s1[0]) and np.array_equal(s0[1], s1[1])
     assert np.array_equal(r0["x"], r1["x"]) and np.array_equal(r0["u"], r1["u"]) and np.array_equal(r0["mode"], r1["mode"])
     assert (r1["mode"][:, :r1["num_nodes"].min()] != 15).any()                          # the robots are trotting by the end
+
+
+def test_golden_front_end_stream(blobs):
+    """the committed fixture tests/golden/frontend_stream.npz (tools/gen_golden_frontend.py) through the C ABI"""
+    from qm_control_amd import api, scenarios
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_golden_frontend as gg
+    G = np.load(os.path.join(root, "tests", "golden", "frontend_stream.npz"))
+    gaits = scenarios.load_gaits(); names, ts, reqs = gg.stream()
+    itf = api.QMInterface(blobs=blobs, max_batch=gg.B, max_nodes=16, max_ref_knots=2, max_events=gg.CAP)
+    mpc = api.SqpMpc(itf); mpc.B = gg.B
+    gs = api.GaitSchedule(itf, gaits, gg.B)
+    x0 = np.tile(itf.getInitialState(), (gg.B, 1))
+    for s in range(gg.STEPS):
+        mpc.set_initial(ts[s], x0)
+        gs.preSolverRun([None if r < 0 else names[r] for r in reqs[s]], ts[s], gg.HORIZON)
+        gs.updateSolverSchedule(gg.HORIZON)
+        ev, mo = gs.solver_schedule()
+        for b in range(gg.B):
+            n = G["n"][s, b]
+            assert np.array_equal(ev[b, :n], G["ev"][s, b, :n]) and np.array_equal(mo[b, :n + 1], G["mo"][s, b, :n + 1])
+    itf.close()
+    itf = api.QMInterface(blobs=blobs, max_batch=6, max_nodes=16, max_ref_knots=2, max_events=8)
+    mpc = api.SqpMpc(itf); mpc.B = 6; mpc.set_initial(G["tgt_t0"], G["tgt_x0"])
+    pub = api.TargetTrajectoriesPublisher(itf, 6, time_to_target=1.0)
+    pub.publish(G["tgt_kind"], G["tgt_cmd"], ee_state=G["tgt_ee"])
+    rt, rx, last = pub.download()
+    assert np.allclose(rt, G["tgt_rt"], rtol=1e-13, atol=0) and np.allclose(rx, G["tgt_rx"], rtol=1e-12, atol=1e-13) and np.allclose(last, G["tgt_last"], rtol=1e-13, atol=0)
+    itf.close()
