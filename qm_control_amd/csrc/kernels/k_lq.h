@@ -466,17 +466,18 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   }
   if (l >= 32 && l < 38) EE[6 + (l - 32)] = ((l - 32) < 3 ? st[ST_MU_EE_POS] : st[ST_MU_EE_ORI]);
   qm_wave_sync();
-  { // r = R0 (u − unom) through column 30
-    qm_d4 Y[2][1], P[2][1];
-#pragma unroll
-    for (int I = 0; I < 2; ++I) { P[I][0] = qm_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; Y[I][0][r] = (c == 14 && row < 30) ? S[LW_V_DU + row] : 0.0; } }
-    qm_gemm_tn<2, 2, 1>(Rm, Y, P, 0, 8, false);
+  { // r = R0 (u − unom): a mat-vec on the register fragments — two partial products per lane and register, then a 16-lane DPP row sum
+    // (as an MFMA it would spend 16 issues of 64 cycles on a single useful column; f64 MFMA and f64 VALU run at the same rate on gfx950)
+    const double d0 = S[LW_V_DU + c], d1 = S[LW_V_DU + 16 + c];
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14 && row < 30) S[LW_V_RV + row] = P[I][0][r]; }
+      for (int r = 0; r < 4; ++r) {
+        double p = Rm[I][0][r] * d0 + Rm[I][1][r] * d1;
+        p += qm_dpp<0x111, 0xf>(0.0, p); p += qm_dpp<0x112, 0xf>(0.0, p); p += qm_dpp<0x114, 0xf>(0.0, p); p += qm_dpp<0x118, 0xf>(0.0, p);   // row_shr 1, 2, 4, 8: lane 15 of each row holds the sum
+        const int row = 16 * I + g + 4 * r;
+        if (c == 15 && row < 30) S[LW_V_RV + row] = p;
+      }
   }
   qm_wave_sync();
   if (l < 30) cost += 0.5 * S[LW_V_DU + l] * S[LW_V_RV + l];

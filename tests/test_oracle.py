@@ -139,7 +139,7 @@ def test_oracle_matches_golden_fixtures(blobs, oracle):
     import glob, os
     from conftest import ROOT
     from qm_control_amd import scenarios
-    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+    files = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "C*_B*_N*.npz")))
     assert files
     for f in files:
         name, Bs, Ns = os.path.basename(f)[:-4].split("_"); B = int(Bs[1:]); N = int(Ns[1:])
