@@ -89,7 +89,8 @@ struct QmLqArgs {
 #define LW_V_RD  (LW_V + 472)         /* diagonal additions of R (32) */
 #define LW_K1    (LW_V + 504)
 #define LW_K2    (LW_K1 + KW_SIZE)
-#define LW_LDS_DOUBLES (LW_K2 + KW_SIZE)
+#define LW_PD    (LW_K2 + KW_SIZE)      /* Pu column descriptors: first source row i0 as double [32], weights [32][3] */
+#define LW_LDS_DOUBLES (LW_PD + 128)
 #define LQ_LDS_BYTES (LW_LDS_DOUBLES * 8)
 
 // value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column
@@ -119,7 +120,36 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
 #pragma unroll
     for (int J = 0; J < MT; ++J) Pu[I][J] = PuF[I][J];
   if (store_pu) qm_frag_store<2, MT>(Pu, rec + SR_PU, QM_MMAX, 30, m);
-  { qm_d4 Bp[2][MT]; qm_frag_zero<2, MT>(Bp); qm_gemm_tn<2, 2, MT>(Bdt, Pu, Bp, 0, 8, false); qm_frag_store<2, MT>(Bp, rec + SR_BP, QM_MMAX, 30, m); }   // Bp = Bd Pu
+  // Every column of Pu is a unit vector or three consecutive entries (a swing leg's null-space column): products with Pu are gathers of
+  // columns / rows of the other factor, not matrix products.  The other factor goes through the LDS tile once and each lane picks the entries
+  // its output elements need (descriptors in LW_PD): ≈ 40 LDS operations per product instead of 8..16 MFMAs of 64 cycles each.
+  double* T = S + LW_T; const double* PD = S + LW_PD;
+  const int g = l >> 4, c = l & 15;
+  // descriptors are (re)read from LDS next to their use: holding them across the whole function costs more registers than this kernel has
+  int ci0[MT]; double cw[MT][3];                               // columns j = 16 J + c this lane holds in (X Pu)
+  auto load_col_desc = [&]() {
+#pragma unroll
+    for (int J = 0; J < MT; ++J) { const int j = 16 * J + c; ci0[J] = (int)PD[j]; cw[J][0] = PD[32 + 3 * j]; cw[J][1] = PD[33 + 3 * j]; cw[J][2] = PD[34 + 3 * j]; }
+  };
+  load_col_desc();
+  auto tile_put = [&](const qm_d4 (&F)[2][2]) {                // fragments (zero padded) -> T[row][col]
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * I + g + 4 * r) * LW_TLD + 16 * J + c] = F[I][J][r];
+  };
+  // Bp = Bd Pu: Bp[row][j] = Σ_k w_k(j) Bdᵀ[i0(j) + k][row]   (the tile holds Bdᵀ: rows = inputs)
+  qm_wave_sync(); tile_put(Bdt); qm_wave_sync();
+  { qm_d4 Bp[2][MT];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < MT; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; const double* src = T + ci0[J] * LW_TLD + row; Bp[I][J][r] = cw[J][0] * src[0] + cw[J][1] * src[LW_TLD] + cw[J][2] * src[2 * LW_TLD]; }
+    qm_frag_store<2, MT>(Bp, rec + SR_BP, QM_MMAX, 30, m); }
   // [R Px | R Pe + r]: Px rows 12..23 (k-steps 3..5); Pe also has rows 0..11 (column 30 only -> tile column 1, k-steps 0..2)
   qm_d4 RPx[2][2]; qm_frag_zero<2, 2>(RPx);
   qm_gemm_tn<2, 2, 2>(Rm, PxA, RPx, 3, 6, false);
@@ -150,11 +180,39 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
         for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < 30 && col < 30) rec[SR_QP + row * 30 + col] = Qa[I][J][r]; } }
   qm_wave_sync();
   lw_get_col30<2>(Qa, S + LW_V_QV, 30);
-  // [Pp | rp] = Puᵀ [R Px | rr]
-  { qm_d4 Pp[MT][2]; qm_frag_zero<MT, 2>(Pp); qm_gemm_tn<2, MT, 2>(Pu, RPx, Pp, 0, 8, false); qm_frag_store<MT, 2>(Pp, rec + SR_PP, 30, m, 30); lw_get_col30<MT>(Pp, S + LW_V_RV, m); }
-  // Rp = Puᵀ R Pu
-  { qm_d4 RPu[2][MT]; qm_frag_zero<2, MT>(RPu); qm_gemm_tn<2, 2, MT>(Rm, Pu, RPu, 0, 8, false);
-    qm_d4 Rp[MT][MT]; qm_frag_zero<MT, MT>(Rp); qm_gemm_tn<2, MT, MT>(Pu, RPu, Rp, 0, 8, false); qm_frag_store<MT, MT>(Rp, rec + SR_RP, QM_MMAX, m, m); }
+  // [Pp | rp] = Puᵀ [R Px | rr]: Pp[j][col] = Σ_k w_k(j) [R Px | rr][i0(j) + k][col]
+  qm_wave_sync(); tile_put(RPx); qm_wave_sync();
+  { qm_d4 Pp[MT][2];
+#pragma unroll
+    for (int I = 0; I < MT; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int j = 16 * I + g + 4 * r; const double* src = T + (int)PD[j] * LW_TLD + 16 * J + c; Pp[I][J][r] = PD[32 + 3 * j] * src[0] + PD[33 + 3 * j] * src[LW_TLD] + PD[34 + 3 * j] * src[2 * LW_TLD]; }
+    qm_frag_store<MT, 2>(Pp, rec + SR_PP, 30, m, 30); lw_get_col30<MT>(Pp, S + LW_V_RV, m); }
+  // Rp = Puᵀ (R Pu): first R Pu[i][j] = Σ_k w_k(j) R[i][i0(j) + k], then the rows of that by the same descriptors
+  qm_wave_sync(); tile_put(Rm); qm_wave_sync();
+  load_col_desc();
+  { qm_d4 RPu[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double v = 0.0;
+          if (J < MT) { const double* src = T + (16 * I + g + 4 * r) * LW_TLD + ci0[J < MT ? J : 0]; v = cw[J < MT ? J : 0][0] * src[0] + cw[J < MT ? J : 0][1] * src[1] + cw[J < MT ? J : 0][2] * src[2]; }
+          RPu[I][J][r] = v;
+        }
+    qm_wave_sync(); tile_put(RPu); qm_wave_sync();
+    qm_d4 Rp[MT][MT];
+#pragma unroll
+    for (int I = 0; I < MT; ++I)
+#pragma unroll
+      for (int J = 0; J < MT; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int j = 16 * I + g + 4 * r; const double* src = T + (int)PD[j] * LW_TLD + 16 * J + c; Rp[I][J][r] = PD[32 + 3 * j] * src[0] + PD[33 + 3 * j] * src[LW_TLD] + PD[34 + 3 * j] * src[2 * LW_TLD]; }
+    qm_frag_store<MT, MT>(Rp, rec + SR_RP, QM_MMAX, m, m); }
   qm_wave_sync();
   if (l < 30) rec[SR_QPV + l] = S[LW_V_QV + l];
   if (l < m) rec[SR_RPV + l] = S[LW_V_RV + l];
@@ -419,6 +477,12 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
       for (int k = 3; k >= 0; --k) { int before = 0; for (int q = 0; q < 4; ++q) if (q < k && !mode_flag(mode, q)) ++before; if (!mode_flag(mode, k) && before == cnt) kk = k; } }
     else if (j < m) { type = 2; t = j - (3 * nst + 2 * (4 - nst)); }
     const int jc = 12 + 3 * contact_to_chain(kk); const double* gg = G + 12 * kk;
+    // column descriptor (every column of Pu is a unit vector or three consecutive entries): source row i0 and weights w0..w2
+    if (g == 0) {
+      const int i0 = (type == 0) ? 3 * kk + t : ((type == 1) ? jc : ((type == 2) ? 24 + t : 0));
+      S[LW_PD + j] = (double)i0;
+      S[LW_PD + 32 + 3 * j] = (type == 1) ? gg[3 + 3 * t] : ((type == 3) ? 0.0 : 1.0); S[LW_PD + 32 + 3 * j + 1] = (type == 1) ? gg[4 + 3 * t] : 0.0; S[LW_PD + 32 + 3 * j + 2] = (type == 1) ? gg[5 + 3 * t] : 0.0;
+    }
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -568,12 +632,6 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   }
   LQT()
   // ---- projected cost + stores ----
-  double rpe = 0.0;
-  if (m <= 16) lw_project<1>(S, rec, dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe); else lw_project<2>(S, rec, dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe);
-  // what K3's forward rollout needs to apply Pu without reading it: the swing legs' null-space blocks and the contact mode
-  if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
-  if (l == 24) rec[SR_MODEF] = (double)mode;
-  if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
   // Px: only rows 12..23 (leg joint velocities) are non-zero and only they are stored / read back by K3 (register (I = 0, r = 3), (1, 0), (1, 1))
 #pragma unroll
   for (int J = 0; J < 2; ++J) {
@@ -581,6 +639,12 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     if (col < 30) { rec[SR_PX + (12 + g) * 30 + col] = PxA[0][J][3]; rec[SR_PX + (16 + g) * 30 + col] = PxA[1][J][0]; rec[SR_PX + (20 + g) * 30 + col] = PxA[1][J][1]; }
     if (dbg && col < 30) { for (int r = 0; r < 3; ++r) rec[SR_PX + (g + 4 * r) * 30 + col] = 0.0; rec[SR_PX + (24 + g) * 30 + col] = 0.0; if (g < 2) rec[SR_PX + (28 + g) * 30 + col] = 0.0; }
   }
+  double rpe = 0.0;
+  if (m <= 16) lw_project<1>(S, rec, dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe); else lw_project<2>(S, rec, dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe);
+  // what K3's forward rollout needs to apply Pu without reading it: the swing legs' null-space blocks and the contact mode
+  if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
+  if (l == 24) rec[SR_MODEF] = (double)mode;
+  if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
   if (l == 0) { rec[SR_SCAL] = (double)m; rec[SR_SCAL + 1] = ctot + rpe; }
   LQT()
   if (a.prof && l == 0) for (int k = 0; k + 1 < np_ && k < 9; ++k) rec[SR_K + k] = (double)(tp_[k + 1] - tp_[k]);

@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       qm_wave_sync();
       WT(8)
       int* Wi = (int*)(S + WL_WLIST);                    // working-set list lives in LDS (wave-uniform reads)
-      unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false; double pscale = 0.0; int myslot = -1;   // position of this lane's row in the working set
+      unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false, vertex = false; double pscale = 0.0; int myslot = -1;   // position of this lane's row in the working set
       for (; it < 100; ++it) {
         if (myslot >= 0) {
 #pragma unroll
@@ -793,7 +793,8 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
 #ifdef QM_WBC_TRACE
         if (l == 0) { printf("L%d it %d nw %d pn %.3e zs %.3e pscale %.3e W:", level, it, nw, pn, zs, pscale); for (int q2 = 0; q2 < nw; ++q2) printf(" %d(%.2e)", Wi[q2], lam[q2]); printf("\n"); }
 #endif
-        if (pn <= 1e-9 * fmax(zs, pscale)) {
+        if (pn <= 1e-9 * fmax(zs, pscale) || vertex) {
+          vertex = false;
           // stationary on the working set: drop a row with a negative multiplier (most negative; lowest constraint index after a degenerate step — Bland)
           const double mylam = (l < nw) ? lam[l] : 0.0; const double lscale = fmax(1.0, wv_max(fabs(mylam)));
           const bool cand = (l < nw) && (mylam < -1e-9 * lscale);
@@ -825,7 +826,12 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
           if (l == 0) printf("   step al %.6e block %d\n", al, block);
 #endif
           degenerate = (al <= 1e-12);
-          if (block >= 0) { if (nw < n && nw < WMAXACT) { if (l == 0) Wi[nw] = block; if (l == block) myslot = nw; wmask |= (1ull << block); ++nw; } else { status[level] = 2; qm_wave_sync(); break; } }
+          if (block >= 0) {
+            if (nw < n && nw < WMAXACT) { if (l == 0) Wi[nw] = block; if (l == block) myslot = nw; wmask |= (1ull << block); ++nw; }
+            else if (nw >= n && al <= 1e-12) vertex = true;      // degenerate vertex: n rows are active already and the (numerically non-zero) step is blocked at once — z is the
+                                                                 // vertex; decide by the multipliers (drop by Bland's rule) instead of growing the working set beyond the dimension
+            else { status[level] = 2; qm_wave_sync(); break; }
+          }
           qm_wave_sync();
         }
       }
