@@ -17,7 +17,11 @@ static std::string g_create_error;
 #define HIP_TRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->fail(std::string(#expr) + ": " + hipGetErrorString(e_)); return QMHIP_ERR_HIP; } } while (0)
 
 struct HipBackend {
-  hipStream_t stream = nullptr; bool profiling = false; std::string error;
+  hipStream_t stream = nullptr;            // MPC stream (K0..K5); host copies
+  hipStream_t stream_b = nullptr;          // WBC stream: the WBC of step k runs beside the MPC kernels of step k + 1 (the reference runs them in two threads too)
+  hipStream_t cur = nullptr;               // stream the next launch / memset goes to
+  hipEvent_t ev_in = nullptr, ev_wbc = nullptr; bool wbc_pending = false;
+  bool profiling = false; std::string error;
   struct Span { std::string name; hipEvent_t a, b; };
   std::vector<Span> spans; std::vector<hipEvent_t> pool;
   std::map<std::string, std::pair<double, int>> acc;
@@ -36,23 +40,28 @@ struct HipBackend {
       const void* p = (const void*)kernel; auto it = lds_set.find(p);
       if (it == lds_set.end() || it->second < (int)lds) { check(hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); lds_set[p] = (int)lds; }
     }
-    Span s; if (profiling) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); hipEventRecord(s.a, stream); }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, stream, args);
+    Span s; if (profiling) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); hipEventRecord(s.a, cur); }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, cur, args);
     check(hipGetLastError(), "kernel launch");
-    if (profiling) { hipEventRecord(s.b, stream); spans.push_back(s); }
+    if (profiling) { hipEventRecord(s.b, cur); spans.push_back(s); }
   }
   void resolve() {
     if (spans.empty()) return;
-    hipStreamSynchronize(stream);
+    hipStreamSynchronize(stream); hipStreamSynchronize(stream_b);
     for (auto& s : spans) { float ms = 0; hipEventElapsedTime(&ms, s.a, s.b); auto& a = acc[s.name]; a.first += ms; a.second += 1; pool.push_back(s.a); pool.push_back(s.b); }
     spans.clear();
   }
   void* alloc(size_t n) { void* p = nullptr; check(hipMalloc(&p, n ? n : 8), "hipMalloc"); return p; }
   void free(void* p) { hipFree(p); }
-  void zero(void* p, size_t n) { check(hipMemsetAsync(p, 0, n, stream), "hipMemsetAsync"); }
-  void to_device(void* d, const void* s, size_t n) { check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "H2D"); check(hipStreamSynchronize(stream), "sync"); }
-  void to_host(void* d, const void* s, size_t n) { check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "D2H"); check(hipStreamSynchronize(stream), "sync"); }
-  void sync() { check(hipStreamSynchronize(stream), "sync"); }
+  void zero(void* p, size_t n) { check(hipMemsetAsync(p, 0, n, cur), "hipMemsetAsync"); }
+  // host copies see the results of BOTH streams and never run beside device work of either (they are not on the hot path)
+  void to_device(void* d, const void* s, size_t n) { sync(); check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "H2D"); check(hipStreamSynchronize(stream), "sync"); }
+  void to_host(void* d, const void* s, size_t n) { sync(); check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "D2H"); check(hipStreamSynchronize(stream), "sync"); }
+  void sync() { check(hipStreamSynchronize(stream), "sync"); check(hipStreamSynchronize(stream_b), "sync"); wbc_pending = false; }
+  // WBC of the current step on stream_b: its inputs were produced on `stream` (ev_in); the next producers on `stream` wait for ev_wbc
+  void wbc_inputs_next() { if (wbc_pending) { hipStreamWaitEvent(stream, ev_wbc, 0); wbc_pending = false; } }
+  void wbc_begin() { hipEventRecord(ev_in, stream); hipStreamWaitEvent(stream_b, ev_in, 0); cur = stream_b; }
+  void wbc_end() { hipEventRecord(ev_wbc, stream_b); cur = stream; wbc_pending = true; }
 };
 
 struct qmhip_ctx {
@@ -91,12 +100,13 @@ static int create_common(const double* mb, const double* st, int device, int max
   if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return QMHIP_ERR_HIP; }
   qmhip_ctx* c = new qmhip_ctx(); c->device = device; c->max_batch = max_batch; c->max_nodes = max_nodes; c->max_ref = max_ref; c->max_ev = max_ev;
   memcpy(c->mb, mb, sizeof(c->mb)); memcpy(c->st, st, sizeof(c->st));
-  if (hipStreamCreate(&c->bk.stream) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
+  if (hipStreamCreate(&c->bk.stream) != hipSuccess || hipStreamCreate(&c->bk.stream_b) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
+  c->bk.cur = c->bk.stream; hipEventCreateWithFlags(&c->bk.ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->bk.ev_wbc, hipEventDisableTiming);
   c->mpc.allocate(c->mb, c->st, max_batch, max_nodes, max_ref, max_ev, false);
   c->wbc.allocate(max_batch);
   c->front.allocate(max_batch);
   c->bk.sync();
-  if (!c->bk.error.empty()) { g_create_error = c->bk.error; c->mpc.release(); c->wbc.release(); c->front.release(); hipStreamDestroy(c->bk.stream); delete c; return QMHIP_ERR_HIP; }
+  if (!c->bk.error.empty()) { g_create_error = c->bk.error; c->mpc.release(); c->wbc.release(); c->front.release(); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c; return QMHIP_ERR_HIP; }
   *out = c; return QMHIP_OK;
 }
 
@@ -123,7 +133,7 @@ int qmhip_create_from_blobs(const double* mb, const double* st, int device, int 
 }
 void qmhip_destroy(qmhip_ctx* c) {
   if (!c) return; hipSetDevice(c->device); c->bk.sync(); c->mpc.release(); c->wbc.release(); c->front.release();
-  for (auto e : c->bk.pool) hipEventDestroy(e); hipStreamDestroy(c->bk.stream); delete c;
+  for (auto e : c->bk.pool) hipEventDestroy(e); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
 }
 const char* qmhip_last_error(const qmhip_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
 int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
@@ -160,7 +170,8 @@ int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, 
     if (k > 0) c->mpc.advance(B, mpc_dt);
     if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon);     // device-resident GaitSchedule active: modifyReferences before every MPC call
     c->mpc.grid(B, horizon, true); for (int it = 0; it < c->sqp_iterations(); ++it) c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true;
-    c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time0 + k * mpc_dt); c->wbc.step(c->mpc.d, B, period, 0);
+    c->bk.wbc_inputs_next(); c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time0 + k * mpc_dt);
+    c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
   }
   return c->hipstate();
 }
@@ -244,10 +255,10 @@ int qmhip_policy_eval(qmhip_ctx* c, int B, const double* t, double* xd, double* 
   if (xd) c->bk.to_host(xd, c->wbc.w.x_des, (size_t)B * 30 * 8); if (ud) c->bk.to_host(ud, c->wbc.w.u_des, (size_t)B * 30 * 8); if (mode) c->bk.to_host(mode, c->wbc.w.mode, (size_t)B * 4);
   return c->hipstate();
 }
-int qmhip_wbc_reset(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->wbc.reset(); return c->hipstate(); }
+int qmhip_wbc_reset(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.cur = c->bk.stream_b; c->wbc.reset(); c->bk.cur = c->bk.stream; return c->hipstate(); }   // ordered with the WBC launches
 int qmhip_wbc_step(qmhip_ctx* c, int B, const double* xd, const double* ud, const double* rbd, const int32_t* mode, double period, const double* time, int variant, double* out, int32_t* qps) {
   if (!c || B <= 0 || B > c->max_batch || !xd || !ud || !rbd || !mode || !time || !(period > 0)) { if (c) c->fail("qmhip_wbc_step: bad argument"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->wbc.upload(B, xd, ud, rbd, mode, time); c->wbc.step(c->mpc.d, B, period, variant);
+  hipSetDevice(c->device); c->wbc.upload(B, xd, ud, rbd, mode, time); c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, variant); c->bk.wbc_end();
   return qmhip_wbc_download(c, B, out, qps);
 }
 int qmhip_wbc_download(qmhip_ctx* c, int B, double* out, int32_t* qps) {
@@ -257,7 +268,10 @@ int qmhip_wbc_download(qmhip_ctx* c, int B, double* out, int32_t* qps) {
 }
 int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double period, double time) {
   int rc = qmhip_mpc_solve_resident(c, B, horizon); if (rc) return rc;
-  c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time); c->wbc.step(c->mpc.d, B, period, 0);
+  // the WBC goes to its own stream: back-to-back steps overlap WBC(k) — one wave per SIMD whose run time is that of the instance with the most
+  // active-set iterations — with the MPC kernels of step k + 1, which fill the SIMDs the finished WBC waves leave behind
+  c->bk.wbc_inputs_next(); c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time);
+  c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
   return c->hipstate();
 }
 
@@ -269,7 +283,7 @@ int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launche
 int qmhip_reset_kernel_ms(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.acc.clear(); return QMHIP_OK; }
 int qmhip_synchronize(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
 int qmhip_last_ls_trials(const qmhip_ctx* c) { return c ? c->mpc.ls_trials_run : -1; }
-int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; } return QMHIP_ERR_ARG; }
+int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "wbc_algo")) { c->wbc.wbc_algo = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; } return QMHIP_ERR_ARG; }
 int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) {
   if (!c || !name || !dst) return QMHIP_ERR_ARG; hipSetDevice(c->device); const QmMpcBuffers& d = c->mpc.d; const void* p = nullptr;
 #define F(n) if (!strcmp(name, #n)) p = d.n;
