@@ -39,10 +39,9 @@ struct QmWbcPipeline {
     bk.to_device(w.x_des, xd, (size_t)B * 30 * 8); bk.to_device(w.u_des, ud, (size_t)B * 30 * 8); bk.to_device(w.rbd, rbd, (size_t)B * QM_NRBD * 8); bk.to_device(w.mode, mode, (size_t)B * 4); bk.to_device(w.time, time, (size_t)B * 8);
   }
   int wbc_stop = 0;   // profiling only
-  int wbc_algo = 0;   // 0 primal, 1 dual active set for the hard rows of levels >= 1
   void step(const QmMpcBuffers& d, int B, double period, int variant) {
     QmWbcArgs a; a.mb = d.mb; a.st = d.st; a.B = B; a.x_des = w.x_des; a.u_des = w.u_des; a.rbd = w.rbd; a.mode = w.mode; a.time = w.time; a.period = period; a.variant = variant;
-    a.input_last = w.input_last; a.out = w.out; a.qp_status = w.qp_status; a.scratch = w.scratch; a.sstride = w.Bmax; a.dbg = w.dbg; a.stop = wbc_stop; a.algo = wbc_algo;
+    a.input_last = w.input_last; a.out = w.out; a.qp_status = w.qp_status; a.scratch = w.scratch; a.sstride = w.Bmax; a.dbg = w.dbg; a.stop = wbc_stop;
     bk.launch(qm_wbc_kernel, B, WBC_BLOCK, WBC_LDS_BYTES, a);   // one wavefront per instance
   }
 };

@@ -30,7 +30,6 @@ struct QmWbcArgs {
   double* out;                                // [B][54]
   int* qp_status;                             // [B][3]  0 ok, 1 iteration limit (nWSR=100), 2 working set overflow
   double* scratch; int sstride;               // unused by the wave kernel (kept so the pipeline ABI is stable)
-  int algo;                                   // hard-row active set of levels >= 1: 0 primal (from the feasible z = 0), 1 dual (Lawson-Hanson on the dual NNLS)
   int stop;                                   // profiling only: 1 return after the rigid-body phase, 2/3/4 after level 0/1/2 (no outputs)
   double* dbg;                                // optional [B][WBC_DBG_SIZE]: qMeas vMeas qDes vDes baseAcc nle x0 x1 x2 M J dJv
 };
@@ -777,64 +776,6 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       WT(8)
       int* Wi = (int*)(S + WL_WLIST);                    // working-set list lives in LDS (wave-uniform reads)
       unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false, vertex = false; double pscale = 0.0; int myslot = -1;   // position of this lane's row in the working set
-      if (a.algo == 1 && level == 1) {                    // (level 2 keeps the primal method: its null space is so small that the working set fills it)
-        // Dual active set: the level problem  min |R z − c|²  s.t.  D z <= f  is strictly convex, its dual is a non-negative least-squares problem in the
-        // multipliers, solved by the Lawson–Hanson scheme with the SAME equality-constrained solve as the primal method: (i) solve with the working set
-        // as equalities; (ii) while some working-set multiplier is not positive, move the multipliers towards the new ones until the first reaches zero,
-        // drop that row, re-solve; (iii) accept z and add the most violated row outside the working set; stop when none is violated.  No feasible start
-        // is needed and the working set grows (almost) monotonically to the final one: ≈ |W*| + 1 solves instead of one per vertex of the primal path.
-        double lamv = 0.0; unsigned long long excl = 0ull; int lastadd = -1;
-        const double fscale = fmax(1.0, wv_max((l < C.nIneq) ? fabs(fb[l]) : 0.0));
-        for (; it < 100; ++it) {
-          if (myslot >= 0) {
-#pragma unroll
-            for (int k = 0; k < WVLD; ++k) S[WL_EROWS + myslot * WVLD + k] = dz[k];
-            S[WL_ERHS + myslot] = fb[l];
-          }
-          qm_wave_sync();
-          WT(10)
-          wv_eq_ls_R(S, G, Tm, n, nw, zn, tfine);
-          WT(9)
-          const double mu = (myslot >= 0) ? lam[myslot] : 0.0; const double lscale = fmax(1.0, wv_max(fabs(mu)));
-          const bool bad = (myslot >= 0) && !(mu > 1e-12 * lscale);
-          if (__ballot(bad) != 0ull) {
-            const double den = lamv - mu; const double ratio = bad ? ((den > 0.0) ? lamv / den : 0.0) : 1e300;
-            const double amin = -wv_max(-ratio);
-            int key = (bad && ratio == amin) ? l : 64; for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; }
-            const int leave = key;                                   // lane (= row) that leaves the working set
-            if (myslot >= 0) lamv = fmax(0.0, lamv + amin * (mu - lamv));
-            if (l == leave) lamv = 0.0;
-            if (leave == lastadd) excl |= (1ull << leave);            // a row that bounces straight back is (numerically) dependent on the working set: leave it out
-            const int worst = __shfl(myslot, leave, 64);
-            wmask &= ~(1ull << leave);
-            if (myslot == worst) myslot = -1; else if (myslot > worst) --myslot;
-            const int nxt = (l + 1 < nw) ? Wi[l + 1] : 0;
-            qm_wave_sync();
-            if (l >= worst && l + 1 < nw) Wi[l] = nxt;
-            --nw; lastadd = -1;
-            qm_wave_sync();
-            continue;
-          }
-          if (myslot >= 0) lamv = mu;
-          double viol = -1e300;
-          if (l < C.nIneq && myslot < 0 && !((excl >> l) & 1ull)) {
-            double dzz = 0.0;
-#pragma unroll
-            for (int k = 0; k < WVLD; ++k) dzz += dz[k] * zn[k];
-            viol = dzz - fb[l];
-          }
-          const double vmax = wv_max(viol);
-          if (!(vmax > 1e-11 * fscale)) break;
-          int key = (viol == vmax) ? l : 64; for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; }
-          const int block = key;
-          if (nw < n && nw < WMAXACT) { if (l == 0) Wi[nw] = block; if (l == block) myslot = nw; wmask |= (1ull << block); ++nw; lastadd = block; }
-          else { status[level] = 2; qm_wave_sync(); break; }
-          qm_wave_sync();
-        }
-        qm_wave_sync();
-        if (l < n) z[l] = zn[l];
-        qm_wave_sync();
-      } else
       for (; it < 100; ++it) {
         if (myslot >= 0) {
 #pragma unroll

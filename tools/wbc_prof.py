@@ -18,3 +18,9 @@ for stop, names in ((-1, ["init+rigid_body", "task build + AZ/g0", "L0 G build +
     if stop == -1: print("total cycles/instance", cyc[:, :12].sum(1).mean())
 itf.debug_set("wbc_stop", 0)
 dbg = None
+# active-set iterations per level (the kernel's run time is that of the slowest instance: one wave per SIMD)
+itf.debug_set("wbc_stop", -4)
+mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
+its = itf.debug_read("wbc_scratch", (B, 432))[:, 13:15]
+print("active-set iterations level 1: mean %.1f max %d;  level 2: mean %.1f max %d;  per instance max %d" % (its[:, 0].mean(), its[:, 0].max(), its[:, 1].mean(), its[:, 1].max(), its.sum(1).max()))
+itf.debug_set("wbc_stop", 0)
