@@ -129,7 +129,7 @@ def main():
             "metric": "MPC+WBC control steps/sec (24-DoF quadruped-manipulator, SQP horizon N=100)", "value": total_steps / elapsed, "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3/C4: trot gait, horizon N=100 (dt 0.015), %d random initial states per GPU (seed 1235), cold start, 1 SQP iteration + policy eval + 3-level WBC" % B,
+            "config": {"workload": "C3/C4: trot gait, horizon N=100 (dt 0.015), %d random initial states per GPU (seed 1235), cold start, 1 SQP iteration + policy eval + 3-level WBC; back-to-back steps, the WBC of a step on its own stream beside the next step's MPC kernels" % B,
                        "instances_per_gpu": B, "parallelism": "shard%d" % world, "all_status_ok": ok, "ls_trials": int(res["ls_trials"])},
             "roofline": roofline,
             "fp64_peak_measured": {"mfma_f64_16x16x4": peak_mfma, "vector_fma": peak_fma, "unit": "TFLOP/s", "note": "roofline.peak stays the 78.6 TFLOP/s data-sheet figure"},
