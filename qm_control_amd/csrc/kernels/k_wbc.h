@@ -828,8 +828,9 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
           degenerate = (al <= 1e-12);
           if (block >= 0) {
             if (nw < n && nw < WMAXACT) { if (l == 0) Wi[nw] = block; if (l == block) myslot = nw; wmask |= (1ull << block); ++nw; }
-            else if (nw >= n && al <= 1e-12) vertex = true;      // degenerate vertex: n rows are active already and the (numerically non-zero) step is blocked at once — z is the
-                                                                 // vertex; decide by the multipliers (drop by Bland's rule) instead of growing the working set beyond the dimension
+            else if (nw >= n) { if (al <= 1e-12) vertex = true; }   // n rows are active already (the working-set rows are numerically dependent, else p would vanish): the set
+                                                                 // cannot grow beyond the dimension.  A step blocked at once means z is a degenerate vertex: decide by the multipliers
+                                                                 // (drop by Bland's rule).  After a partial step the same rows are solved again and the remainder ends up here.
             else { status[level] = 2; qm_wave_sync(); break; }
           }
           qm_wave_sync();

@@ -94,3 +94,23 @@ def test_control_step_other_gaits(blobs, oracle, gait):
         assert rel_err(out[b], w[b]) <= TOL, b
         assert rel_err(out[b, 36:], w[b, 36:]) <= TOL, b
     itf.close()
+
+
+@pytest.mark.parametrize("gait,inst", [("standing_pace", 244), ("lindyhop", 137)])
+def test_degenerate_vertices_are_resolved(blobs, oracle, gait, inst):
+    """regression: instances whose level-2 working set fills the (small) null space — a further blocking row used to be reported as a working-set
+    overflow (status 2) although the torques were right; every instance of the batch must finish with status 0 and the named one match the oracle"""
+    import pyoracle
+    from qm_control_amd import api, scenarios
+    B, N = 256, 60
+    cfg = scenarios.gait_config(gait, batch=B, n_intervals=N, seed=3)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=N + 80, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+    wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+    res = mpc.download(); out, st = wbc.download(B)
+    assert (res["status"] == 0).all() and (st == 0).all()
+    idx = np.array([inst])
+    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 1, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx], cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"])
+    assert bad == 0 and rel_err(out[inst], w[0]) <= TOL
+    itf.close()
