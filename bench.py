@@ -24,9 +24,9 @@ sys.path.insert(0, ROOT)
 KERNEL_MODEL = {
     # K1b: LQ approximation + projection. bytes: stage record written (Ap Bp, the upper tiles of Qp, Pp Rp, the 12 non-zero rows of Px, vectors, swing blocks = 3533 doubles; Pu is not stored) + kin record / inputs read (~620)
     "lq": {"flop": 190e3 + 410e3, "bytes": (3533 + 620) * 8.0, "unit": "interval"},
-    # K3: backward sweep reads [Ap|bp] Bp [Qp|qp] [Pp|rp] Rp (3282) and writes L W y (882); forward rollout reads Ap Bp W L, the 12 non-zero rows of Px, vectors and
-    #     the swing blocks (2815; Pu is rebuilt from the contact mode), x/dx/du (120)
-    "riccati": {"flop": 250e3, "bytes": (3282 + 882 + 2815 + 120) * 8.0, "unit": "interval"},
+    # K3: backward sweep reads [Ap|bp] Bp [Qp|qp] [Pp|rp] Rp (3282) and writes L W y (882); forward rollout reads the 12 momentum / base-pose rows of Ap Bp, W L,
+    #     the 12 non-zero rows of Px, vectors and the swing blocks (1952; joint rows are x_j + dt u_j, Pu is rebuilt from the contact mode), x/dx/du (120)
+    "riccati": {"flop": 250e3, "bytes": (3282 + 882 + 1952 + 120) * 8.0, "unit": "interval"},
     # K5-K7: rigid-body pass + 3-level cascade; bytes: inputs/outputs + tip/Jacobian scratch (~0.9k doubles)
     "wbc": {"flop": 2.0e6, "bytes": 900 * 8.0, "unit": "instance"},
 }

@@ -41,6 +41,7 @@ struct QmMpcPipeline {
   int ls_trials_run = 0;
   int riccati_skip = 0;   // profiling only
   int lq_prof = 0;        // profiling only
+  int lq_grid = 0;        // workgroups of the (persistent) LQ kernel; 0: one per node
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
@@ -106,7 +107,7 @@ struct QmMpcPipeline {
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof;
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, 0, q);
-    bk.launch(qm_lq_kernel, B * d.nmax, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node
+    bk.launch(qm_lq_kernel, (lq_grid > 0 && lq_grid < B * d.nmax) ? lq_grid : B * d.nmax, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node
     QmLsArgs l = ls_args(B);
     { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, B, 64, 0, lb); }   // also arms the line search: alpha = 1, done = 0
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;

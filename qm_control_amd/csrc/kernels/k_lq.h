@@ -644,6 +644,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   // what K3's forward rollout needs to apply Pu without reading it: the swing legs' null-space blocks and the contact mode
   if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
   if (l == 24) rec[SR_MODEF] = (double)mode;
+  if (l == 25) rec[SR_MODEF + 1] = dt;                 // the joint rows of the projected dynamics are not read back by the rollout: x_j+ = x_j + dt u_j
   if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
   if (l == 0) { rec[SR_SCAL] = (double)m; rec[SR_SCAL + 1] = ctot + rpe; }
   LQT()
