@@ -33,6 +33,8 @@ struct QmMpcBuffers {
   double* alpha = nullptr; int* done = nullptr; double* xs = nullptr; double* us = nullptr; double* out_perf = nullptr;
   // grid of the solve that produced (xs, us): the warm start of the next solve interpolates on it
   int* prev_n = nullptr; double* prev_t = nullptr; int* prev_ev = nullptr;
+  // line search: instances still searching after trial t (device counters + their host-visible copy)
+  int* open_cnt = nullptr; int* tickets = nullptr; int* host_open_dev = nullptr; volatile int* host_open = nullptr;
 };
 
 template <class BK>
@@ -61,11 +63,14 @@ struct QmMpcPipeline {
     d.perf = A<double>(NB * PF_SIZE); d.base_sum = A<double>((size_t)Bmax * 4); d.perf_sum = A<double>((size_t)Bmax * 4); d.step_info = A<double>((size_t)Bmax * 4);
     d.alpha = A<double>(Bmax); d.done = A<int>(Bmax); d.xs = A<double>(NB * 30); d.us = A<double>(NB * 30); d.out_perf = A<double>((size_t)Bmax * 10);
     d.prev_n = A<int>(Bmax); d.prev_t = A<double>(NB); d.prev_ev = A<int>(NB);
+    d.open_cnt = A<int>(QM_LS_MAX_TRIALS); d.tickets = A<int>(QM_LS_MAX_TRIALS);
+    { void* hv = nullptr; d.host_open_dev = (int*)bk.alloc_mapped(QM_LS_MAX_TRIALS * sizeof(int), &hv); d.host_open = (volatile int*)hv; for (int i = 0; i < QM_LS_MAX_TRIALS; ++i) d.host_open[i] = 0; }
   }
   void release() {
     void* ps[] = {d.mb, d.st, d.t0, d.x0, d.ref_t, d.ref_x, d.ev, d.modes, d.n_nodes, d.node_t, d.node_ts, d.node_dt, d.node_ev, d.node_mode, d.zvel, d.zpos, d.xref, d.eeref, d.status,
-                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev};
+                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev, d.open_cnt, d.tickets};
     for (void* p : ps) if (p) bk.free(p);
+    if (d.host_open) bk.free_mapped((void*)d.host_open);
     d = QmMpcBuffers();
   }
 
@@ -79,7 +84,7 @@ struct QmMpcPipeline {
   QmLsArgs ls_args(int B) {
     QmLsArgs a; a.mb = d.mb; a.st = d.st; a.B = B; a.nmax = d.nmax; a.n_nodes = d.n_nodes; a.node_ts = d.node_ts; a.node_dt = d.node_dt; a.node_ev = d.node_ev; a.node_mode = d.node_mode;
     a.zvel = d.zvel; a.zpos = d.zpos; a.xref = d.xref; a.eeref = d.eeref; a.x0 = d.x0; a.x = d.x; a.u = d.u; a.dx = d.dx; a.du = d.du; a.alpha = d.alpha; a.done = d.done;
-    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.with_alpha = 0;
+    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.with_alpha = 0; a.open_cnt = d.open_cnt; a.tickets = d.tickets; a.host_open = (volatile int*)d.host_open_dev;
     return a;
   }
 
@@ -101,30 +106,30 @@ struct QmMpcPipeline {
     QmAdvanceArgs v; v.B = B; v.nmax = d.nmax; v.n_nodes = d.n_nodes; v.node_t = d.node_t; v.node_ev = d.node_ev; v.xs = d.xs; v.dt = dt; v.t0 = d.t0; v.x0 = d.x0;
     bk.launch(qm_advance_kernel, (B + 63) / 64, 64, 0, v);
   }
-  // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min)
-  void sqp_iteration(int B, int max_trials = 14) {
+  // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min).  `last`: no further iteration of this solve
+  // follows, so the accepted step only has to reach the primal solution (xs, us), not the iterate (x, u) — the next solve starts from xs / us or cold
+  void sqp_iteration(int B, int max_trials = 14, bool last = false) {
     const int nodes_threads = d.nmax * B;
+    if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof;
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, 0, q);
-    bk.launch(qm_lq_kernel, (lq_grid > 0 && lq_grid < B * d.nmax) ? lq_grid : B * d.nmax, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node
+    bk.launch(qm_lq_kernel, B * d.nmax, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node
     QmLsArgs l = ls_args(B);
-    { QmLsArgs lb = l; lb.perf_sum = d.base_sum; lb.with_alpha = 0; bk.launch(qm_perf_sum_kernel, B, 64, 0, lb); }   // also arms the line search: alpha = 1, done = 0
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
+    r.perf = d.perf; r.base_sum = d.base_sum; r.alpha = d.alpha; r.done = d.done; r.out_perf = d.out_perf; r.open_cnt = d.open_cnt; r.tickets = d.tickets;   // baseline merit + arming of the line search
     bk.launch(qm_riccati_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // one wavefront per instance
-    std::vector<int> done_h((size_t)B);
     ls_trials_run = 0;
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;
       bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, 0, l);
-      { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision
+      { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching
       ++ls_trials_run;
-      bk.to_host(done_h.data(), d.done, (size_t)B * 4);
-      bool all = true; for (int b = 0; b < B; ++b) if (done_h[b] == 0) { all = false; break; }
-      if (all) break;
+      bk.wait_launched();                                  // the last block of the launch has published the count in host-visible memory
+      if (d.host_open[t] == 0) break;
     }
     bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
-    bk.launch(qm_ls_commit_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
+    if (!last) bk.launch(qm_ls_commit_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
     solved_B = B;
   }
 };

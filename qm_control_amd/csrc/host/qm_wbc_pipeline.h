@@ -35,6 +35,10 @@ struct QmWbcPipeline {
   void policy_eval(const QmMpcBuffers& d, int B, const double* t_host) { bk.to_device(w.t, t_host, (size_t)B * 8); bk.launch(qm_policy_kernel, (B + 63) / 64, 64, 0, pargs(d, B, w.t)); }
   void policy_eval_at_t0(const QmMpcBuffers& d, int B) { bk.launch(qm_policy_kernel, (B + 63) / 64, 64, 0, pargs(d, B, d.t0)); }
   void measured_from_x0(const QmMpcBuffers& d, int B, double time) { QmMeasArgs m; m.mb = d.mb; m.B = B; m.x0 = d.x0; m.time = time; m.rbd = w.rbd; m.time_out = w.time; bk.launch(qm_measured_kernel, (B + 63) / 64, 64, 0, m); }
+  void policy_at_t0_and_measured(const QmMpcBuffers& d, int B, double time) {
+    QmPolicyMeasArgs a; a.p = pargs(d, B, d.t0); a.m.mb = d.mb; a.m.B = B; a.m.x0 = d.x0; a.m.time = time; a.m.rbd = w.rbd; a.m.time_out = w.time;
+    bk.launch(qm_policy_measured_kernel, (2 * B + 63) / 64, 64, 0, a);
+  }
   void upload(int B, const double* xd, const double* ud, const double* rbd, const int* mode, const double* time) {
     bk.to_device(w.x_des, xd, (size_t)B * 30 * 8); bk.to_device(w.u_des, ud, (size_t)B * 30 * 8); bk.to_device(w.rbd, rbd, (size_t)B * QM_NRBD * 8); bk.to_device(w.mode, mode, (size_t)B * 4); bk.to_device(w.time, time, (size_t)B * 8);
   }

@@ -31,7 +31,7 @@ struct HipBackend {
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
     if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel) return "riccati";
-    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_wbc_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel) return "policy";
+    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_wbc_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy";
     return "ls_misc";
   }
   template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {
@@ -58,6 +58,10 @@ struct HipBackend {
   void to_device(void* d, const void* s, size_t n) { sync(); check(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, stream), "H2D"); check(hipStreamSynchronize(stream), "sync"); }
   void to_host(void* d, const void* s, size_t n) { sync(); check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "D2H"); check(hipStreamSynchronize(stream), "sync"); }
   void sync() { check(hipStreamSynchronize(stream), "sync"); check(hipStreamSynchronize(stream_b), "sync"); wbc_pending = false; }
+  // host-visible (pinned, mapped) memory for flags a kernel publishes: returns the device-side address, *host_view the host-side one
+  void* alloc_mapped(size_t n, void** host_view) { void* h = nullptr; void* dv = nullptr; check(hipHostMalloc(&h, n ? n : 8, hipHostMallocMapped), "hipHostMalloc"); check(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer"); *host_view = h; return dv; }
+  void free_mapped(void* host_view) { hipHostFree(host_view); }
+  void wait_launched() { check(hipStreamSynchronize(cur), "sync"); }     // everything launched so far on the current stream has completed
   // WBC of the current step on stream_b: its inputs were produced on `stream` (ev_in); the next producers on `stream` wait for ev_wbc
   void wbc_inputs_next() { if (wbc_pending) { hipStreamWaitEvent(stream, ev_wbc, 0); wbc_pending = false; } }
   void wbc_begin() { hipEventRecord(ev_in, stream); hipStreamWaitEvent(stream_b, ev_in, 0); cur = stream_b; }
@@ -148,7 +152,7 @@ int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, in
 }
 int qmhip_mpc_solve_resident(qmhip_ctx* c, int B, double horizon) {
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident: bad argument"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->mpc.grid(B, horizon); for (int it = 0; it < c->sqp_iterations(); ++it) c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
+  hipSetDevice(c->device); c->mpc.grid(B, horizon); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true; return c->hipstate();
 }
 int qmhip_mpc_set_initial(qmhip_ctx* c, int B, const double* t0, const double* x0) {
   if (!c || B <= 0 || B > c->max_batch || !t0 || !x0) { if (c) c->fail("qmhip_mpc_set_initial: bad argument"); return QMHIP_ERR_ARG; }
@@ -156,7 +160,7 @@ int qmhip_mpc_set_initial(qmhip_ctx* c, int B, const double* t0, const double* x
 }
 int qmhip_mpc_solve_resident_warm(qmhip_ctx* c, int B, double horizon) {
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident_warm: bad argument"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->mpc.grid(B, horizon, true); for (int it = 0; it < c->sqp_iterations(); ++it) c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true; return c->hipstate();
+  hipSetDevice(c->device); c->mpc.grid(B, horizon, true); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true; return c->hipstate();
 }
 int qmhip_mpc_advance_resident(qmhip_ctx* c, int B, double dt) {
   if (!c || B <= 0 || B > c->max_batch) { if (c) c->fail("qmhip_mpc_advance_resident: bad argument"); return QMHIP_ERR_ARG; }
@@ -169,8 +173,8 @@ int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, 
   for (int k = 0; k < n_steps; ++k) {
     if (k > 0) c->mpc.advance(B, mpc_dt);
     if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon);     // device-resident GaitSchedule active: modifyReferences before every MPC call
-    c->mpc.grid(B, horizon, true); for (int it = 0; it < c->sqp_iterations(); ++it) c->mpc.sqp_iteration(B); c->lastB = B; c->have_solution = true;
-    c->bk.wbc_inputs_next(); c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time0 + k * mpc_dt);
+    c->mpc.grid(B, horizon, true); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true;
+    c->bk.wbc_inputs_next(); c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time0 + k * mpc_dt);
     c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
   }
   return c->hipstate();
@@ -270,7 +274,7 @@ int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double peri
   int rc = qmhip_mpc_solve_resident(c, B, horizon); if (rc) return rc;
   // the WBC goes to its own stream: back-to-back steps overlap WBC(k) — one wave per SIMD whose run time is that of the instance with the most
   // active-set iterations — with the MPC kernels of step k + 1, which fill the SIMDs the finished WBC waves leave behind
-  c->bk.wbc_inputs_next(); c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time);
+  c->bk.wbc_inputs_next(); c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time);
   c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
   return c->hipstate();
 }

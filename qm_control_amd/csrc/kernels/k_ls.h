@@ -28,7 +28,10 @@ struct QmLsArgs {
   double* out_perf;                     // [B][10] baseline(4) after(4) alpha armijo
   int trial;                            // index of the current trial (0-based)
   int with_alpha;                       // perf_sum: 1 = initial-state defect of the trial iterate, 0 = of the base iterate
+  int* open_cnt; int* tickets;          // [QM_LS_MAX_TRIALS] instances still searching after trial t / blocks that have passed; zeroed by the baseline sum
+  volatile int* host_open;              // [QM_LS_MAX_TRIALS] host-visible copy of open_cnt[t], written by the last block of trial t (the host never copies flags)
 };
+#define QM_LS_MAX_TRIALS 16
 
 // cost value of one intermediate node (a2 + a6 + a7 + a5), not yet × dt; K must hold base, legs and arm
 __device__ __forceinline__ double node_cost_value(const double* mb, const double* st, const double* x, const double* u, const double* K, int mode,
@@ -117,23 +120,22 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
 // nodes, DPP wave reduction).  with_alpha == 0: baseline of the current iterate, also arms the line search (alpha = 1, done = 0);
 // with_alpha == 1: the trial point, followed by the filter line-search decision of this instance
 // ([upstream ocs2_sqp SqpSolver::takeStep / FilterLinesearch]): accept, halve alpha, or give up.
-__global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
+// returns true when the instance is still searching after this trial
+__device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b, const int l) {
   const int with_alpha = a.with_alpha;
-  const int b = blockIdx.x, l = threadIdx.x & 63;
-  if (b >= a.B) return;
-  if (with_alpha && a.done[b] != 0) return;
+  if (with_alpha && a.done[b] != 0) return false;
   const int n = a.n_nodes[b]; double c = 0.0, d = 0.0, e = 0.0;
   for (int i = l; i < n; i += 64) { const double* pf = a.perf + (size_t)(i * a.B + b) * PF_SIZE; c += pf[0]; d += pf[1]; e += pf[2]; }
   const double al0 = with_alpha ? a.alpha[b] : 0.0;
   if (l < 30) { const double dd = a.x0[(size_t)b * 30 + l] - (a.x[b * 30 + l] + al0 * a.dx[b * 30 + l]); d += dd * dd; }
   c = qm_wave_sum(c); d = qm_wave_sum(d); e = qm_wave_sum(e);
-  if (l != 0) return;
+  if (l != 0) return false;
   a.perf_sum[b * 4] = c; a.perf_sum[b * 4 + 1] = c; a.perf_sum[b * 4 + 2] = d; a.perf_sum[b * 4 + 3] = e;
   if (!with_alpha) {
     a.alpha[b] = 1.0; a.done[b] = 0;
     for (int q = 0; q < 4; ++q) { a.out_perf[b * 10 + q] = a.perf_sum[b * 4 + q]; a.out_perf[b * 10 + 4 + q] = a.perf_sum[b * 4 + q]; }
     a.out_perf[b * 10 + 8] = 0.0;
-    return;
+    return false;
   }
   if (a.trial == 0) a.out_perf[b * 10 + 9] = a.step_info[b * 4];
   const double gMax = a.st[ST_G_MAX], gMin = a.st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
@@ -144,12 +146,27 @@ __global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
   if (theta > gMax) acc = theta < (1.0 - gammaC) * theta0;
   else if (theta < gMin && theta0 < gMin && al * armijo < 0.0) acc = ps[0] < bs[0] + armijoFactor * al * armijo;
   else acc = ps[0] < (bs[0] - gammaC * theta0) || theta < (1.0 - gammaC) * theta0;
-  if (acc) { a.done[b] = 1; for (int q = 0; q < 4; ++q) a.out_perf[b * 10 + 4 + q] = ps[q]; a.out_perf[b * 10 + 8] = al; return; }
+  if (acc) { a.done[b] = 1; for (int q = 0; q < 4; ++q) a.out_perf[b * 10 + 4 + q] = ps[q]; a.out_perf[b * 10 + 8] = al; return false; }
   al *= alphaDecay;
   const double dxn = sqrt(a.step_info[b * 4 + 1]), dun = sqrt(a.step_info[b * 4 + 2]);
-  if ((al * dun < a.st[ST_DELTA_TOL] && al * dxn < a.st[ST_DELTA_TOL]) || !(al >= alphaMin)) { a.done[b] = 2; a.alpha[b] = 0.0; return; }
+  if ((al * dun < a.st[ST_DELTA_TOL] && al * dxn < a.st[ST_DELTA_TOL]) || !(al >= alphaMin)) { a.done[b] = 2; a.alpha[b] = 0.0; return false; }
   a.alpha[b] = al;
+  return true;
 }
+__global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
+  const int b = blockIdx.x, l = threadIdx.x & 63;
+  if (b >= a.B) return;
+  const bool open = qm_perf_sum_body(a, b, l);
+  // the host only needs to know whether ANY instance is still searching: count them, and let the block that arrives last publish the count
+  // in host-visible memory (one stream synchronisation instead of a flag copy + two)
+  if (a.with_alpha && a.open_cnt && l == 0) {
+    const int t = a.trial;
+    if (open) atomicAdd(a.open_cnt + t, 1);
+    __threadfence();
+    if (atomicAdd(a.tickets + t, 1) == a.B - 1) { a.host_open[t] = atomicAdd(a.open_cnt + t, 0); __threadfence_system(); }
+  }
+}
+
 
 // one thread per (node, instance, component): consecutive threads touch consecutive doubles
 __global__ void qm_ls_apply_kernel(QmLsArgs a) {

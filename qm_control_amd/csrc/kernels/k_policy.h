@@ -15,22 +15,23 @@ struct QmPolicyArgs {
   double* x_des; double* u_des; int* mode;                         // [B][30], [B][30], [B]
 };
 
-__global__ void qm_policy_kernel(QmPolicyArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+__device__ __forceinline__ void qm_policy_body(const QmPolicyArgs& a, const int b) {
   const int n = a.n_nodes[b]; const double t = a.t[b];
   int idx; double al; grid_policy_segment(a.node_t, a.node_ev, n, a.B, b, t, &idx, &al);
   const int i0 = idx * a.B + b, i1 = ((n > 1 ? idx + 1 : idx)) * a.B + b;
   for (int q = 0; q < 30; ++q) { a.x_des[(size_t)b * 30 + q] = al * a.xs[i0 * 30 + q] + (1.0 - al) * a.xs[i1 * 30 + q]; a.u_des[(size_t)b * 30 + q] = al * a.us[i0 * 30 + q] + (1.0 - al) * a.us[i1 * 30 + q]; }
   a.mode[b] = a.modes[(size_t)b * (a.nev + 1) + grid_find_index(a.ev + (size_t)b * a.nev, a.nev, t)];
 }
+__global__ void qm_policy_kernel(QmPolicyArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  qm_policy_body(a, b);
+}
 
 // measured rbd state (55) built from x0: zero velocities, EE pose by FK (layout of
 // qm_estimation/src/StateEstimateBase.cpp:41-103)
 struct QmMeasArgs { const double* mb; int B; const double* x0; double time; double* rbd; double* time_out; };
-__global__ void qm_measured_kernel(QmMeasArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+__device__ __forceinline__ void qm_measured_body(const QmMeasArgs& a, const int b) {
   const double* x = a.x0 + (size_t)b * 30; double* r = a.rbd + (size_t)b * QM_NRBD;
   for (int q = 0; q < QM_NRBD; ++q) r[q] = 0.0;
   for (int q = 0; q < 3; ++q) { r[q] = x[9 + q]; r[3 + q] = x[6 + q]; }
@@ -40,4 +41,16 @@ __global__ void qm_measured_kernel(QmMeasArgs a) {
   for (int q = 0; q < 3; ++q) r[48 + q] = K[KW_ARM + 36 + q];
   for (int q = 0; q < 4; ++q) r[51 + q] = qq[q];
   a.time_out[b] = a.time;
+}
+__global__ void qm_measured_kernel(QmMeasArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  qm_measured_body(a, b);
+}
+// the benchmark / closed-loop step evaluates the policy at t0 and builds the measured state in one launch (one thread per instance each:
+// the first B threads take the policy, the next B the measured state)
+struct QmPolicyMeasArgs { QmPolicyArgs p; QmMeasArgs m; };
+__global__ void qm_policy_measured_kernel(QmPolicyMeasArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < a.p.B) qm_policy_body(a.p, g); else if (g - a.p.B < a.m.B) qm_measured_body(a.m, g - a.p.B);
 }

@@ -35,6 +35,9 @@ struct QmRiccatiArgs {
   double* stage;                               // [B][nmax][SR_SIZE]  (L, W, y are written here)
   double* dx; double* du;                      // [nmax][B][30]
   double* step_info;                           // [B][4]: armijo, |dx|², |du|², chol status
+  // baseline performance of the current iterate (sum of K1b's node terms) + arming of the line search, done by the instance's wave before the sweep
+  // (what a separate one-wave-per-instance launch did: qm_perf_sum_kernel with with_alpha == 0); perf == nullptr: skipped
+  const double* perf; double* base_sum; double* alpha; int* done; double* out_perf; int* open_cnt; int* tickets;
   int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages: results are then
                                                // meaningless; 32: results intact, per-phase cycle counts are written to SR_K of each instance's first stage record)
 };
@@ -290,6 +293,18 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15, b = blockIdx.x;
   if (b >= a.B) return;
   const int n = a.n_nodes[b];
+  if (a.perf) {
+    double pc = 0.0, pd = 0.0, pe = 0.0;
+    for (int i = l; i < n; i += 64) { const double* pf = a.perf + (size_t)(i * a.B + b) * PF_SIZE; pc += pf[0]; pd += pf[1]; pe += pf[2]; }
+    if (l < 30) { const double dd = a.x0[(size_t)b * 30 + l] - a.x[b * 30 + l]; pd += dd * dd; }
+    pc = qm_wave_sum(pc); pd = qm_wave_sum(pd); pe = qm_wave_sum(pe);
+    if (l == 0) {
+      const double ps[4] = {pc, pc, pd, pe};
+      for (int q = 0; q < 4; ++q) { a.base_sum[b * 4 + q] = ps[q]; a.out_perf[b * 10 + q] = ps[q]; a.out_perf[b * 10 + 4 + q] = ps[q]; }
+      a.out_perf[b * 10 + 8] = 0.0; a.alpha[b] = 1.0; a.done[b] = 0;
+    }
+    if (b == 0 && l < 16) { a.open_cnt[l] = 0; a.tickets[l] = 0; }
+  }
   for (int k = l; k < n; k += 64) { const int ev = a.node_ev[k * a.B + b]; const int mk = (ev == QM_EV_PRE) ? 0 : (int)a.stage[((size_t)b * a.nmax + k) * SR_SIZE + SR_SCAL]; nlist[k] = (mk & 255) | (ev << 8); }
   qm_wave_sync();
   int chol_fail = 0;

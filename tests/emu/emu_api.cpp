@@ -13,6 +13,9 @@ struct EmuBackend {
   void to_device(void* d, const void* s, size_t n) { memcpy(d, s, n); }
   void to_host(void* d, const void* s, size_t n) { memcpy(d, s, n); }
   void sync() {}
+  void* alloc_mapped(size_t n, void** host_view) { void* p = malloc(n ? n : 8); *host_view = p; return p; }
+  void free_mapped(void* p) { ::free(p); }
+  void wait_launched() {}
 };
 
 struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; EmuCtx() : mpc(bk), wbc(bk), front(bk) {} };
@@ -60,7 +63,7 @@ void emu_wbc_step(void* h, int B, const double* xd, const double* ud, const doub
 // the benchmark's whole control step on resident data (same calls as qmhip_control_step_resident)
 void emu_control_step(void* h, int B, double horizon, double period, double time, double* out, int* status, double* rbd_out) {
   EmuCtx* c = (EmuCtx*)h; c->mpc.grid(B, horizon); c->mpc.sqp_iteration(B);
-  c->wbc.policy_eval_at_t0(c->mpc.d, B); c->wbc.measured_from_x0(c->mpc.d, B, time); c->wbc.step(c->mpc.d, B, period, 0);
+  c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time); c->wbc.step(c->mpc.d, B, period, 0);
   memcpy(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); memcpy(status, c->wbc.w.qp_status, (size_t)B * 3 * 4); if (rbd_out) memcpy(rbd_out, c->wbc.w.rbd, (size_t)B * QM_NRBD * 8);
 }
 // reference / gait front-end (same calls as the qmhip_gait_* / qmhip_target_* entry points)

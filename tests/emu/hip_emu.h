@@ -78,6 +78,9 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
 #define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __threadfence() ((void)0)
+#define __threadfence_system() ((void)0)
+inline int atomicAdd(int* p, int v) { const int o = *p; *p += v; return o; }   /* blocks run one after the other on the host */
 struct double2 { double x, y; };
 inline double2 make_double2(double a, double b) { double2 r; r.x = a; r.y = b; return r; }
 
