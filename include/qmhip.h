@@ -140,6 +140,25 @@ int qmhip_wbc_reset(qmhip_ctx* ctx);
 int qmhip_control_step_resident(qmhip_ctx* ctx, int B, double horizon, double period, double time);
 int qmhip_wbc_download(qmhip_ctx* ctx, int B, double* out /*[B][54]*/, int32_t* qp_status /*[B][3]*/);
 
+/* ---- batched rigid-body plant: stands where Gazebo + qm_gazebo::QMHWSim stand in the reference.
+ *      sim_set_command = HybridJointHandle::setCommand as QMController::updateControlLaw issues it (qm_controllers/src/QMController.cpp:177-190):
+ *        per joint posDes, velDes, kp, kd, ff in the reference's joint order (LF, LH, RF, RH, arm).
+ *      sim_step = one simulation step: QMHWSim::writeSim (qm_gazebo/src/QMHWSim.cpp:98-116: the held command enters the delay buffer, commands older than
+ *        `delay` — qm_gazebo/config/default.yaml:2 — are dropped, the oldest survivor is applied: tau = kp (posDes − q) + kd (velDes − qd) + ff, saturated at
+ *        the URDF effort limit), then n_substeps semi-implicit Euler steps of the floating-base forward dynamics with penalty ground contact of the four
+ *        feet, then QMHWSim::readSim (QMHWSim.cpp:60-75): rbd[b] is the state in the estimator's layout (qm_estimation/src/StateEstimateBase.cpp:41-103),
+ *        contact[b] the four contact flags (LF RF LH RH).  rbd / contact may be null (results stay resident).
+ *      sim_reset: generalized coordinates q = [pos(3), zyx(3), joints(18)], v = [world linear velocity, zyx rates, joint rates], time per instance;
+ *        clears the delay buffer ("Simulation reset", QMHWSim.cpp:101-103).
+ *      sim_set_params: {contact stiffness [N/m], contact damping [N s/m], friction coefficient, friction regularisation speed [m/s], foot radius [m],
+ *        command delay [s], saturate efforts (0/1)}; Gazebo's ODE contact solver is not part of the reference's sources, the contact model is this library's own.
+ *      sim_get_state: q, v, time, contact forces [B][12] (world frame) of the last sub-step, status [B] (0 ok, 1 mass matrix not positive definite); any may be null. */
+int qmhip_sim_set_params(qmhip_ctx* ctx, const double* params, int n);
+int qmhip_sim_reset(qmhip_ctx* ctx, int B, const double* q /*[B][24]*/, const double* v /*[B][24]*/, const double* time /*[B]*/);
+int qmhip_sim_set_command(qmhip_ctx* ctx, int B, const double* pos_des /*[B][18]*/, const double* vel_des, const double* kp, const double* kd, const double* ff);
+int qmhip_sim_step(qmhip_ctx* ctx, int B, double period, int n_substeps, double* rbd /*[B][55]*/, int32_t* contact /*[B][4]*/);
+int qmhip_sim_get_state(qmhip_ctx* ctx, int B, double* q, double* v, double* time, double* force /*[B][12]*/, int32_t* status /*[B]*/);
+
 /* ---- instrumentation (ocs2 benchmark::RepeatedTimer analogue, QMController.cpp:145-147,321-323) ----
  * per-kernel HIP-event timing on the context stream; names: "grid","lq","riccati","ls_eval","ls_misc","wbc" */
 int qmhip_set_profiling(qmhip_ctx* ctx, int enable);

@@ -171,6 +171,26 @@ class Oracle:
         self.lib.qmo_rbd_from_q(self.h, _p(q), None if vv is None else _p(vv), _p(rbd))
         return rbd
 
+    # ---- batched-plant restatement (oracle/src/sim.h) ----
+    def sim_params(self, **params):
+        cur = dict(contact_stiffness=4.0e4, contact_damping=200.0, friction=0.8, friction_speed_eps=1.0e-2, foot_radius=0.02, delay=0.009, saturate_effort=1.0)
+        cur.update(params)
+        v = np.array([cur[k] for k in ("contact_stiffness", "contact_damping", "friction", "friction_speed_eps", "foot_radius", "delay", "saturate_effort")], float)
+        self.lib.qmo_sim_params(self.h, _p(v))
+
+    def sim_reset(self, q, v, time=0.0):
+        q = np.ascontiguousarray(q, float); v = np.ascontiguousarray(v, float)
+        self.lib.qmo_sim_reset(self.h, _p(q), _p(v), C.c_double(time))
+
+    def sim_command(self, pos, vel, kp, kd, ff):
+        a = [np.ascontiguousarray(np.broadcast_to(x, (18,)), float) for x in (pos, vel, kp, kd, ff)]
+        self.lib.qmo_sim_command(self.h, *[_p(x) for x in a])
+
+    def sim_step(self, period, nsub=2):
+        q = np.zeros(24); v = np.zeros(24); t = C.c_double(0); f = np.zeros(12); c = np.zeros(4, np.int32)
+        st = self.lib.qmo_sim_step(self.h, C.c_double(period), C.c_int(nsub), _p(q), _p(v), C.byref(t), _p(f), _pi(c))
+        return dict(q=q, v=v, time=t.value, force=f, contact=c, status=st, rbd=self.rbd_from_q(q, v))
+
     def wbc(self, xdes, udes, rbd, mode, period, time, mpc_variant=False, debug=False):
         xdes = np.ascontiguousarray(xdes, float); udes = np.ascontiguousarray(udes, float); rbd = np.ascontiguousarray(rbd, float)
         out = np.zeros(54); st = np.zeros(3, np.int32); dbg = np.zeros(24 * 4 + 6 + 24 + 36 * 3 + 576 + 288 + 288)

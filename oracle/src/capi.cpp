@@ -2,12 +2,13 @@
 // cpu_baseline leg, __graft_entry__.smoke()).  Nothing under qm_control_amd/ may link or load this.
 #include "sqp.h"
 #include "wbc.h"
+#include "sim.h"
 #include <cstdio>
 #include <thread>
 #include <atomic>
 
 struct Oracle {
-  Model M; Problem P; SqpResult R; WbcState W; WbcDebug dbg;
+  Model M; Problem P; SqpResult R; WbcState W; WbcDebug dbg; SimState sim; SimParams simp;
   Oracle() { P.M = &M; }
 };
 
@@ -150,6 +151,18 @@ int qmo_wbc(void* h, const double* xdes, const double* udes, const double* rbd, 
     put(d.qMeas); put(d.vMeas); put(d.qDes); put(d.vDes); put(d.baseAcc); put(d.nle); put(d.x0); put(d.x1); put(d.x2); put(d.Mq.a); put(d.J.a); put(d.dJ.a);
   }
   return 0;
+}
+
+// ---- batched-plant restatement (oracle/src/sim.h) ----
+void qmo_sim_params(void* h, const double* p) { SimParams& q = ((Oracle*)h)->simp; q.k_n = p[0]; q.d_n = p[1]; q.mu = p[2]; q.v_eps = p[3]; q.foot_radius = p[4]; q.delay = p[5]; q.saturate = p[6] != 0.0; }
+void qmo_sim_reset(void* h, const double* q, const double* v, double time) { Oracle* o = (Oracle*)h; o->sim = SimState(); for (int i = 0; i < QM_NQ; ++i) { o->sim.q[i] = q[i]; o->sim.v[i] = v[i]; } o->sim.time = time; }
+void qmo_sim_command(void* h, const double* pos, const double* vel, const double* kp, const double* kd, const double* ff) {
+  SimCmd& c = ((Oracle*)h)->sim.held; for (int j = 0; j < QM_NJ; ++j) { c.pos[j] = pos[j]; c.vel[j] = vel[j]; c.kp[j] = kp[j]; c.kd[j] = kd[j]; c.ff[j] = ff[j]; }
+}
+int qmo_sim_step(void* h, double period, int nsub, double* q, double* v, double* time, double* force, int* contact) {
+  Oracle* o = (Oracle*)h; simStep(o->M, o->simp, o->sim, period, nsub);
+  for (int i = 0; i < QM_NQ; ++i) { q[i] = o->sim.q[i]; v[i] = o->sim.v[i]; } *time = o->sim.time; for (int i = 0; i < 12; ++i) force[i] = o->sim.force[i]; for (int i = 0; i < 4; ++i) contact[i] = o->sim.contact[i];
+  return o->sim.status;
 }
 // rbd state (55) from generalized coordinates: zero velocities, EE pose by FK (StateEstimateBase.cpp:41-103 layout)
 void qmo_rbd_from_q(void* h, const double* q, const double* v /*24 pinocchio, may be null*/, double* rbd) {

@@ -23,7 +23,8 @@ EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_la
            "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
            "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_microbench_fp64",
            "qmhip_gait_set_templates", "qmhip_gait_reset", "qmhip_gait_insert_template", "qmhip_gait_update_resident", "qmhip_gait_download", "qmhip_schedule_download",
-           "qmhip_target_reset", "qmhip_target_from_command", "qmhip_target_download"]
+           "qmhip_target_reset", "qmhip_target_from_command", "qmhip_target_download",
+           "qmhip_sim_set_params", "qmhip_sim_reset", "qmhip_sim_set_command", "qmhip_sim_step", "qmhip_sim_get_state"]
 
 
 class QmhipError(RuntimeError):
@@ -229,6 +230,50 @@ class HierarchicalWbc:
         out = np.zeros((B, 54)); st = np.zeros((B, 3), np.int32)
         self.itf._check(self.lib.qmhip_wbc_download(self.itf.h, B, _p(out), _pi(st)), "qmhip_wbc_download")
         return out, st
+
+
+class QMHWSim:
+    """qm_gazebo::QMHWSim-shaped front of the batched rigid-body plant (qm_gazebo/src/QMHWSim.cpp:60-116): `setCommand` is what
+    QMController::updateControlLaw issues through the hybrid joint handles, `step(period)` = writeSim (delay buffer + joint PD law) + the physics step +
+    readSim (rbd state in the estimator's layout, contact flags)."""
+    PARAMS = ("contact_stiffness", "contact_damping", "friction", "friction_speed_eps", "foot_radius", "delay", "saturate_effort")
+
+    def __init__(self, interface, **params):
+        self.itf = interface
+        self.lib = interface.lib
+        self.B = 0
+        if params:
+            self.set_params(**params)
+
+    def set_params(self, **params):
+        cur = dict(contact_stiffness=4.0e4, contact_damping=200.0, friction=0.8, friction_speed_eps=1.0e-2, foot_radius=0.02, delay=0.009, saturate_effort=1.0)
+        cur.update(getattr(self, "params", {}))
+        for k in params:
+            if k not in cur:
+                raise KeyError(k)
+        cur.update(params); self.params = cur
+        v = _f([float(cur[k]) for k in self.PARAMS])
+        self.itf._check(self.lib.qmhip_sim_set_params(self.itf.h, _p(v), 7), "qmhip_sim_set_params")
+
+    def reset(self, q, v, time=0.0):
+        q = _f(q); B = q.shape[0]; v = _f(v, (B, 24)); t = _f(np.broadcast_to(time, (B,)))
+        assert q.shape == (B, 24)
+        self.itf._check(self.lib.qmhip_sim_reset(self.itf.h, B, _p(q), _p(v), _p(t)), "qmhip_sim_reset")
+        self.B = B
+
+    def setCommand(self, posDes, velDes, kp, kd, ff):
+        B = self.B; a = [_f(np.broadcast_to(x, (B, 18))) for x in (posDes, velDes, kp, kd, ff)]
+        self.itf._check(self.lib.qmhip_sim_set_command(self.itf.h, B, *[_p(x) for x in a]), "qmhip_sim_set_command")
+
+    def step(self, period, n_substeps=2, download=True):
+        B = self.B; rbd = np.zeros((B, 55)) if download else None; contact = np.zeros((B, 4), np.int32) if download else None
+        self.itf._check(self.lib.qmhip_sim_step(self.itf.h, B, C.c_double(period), int(n_substeps), _p(rbd), _pi(contact)), "qmhip_sim_step")
+        return rbd, contact
+
+    def state(self):
+        B = self.B; q = np.zeros((B, 24)); v = np.zeros((B, 24)); t = np.zeros(B); f = np.zeros((B, 12)); st = np.zeros(B, np.int32)
+        self.itf._check(self.lib.qmhip_sim_get_state(self.itf.h, B, _p(q), _p(v), _p(t), _p(f), _pi(st)), "qmhip_sim_get_state")
+        return dict(q=q, v=v, time=t, force=f, status=st)
 
 
 GAIT_MAX_PHASES, GAIT_EVENT_SLOTS = 16, 256

@@ -1,0 +1,35 @@
+// qm_sim_pipeline.h — launches of the batched rigid-body plant (backend-templated like qm_pipeline.h)
+#pragma once
+#include "qm_pipeline.h"
+#include "../kernels/k_sim.h"
+
+struct QmSimBuffers {
+  int Bmax = 0;
+  double* q = nullptr; double* v = nullptr; double* time = nullptr; double* cmd = nullptr; double* ring = nullptr; int* ring_n = nullptr;
+  double* rbd = nullptr; int* contact = nullptr; double* force = nullptr; int* status = nullptr;
+};
+
+template <class BK>
+struct QmSimPipeline {
+  BK& bk; QmSimBuffers s; QmSimParams p;
+  explicit QmSimPipeline(BK& b) : bk(b) { p.k_n = 4.0e4; p.d_n = 200.0; p.mu = 0.8; p.v_eps = 1.0e-2; p.foot_radius = 0.02; p.delay = 0.009; p.saturate = 1; }
+  template <class T> T* A(size_t n) { T* ptr = (T*)bk.alloc(n * sizeof(T)); bk.zero(ptr, n * sizeof(T)); return ptr; }
+  void allocate(int Bmax) {
+    if (s.Bmax) return;
+    s.Bmax = Bmax; s.q = A<double>((size_t)Bmax * 24); s.v = A<double>((size_t)Bmax * 24); s.time = A<double>(Bmax); s.cmd = A<double>((size_t)Bmax * (QM_SIM_CMD - 1));
+    s.ring = A<double>((size_t)Bmax * QM_SIM_SLOTS * QM_SIM_CMD); s.ring_n = A<int>((size_t)Bmax * 2); s.rbd = A<double>((size_t)Bmax * QM_NRBD); s.contact = A<int>((size_t)Bmax * 4);
+    s.force = A<double>((size_t)Bmax * 12); s.status = A<int>(Bmax);
+  }
+  void release() { void* ps[] = {s.q, s.v, s.time, s.cmd, s.ring, s.ring_n, s.rbd, s.contact, s.force, s.status}; for (void* ptr : ps) if (ptr) bk.free(ptr); s = QmSimBuffers(); }
+  // "Simulation reset" of QMHWSim::writeSim: state set, delay buffer and held command cleared
+  void reset(int B, const double* q_host, const double* v_host, const double* time_host) {
+    bk.to_device(s.q, q_host, (size_t)B * 24 * 8); bk.to_device(s.v, v_host, (size_t)B * 24 * 8); bk.to_device(s.time, time_host, (size_t)B * 8);
+    bk.zero(s.ring_n, (size_t)s.Bmax * 2 * sizeof(int)); bk.zero(s.cmd, (size_t)s.Bmax * (QM_SIM_CMD - 1) * 8);
+  }
+  void set_command(int B, const double* cmd_host) { bk.to_device(s.cmd, cmd_host, (size_t)B * (QM_SIM_CMD - 1) * 8); }
+  void step(const double* mb_dev, int B, double period, int nsub) {
+    QmSimArgs a; a.mb = mb_dev; a.B = B; a.nsub = nsub; a.h = period / nsub; a.p = p; a.q = s.q; a.v = s.v; a.time = s.time; a.cmd = s.cmd; a.ring = s.ring; a.ring_n = s.ring_n;
+    a.rbd = s.rbd; a.contact = s.contact; a.force = s.force; a.status = s.status;
+    bk.launch(qm_sim_kernel, B, 64, SIM_LDS_BYTES, a);   // one wavefront per instance
+  }
+};

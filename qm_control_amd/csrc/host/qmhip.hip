@@ -10,6 +10,7 @@
 #include "qm_model_io.h"
 #include "qm_pipeline.h"
 #include "qm_wbc_pipeline.h"
+#include "qm_sim_pipeline.h"
 #include "qm_front_pipeline.h"
 
 static std::string g_create_error;
@@ -31,7 +32,7 @@ struct HipBackend {
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
     if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel) return "riccati";
-    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_wbc_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy";
+    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy";
     return "ls_misc";
   }
   template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {
@@ -71,9 +72,9 @@ struct HipBackend {
 struct qmhip_ctx {
   int device = 0, max_batch = 0, max_nodes = 0, max_ref = 0, max_ev = 0;
   double mb[MB_SIZE], st[ST_SIZE];
-  HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc; QmFrontPipeline<HipBackend> front;
+  HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc; QmFrontPipeline<HipBackend> front; QmSimPipeline<HipBackend> sim;
   std::string error; int lastB = 0; bool have_solution = false; int front_B = 0;
-  qmhip_ctx() : mpc(bk), wbc(bk), front(bk) {}
+  qmhip_ctx() : mpc(bk), wbc(bk), front(bk), sim(bk) {}
   void fail(const std::string& m) { error = m; }
   // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
   // them (an instance whose line search finds no step just keeps its iterate)
@@ -136,7 +137,7 @@ int qmhip_create_from_blobs(const double* mb, const double* st, int device, int 
   return create_common(mb, st, device, max_batch, max_nodes, max_ref, max_ev, out);
 }
 void qmhip_destroy(qmhip_ctx* c) {
-  if (!c) return; hipSetDevice(c->device); c->bk.sync(); c->mpc.release(); c->wbc.release(); c->front.release();
+  if (!c) return; hipSetDevice(c->device); c->bk.sync(); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release();
   for (auto e : c->bk.pool) hipEventDestroy(e); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
 }
 const char* qmhip_last_error(const qmhip_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
@@ -276,6 +277,41 @@ int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double peri
   // active-set iterations — with the MPC kernels of step k + 1, which fill the SIMDs the finished WBC waves leave behind
   c->bk.wbc_inputs_next(); c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time);
   c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
+  return c->hipstate();
+}
+
+// ---- batched rigid-body plant (QMHWSim.cpp:60-116) ----
+int qmhip_sim_set_params(qmhip_ctx* c, const double* p, int n) {
+  if (!c || !p || n < 1 || n > 7) { if (c) c->fail("qmhip_sim_set_params: bad argument"); return QMHIP_ERR_ARG; }
+  QmSimParams& q = c->sim.p; double* f[6] = {&q.k_n, &q.d_n, &q.mu, &q.v_eps, &q.foot_radius, &q.delay};
+  for (int i = 0; i < n && i < 6; ++i) *f[i] = p[i]; if (n == 7) q.saturate = p[6] != 0.0;
+  if (!(q.k_n >= 0) || !(q.d_n >= 0) || !(q.mu >= 0) || !(q.v_eps > 0) || !(q.delay >= 0)) { c->fail("qmhip_sim_set_params: negative parameter"); return QMHIP_ERR_ARG; }
+  return QMHIP_OK;
+}
+int qmhip_sim_reset(qmhip_ctx* c, int B, const double* q, const double* v, const double* time) {
+  if (!c || B <= 0 || B > c->max_batch || !q || !v || !time) { if (c) c->fail("qmhip_sim_reset: bad argument"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->sim.allocate(c->max_batch); c->sim.reset(B, q, v, time); return c->hipstate();
+}
+int qmhip_sim_set_command(qmhip_ctx* c, int B, const double* pos_des, const double* vel_des, const double* kp, const double* kd, const double* ff) {
+  if (!c || B <= 0 || B > c->max_batch || !pos_des || !vel_des || !kp || !kd || !ff) { if (c) c->fail("qmhip_sim_set_command: bad argument"); return QMHIP_ERR_ARG; }
+  if (!c->sim.s.Bmax) { c->fail("qmhip_sim_set_command: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
+  std::vector<double> cmd((size_t)B * (QM_SIM_CMD - 1)); const double* src[5] = {pos_des, vel_des, kp, kd, ff};
+  for (int b = 0; b < B; ++b) for (int k = 0; k < 5; ++k) for (int j = 0; j < 18; ++j) cmd[(size_t)b * (QM_SIM_CMD - 1) + 18 * k + j] = src[k][(size_t)b * 18 + j];
+  hipSetDevice(c->device); c->sim.set_command(B, cmd.data()); return c->hipstate();
+}
+int qmhip_sim_step(qmhip_ctx* c, int B, double period, int n_substeps, double* rbd, int32_t* contact) {
+  if (!c || B <= 0 || B > c->max_batch || !(period > 0) || n_substeps < 1) { if (c) c->fail("qmhip_sim_step: bad argument"); return QMHIP_ERR_ARG; }
+  if (!c->sim.s.Bmax) { c->fail("qmhip_sim_step: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
+  hipSetDevice(c->device); c->sim.step(c->mpc.d.mb, B, period, n_substeps);
+  if (rbd) c->bk.to_host(rbd, c->sim.s.rbd, (size_t)B * QM_NRBD * 8); if (contact) c->bk.to_host(contact, c->sim.s.contact, (size_t)B * 4 * 4);
+  return c->hipstate();
+}
+int qmhip_sim_get_state(qmhip_ctx* c, int B, double* q, double* v, double* time, double* force, int32_t* status) {
+  if (!c || B <= 0 || B > c->max_batch) { if (c) c->fail("qmhip_sim_get_state: bad argument"); return QMHIP_ERR_ARG; }
+  if (!c->sim.s.Bmax) { c->fail("qmhip_sim_get_state: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
+  hipSetDevice(c->device);
+  if (q) c->bk.to_host(q, c->sim.s.q, (size_t)B * 24 * 8); if (v) c->bk.to_host(v, c->sim.s.v, (size_t)B * 24 * 8); if (time) c->bk.to_host(time, c->sim.s.time, (size_t)B * 8);
+  if (force) c->bk.to_host(force, c->sim.s.force, (size_t)B * 12 * 8); if (status) c->bk.to_host(status, c->sim.s.status, (size_t)B * 4);
   return c->hipstate();
 }
 

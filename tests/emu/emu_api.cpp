@@ -3,6 +3,7 @@
 #include "hip_emu.h"
 #include "../../qm_control_amd/csrc/host/qm_pipeline.h"
 #include "../../qm_control_amd/csrc/host/qm_wbc_pipeline.h"
+#include "../../qm_control_amd/csrc/host/qm_sim_pipeline.h"
 #include "../../qm_control_amd/csrc/host/qm_front_pipeline.h"
 
 struct EmuBackend {
@@ -18,13 +19,13 @@ struct EmuBackend {
   void wait_launched() {}
 };
 
-struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; EmuCtx() : mpc(bk), wbc(bk), front(bk) {} };
+struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; QmSimPipeline<EmuBackend> sim; EmuCtx() : mpc(bk), wbc(bk), front(bk), sim(bk) {} };
 
 extern "C" {
 void* emu_create(const double* mb, const double* st, int Bmax, int nmax, int nref, int nev) {
   EmuCtx* c = new EmuCtx(); c->mpc.allocate(mb, st, Bmax, nmax, nref, nev, true); c->wbc.allocate(Bmax, true); c->front.allocate(Bmax); c->front.phase_transition_stance_time = st[ST_PHASE_TRANS_STANCE]; return c;
 }
-void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; c->mpc.release(); c->wbc.release(); c->front.release(); delete c; }
+void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); delete c; }
 int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes, double horizon, int max_trials) {
   EmuCtx* c = (EmuCtx*)h;
   c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes);
@@ -56,6 +57,15 @@ void emu_policy_eval(void* h, int B, const double* t, double* xd, double* ud, in
   memcpy(xd, c->wbc.w.x_des, (size_t)B * 30 * 8); memcpy(ud, c->wbc.w.u_des, (size_t)B * 30 * 8); memcpy(mode, c->wbc.w.mode, (size_t)B * 4);
 }
 void emu_wbc_reset(void* h) { ((EmuCtx*)h)->wbc.reset(); }
+// batched rigid-body plant (same calls as the qmhip_sim_* entry points)
+void emu_sim_params(void* h, const double* p) { QmSimParams& q = ((EmuCtx*)h)->sim.p; q.k_n = p[0]; q.d_n = p[1]; q.mu = p[2]; q.v_eps = p[3]; q.foot_radius = p[4]; q.delay = p[5]; q.saturate = p[6] != 0.0; }
+void emu_sim_reset(void* h, int B, const double* q, const double* v, const double* time) { EmuCtx* c = (EmuCtx*)h; c->sim.allocate(c->mpc.d.Bmax); c->sim.reset(B, q, v, time); }
+void emu_sim_command(void* h, int B, const double* cmd90) { ((EmuCtx*)h)->sim.set_command(B, cmd90); }
+void emu_sim_step(void* h, int B, double period, int nsub, double* rbd, int* contact, double* q, double* v, double* force, int* status) {
+  EmuCtx* c = (EmuCtx*)h; c->sim.step(c->mpc.d.mb, B, period, nsub);
+  memcpy(rbd, c->sim.s.rbd, (size_t)B * QM_NRBD * 8); memcpy(contact, c->sim.s.contact, (size_t)B * 16); memcpy(q, c->sim.s.q, (size_t)B * 24 * 8); memcpy(v, c->sim.s.v, (size_t)B * 24 * 8);
+  memcpy(force, c->sim.s.force, (size_t)B * 12 * 8); memcpy(status, c->sim.s.status, (size_t)B * 4);
+}
 void emu_wbc_step(void* h, int B, const double* xd, const double* ud, const double* rbd, const int* mode, double period, const double* time, int variant, double* out, int* status, double* dbg) {
   EmuCtx* c = (EmuCtx*)h; c->wbc.upload(B, xd, ud, rbd, mode, time); c->wbc.step(c->mpc.d, B, period, variant);
   memcpy(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); memcpy(status, c->wbc.w.qp_status, (size_t)B * 3 * 4); if (dbg) memcpy(dbg, c->wbc.w.dbg, (size_t)B * WBC_DBG_SIZE * 8);

@@ -158,6 +158,26 @@ class Emu:
             e["M"] = e["M"].reshape(24, 24); e["J"] = e["J"].reshape(12, 24); d.append(e)
         return out, st, d
 
+    # batched rigid-body plant
+    def sim_params(self, **params):
+        cur = dict(contact_stiffness=4.0e4, contact_damping=200.0, friction=0.8, friction_speed_eps=1.0e-2, foot_radius=0.02, delay=0.009, saturate_effort=1.0)
+        cur.update(params)
+        v = np.array([cur[k] for k in ("contact_stiffness", "contact_damping", "friction", "friction_speed_eps", "foot_radius", "delay", "saturate_effort")], float)
+        self.lib.emu_sim_params(self.h, _p(v))
+
+    def sim_reset(self, q, v, time=0.0):
+        q = np.ascontiguousarray(q, float); B = q.shape[0]; v = np.ascontiguousarray(v, float); t = np.ascontiguousarray(np.broadcast_to(time, (B,)), float)
+        self.lib.emu_sim_reset(self.h, C.c_int(B), _p(q), _p(v), _p(t)); self.simB = B
+
+    def sim_command(self, pos, vel, kp, kd, ff):
+        B = self.simB; cmd = np.concatenate([np.ascontiguousarray(np.broadcast_to(x, (B, 18)), float) for x in (pos, vel, kp, kd, ff)], axis=1)
+        cmd = np.ascontiguousarray(cmd); self.lib.emu_sim_command(self.h, C.c_int(B), _p(cmd))
+
+    def sim_step(self, period, nsub=2):
+        B = self.simB; rbd = np.zeros((B, 55)); contact = np.zeros((B, 4), np.int32); q = np.zeros((B, 24)); v = np.zeros((B, 24)); f = np.zeros((B, 12)); st = np.zeros(B, np.int32)
+        self.lib.emu_sim_step(self.h, C.c_int(B), C.c_double(period), C.c_int(nsub), _p(rbd), _pi(contact), _p(q), _p(v), _p(f), _pi(st))
+        return dict(rbd=rbd, contact=contact, q=q, v=v, force=f, status=st)
+
     def control_step(self, cfg, batch=None):
         """upload + the benchmark's whole control step (MPC iteration, policy at t0, WBC on the synthetic measured state)"""
         B = cfg["B"] if batch is None else batch

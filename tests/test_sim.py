@@ -1,0 +1,93 @@
+"""Batched rigid-body plant: the emulated kernel against the CPU oracle's restatement (oracle/src/sim.h) — command law with the
+delay buffer of QMHWSim::writeSim, forward dynamics, penalty contact — plus physical sanity checks of the oracle itself."""
+import numpy as np
+import pytest
+from conftest import rel_err
+
+
+def nominal_q(st, z=None):
+    q = np.array(st[936:960], float)      # initialState: base pose + joints
+    if z is not None:
+        q[2] = z
+    return q
+
+
+def stand_height(oracle, st):
+    """base height at which the nominal feet just touch the ground (foot radius 0.02)"""
+    q = nominal_q(st); rbd = oracle.rbd_from_q(q)
+    import ctypes as C
+    pos = np.zeros(3); R = np.zeros(9)
+    zs = []
+    for f in range(4):
+        oracle.lib.qmo_frame_pose(oracle.h, q.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(f), pos.ctypes.data_as(C.POINTER(C.c_double)), R.ctypes.data_as(C.POINTER(C.c_double)))
+        zs.append(pos[2])
+    return q[2] - min(zs) + 0.02
+
+
+def random_cases(oracle, st, n, seed):
+    rng = np.random.default_rng(seed); z0 = stand_height(oracle, st); cases = []
+    for k in range(n):
+        q = nominal_q(st, z0 - 0.004 + 0.01 * rng.random()); q[3:6] += 0.05 * rng.normal(size=3); q[6:] += 0.05 * rng.normal(size=18)
+        v = 0.2 * rng.normal(size=24)
+        kp = np.concatenate([np.full(12, 0.0 if k % 2 else 60.0), np.full(6, 20.0)]); kd = np.concatenate([np.full(12, 3.0), np.full(6, 0.5)])   # kd as the reference commands them (QMController.cpp:183,188; cfg/weight.cfg:8)
+        cases.append(dict(q=q, v=v, pos=nominal_q(st)[6:] + 0.05 * rng.normal(size=18), vel=0.1 * rng.normal(size=18), kp=kp, kd=kd, ff=5.0 * rng.normal(size=18)))
+    return cases
+
+
+def test_oracle_free_fall_and_static_stance(blobs, oracle):
+    mb, st = blobs
+    # free fall far above the ground with no command: base accelerates with g, total momentum in x/y stays zero
+    oracle.sim_params(); q = nominal_q(st, 2.0); oracle.sim_reset(q, np.zeros(24), 0.0); oracle.sim_command(0, 0, 0, 0, 0)
+    for _ in range(10):
+        r = oracle.sim_step(0.001, 1)
+    assert r["status"] == 0 and not r["contact"].any()
+    assert abs(r["v"][2] + 9.81 * 0.01) < 5e-3 and np.abs(r["force"]).max() == 0.0
+    # standing on compliant legs with the contact active: the conjugate momentum of the base z translation, (M v)[2] = total vertical momentum, changes by
+    # the impulse of (sum of normal forces − weight) — Newton's law for the whole tree, whatever the joints do
+    z0 = stand_height(oracle, st); q = nominal_q(st, z0 - 0.002)
+    kp = np.concatenate([np.full(12, 300.0), np.full(6, 20.0)]); kd = np.concatenate([np.full(12, 3.0), np.full(6, 0.5)])   # explicit joint law: kd h must stay below 2 x the joint inertia (wrist: 5.8e-4)
+    oracle.sim_reset(q, np.zeros(24), 0.0); oracle.sim_command(q[6:], 0.0, kp, kd, 0.0)
+    weight = mb[654] * 9.81; imp = 0.0; h = 0.001
+    for k in range(200):
+        r = oracle.sim_step(h, 1); imp += (r["force"][2::3].sum() - weight) * h
+        if k % 50 == 49:
+            M = oracle.wbc(st[930:960], np.zeros(30), oracle.rbd_from_q(r["q"], np.zeros(24)), 15, 0.002, 20.0, debug=True)[2]["M"]
+            assert abs((M @ r["v"])[2] - imp) < 0.02 * max(1.0, abs(imp)), (k, (M @ r["v"])[2], imp)
+    assert r["status"] == 0 and r["contact"].all()
+    assert abs(r["q"][2] - z0) < 0.01 and np.abs(r["q"][3:6]).max() < 0.05 and np.isfinite(r["v"]).all()
+
+
+def test_oracle_command_delay(blobs, oracle):
+    """a feed-forward torque step reaches the joints `delay` after it was commanded (QMHWSim.cpp:100-113)"""
+    mb, st = blobs
+    oracle.sim_params(delay=0.009, saturate_effort=0.0); q = nominal_q(st, 2.0); oracle.sim_reset(q, np.zeros(24), 0.0); oracle.sim_command(0, 0, 0, 0, 0)
+    for _ in range(3):
+        oracle.sim_step(0.001, 1)
+    ff = np.zeros(18); ff[17] = 1.0                       # last arm joint
+    oracle.sim_command(0, 0, 0, 0, ff)
+    acc = []
+    for k in range(14):
+        v0 = oracle.sim_step(0.001, 1)["v"][23]; acc.append(v0)
+    dv = np.diff(np.array([0.0] + acc))                   # joint-velocity increments per step
+    first = int(np.argmax(np.abs(dv) > 1e-3 * np.abs(dv).max()))
+    assert first in (8, 9), (first, dv)          # the applied command is the oldest one not older than the delay: its age lies in (delay - period, delay]
+
+
+@pytest.mark.parametrize("nsub", [1, 2])
+def test_emulated_plant_vs_oracle(blobs, oracle, nsub):
+    import emu_harness
+    mb, st = blobs
+    cases = random_cases(oracle, st, 4, 5)
+    B = len(cases); arr = lambda k: np.array([c[k] for c in cases])
+    e = emu_harness.Emu(mb, st, 8, 8, 2, 2)
+    e.sim_params(); e.sim_reset(arr("q"), arr("v"), 1.0); e.sim_command(arr("pos"), arr("vel"), arr("kp"), arr("kd"), arr("ff"))
+    steps = 12
+    out = [e.sim_step(0.001, nsub) for _ in range(steps)]
+    for b, c in enumerate(cases):
+        oracle.sim_params(); oracle.sim_reset(c["q"], c["v"], 1.0); oracle.sim_command(c["pos"], c["vel"], c["kp"], c["kd"], c["ff"])
+        for k in range(steps):
+            r = oracle.sim_step(0.001, nsub)
+            assert r["status"] == 0 and out[k]["status"][b] == 0
+            assert rel_err(out[k]["q"][b], r["q"]) < 1e-9 and rel_err(out[k]["v"][b], r["v"]) < 1e-7, (b, k)
+            assert rel_err(out[k]["force"][b], r["force"]) < 1e-6 and list(out[k]["contact"][b]) == list(r["contact"]), (b, k)
+            assert rel_err(out[k]["rbd"][b], r["rbd"]) < 1e-7, (b, k)
