@@ -158,6 +158,15 @@ int qmhip_sim_reset(qmhip_ctx* ctx, int B, const double* q /*[B][24]*/, const do
 int qmhip_sim_set_command(qmhip_ctx* ctx, int B, const double* pos_des /*[B][18]*/, const double* vel_des, const double* kp, const double* kd, const double* ff);
 int qmhip_sim_step(qmhip_ctx* ctx, int B, double period, int n_substeps, double* rbd /*[B][55]*/, int32_t* contact /*[B][4]*/);
 int qmhip_sim_get_state(qmhip_ctx* ctx, int B, double* q, double* v, double* time, double* force /*[B][12]*/, int32_t* status /*[B]*/);
+/*      closed_loop_sim: n_ticks of the whole controller around the plant, device resident — QMController::update + mpcThread_
+ *        (qm_controllers/src/QMController.cpp:128-175, 202-244, 315-332): state estimate = the plant's state ("ground truth" estimator,
+ *        currentObservation_.state = computeCentroidalStateFromRbdModel), an MPC call on that observation every mpc_every ticks (warm-started SQP; the
+ *        gait front-end refreshes the mode schedule first when it is active), policy evaluation at the plant time, WBC on the measured state,
+ *        updateControlLaw (QMController.cpp:177-190: legs kp 0 / kd 3 once time > 10, arm arm_kp / arm_kd, WBC torque as feed-forward), one
+ *        simulation step.  Needs qmhip_mpc_upload (reference, schedule) and qmhip_sim_reset before; the tick counter restarts at sim_reset.
+ *        The reference runs the MPC in its own thread; here it is synchronous with the tick that triggers it.  On the first tick after a reset the
+ *        WBC's joint-acceleration state inputLast_ (WbcBase.cpp:212-213) is primed with the planned input (zero joint acceleration). */
+int qmhip_closed_loop_sim(qmhip_ctx* ctx, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd);
 
 /* ---- instrumentation (ocs2 benchmark::RepeatedTimer analogue, QMController.cpp:145-147,321-323) ----
  * per-kernel HIP-event timing on the context stream; names: "grid","lq","riccati","ls_eval","ls_misc","wbc" */

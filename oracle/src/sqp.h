@@ -14,7 +14,10 @@ inline double intervalEnd(const Node& n) { return n.ev == QM_EV_PRE ? n.t - kWea
 
 // [upstream timeDiscretizationWithEvents]
 inline std::vector<Node> timeDiscretizationWithEvents(double t0, double tf, double dt, const Vec& ev) {
-  const double dtMin = 10.0 * kLimitEps;
+  // minimum step: [upstream]'s default is a few machine epsilons; a grid node that falls within weakEpsilon BEFORE an event would then open an interval whose
+  // adapted duration (intervalEnd − intervalStart, ±weakEpsilon at events) is NEGATIVE — a fixed-rate loop (t0 = k · 1 ms, events on the same raster)
+  // hits that exactly.  Steps shorter than 10 weakEpsilon are merged instead (robustness deviation, identical grids otherwise).
+  const double dtMin = 10.0 * kWeakEps;
   std::vector<Node> g; g.push_back({t0, QM_EV_NONE});
   int k = findIndexInTimeArray(ev, t0);
   Node next = g.back();

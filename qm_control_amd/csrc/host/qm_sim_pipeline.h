@@ -2,6 +2,7 @@
 #pragma once
 #include "qm_pipeline.h"
 #include "../kernels/k_sim.h"
+#include "../kernels/k_loop.h"
 
 struct QmSimBuffers {
   int Bmax = 0;
@@ -27,8 +28,16 @@ struct QmSimPipeline {
     bk.zero(s.ring_n, (size_t)s.Bmax * 2 * sizeof(int)); bk.zero(s.cmd, (size_t)s.Bmax * (QM_SIM_CMD - 1) * 8);
   }
   void set_command(int B, const double* cmd_host) { bk.to_device(s.cmd, cmd_host, (size_t)B * (QM_SIM_CMD - 1) * 8); }
+  // currentObservation_ of the MPC (x0, t0) from the plant state
+  void observe(const QmMpcBuffers& d, int B) { QmObserveArgs o; o.mb = d.mb; o.B = B; o.rbd = s.rbd; o.time = s.time; o.x0 = d.x0; o.t0 = d.t0; bk.launch(qm_observe_kernel, (B + 63) / 64, 64, 0, o); }
+  // hybrid joint command from the evaluated policy and the WBC torques
+  void command(int B, const double* x_des, const double* u_des, const double* wbc_out, double arm_kp, double arm_kd) {
+    QmCommandArgs c; c.B = B; c.x_des = x_des; c.u_des = u_des; c.wbc_out = wbc_out; c.time = s.time; c.arm_kp = arm_kp; c.arm_kd = arm_kd; c.cmd = s.cmd;
+    bk.launch(qm_command_kernel, (B * QM_NJ + 63) / 64, 64, 0, c);
+  }
+  // rbd state / contact flags of the current plant state without advancing it (nsub = 0 is not a step: the delay buffer is left alone)
   void step(const double* mb_dev, int B, double period, int nsub) {
-    QmSimArgs a; a.mb = mb_dev; a.B = B; a.nsub = nsub; a.h = period / nsub; a.p = p; a.q = s.q; a.v = s.v; a.time = s.time; a.cmd = s.cmd; a.ring = s.ring; a.ring_n = s.ring_n;
+    QmSimArgs a; a.mb = mb_dev; a.B = B; a.nsub = nsub; a.h = nsub > 0 ? period / nsub : 0.0; a.p = p; a.q = s.q; a.v = s.v; a.time = s.time; a.cmd = s.cmd; a.ring = s.ring; a.ring_n = s.ring_n;
     a.rbd = s.rbd; a.contact = s.contact; a.force = s.force; a.status = s.status;
     bk.launch(qm_sim_kernel, B, 64, SIM_LDS_BYTES, a);   // one wavefront per instance
   }

@@ -60,6 +60,7 @@ struct HipBackend {
   void to_host(void* d, const void* s, size_t n) { sync(); check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "D2H"); check(hipStreamSynchronize(stream), "sync"); }
   void sync() { check(hipStreamSynchronize(stream), "sync"); check(hipStreamSynchronize(stream_b), "sync"); wbc_pending = false; }
   // host-visible (pinned, mapped) memory for flags a kernel publishes: returns the device-side address, *host_view the host-side one
+  void copy_dd(void* d, const void* s, size_t n) { check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, cur), "D2D"); }
   void* alloc_mapped(size_t n, void** host_view) { void* h = nullptr; void* dv = nullptr; check(hipHostMalloc(&h, n ? n : 8, hipHostMallocMapped), "hipHostMalloc"); check(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer"); *host_view = h; return dv; }
   void free_mapped(void* host_view) { hipHostFree(host_view); }
   void wait_launched() { check(hipStreamSynchronize(cur), "sync"); }     // everything launched so far on the current stream has completed
@@ -73,7 +74,7 @@ struct qmhip_ctx {
   int device = 0, max_batch = 0, max_nodes = 0, max_ref = 0, max_ev = 0;
   double mb[MB_SIZE], st[ST_SIZE];
   HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc; QmFrontPipeline<HipBackend> front; QmSimPipeline<HipBackend> sim;
-  std::string error; int lastB = 0; bool have_solution = false; int front_B = 0;
+  std::string error; int lastB = 0; bool have_solution = false; int front_B = 0; long sim_ticks = 0;
   qmhip_ctx() : mpc(bk), wbc(bk), front(bk), sim(bk) {}
   void fail(const std::string& m) { error = m; }
   // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
@@ -290,7 +291,7 @@ int qmhip_sim_set_params(qmhip_ctx* c, const double* p, int n) {
 }
 int qmhip_sim_reset(qmhip_ctx* c, int B, const double* q, const double* v, const double* time) {
   if (!c || B <= 0 || B > c->max_batch || !q || !v || !time) { if (c) c->fail("qmhip_sim_reset: bad argument"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->sim.allocate(c->max_batch); c->sim.reset(B, q, v, time); return c->hipstate();
+  hipSetDevice(c->device); c->sim.allocate(c->max_batch); c->sim.reset(B, q, v, time); c->sim_ticks = 0; c->sim.step(c->mpc.d.mb, B, 0.0, 0); return c->hipstate();   // rbd / contact of the reset state
 }
 int qmhip_sim_set_command(qmhip_ctx* c, int B, const double* pos_des, const double* vel_des, const double* kp, const double* kd, const double* ff) {
   if (!c || B <= 0 || B > c->max_batch || !pos_des || !vel_des || !kp || !kd || !ff) { if (c) c->fail("qmhip_sim_set_command: bad argument"); return QMHIP_ERR_ARG; }
@@ -312,6 +313,30 @@ int qmhip_sim_get_state(qmhip_ctx* c, int B, double* q, double* v, double* time,
   hipSetDevice(c->device);
   if (q) c->bk.to_host(q, c->sim.s.q, (size_t)B * 24 * 8); if (v) c->bk.to_host(v, c->sim.s.v, (size_t)B * 24 * 8); if (time) c->bk.to_host(time, c->sim.s.time, (size_t)B * 8);
   if (force) c->bk.to_host(force, c->sim.s.force, (size_t)B * 12 * 8); if (status) c->bk.to_host(status, c->sim.s.status, (size_t)B * 4);
+  return c->hipstate();
+}
+
+// device-resident control loop around the plant: per tick [state estimate (ground truth) -> MPC call every mpc_every ticks (warm-started SQP on the observation)
+// -> policy at the plant time -> WBC on the measured state -> hybrid joint command -> one simulation step]; QMController::update + mpcThread_
+// (qm_controllers/src/QMController.cpp:128-175, 315-332), the MPC synchronous with the tick it is triggered on
+int qmhip_closed_loop_sim(qmhip_ctx* c, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd) {
+  if (!c || B <= 0 || B > c->max_batch || n_ticks <= 0 || !(period > 0) || n_substeps < 1 || mpc_every < 1 || !(horizon > 0)) { if (c) c->fail("qmhip_closed_loop_sim: bad argument"); return QMHIP_ERR_ARG; }
+  if (!c->sim.s.Bmax) { c->fail("qmhip_closed_loop_sim: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
+  hipSetDevice(c->device); c->bk.sync();
+  for (int k = 0; k < n_ticks; ++k) {
+    if ((c->sim_ticks % mpc_every) == 0) {
+      c->sim.observe(c->mpc.d, B);
+      if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon);
+      c->mpc.grid(B, horizon, true); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true;
+    }
+    c->bk.launch(qm_policy_kernel, (B + 63) / 64, 64, 0, c->wbc.pargs(c->mpc.d, B, c->sim.s.time));
+    if (c->sim_ticks == 0) c->bk.copy_dd(c->wbc.w.input_last, c->wbc.w.u_des, (size_t)B * 30 * 8);   // first tick after a reset: inputLast_ primed with the planned input (the reference's
+                                                                                                  // WBC has been running since time 0 when the legs are switched on at time 10): zero joint acceleration
+    c->wbc.step(c->mpc.d, B, period, 0, c->sim.s.rbd, c->sim.s.time);
+    c->sim.command(B, c->wbc.w.x_des, c->wbc.w.u_des, c->wbc.w.out, arm_kp, arm_kd);
+    c->sim.step(c->mpc.d.mb, B, period, n_substeps);
+    ++c->sim_ticks;
+  }
   return c->hipstate();
 }
 

@@ -110,12 +110,14 @@ __global__ void __launch_bounds__(64) qm_sim_kernel(QmSimArgs a) {
   qm_wave_sync();
   // ---- delay buffer (QMHWSim.cpp:100-110), once per call like writeSim once per simulation step: drop what is older than `delay`, push the held
   //      command with the current time stamp, apply the oldest survivor during this step ----
-  while (cnt > 0 && ring[((head + cnt - 1) % QM_SIM_SLOTS) * QM_SIM_CMD] + a.p.delay < time) --cnt;
-  head = (head + QM_SIM_SLOTS - 1) % QM_SIM_SLOTS; if (cnt < QM_SIM_SLOTS) ++cnt;
-  { double* slot = ring + head * QM_SIM_CMD; if (l == 0) slot[0] = time; for (int i = l; i < QM_SIM_CMD - 1; i += 64) slot[1 + i] = a.cmd[(size_t)b * (QM_SIM_CMD - 1) + i]; }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  qm_wave_sync();
-  const double* use = ring + ((head + cnt - 1) % QM_SIM_SLOTS) * QM_SIM_CMD;
+  if (a.nsub > 0) {                       // nsub == 0: hand-over of the current state only (after a reset), not a simulation step
+    while (cnt > 0 && ring[((head + cnt - 1) % QM_SIM_SLOTS) * QM_SIM_CMD] + a.p.delay < time) --cnt;
+    head = (head + QM_SIM_SLOTS - 1) % QM_SIM_SLOTS; if (cnt < QM_SIM_SLOTS) ++cnt;
+    { double* slot = ring + head * QM_SIM_CMD; if (l == 0) slot[0] = time; for (int i = l; i < QM_SIM_CMD - 1; i += 64) slot[1 + i] = a.cmd[(size_t)b * (QM_SIM_CMD - 1) + i]; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    qm_wave_sync();
+  }
+  const double* use = ring + ((head + (cnt > 0 ? cnt : 1) - 1) % QM_SIM_SLOTS) * QM_SIM_CMD;
   for (int s = 0; s < a.nsub; ++s) {
     time += a.h;
     sim_dynamics_terms(mb, S, l, true);
@@ -169,6 +171,6 @@ __global__ void __launch_bounds__(64) qm_sim_kernel(QmSimArgs a) {
   if (l >= 6 && l < 24) { r[l] = q[l]; r[24 + l] = v[l]; }
   if (l == 4) { double qq[4]; mat_to_quat(S + SL_TIP + 27, qq); for (int i = 0; i < 3; ++i) r[48 + i] = S[SL_TIP + 24 + i]; for (int i = 0; i < 4; ++i) r[51 + i] = qq[i]; }
   if (l < 4) a.contact[b * 4 + l] = (a.p.foot_radius - S[SL_TIP + 6 * l + 2] > 0.0) ? 1 : 0;
-  if (l < 12) a.force[(size_t)b * 12 + l] = fc[l];
+  if (l < 12) a.force[(size_t)b * 12 + l] = (a.nsub > 0) ? fc[l] : 0.0;
   if (l == 0) { a.time[b] = time; a.ring_n[b * 2] = head; a.ring_n[b * 2 + 1] = cnt; a.status[b] = bad; }
 }

@@ -15,6 +15,7 @@ _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 STANCE, LF_RH, RF_LH = 15, 9, 6
 # layout offsets (include/qmhip_layout.h)
 MB_QLO, MB_QHI, MB_QNOM = 288, 306, 667
+MB_ROBOTMASS, MB_INOM, MB_RNOM = 654, 655, 664
 ST_XINIT, ST_SQP_DT = 930, 991
 EE_NOMINAL_POS = np.array([0.52, 0.09, 0.38 + 0.4])          # QMController.cpp:107 (+ base height)
 EE_NOMINAL_QUAT = np.array([0.5, -0.5, 0.5, -0.5])           # Quaternion(w=-.5,.5,-.5,.5).coeffs() -> xyzw

@@ -17,6 +17,7 @@ struct EmuBackend {
   void* alloc_mapped(size_t n, void** host_view) { void* p = malloc(n ? n : 8); *host_view = p; return p; }
   void free_mapped(void* p) { ::free(p); }
   void wait_launched() {}
+  void copy_dd(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 };
 
 struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; QmSimPipeline<EmuBackend> sim; EmuCtx() : mpc(bk), wbc(bk), front(bk), sim(bk) {} };

@@ -57,3 +57,70 @@ def test_command_delay_and_full_batch(blobs, oracle):
     assert (s["status"] == 0).all() and np.isfinite(s["q"]).all() and contact.all()
     assert np.abs(s["q"][:, 2] - z0).max() < 0.02 and np.abs(s["q"][:, 3:6]).max() < 0.1
     itf.close()
+
+
+def _rot_zyx(z, y, x):
+    cz, sz, cy, sy, cx, sx = np.cos(z), np.sin(z), np.cos(y), np.sin(y), np.cos(x), np.sin(x)
+    return np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx], [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx], [-sy, cy * sx, cy * cx]])
+
+
+def centroidal_from_rbd(mb, rbd):
+    """computeCentroidalStateFromRbdModel [upstream], SRBD: normalized momentum = A_b(q) v_base / m"""
+    from qm_control_amd import scenarios as sc
+    R = _rot_zyx(*rbd[0:3]); Inom = mb[sc.MB_INOM:sc.MB_INOM + 9].reshape(3, 3); rnom = mb[sc.MB_RNOM:sc.MB_RNOM + 3]; m = mb[sc.MB_ROBOTMASS]
+    w = rbd[24:27]; x = np.zeros(30)
+    x[0:3] = rbd[27:30] + np.cross(R @ rnom, w); x[3:6] = (R @ Inom @ R.T @ w) / m; x[6:9] = rbd[3:6]; x[9:12] = rbd[0:3]; x[12:30] = rbd[6:24]
+    return x
+
+
+def oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0):
+    """QMController::update around the oracle's plant, same order of operations as qmhip_closed_loop_sim"""
+    oracle.set_schedule(cfg["ev"][0], cfg["modes"][0]); oracle.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
+    oracle.wbc_reset(); oracle.sim_params(); oracle.sim_reset(q0, np.zeros(24), time0); oracle.sim_command(0, 0, 0, 0, 0)
+    rbd = oracle.rbd_from_q(q0, np.zeros(24)); time = time0; log = []
+    pos = np.zeros(18); vel = np.zeros(18); kp = np.zeros(18); kd = np.zeros(18); ff = np.zeros(18)
+    for k in range(n_ticks):
+        if k % mpc_every == 0:
+            oracle.mpc_step(time, time + horizon, centroidal_from_rbd(mb, rbd), warm=(k > 0))
+        xd, ud, mode = oracle.eval_policy(time)
+        if k == 0:
+            oracle.wbc_set_input_last(ud)          # inputLast_ primed with the planned input at the first tick (qmhip_closed_loop_sim)
+        out, st = oracle.wbc(xd, ud, rbd, mode, period, time)
+        if time > 10.0:
+            pos[:12] = xd[12:24]; vel[:12] = ud[12:24]; kp[:12] = 0.0; kd[:12] = 3.0; ff[:12] = out[36:48]
+        pos[12:] = xd[24:30]; vel[12:] = 0.0; kp[12:] = arm_kp; kd[12:] = arm_kd; ff[12:] = out[48:54]
+        oracle.sim_command(pos, vel, kp, kd, ff)
+        r = oracle.sim_step(period, nsub); rbd = r["rbd"]; time = r["time"]
+        log.append(dict(q=r["q"].copy(), v=r["v"].copy(), tau=out[36:].copy(), wbc_status=list(st), mode=mode))
+    return log
+
+
+@pytest.mark.parametrize("gait", ["stance", "trot"])
+def test_closed_loop_around_the_plant_vs_oracle(blobs, oracle, gait):
+    """qmhip_closed_loop_sim (state estimate -> MPC -> policy -> WBC -> updateControlLaw -> simulation step, device resident) against the same loop built
+    from the oracle's pieces: 24 ticks with an MPC call every 8"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    from qm_control_amd import api
+    mb, st = blobs
+    B = 2; horizon = 0.6; c = setup(gait, B, horizon, t_start=20.0 if gait == "stance" else 20.3)   # trot: the first gait event falls inside the horizon
+    q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset()
+    t_start = float(c["t0"][0]); sim.reset(np.tile(q0, (B, 1)), np.zeros((B, 24)), t_start)
+    n_ticks = 24; dev = []
+    for k in range(n_ticks):
+        sim.closed_loop(1, 0.001, horizon, n_substeps=2, mpc_every=8); s = sim.state(); out, st3 = wbc.download(B); s["tau"] = out[:, 36:]; s["wbc_status"] = st3; s["mpc_status"] = mpc.download()["status"]; dev.append(s)
+    log = oracle_closed_loop(oracle, mb, c, q0, n_ticks, 0.001, 2, 8, horizon, 0.0, 0.5, t_start)
+    if os.environ.get("QM_SIM_TRACE"):
+        for k in range(n_ticks):
+            print(k, "dev mpc", dev[k]["mpc_status"], "wbc", dev[k]["wbc_status"][0], "| oracle wbc", log[k]["wbc_status"], "mode", log[k]["mode"], "| tau err %.2e q err %.2e v err %.2e" % (rel_err(dev[k]["tau"][0], log[k]["tau"]), rel_err(dev[k]["q"][0], log[k]["q"]), rel_err(dev[k]["v"][0], log[k]["v"])), "max tau", np.abs(log[k]["tau"]).max().round(1))
+    for k in range(n_ticks):
+        assert (dev[k]["mpc_status"] == 0).all() and (dev[k]["wbc_status"] == 0).all() and log[k]["wbc_status"] == [0, 0, 0], k
+        for b in range(B):
+            assert rel_err(dev[k]["tau"][b], log[k]["tau"]) < 1e-5, (k, b, rel_err(dev[k]["tau"][b], log[k]["tau"]))
+            assert rel_err(dev[k]["q"][b], log[k]["q"]) < 1e-7 and rel_err(dev[k]["v"][b], log[k]["v"]) < 1e-5, (k, b)
+    itf.close()
