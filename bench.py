@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plant-loop", action="store_true", help="skip the secondary closed-loop-around-the-plant figure")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,6 +100,20 @@ def main():
     res_cl = mpc.download(); _, qps_cl = wbc.download(B)
     closed_loop = {"value": B * cl_steps / tcl, "unit": "steps/s per GPU", "steps": cl_steps, "mpc_dt": cl_dt, "ms_per_step": tcl / cl_steps * 1e3,
                    "all_status_ok": bool((res_cl["status"] == 0).all() and (qps_cl == 0).all()), "ls_trials_last": int(res_cl["ls_trials"])}
+    # secondary figure (NOT the headline value): the whole controller around the batched rigid-body plant, device resident —
+    # per 1 ms tick [state estimate -> MPC every 10 ticks (warm) -> policy -> WBC -> updateControlLaw -> plant step with the 9 ms command delay]
+    plant = None
+    if not args.no_plant_loop:
+        sim = api.QMHWSim(itf); t_shift = 20.0                                  # the reference switches the legs on at time > 10 (QMController.cpp:179)
+        mpc.set_problem(cfg["t0"] + t_shift, cfg["x0"], cfg["ref_t"] + t_shift, cfg["ref_x"], cfg["ev"] + t_shift, cfg["modes"]); wbc.reset()
+        q0 = np.array(cfg["x0"][:, 6:30]); q0[:, 0:2] = 0.0; q0[:, 2] = 0.385; q0[:, 3:6] = 0.0
+        sim.reset(q0, np.zeros((B, 24)), cfg["t0"] + t_shift)
+        sim.closed_loop(10, 0.001, cfg["horizon"], n_substeps=2, mpc_every=10); itf.synchronize()
+        n_ticks = 30; tp = time.perf_counter(); sim.closed_loop(n_ticks, 0.001, cfg["horizon"], n_substeps=2, mpc_every=10); itf.synchronize(); tp = time.perf_counter() - tp
+        sp = sim.state(); res_p = mpc.download(); _, qps_p = wbc.download(B)
+        plant = {"value": B * n_ticks / tp, "unit": "plant + controller ticks/s per GPU (1 ms ticks, MPC every 10th)", "ticks": n_ticks, "ms_per_tick": tp / n_ticks * 1e3,
+                 "realtime_factor_per_instance": n_ticks * 0.001 / tp, "all_status_ok": bool((res_p["status"] == 0).all() and (qps_p == 0).all() and (sp["status"] == 0).all()),
+                 "all_finite": bool(np.isfinite(sp["q"]).all()), "base_height_range": [float(sp["q"][:, 2].min()), float(sp["q"][:, 2].max())]}
     ok = bool((res["status"] == 0).all() and (qps == 0).all())
     n_intervals = int(sum(int(res["num_nodes"][b]) - 1 - int((res["event"][b, :res["num_nodes"][b]] == 1).sum()) for b in range(B)))
     # roofline of the dominant kernel (largest average launch duration among the modelled kernels), both ceilings priced
@@ -136,6 +151,7 @@ def main():
             "roofline_all": {k: {kk: v[kk] for kk in ("avg_launch_ms", "tflops", "frac_fp64", "tbs", "frac_hbm")} for k, v in roofs.items()},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in kms.items()},
             "closed_loop_warm_start": closed_loop,
+            "closed_loop_plant": plant,
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a property of the box: reported on the single-GPU line only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

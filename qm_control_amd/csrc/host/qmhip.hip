@@ -352,6 +352,7 @@ int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { if (!c || !key) 
 int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) {
   if (!c || !name || !dst) return QMHIP_ERR_ARG; hipSetDevice(c->device); const QmMpcBuffers& d = c->mpc.d; const void* p = nullptr;
 #define F(n) if (!strcmp(name, #n)) p = d.n;
+  if (!strcmp(name, "sim_rbd")) p = c->sim.s.rbd; if (!strcmp(name, "sim_cmd")) p = c->sim.s.cmd;
   F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
 #undef F
   if (!p) p = c->wbc.buffer(name);
