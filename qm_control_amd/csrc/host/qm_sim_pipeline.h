@@ -1,6 +1,7 @@
 // qm_sim_pipeline.h — launches of the batched rigid-body plant (backend-templated like qm_pipeline.h)
 #pragma once
 #include "qm_pipeline.h"
+#include "qm_wbc_pipeline.h"
 #include "../kernels/k_sim.h"
 #include "../kernels/k_loop.h"
 
@@ -42,3 +43,27 @@ struct QmSimPipeline {
     bk.launch(qm_sim_kernel, B, 64, SIM_LDS_BYTES, a);   // one wavefront per instance
   }
 };
+
+// n_ticks of the whole controller around the plant (QMController::update + the body of mpcThread_, qm_controllers/src/QMController.cpp:128-175, 315-332), all on
+// resident data: state estimate (the plant's state) -> every mpc_every ticks an MPC call on that observation (pre_mpc: the gait front-end's schedule refresh,
+// then a warm-started solve with sqp_iters SQP iterations) -> policy at the plant time -> WBC on the measured state -> hybrid joint command -> simulation step.
+// Shared by the product (qmhip_closed_loop_sim) and the host emulator of the tests.
+template <class BK, class PreMpc>
+void qm_closed_loop_sim_ticks(BK& bk, QmMpcPipeline<BK>& mpc, QmWbcPipeline<BK>& wbc, QmSimPipeline<BK>& sim, long& sim_ticks, int B, int n_ticks, double period, int n_substeps,
+                              int mpc_every, double horizon, double arm_kp, double arm_kd, int sqp_iters, PreMpc pre_mpc) {
+  for (int k = 0; k < n_ticks; ++k) {
+    if ((sim_ticks % mpc_every) == 0) {
+      sim.observe(mpc.d, B);
+      pre_mpc();
+      mpc.grid(B, horizon, true); for (int it = 0; it < sqp_iters; ++it) mpc.sqp_iteration(B, 14, it + 1 == sqp_iters);
+    }
+    bk.launch(qm_policy_kernel, (B + 63) / 64, 64, 0, wbc.pargs(mpc.d, B, sim.s.time));
+    // first tick after a reset: inputLast_ primed with the planned input (the reference's WBC has been running since time 0 when the legs are switched on at
+    // time 10): zero joint acceleration
+    if (sim_ticks == 0) bk.copy_dd(wbc.w.input_last, wbc.w.u_des, (size_t)B * 30 * 8);
+    wbc.step(mpc.d, B, period, 0, sim.s.rbd, sim.s.time);
+    sim.command(B, wbc.w.x_des, wbc.w.u_des, wbc.w.out, arm_kp, arm_kd);
+    sim.step(mpc.d.mb, B, period, n_substeps);
+    ++sim_ticks;
+  }
+}

@@ -323,20 +323,9 @@ int qmhip_closed_loop_sim(qmhip_ctx* c, int B, int n_ticks, double period, int n
   if (!c || B <= 0 || B > c->max_batch || n_ticks <= 0 || !(period > 0) || n_substeps < 1 || mpc_every < 1 || !(horizon > 0)) { if (c) c->fail("qmhip_closed_loop_sim: bad argument"); return QMHIP_ERR_ARG; }
   if (!c->sim.s.Bmax) { c->fail("qmhip_closed_loop_sim: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); c->bk.sync();
-  for (int k = 0; k < n_ticks; ++k) {
-    if ((c->sim_ticks % mpc_every) == 0) {
-      c->sim.observe(c->mpc.d, B);
-      if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon);
-      c->mpc.grid(B, horizon, true); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true;
-    }
-    c->bk.launch(qm_policy_kernel, (B + 63) / 64, 64, 0, c->wbc.pargs(c->mpc.d, B, c->sim.s.time));
-    if (c->sim_ticks == 0) c->bk.copy_dd(c->wbc.w.input_last, c->wbc.w.u_des, (size_t)B * 30 * 8);   // first tick after a reset: inputLast_ primed with the planned input (the reference's
-                                                                                                  // WBC has been running since time 0 when the legs are switched on at time 10): zero joint acceleration
-    c->wbc.step(c->mpc.d, B, period, 0, c->sim.s.rbd, c->sim.s.time);
-    c->sim.command(B, c->wbc.w.x_des, c->wbc.w.u_des, c->wbc.w.out, arm_kp, arm_kd);
-    c->sim.step(c->mpc.d.mb, B, period, n_substeps);
-    ++c->sim_ticks;
-  }
+  qm_closed_loop_sim_ticks(c->bk, c->mpc, c->wbc, c->sim, c->sim_ticks, B, n_ticks, period, n_substeps, mpc_every, horizon, arm_kp, arm_kd, c->sqp_iterations(),
+                           [&]() { if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon); });
+  c->lastB = B; c->have_solution = true;
   return c->hipstate();
 }
 

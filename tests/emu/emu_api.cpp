@@ -47,6 +47,7 @@ void emu_upload(void* h, int B, const double* t0, const double* x0, const double
 // raw buffer access for parity tests: name -> pointer
 void* emu_buffer(void* h, const char* name) {
   QmMpcBuffers& d = ((EmuCtx*)h)->mpc.d;
+  { EmuCtx* c = (EmuCtx*)h; if (!strcmp(name, "sim_q")) return (void*)c->sim.s.q; if (!strcmp(name, "sim_v")) return (void*)c->sim.s.v; if (!strcmp(name, "wbc_out")) return (void*)c->wbc.w.out; if (!strcmp(name, "wbc_qp_status")) return (void*)c->wbc.w.qp_status; }
 #define F(n) if (!strcmp(name, #n)) return (void*)d.n;
   F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(lqdbg) F(perf) F(base_sum)
   F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
@@ -62,6 +63,11 @@ void emu_wbc_reset(void* h) { ((EmuCtx*)h)->wbc.reset(); }
 void emu_sim_params(void* h, const double* p) { QmSimParams& q = ((EmuCtx*)h)->sim.p; q.k_n = p[0]; q.d_n = p[1]; q.mu = p[2]; q.v_eps = p[3]; q.foot_radius = p[4]; q.delay = p[5]; q.saturate = p[6] != 0.0; }
 void emu_sim_reset(void* h, int B, const double* q, const double* v, const double* time) { EmuCtx* c = (EmuCtx*)h; c->sim.allocate(c->mpc.d.Bmax); c->sim.reset(B, q, v, time); }
 void emu_sim_command(void* h, int B, const double* cmd90) { ((EmuCtx*)h)->sim.set_command(B, cmd90); }
+static long g_emu_sim_ticks = 0;
+void emu_closed_loop_sim(void* h, int B, int n_ticks, double period, int nsub, int mpc_every, double horizon, double arm_kp, double arm_kd, int restart) {
+  EmuCtx* c = (EmuCtx*)h; if (restart) { g_emu_sim_ticks = 0; c->sim.step(c->mpc.d.mb, B, 0.0, 0); }
+  qm_closed_loop_sim_ticks(c->bk, c->mpc, c->wbc, c->sim, g_emu_sim_ticks, B, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, 1, []() {});
+}
 void emu_sim_step(void* h, int B, double period, int nsub, double* rbd, int* contact, double* q, double* v, double* force, int* status) {
   EmuCtx* c = (EmuCtx*)h; c->sim.step(c->mpc.d.mb, B, period, nsub);
   memcpy(rbd, c->sim.s.rbd, (size_t)B * QM_NRBD * 8); memcpy(contact, c->sim.s.contact, (size_t)B * 16); memcpy(q, c->sim.s.q, (size_t)B * 24 * 8); memcpy(v, c->sim.s.v, (size_t)B * 24 * 8);

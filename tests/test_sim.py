@@ -91,3 +91,61 @@ def test_emulated_plant_vs_oracle(blobs, oracle, nsub):
             assert rel_err(out[k]["q"][b], r["q"]) < 1e-9 and rel_err(out[k]["v"][b], r["v"]) < 1e-7, (b, k)
             assert rel_err(out[k]["force"][b], r["force"]) < 1e-6 and list(out[k]["contact"][b]) == list(r["contact"]), (b, k)
             assert rel_err(out[k]["rbd"][b], r["rbd"]) < 1e-7, (b, k)
+
+
+def _rot_zyx(z, y, x):
+    cz, sz, cy, sy, cx, sx = np.cos(z), np.sin(z), np.cos(y), np.sin(y), np.cos(x), np.sin(x)
+    return np.array([[cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx], [sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx], [-sy, cy * sx, cy * cx]])
+
+
+def centroidal_from_rbd(mb, rbd):
+    """computeCentroidalStateFromRbdModel [upstream], SRBD: normalized momentum = A_b(q) v_base / m"""
+    from qm_control_amd import scenarios as sc
+    R = _rot_zyx(*rbd[0:3]); Inom = mb[sc.MB_INOM:sc.MB_INOM + 9].reshape(3, 3); rnom = mb[sc.MB_RNOM:sc.MB_RNOM + 3]; m = mb[sc.MB_ROBOTMASS]
+    w = rbd[24:27]; x = np.zeros(30)
+    x[0:3] = rbd[27:30] + np.cross(R @ rnom, w); x[3:6] = (R @ Inom @ R.T @ w) / m; x[6:9] = rbd[3:6]; x[9:12] = rbd[0:3]; x[12:30] = rbd[6:24]
+    return x
+
+
+def oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0):
+    """QMController::update around the oracle's plant, same order of operations as qmhip_closed_loop_sim"""
+    oracle.set_schedule(cfg["ev"][0], cfg["modes"][0]); oracle.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
+    oracle.wbc_reset(); oracle.sim_params(); oracle.sim_reset(q0, np.zeros(24), time0); oracle.sim_command(0, 0, 0, 0, 0)
+    rbd = oracle.rbd_from_q(q0, np.zeros(24)); time = time0; log = []
+    pos = np.zeros(18); vel = np.zeros(18); kp = np.zeros(18); kd = np.zeros(18); ff = np.zeros(18)
+    for k in range(n_ticks):
+        if k % mpc_every == 0:
+            oracle.mpc_step(time, time + horizon, centroidal_from_rbd(mb, rbd), warm=(k > 0))
+        xd, ud, mode = oracle.eval_policy(time)
+        if k == 0:
+            oracle.wbc_set_input_last(ud)          # inputLast_ primed with the planned input at the first tick (qmhip_closed_loop_sim)
+        out, st = oracle.wbc(xd, ud, rbd, mode, period, time)
+        if time > 10.0:
+            pos[:12] = xd[12:24]; vel[:12] = ud[12:24]; kp[:12] = 0.0; kd[:12] = 3.0; ff[:12] = out[36:48]
+        pos[12:] = xd[24:30]; vel[12:] = 0.0; kp[12:] = arm_kp; kd[12:] = arm_kd; ff[12:] = out[48:54]
+        oracle.sim_command(pos, vel, kp, kd, ff)
+        r = oracle.sim_step(period, nsub); rbd = r["rbd"]; time = r["time"]
+        log.append(dict(q=r["q"].copy(), v=r["v"].copy(), tau=out[36:].copy(), wbc_status=list(st), mode=mode))
+    return log
+
+
+def test_emulated_closed_loop_around_the_plant_vs_oracle(blobs, oracle):
+    """the product's tick sequence (qm_closed_loop_sim_ticks: state estimate -> MPC -> policy -> WBC -> updateControlLaw -> simulation step) on the host emulator
+    against the same loop built from the oracle's pieces: 10 ticks of a stance -> trot schedule with MPC calls at ticks 0 and 6"""
+    import os, sys, emu_harness
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    mb, st = blobs
+    horizon = 0.45; c = setup("trot", 1, horizon, t_start=20.2)
+    q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
+    e = emu_harness.Emu(mb, st, 1, 64, 2, c["ev"].shape[1])
+    c["horizon"] = horizon; c["B"] = 1; e.grid_only(c, batch=1)   # uploads reference and schedule
+    e.lib.emu_wbc_reset(e.h); e.sim_params(); e.sim_reset(q0[None], np.zeros((1, 24)), 20.2); e.sim_command(0, 0, 0, 0, 0)
+    n_ticks = 10; dev = []
+    for k in range(n_ticks):
+        e.closed_loop_sim(1, 0.001, horizon, nsub=2, mpc_every=6, restart=(k == 0)); dev.append(e.sim_state())
+    log = oracle_closed_loop(oracle, mb, c, q0, n_ticks, 0.001, 2, 6, horizon, 0.0, 0.5, 20.2)
+    for k in range(n_ticks):
+        assert dev[k]["mpc_status"][0] == 0 and list(dev[k]["wbc_status"][0]) == [0, 0, 0], k
+        assert rel_err(dev[k]["tau"][0], log[k]["tau"]) < 1e-6 and rel_err(dev[k]["q"][0], log[k]["q"]) < 1e-9 and rel_err(dev[k]["v"][0], log[k]["v"]) < 1e-7, k
