@@ -354,6 +354,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   const int half = l >> 5, r = l & 31;
   if (l < 31) buf[RF_PX + 12 * 31 + l] = 0.0;              // the zero row of the Px block (no stage writes it; a wave sync precedes its first use)
   if (l < 19) buf[RF_PU + l] = 0.0;
+  int pu_mode = -1, pu_col = 0, pu_kind = 0, pu_off = 128;     // (Pu ut) source of this lane's du row, cached per contact mode
   double pf[RF_NLOAD];
   auto fetch = [&](int k) {
     const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
@@ -393,35 +394,42 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
       for (int q = 0; q < 30; ++q) { const double dq = qm_bcast(dxl, q); ap[q % 3] += rowA[q] * dq; tp[q % 3] += rowW[q] * dq; }
       acc += (ap[0] + ap[1]) + ap[2]; t += (tp[0] + tp[1]) + tp[2]; }
     RFT(3)
-    // Lᵀ v = t (lane i keeps v_i), ut = −v
-    double v = 0.0;
+    // Lᵀ v = t (lane i keeps v_i), ut = −v.  Everything that does not depend on t is prepared BEFORE the dependent chain: the lane's 18 entries of L
+    // (independent LDS reads, masked once) are scaled by the pivots' reciprocals 1/L_qq (the stored diagonal, broadcast off the chain), so that one step of the
+    // chain is only broadcast t_q -> fused multiply-add:  t_i -= (L[q][i] / L_qq) t_q  for i < q;  v_q = t_q / L_qq falls out at the end on lane q.
+    double Lr[QM_MMAX], mydiag = 0.0;
+    { const int lc = (l < QM_MMAX) ? l : 0;
 #pragma unroll
-    for (int q = QM_MMAX - 1; q >= 0; --q) {                     // steps q >= m are no-ops (lane q carries lq == 0): no uniform branch in the chain
-      const double lq = (l <= q && l < m && q < m) ? buf[RF_L + q * 19 + l] : 0.0;   // L[q][l] (row q = l: 1/L_qq)
-      const double vq = qm_bcast(t * lq, q);
-      if (l == q) v = vq;
-      t -= lq * vq;                                       // lanes i < q: L[q][i] v_q   (lane q: its t is dead)
-    }
+      for (int q = 0; q < QM_MMAX; ++q) { const double e = buf[RF_L + q * 19 + lc]; Lr[q] = (l <= q && l < m && q < m) ? e : 0.0; }   // L[q][l] (row q = l: 1/L_qq)
+#pragma unroll
+      for (int q = 0; q < QM_MMAX; ++q) { const double dq = qm_bcast(Lr[q], q); if (l == q) mydiag = Lr[q]; Lr[q] = (l < q) ? Lr[q] * dq : 0.0; } }
+#pragma unroll
+    for (int q = QM_MMAX - 1; q >= 1; --q) t -= Lr[q] * qm_bcast(t, q);     // steps q >= m are no-ops (Lr[q] == 0 on every lane): no uniform branch in the chain
+    const double v = t * mydiag;                                              // lanes >= m: mydiag == 0
     const double ut = -v;
     RFT(4)
     // (Pu ut)[row] for the lanes that hold a row of du: a stance force component or an arm joint velocity IS one entry of ut, a swing leg's
     // joint velocity combines the two null-space coordinates of its leg, swing forces get nothing (Pe carries −F)
     double puut;
     { const int md = (int)vecs[152];
-      int nst = 0;
+      if (md != pu_mode) {                                   // the lane's source columns only change with the contact mode (wave-uniform test, a few times per sweep)
+        pu_mode = md;
+        int nst = 0;
 #pragma unroll
-      for (int kq = 0; kq < 4; ++kq) nst += mode_flag(md, kq);
-      const int row = half ? rr : 0;
-      const int kk = (row < 12) ? row / 3 : ((row < 24) ? chain_to_contact((row - 12) / 3) : 0), r3 = (row < 12) ? row % 3 : ((row < 24) ? (row - 12) % 3 : row - 24);
-      int before_st = 0, before_sw = 0;
+        for (int kq = 0; kq < 4; ++kq) nst += mode_flag(md, kq);
+        const int row = half ? rr : 0;
+        const int kk = (row < 12) ? row / 3 : ((row < 24) ? chain_to_contact((row - 12) / 3) : 0), r3 = (row < 12) ? row % 3 : ((row < 24) ? (row - 12) % 3 : row - 24);
+        int before_st = 0, before_sw = 0;
 #pragma unroll
-      for (int kq = 0; kq < 4; ++kq) if (kq < kk) { before_st += mode_flag(md, kq); before_sw += !mode_flag(md, kq); }
-      const bool st = mode_flag(md, kk);
-      const int col = (row < 12) ? 3 * before_st + r3 : ((row < 24) ? 3 * nst + 2 * before_sw : 3 * nst + 2 * (4 - nst) + r3);
-      const double c1 = (row < 12) ? (st ? 1.0 : 0.0) : ((row < 24) ? (st ? 0.0 : vecs[128 + 6 * kk + r3]) : 1.0);
-      const double c2 = (row >= 12 && row < 24 && !st) ? vecs[128 + 6 * kk + 3 + r3] : 0.0;
-      const double u1 = __shfl(ut, col & 63, 64), u2 = __shfl(ut, (col + 1) & 63, 64);
-      puut = (half && r < 30) ? c1 * u1 + c2 * u2 : 0.0; }
+        for (int kq = 0; kq < 4; ++kq) if (kq < kk) { before_st += mode_flag(md, kq); before_sw += !mode_flag(md, kq); }
+        const bool st = mode_flag(md, kk);
+        pu_col = (row < 12) ? 3 * before_st + r3 : ((row < 24) ? 3 * nst + 2 * before_sw : 3 * nst + 2 * (4 - nst) + r3);
+        pu_kind = !(half && r < 30) ? 0 : ((row < 12) ? (st ? 1 : 0) : ((row < 24) ? (st ? 0 : 2) : 1));      // 0: nothing, 1: one entry of ut, 2: a swing leg's 3x2 block
+        pu_off = 128 + 6 * kk + r3;
+      }
+      const double c1 = (pu_kind == 2) ? vecs[pu_off] : ((pu_kind == 1) ? 1.0 : 0.0), c2 = (pu_kind == 2) ? vecs[pu_off + 3] : 0.0;
+      const double u1 = __shfl(ut, pu_col & 63, 64), u2 = __shfl(ut, (pu_col + 1) & 63, 64);
+      puut = c1 * u1 + c2 * u2; }
     armijo += qv * dxl + rp * ut;
     { double bp[3] = {0.0, 0.0, 0.0};
 #pragma unroll
