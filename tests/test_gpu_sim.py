@@ -88,3 +88,32 @@ def test_closed_loop_around_the_plant_vs_oracle(blobs, oracle, gait):
             assert rel_err(dev[k]["tau"][b], log[k]["tau"]) < 1e-5, (k, b, rel_err(dev[k]["tau"][b], log[k]["tau"]))
             assert rel_err(dev[k]["q"][b], log[k]["q"]) < 1e-7 and rel_err(dev[k]["v"][b], log[k]["v"]) < 1e-5, (k, b)
     itf.close()
+
+
+def test_plant_and_closed_loop_match_the_goldens(blobs):
+    """qmhip_sim_* and qmhip_closed_loop_sim against the committed fixtures (tests/golden/sim_*.npz, tools/gen_golden_sim.py)"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    from qm_control_amd import api
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_plant_B4_T12.npz")); B = 4
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=128); sim = api.QMHWSim(itf)
+    arr = lambda k: np.array([g["in_%s_%d" % (k, b)] for b in range(B)])
+    sim.reset(arr("q"), arr("v"), 1.0); sim.setCommand(arr("pos"), arr("vel"), arr("kp"), arr("kd"), arr("ff"))
+    for k in range(12):
+        rbd, contact = sim.step(0.001, 2); s = sim.state()
+        for b in range(B):
+            assert rel_err(s["q"][b], g["q_%d" % b][k]) < 1e-9 and rel_err(s["v"][b], g["v_%d" % b][k]) < 1e-7 and rel_err(rbd[b], g["rbd_%d" % b][k]) < 1e-7
+            assert list(contact[b]) == list(g["contact_%d" % b][k]) and rel_err(s["force"][b], g["force_%d" % b][k]) < 1e-6
+    itf.close()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_closed_loop_trot_T20.npz")); horizon = float(g["horizon"]); t_start = float(g["t_start"])
+    c = setup("trot", 1, horizon, t_start=t_start)
+    itf = api.QMInterface(blobs=blobs, max_batch=1, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset(); sim.reset(g["q0"][None], np.zeros((1, 24)), t_start)
+    for k in range(20):
+        sim.closed_loop(1, 0.001, horizon, n_substeps=2, mpc_every=int(g["mpc_every"])); s = sim.state(); out, st3 = wbc.download(1)
+        assert (st3 == 0).all() and (mpc.download()["status"] == 0).all()
+        assert rel_err(s["q"][0], g["q"][k]) < 1e-7 and rel_err(out[0, 36:], g["tau"][k]) < 1e-4, k
+    itf.close()

@@ -149,3 +149,23 @@ def test_emulated_closed_loop_around_the_plant_vs_oracle(blobs, oracle):
     for k in range(n_ticks):
         assert dev[k]["mpc_status"][0] == 0 and list(dev[k]["wbc_status"][0]) == [0, 0, 0], k
         assert rel_err(dev[k]["tau"][0], log[k]["tau"]) < 1e-6 and rel_err(dev[k]["q"][0], log[k]["q"]) < 1e-9 and rel_err(dev[k]["v"][0], log[k]["v"]) < 1e-7, k
+
+
+def test_oracle_reproduces_the_plant_goldens(blobs, oracle):
+    """the frozen plant / closed-loop trajectories (tools/gen_golden_sim.py) against a fresh run of the oracle"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    mb, st = blobs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_plant_B4_T12.npz"))
+    for b in range(4):
+        oracle.sim_params(); oracle.sim_reset(g["in_q_%d" % b], g["in_v_%d" % b], 1.0); oracle.sim_command(*[g["in_%s_%d" % (k, b)] for k in ("pos", "vel", "kp", "kd", "ff")])
+        for k in range(12):
+            r = oracle.sim_step(0.001, 2)
+            assert rel_err(r["q"], g["q_%d" % b][k]) < 1e-12 and rel_err(r["v"], g["v_%d" % b][k]) < 1e-10 and list(r["contact"]) == list(g["contact_%d" % b][k])
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sim_closed_loop_trot_T20.npz"))
+    c = setup("trot", 1, float(g["horizon"]), t_start=float(g["t_start"]))
+    log = oracle_closed_loop(oracle, mb, c, g["q0"], 20, 0.001, 2, int(g["mpc_every"]), float(g["horizon"]), 0.0, 0.5, float(g["t_start"]))
+    for k in range(20):
+        assert rel_err(log[k]["q"], g["q"][k]) < 1e-10 and rel_err(log[k]["tau"], g["tau"][k]) < 1e-7 and log[k]["mode"] == int(g["mode"][k]), k
