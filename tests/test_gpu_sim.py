@@ -117,3 +117,31 @@ def test_plant_and_closed_loop_match_the_goldens(blobs):
         assert (st3 == 0).all() and (mpc.download()["status"] == 0).all()
         assert rel_err(s["q"][0], g["q"][k]) < 1e-7 and rel_err(out[0, 36:], g["tau"][k]) < 1e-4, k
     itf.close()
+
+
+def test_every_gait_template_walks_on_the_plant(blobs):
+    """stance for 0.5 s, then each of the 12 templates of gait.info tiled, base commanded 0.3 m ahead: every instance stays upright, no non-zero MPC / WBC status
+    (1.2 s of plant time per gait; tools/sim_gait_sweep.py is the long version)"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    from qm_control_amd import api, scenarios
+    B = 4; horizon = 1.0; ticks = 1200; rng = np.random.default_rng(11)
+    for name, g in scenarios.load_gaits().items():
+        c = setup("stance", B, horizon)
+        e, m = scenarios.tile_gait(g["switchingTimes"], g["modeSequence"], 20.5, 20.0 + 1e-3 * ticks + 3.0)
+        c["ev"], c["modes"] = scenarios._pad_schedules([e] * B, [m] * B); c["ref_x"][:, 1, 6] += 0.3
+        q = np.tile(c["xbar"][6:30], (B, 1)); q[:, 2] = 0.385; q[:, 6:18] += 0.02 * rng.normal(size=(B, 12))
+        itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=160, max_ref_knots=2, max_events=c["ev"].shape[1])
+        mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+        sim.reset(q, np.zeros((B, 24)), 20.0); rbd0, _ = sim.step(1e-9, 1)
+        for b in range(B):
+            c["ref_x"][b, :, 30:37] = rbd0[b, 48:55]
+        mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset(); sim.reset(q, np.zeros((B, 24)), 20.0)
+        for k in range(0, ticks, 200):
+            sim.closed_loop(200, 0.001, horizon, n_substeps=2, mpc_every=10)
+            assert (mpc.download()["status"] == 0).all() and (wbc.download(B)[1] == 0).all(), (name, k)
+        s = sim.state()
+        assert np.isfinite(s["q"]).all() and (np.abs(s["q"][:, 3:5]) < 0.3).all() and (s["q"][:, 2] > 0.3).all() and (s["status"] == 0).all(), name
+        itf.close()
