@@ -145,3 +145,16 @@ def test_every_gait_template_walks_on_the_plant(blobs):
         s = sim.state()
         assert np.isfinite(s["q"]).all() and (np.abs(s["q"][:, 3:5]) < 0.3).all() and (s["q"][:, 2] > 0.3).all() and (s["status"] == 0).all(), name
         itf.close()
+
+
+def test_operator_commands_drive_the_plant(blobs):
+    """gait command (device GaitSchedule) + cmd_vel stream (device target publisher) + qmhip_closed_loop_sim: the robots stand, trot forward, and return to stance"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_teleop_demo import run
+    log = run(blobs, "trot", B=4, vx=0.3, walk_s=1.0, verbose=False)
+    assert all(l["ok"] for l in log)
+    assert max(l["tilt"].max() for l in log) < 0.2 and min(l["z"].min() for l in log) > 0.33
+    assert any(l["mode"] in (6, 9) for l in log if l["label"] == "walk") and log[-1]["mode"] == 15
+    assert (log[-1]["x"] > 0.05).all()
