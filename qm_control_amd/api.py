@@ -124,6 +124,7 @@ class QMInterface:
 
     # instrumentation
     def set_profiling(self, on):
+        """False / True: spans around no / every launch; 2: only around the modelled kernels (lq, riccati, wbc)"""
         self.lib.qmhip_set_profiling(self.h, int(on))
 
     def kernel_ms(self, name):

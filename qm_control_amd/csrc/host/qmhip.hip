@@ -22,7 +22,8 @@ struct HipBackend {
   hipStream_t stream_b = nullptr;          // WBC stream: the WBC of step k runs beside the MPC kernels of step k + 1 (the reference runs them in two threads too)
   hipStream_t cur = nullptr;               // stream the next launch / memset goes to
   hipEvent_t ev_in = nullptr, ev_wbc = nullptr; bool wbc_pending = false;
-  bool profiling = false; std::string error;
+  int profiling = 0;   // 0 off, 1 HIP-event span around every launch, 2 only around the modelled kernels (lq, riccati, wbc): two event records cost ≈ a launch
+  std::string error;
   struct Span { std::string name; hipEvent_t a, b; };
   std::vector<Span> spans; std::vector<hipEvent_t> pool;
   std::map<std::string, std::pair<double, int>> acc;
@@ -41,10 +42,12 @@ struct HipBackend {
       const void* p = (const void*)kernel; auto it = lds_set.find(p);
       if (it == lds_set.end() || it->second < (int)lds) { check(hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); lds_set[p] = (int)lds; }
     }
-    Span s; if (profiling) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); hipEventRecord(s.a, cur); }
+    const void* kp_ = (const void*)kernel;
+    const bool span = profiling == 1 || (profiling == 2 && (kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_riccati_kernel || kp_ == (const void*)qm_wbc_kernel));
+    Span s; if (span) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); hipEventRecord(s.a, cur); }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, cur, args);
     check(hipGetLastError(), "kernel launch");
-    if (profiling) { hipEventRecord(s.b, cur); spans.push_back(s); }
+    if (span) { hipEventRecord(s.b, cur); spans.push_back(s); }
   }
   void resolve() {
     if (spans.empty()) return;
@@ -329,7 +332,7 @@ int qmhip_closed_loop_sim(qmhip_ctx* c, int B, int n_ticks, double period, int n
   return c->hipstate();
 }
 
-int qmhip_set_profiling(qmhip_ctx* c, int en) { if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.profiling = en != 0; return QMHIP_OK; }
+int qmhip_set_profiling(qmhip_ctx* c, int en) { if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.profiling = (en == 2) ? 2 : (en != 0); return QMHIP_OK; }
 int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launches) {
   if (!c || !name) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.resolve(); auto it = c->bk.acc.find(name);
   if (ms) *ms = it == c->bk.acc.end() ? 0.0 : it->second.first; if (launches) *launches = it == c->bk.acc.end() ? 0 : it->second.second; return QMHIP_OK;
