@@ -167,6 +167,11 @@ int qmhip_sim_get_state(qmhip_ctx* ctx, int B, double* q, double* v, double* tim
  *        The reference runs the MPC in its own thread; here it is synchronous with the tick that triggers it.  On the first tick after a reset the
  *        WBC's joint-acceleration state inputLast_ (WbcBase.cpp:212-213) is primed with the planned input (zero joint acceleration). */
 int qmhip_closed_loop_sim(qmhip_ctx* ctx, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd);
+/*      closed_loop_sim_pipelined: the same loop with the MPC BESIDE the control ticks, like mpcThread_ beside QMController::update (QMController.cpp:315-332): the
+ *        MPC call triggered at a tick observes the plant at that tick and computes on its own stream while the next mpc_every ticks run on the policy published
+ *        before; its solution is published (MPC_MRT_Interface's policy buffer) when those ticks are done — a latency of one MPC period, deterministic instead of
+ *        thread-timing dependent.  The first call after a reset is synchronous.  n_ticks and the tick counter must be multiples of mpc_every. */
+int qmhip_closed_loop_sim_pipelined(qmhip_ctx* ctx, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd);
 
 /* ---- instrumentation (ocs2 benchmark::RepeatedTimer analogue, QMController.cpp:145-147,321-323) ----
  * per-kernel HIP-event timing on the stream each kernel runs on; names: "grid","lq_kin","lq","riccati","ls_eval","ls_misc","policy","wbc","sim".

@@ -24,7 +24,7 @@ EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_la
            "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_microbench_fp64",
            "qmhip_gait_set_templates", "qmhip_gait_reset", "qmhip_gait_insert_template", "qmhip_gait_update_resident", "qmhip_gait_download", "qmhip_schedule_download",
            "qmhip_target_reset", "qmhip_target_from_command", "qmhip_target_download",
-           "qmhip_sim_set_params", "qmhip_sim_reset", "qmhip_sim_set_command", "qmhip_sim_step", "qmhip_sim_get_state", "qmhip_closed_loop_sim"]
+           "qmhip_sim_set_params", "qmhip_sim_reset", "qmhip_sim_set_command", "qmhip_sim_step", "qmhip_sim_get_state", "qmhip_closed_loop_sim", "qmhip_closed_loop_sim_pipelined"]
 
 
 class QmhipError(RuntimeError):
@@ -271,10 +271,11 @@ class QMHWSim:
         self.itf._check(self.lib.qmhip_sim_step(self.itf.h, B, C.c_double(period), int(n_substeps), _p(rbd), _pi(contact)), "qmhip_sim_step")
         return rbd, contact
 
-    def closed_loop(self, n_ticks, period, horizon, n_substeps=2, mpc_every=10, arm_kp=0.0, arm_kd=0.5):
+    def closed_loop(self, n_ticks, period, horizon, n_substeps=2, mpc_every=10, arm_kp=0.0, arm_kd=0.5, pipelined=False):
         """n_ticks of [state estimate -> MPC every mpc_every ticks -> policy -> WBC -> updateControlLaw -> simulation step] on the device (QMController::update);
         arm gains default to the reference's dynamic-reconfigure defaults (qm_controllers/cfg/weight.cfg:7-8)"""
-        self.itf._check(self.lib.qmhip_closed_loop_sim(self.itf.h, self.B, int(n_ticks), C.c_double(period), int(n_substeps), int(mpc_every), C.c_double(horizon), C.c_double(arm_kp), C.c_double(arm_kd)), "qmhip_closed_loop_sim")
+        fn = self.lib.qmhip_closed_loop_sim_pipelined if pipelined else self.lib.qmhip_closed_loop_sim     # pipelined: the MPC beside the ticks, one period of latency
+        self.itf._check(fn(self.itf.h, self.B, int(n_ticks), C.c_double(period), int(n_substeps), int(mpc_every), C.c_double(horizon), C.c_double(arm_kp), C.c_double(arm_kd)), "qmhip_closed_loop_sim")
 
     def state(self):
         B = self.B; q = np.zeros((B, 24)); v = np.zeros((B, 24)); t = np.zeros(B); f = np.zeros((B, 12)); st = np.zeros(B, np.int32)

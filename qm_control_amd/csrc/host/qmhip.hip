@@ -63,6 +63,9 @@ struct HipBackend {
   void to_host(void* d, const void* s, size_t n) { sync(); check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, stream), "D2H"); check(hipStreamSynchronize(stream), "sync"); }
   void sync() { check(hipStreamSynchronize(stream), "sync"); check(hipStreamSynchronize(stream_b), "sync"); wbc_pending = false; }
   // host-visible (pinned, mapped) memory for flags a kernel publishes: returns the device-side address, *host_view the host-side one
+  hipEvent_t ev_order = nullptr;
+  void stream_select(int s) { cur = s ? stream_b : stream; }
+  void stream_order(int a, int b) { if (!ev_order) hipEventCreateWithFlags(&ev_order, hipEventDisableTiming); hipEventRecord(ev_order, a ? stream_b : stream); hipStreamWaitEvent(b ? stream_b : stream, ev_order, 0); }
   void copy_dd(void* d, const void* s, size_t n) { check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, cur), "D2D"); }
   void* alloc_mapped(size_t n, void** host_view) { void* h = nullptr; void* dv = nullptr; check(hipHostMalloc(&h, n ? n : 8, hipHostMallocMapped), "hipHostMalloc"); check(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer"); *host_view = h; return dv; }
   void free_mapped(void* host_view) { hipHostFree(host_view); }
@@ -329,6 +332,17 @@ int qmhip_closed_loop_sim(qmhip_ctx* c, int B, int n_ticks, double period, int n
   qm_closed_loop_sim_ticks(c->bk, c->mpc, c->wbc, c->sim, c->sim_ticks, B, n_ticks, period, n_substeps, mpc_every, horizon, arm_kp, arm_kd, c->sqp_iterations(),
                            [&]() { if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon); });
   c->lastB = B; c->have_solution = true;
+  return c->hipstate();
+}
+
+int qmhip_closed_loop_sim_pipelined(qmhip_ctx* c, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd) {
+  if (!c || B <= 0 || B > c->max_batch || n_ticks <= 0 || !(period > 0) || n_substeps < 1 || mpc_every < 1 || !(horizon > 0)) { if (c) c->fail("qmhip_closed_loop_sim_pipelined: bad argument"); return QMHIP_ERR_ARG; }
+  if (!c->sim.s.Bmax) { c->fail("qmhip_closed_loop_sim_pipelined: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
+  if (n_ticks % mpc_every || c->sim_ticks % mpc_every) { c->fail("qmhip_closed_loop_sim_pipelined: n_ticks and the tick counter must be multiples of mpc_every"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->bk.sync();
+  qm_closed_loop_sim_pipelined(c->bk, c->mpc, c->wbc, c->sim, c->sim_ticks, B, n_ticks, period, n_substeps, mpc_every, horizon, arm_kp, arm_kd, c->sqp_iterations(),
+                               [&]() { if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon); });
+  c->lastB = B; c->have_solution = true; c->bk.sync();
   return c->hipstate();
 }
 

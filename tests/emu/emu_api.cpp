@@ -17,6 +17,8 @@ struct EmuBackend {
   void* alloc_mapped(size_t n, void** host_view) { void* p = malloc(n ? n : 8); *host_view = p; return p; }
   void free_mapped(void* p) { ::free(p); }
   void wait_launched() {}
+  void stream_select(int) {}
+  void stream_order(int, int) {}
   void copy_dd(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 };
 
@@ -67,6 +69,10 @@ static long g_emu_sim_ticks = 0;
 void emu_closed_loop_sim(void* h, int B, int n_ticks, double period, int nsub, int mpc_every, double horizon, double arm_kp, double arm_kd, int restart) {
   EmuCtx* c = (EmuCtx*)h; if (restart) { g_emu_sim_ticks = 0; c->sim.step(c->mpc.d.mb, B, 0.0, 0); }
   qm_closed_loop_sim_ticks(c->bk, c->mpc, c->wbc, c->sim, g_emu_sim_ticks, B, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, 1, []() {});
+}
+void emu_closed_loop_sim_pipelined(void* h, int B, int n_ticks, double period, int nsub, int mpc_every, double horizon, double arm_kp, double arm_kd, int restart) {
+  EmuCtx* c = (EmuCtx*)h; if (restart) { g_emu_sim_ticks = 0; c->sim.s.p_valid = false; c->sim.step(c->mpc.d.mb, B, 0.0, 0); }
+  qm_closed_loop_sim_pipelined(c->bk, c->mpc, c->wbc, c->sim, g_emu_sim_ticks, B, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, 1, []() {});
 }
 void emu_sim_step(void* h, int B, double period, int nsub, double* rbd, int* contact, double* q, double* v, double* force, int* status) {
   EmuCtx* c = (EmuCtx*)h; c->sim.step(c->mpc.d.mb, B, period, nsub);

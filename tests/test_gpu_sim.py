@@ -158,3 +158,29 @@ def test_operator_commands_drive_the_plant(blobs):
     assert max(l["tilt"].max() for l in log) < 0.2 and min(l["z"].min() for l in log) > 0.33
     assert any(l["mode"] in (6, 9) for l in log if l["label"] == "walk") and log[-1]["mode"] == 15
     assert (log[-1]["x"] > 0.05).all()
+
+
+def test_pipelined_loop_vs_oracle(blobs, oracle):
+    """qmhip_closed_loop_sim_pipelined — the MPC on its own stream beside the control ticks, its solution used one MPC period after its observation — against the
+    oracle's loop with the same latency (stance -> trot schedule, 4 periods of 8 ticks)"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    from qm_control_amd import api
+    mb, st = blobs
+    B = 2; horizon = 0.6; c = setup("trot", B, horizon, t_start=20.3); q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset(); sim.reset(np.tile(q0, (B, 1)), np.zeros((B, 24)), 20.3)
+    dev = []
+    for p in range(4):
+        sim.closed_loop(8, 0.001, horizon, n_substeps=2, mpc_every=8, pipelined=True); s = sim.state(); out, st3 = wbc.download(B); s["tau"] = out[:, 36:]
+        assert (st3 == 0).all() and (mpc.download()["status"] == 0).all(), p
+        dev.append(s)
+    log = oracle_closed_loop(oracle, mb, c, q0, 32, 0.001, 2, 8, horizon, 0.0, 0.5, 20.3, pipelined=True)
+    for p in range(4):
+        k = 8 * p + 7
+        for b in range(B):
+            assert rel_err(dev[p]["tau"][b], log[k]["tau"]) < 1e-4 and rel_err(dev[p]["q"][b], log[k]["q"]) < 1e-7 and rel_err(dev[p]["v"][b], log[k]["v"]) < 1e-4, (p, b)
+    itf.close()

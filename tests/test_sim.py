@@ -107,25 +107,42 @@ def centroidal_from_rbd(mb, rbd):
     return x
 
 
-def oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0):
-    """QMController::update around the oracle's plant, same order of operations as qmhip_closed_loop_sim"""
+def oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0, pipelined=False):
+    """QMController::update around the oracle's plant, same order of operations as qmhip_closed_loop_sim; pipelined: as qmhip_closed_loop_sim_pipelined — the MPC
+    triggered at a tick observes the plant there, its solution is used from the next MPC period on (the first one is synchronous)"""
     oracle.set_schedule(cfg["ev"][0], cfg["modes"][0]); oracle.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
     oracle.wbc_reset(); oracle.sim_params(); oracle.sim_reset(q0, np.zeros(24), time0); oracle.sim_command(0, 0, 0, 0, 0)
-    rbd = oracle.rbd_from_q(q0, np.zeros(24)); time = time0; log = []
+    st = dict(rbd=oracle.rbd_from_q(q0, np.zeros(24)), time=time0, k=0); log = []
     pos = np.zeros(18); vel = np.zeros(18); kp = np.zeros(18); kd = np.zeros(18); ff = np.zeros(18)
-    for k in range(n_ticks):
-        if k % mpc_every == 0:
-            oracle.mpc_step(time, time + horizon, centroidal_from_rbd(mb, rbd), warm=(k > 0))
+
+    def tick():
+        time, rbd = st["time"], st["rbd"]
         xd, ud, mode = oracle.eval_policy(time)
-        if k == 0:
+        if st["k"] == 0:
             oracle.wbc_set_input_last(ud)          # inputLast_ primed with the planned input at the first tick (qmhip_closed_loop_sim)
-        out, st = oracle.wbc(xd, ud, rbd, mode, period, time)
+        out, wst = oracle.wbc(xd, ud, rbd, mode, period, time)
         if time > 10.0:
             pos[:12] = xd[12:24]; vel[:12] = ud[12:24]; kp[:12] = 0.0; kd[:12] = 3.0; ff[:12] = out[36:48]
         pos[12:] = xd[24:30]; vel[12:] = 0.0; kp[12:] = arm_kp; kd[12:] = arm_kd; ff[12:] = out[48:54]
         oracle.sim_command(pos, vel, kp, kd, ff)
-        r = oracle.sim_step(period, nsub); rbd = r["rbd"]; time = r["time"]
-        log.append(dict(q=r["q"].copy(), v=r["v"].copy(), tau=out[36:].copy(), wbc_status=list(st), mode=mode))
+        r = oracle.sim_step(period, nsub); st["rbd"] = r["rbd"]; st["time"] = r["time"]; st["k"] += 1
+        log.append(dict(q=r["q"].copy(), v=r["v"].copy(), tau=out[36:].copy(), wbc_status=list(wst), mode=mode))
+
+    if not pipelined:
+        for k in range(n_ticks):
+            if k % mpc_every == 0:
+                oracle.mpc_step(st["time"], st["time"] + horizon, centroidal_from_rbd(mb, st["rbd"]), warm=(k > 0))
+            tick()
+        return log
+    assert n_ticks % mpc_every == 0
+    for p in range(n_ticks // mpc_every):
+        t_obs, x_obs = st["time"], centroidal_from_rbd(mb, st["rbd"])
+        if p == 0:
+            oracle.mpc_step(t_obs, t_obs + horizon, x_obs, warm=False)
+        for _ in range(mpc_every):
+            tick()
+        if p > 0:
+            oracle.mpc_step(t_obs, t_obs + horizon, x_obs, warm=True)
     return log
 
 
@@ -169,3 +186,26 @@ def test_oracle_reproduces_the_plant_goldens(blobs, oracle):
     log = oracle_closed_loop(oracle, mb, c, g["q0"], 20, 0.001, 2, int(g["mpc_every"]), float(g["horizon"]), 0.0, 0.5, float(g["t_start"]))
     for k in range(20):
         assert rel_err(log[k]["q"], g["q"][k]) < 1e-10 and rel_err(log[k]["tau"], g["tau"][k]) < 1e-7 and log[k]["mode"] == int(g["mode"][k]), k
+
+
+
+def test_emulated_pipelined_loop_vs_oracle(blobs, oracle):
+    """qm_closed_loop_sim_pipelined (the MPC beside the ticks, its solution used one period after its observation) on the host emulator against the oracle's loop
+    with the same latency: 3 periods of 4 ticks"""
+    import os, sys, emu_harness
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    mb, st = blobs
+    horizon = 0.45; c = setup("trot", 1, horizon, t_start=20.2); c["horizon"] = horizon; c["B"] = 1
+    q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
+    e = emu_harness.Emu(mb, st, 1, 64, 2, c["ev"].shape[1]); e.grid_only(c, batch=1)
+    e.lib.emu_wbc_reset(e.h); e.sim_params(); e.sim_reset(q0[None], np.zeros((1, 24)), 20.2); e.sim_command(0, 0, 0, 0, 0)
+    dev = []
+    for p in range(3):
+        e.closed_loop_sim(4, 0.001, horizon, nsub=2, mpc_every=4, restart=(p == 0), pipelined=True); dev.append(e.sim_state())
+    log = oracle_closed_loop(oracle, mb, c, q0, 12, 0.001, 2, 4, horizon, 0.0, 0.5, 20.2, pipelined=True)
+    for p in range(3):
+        k = 4 * p + 3
+        assert dev[p]["mpc_status"][0] == 0 and list(dev[p]["wbc_status"][0]) == [0, 0, 0], p
+        assert rel_err(dev[p]["tau"][0], log[k]["tau"]) < 1e-6 and rel_err(dev[p]["q"][0], log[k]["q"]) < 1e-9 and rel_err(dev[p]["v"][0], log[k]["v"]) < 1e-7, p

@@ -18,7 +18,7 @@ for b in range(B):
 mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset(); sim.reset(q, np.zeros((B, 24)), 20.0)
 t = time.time(); bad_mpc = np.zeros(B, bool); bad_wbc = np.zeros(B, bool); dev = np.zeros(B)
 for k in range(0, ticks, 100):
-    sim.closed_loop(100, 0.001, horizon, n_substeps=2, mpc_every=10)
+    sim.closed_loop(100, 0.001, horizon, n_substeps=2, mpc_every=10, pipelined=bool(int(os.environ.get("PIPELINED", "0"))))
     res = mpc.download(); _, st3 = wbc.download(B); rbd = itf.debug_read("sim_rbd", (B, 55))
     bad_mpc |= res["status"] != 0; bad_wbc |= (st3 != 0).any(1); dev = np.maximum(dev, np.linalg.norm(rbd[:, 48:51] - rbd0[:, 48:51], axis=1))
 s = sim.state(); up = np.isfinite(s["q"]).all(1) & (np.abs(s["q"][:, 3:5]).max(1) < 0.3) & (s["q"][:, 2] > 0.3)
