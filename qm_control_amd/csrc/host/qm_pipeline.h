@@ -43,7 +43,6 @@ struct QmMpcPipeline {
   int ls_trials_run = 0;
   int riccati_skip = 0;   // profiling only
   int lq_prof = 0;        // profiling only
-  int lq_grid = 0;        // workgroups of the (persistent) LQ kernel; 0: one per node
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
