@@ -35,6 +35,8 @@ struct QmMpcBuffers {
   int* prev_n = nullptr; double* prev_t = nullptr; int* prev_ev = nullptr;
   // line search: instances still searching after trial t (device counters + their host-visible copy)
   int* open_cnt = nullptr; int* tickets = nullptr; int* host_open_dev = nullptr; volatile int* host_open = nullptr;
+  // largest node count of the batch, published by K0 (the per-node launches cover only that many nodes per instance)
+  int* ncap_dev = nullptr; int* host_ncap_dev = nullptr; volatile int* host_ncap = nullptr;
 };
 
 template <class BK>
@@ -44,6 +46,7 @@ struct QmMpcPipeline {
   int riccati_skip = 0;   // profiling only
   int lq_prof = 0;        // profiling only
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
+  int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
   template <class T> T* A(size_t n) { T* p = (T*)bk.alloc(n * sizeof(T)); bk.zero(p, n * sizeof(T)); return p; }
@@ -63,13 +66,15 @@ struct QmMpcPipeline {
     d.alpha = A<double>(Bmax); d.done = A<int>(Bmax); d.xs = A<double>(NB * 30); d.us = A<double>(NB * 30); d.out_perf = A<double>((size_t)Bmax * 10);
     d.prev_n = A<int>(Bmax); d.prev_t = A<double>(NB); d.prev_ev = A<int>(NB);
     d.open_cnt = A<int>(QM_LS_MAX_TRIALS); d.tickets = A<int>(QM_LS_MAX_TRIALS);
+    d.ncap_dev = A<int>(2); { void* hv = nullptr; d.host_ncap_dev = (int*)bk.alloc_mapped(sizeof(int), &hv); d.host_ncap = (volatile int*)hv; d.host_ncap[0] = 0; }
     { void* hv = nullptr; d.host_open_dev = (int*)bk.alloc_mapped(QM_LS_MAX_TRIALS * sizeof(int), &hv); d.host_open = (volatile int*)hv; for (int i = 0; i < QM_LS_MAX_TRIALS; ++i) d.host_open[i] = 0; }
   }
   void release() {
     void* ps[] = {d.mb, d.st, d.t0, d.x0, d.ref_t, d.ref_x, d.ev, d.modes, d.n_nodes, d.node_t, d.node_ts, d.node_dt, d.node_ev, d.node_mode, d.zvel, d.zpos, d.xref, d.eeref, d.status,
-                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev, d.open_cnt, d.tickets};
+                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev, d.open_cnt, d.tickets, d.ncap_dev};
     for (void* p : ps) if (p) bk.free(p);
     if (d.host_open) bk.free_mapped((void*)d.host_open);
+    if (d.host_ncap) bk.free_mapped((void*)d.host_ncap);
     d = QmMpcBuffers();
   }
 
@@ -96,6 +101,7 @@ struct QmMpcPipeline {
     QmGridArgs g; g.mb = d.mb; g.st = d.st; g.B = B; g.nmax = d.nmax; g.nref = d.nref; g.nev = d.nev; g.t0 = d.t0; g.x0 = d.x0; g.ref_t = d.ref_t; g.ref_x = d.ref_x; g.ev = d.ev; g.modes = d.modes;
     g.horizon = horizon; g.n_nodes = d.n_nodes; g.node_t = d.node_t; g.node_ts = d.node_ts; g.node_dt = d.node_dt; g.node_ev = d.node_ev; g.node_mode = d.node_mode;
     g.zvel = d.zvel; g.zpos = d.zpos; g.xref = d.xref; g.eeref = d.eeref; g.x = d.x; g.u = d.u; g.status = d.status;
+    g.ncap_dev = d.ncap_dev; g.host_ncap = (volatile int*)d.host_ncap_dev; d.host_ncap[0] = -1; ncap = 0;
     g.warm = warm ? 1 : 0; g.prev_n = d.prev_n; g.prev_t = d.prev_t; g.prev_ev = d.prev_ev; g.prev_xs = d.xs; g.prev_us = d.us;
     bk.launch(qm_grid_kernel, (B + 63) / 64, 64, 0, g);
     bk.launch(qm_grid_nodes_kernel, (d.nmax * B + 63) / 64, 64, 0, g);
@@ -108,12 +114,13 @@ struct QmMpcPipeline {
   // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min).  `last`: no further iteration of this solve
   // follows, so the accepted step only has to reach the primal solution (xs, us), not the iterate (x, u) — the next solve starts from xs / us or cold
   void sqp_iteration(int B, int max_trials = 14, bool last = false) {
-    const int nodes_threads = d.nmax * B;
+    if (ncap == 0) { bk.wait_flag(d.host_ncap, -1); ncap = d.host_ncap[0]; if (ncap < 1 || ncap > d.nmax) ncap = d.nmax; }   // K0 ran first in the stream: published long before K1a is done
+    const int nodes_threads = ncap * B;
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
-    q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof;
+    q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof; q.ncap = ncap;
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, 0, q);
-    bk.launch(qm_lq_kernel, B * d.nmax, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node
+    bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node; an empty workgroup costs the dispatcher as much as a full one
     QmLsArgs l = ls_args(B);
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
     r.perf = d.perf; r.base_sum = d.base_sum; r.alpha = d.alpha; r.done = d.done; r.out_perf = d.out_perf; r.open_cnt = d.open_cnt; r.tickets = d.tickets;   // baseline merit + arming of the line search

@@ -70,6 +70,10 @@ struct HipBackend {
   void* alloc_mapped(size_t n, void** host_view) { void* h = nullptr; void* dv = nullptr; check(hipHostMalloc(&h, n ? n : 8, hipHostMallocMapped), "hipHostMalloc"); check(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer"); *host_view = h; return dv; }
   void free_mapped(void* host_view) { hipHostFree(host_view); }
   void wait_launched() { check(hipStreamSynchronize(cur), "sync"); }     // everything launched so far on the current stream has completed
+  // spin on a host-visible word a kernel already launched on `stream` overwrites (anything but `pending`); falls back to a stream synchronisation
+  void wait_flag(volatile int* word, int pending) {
+    for (long spin = 0; *word == pending; ++spin) if (spin > 50000000L) { check(hipStreamSynchronize(stream), "sync"); if (*word == pending && error.empty()) error = "a kernel did not publish its host-visible word"; return; }
+  }
   // WBC of the current step on stream_b: its inputs were produced on `stream` (ev_in); the next producers on `stream` wait for ev_wbc
   void wbc_inputs_next() { if (wbc_pending) { hipStreamWaitEvent(stream, ev_wbc, 0); wbc_pending = false; } }
   void wbc_begin() { hipEventRecord(ev_in, stream); hipStreamWaitEvent(stream_b, ev_in, 0); cur = stream_b; }

@@ -32,6 +32,8 @@ struct QmGridArgs {
   double* zvel; double* zpos;   // [nmax][B][4]
   double* xref;           // [nmax][B][30]
   double* eeref;          // [nmax][B][7]
+  int* ncap_dev; volatile int* host_ncap;   // optional: {max n_nodes, tickets} on the device; host-visible word the last block publishes the batch's largest node count in
+                                            // (the per-node launches that follow cover only that many nodes per instance: empty workgroups are not free)
   double* x; double* u;   // [nmax][B][30] initial guess (cold start, or warm start from the previous primal solution)
   // warm start ([upstream ocs2_sqp multiple_shooting::initializeStateInputTrajectories]): previous grid + primal solution; warm == 0 -> cold
   int warm; const int* prev_n; const double* prev_t; const int* prev_ev; const double* prev_xs; const double* prev_us;
@@ -65,14 +67,14 @@ __device__ __forceinline__ void grid_time_segment(const double* ta, int n, doubl
 
 __global__ void qm_grid_kernel(QmGridArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+  int n = 0;
+  if (b < a.B) {
   const double* ev = a.ev + (size_t)b * a.nev; const int* modes = a.modes + (size_t)b * (a.nev + 1);
   const double t0 = a.t0[b], tf = t0 + a.horizon, dt = a.st[ST_SQP_DT];
   const double dtMin = 10.0 * QM_WEAK_EPS;   // steps shorter than this are merged: with [upstream]'s few-epsilon default a node within weakEpsilon before an event opens an
                                              // interval of negative adapted duration (a fixed-rate loop with events on the same raster hits that exactly)
   int status = 0;
   // ---- time discretisation with events ----
-  int n = 0;
   a.node_t[0 * a.B + b] = t0; a.node_ev[0 * a.B + b] = QM_EV_NONE; n = 1;
   int k = grid_find_index(ev, a.nev, t0);
   double nt = t0; double backT = t0;
@@ -87,6 +89,15 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
   }
   a.n_nodes[b] = n;
   a.status[b] = status;
+  }
+  if (a.ncap_dev) {     // largest node count of the batch -> host (64-thread blocks = one wavefront each; the block that arrives last publishes and re-arms the counters)
+    double m = (double)n;
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(a.ncap_dev, (int)m); __threadfence();
+      if (atomicAdd(a.ncap_dev + 1, 1) == (int)gridDim.x - 1) { a.host_ncap[0] = atomicMax(a.ncap_dev, 0); a.ncap_dev[0] = 0; a.ncap_dev[1] = 0; __threadfence_system(); }
+    }
+  }
 }
 
 // [upstream PrimalSolution interpolation] segment of time t on a stored node grid of instance b: PreEvent nodes nudged down, PostEvent nodes

@@ -40,6 +40,7 @@ struct QmLqArgs {
   double* dbg;               // optional [B][nmax][LQ_DBG_SIZE] unprojected LQ data (parity tests); may be null
   double* kin;               // [nmax][B][KR_SIZE] kin records (K1a -> K1b)
   int prof;                  // profiling only: thread 0 leaves phase cycle stamps in the (unused) SR_K field of the record
+  int ncap;                  // K1b: nodes per instance covered by the launch (the batch's largest node count, <= nmax)
 };
 
 // debug record (unprojected LQ): A(900) B(900) b(30) Q(900) R(900) q(30) r(30) C(16x30) D(16x30) e(16) c nc
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   extern __shared__ double qm_smem[];
   double* S = qm_smem;
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
-  const int b = blockIdx.x / a.nmax, i = blockIdx.x - b * a.nmax;
+  const int b = blockIdx.x / a.ncap, i = blockIdx.x - b * a.ncap;
   const int nb = i * a.B + b;                       // node-major index
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   double* rec = a.stage + ((size_t)b * a.nmax + i) * SR_SIZE;

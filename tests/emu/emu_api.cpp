@@ -17,6 +17,7 @@ struct EmuBackend {
   void* alloc_mapped(size_t n, void** host_view) { void* p = malloc(n ? n : 8); *host_view = p; return p; }
   void free_mapped(void* p) { ::free(p); }
   void wait_launched() {}
+  void wait_flag(volatile int*, int) {}
   void stream_select(int) {}
   void stream_order(int, int) {}
   void copy_dd(void* d, const void* s, size_t n) { memcpy(d, s, n); }
