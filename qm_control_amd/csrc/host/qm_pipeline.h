@@ -47,6 +47,7 @@ struct QmMpcPipeline {
   int lq_prof = 0;        // profiling only
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
+  bool ncap_pending = false;   // K0 has been launched and its count not been read yet
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
   template <class T> T* A(size_t n) { T* p = (T*)bk.alloc(n * sizeof(T)); bk.zero(p, n * sizeof(T)); return p; }
@@ -101,7 +102,8 @@ struct QmMpcPipeline {
     QmGridArgs g; g.mb = d.mb; g.st = d.st; g.B = B; g.nmax = d.nmax; g.nref = d.nref; g.nev = d.nev; g.t0 = d.t0; g.x0 = d.x0; g.ref_t = d.ref_t; g.ref_x = d.ref_x; g.ev = d.ev; g.modes = d.modes;
     g.horizon = horizon; g.n_nodes = d.n_nodes; g.node_t = d.node_t; g.node_ts = d.node_ts; g.node_dt = d.node_dt; g.node_ev = d.node_ev; g.node_mode = d.node_mode;
     g.zvel = d.zvel; g.zpos = d.zpos; g.xref = d.xref; g.eeref = d.eeref; g.x = d.x; g.u = d.u; g.status = d.status;
-    g.ncap_dev = d.ncap_dev; g.host_ncap = (volatile int*)d.host_ncap_dev; d.host_ncap[0] = -1; ncap = 0;
+    if (ncap_pending) bk.wait_flag(d.host_ncap, -1);          // a grid whose count was never read: let it publish before the word is re-armed
+    g.ncap_dev = d.ncap_dev; g.host_ncap = (volatile int*)d.host_ncap_dev; d.host_ncap[0] = -1; ncap = 0; ncap_pending = true;
     g.warm = warm ? 1 : 0; g.prev_n = d.prev_n; g.prev_t = d.prev_t; g.prev_ev = d.prev_ev; g.prev_xs = d.xs; g.prev_us = d.us;
     bk.launch(qm_grid_kernel, (B + 63) / 64, 64, 0, g);
     bk.launch(qm_grid_nodes_kernel, (d.nmax * B + 63) / 64, 64, 0, g);
@@ -114,7 +116,7 @@ struct QmMpcPipeline {
   // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min).  `last`: no further iteration of this solve
   // follows, so the accepted step only has to reach the primal solution (xs, us), not the iterate (x, u) — the next solve starts from xs / us or cold
   void sqp_iteration(int B, int max_trials = 14, bool last = false) {
-    if (ncap == 0) { bk.wait_flag(d.host_ncap, -1); ncap = d.host_ncap[0]; if (ncap < 1 || ncap > d.nmax) ncap = d.nmax; }   // K0 ran first in the stream: published long before K1a is done
+    if (ncap == 0) { if (ncap_pending) bk.wait_flag(d.host_ncap, -1); ncap = ncap_pending ? d.host_ncap[0] : d.nmax; ncap_pending = false; if (ncap < 1 || ncap > d.nmax) ncap = d.nmax; }   // K0 ran first in the stream: published long before K1a is done
     const int nodes_threads = ncap * B;
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
