@@ -165,7 +165,7 @@ def main():
             import pyoracle
             cores = min(os.cpu_count() or 1, 64); S = min(B, 128)
             tb = time.perf_counter()
-            bad, _, _, w = pyoracle.batch_step(blobs[0], blobs[1], cores, cfg["t0"][:S], cfg["horizon"], cfg["x0"][:S], cfg["ref_t"][:S], cfg["ref_x"][:S], cfg["ev"][:S], cfg["modes"][:S], cfg["period"], cfg["time"])
+            bad, _, _, w = pyoracle.batch_step(*pyoracle.load_blobs(), cores, cfg["t0"][:S], cfg["horizon"], cfg["x0"][:S], cfg["ref_t"][:S], cfg["ref_x"][:S], cfg["ev"][:S], cfg["modes"][:S], cfg["period"], cfg["time"])
             tcpu = time.perf_counter() - tb
             err = float(np.abs(out[:S] - w).max() / np.abs(w).max())
             line["cpu_baseline"] = {"value": S / tcpu, "unit": "steps/s", "cores": cores, "kind": "port",

@@ -13,6 +13,12 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
 
+def load_blobs():
+    """the ORACLE's own model / settings blobs: written by the numpy front-end oracle/front.py (tools/gen_blobs.py), independent of the
+    product's C++ ingestion, whose blobs (qm_control_amd/data) the product runs on"""
+    return np.load(os.path.join(_HERE, "data", "model_blob.npy")), np.load(os.path.join(_HERE, "data", "settings_blob.npy"))
+
+
 def build(force=False):
     if force or not os.path.exists(_LIB):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
@@ -203,6 +209,20 @@ class Oracle:
             d[k] = dbg[o:o + n].copy(); o += n
         d["M"] = d["M"].reshape(24, 24); d["J"] = d["J"].reshape(12, 24); d["dJ"] = d["dJ"].reshape(12, 24)
         return out, st, d
+
+
+def _wbc_tasks(self):
+    """the three priority levels of the last wbc() call as dicts A, b, D, f (what WbcBase hands to HoQp)"""
+    out = []
+    for level in range(3):
+        dims = np.zeros(2, np.int32); A = np.zeros((64, 36)); b = np.zeros(64); D = np.zeros((128, 36)); f = np.zeros(128)
+        rc = self.lib.qmo_wbc_task(self.h, C.c_int(level), _pi(dims), _p(A), _p(b), _p(D), _p(f))
+        assert rc == 0
+        out.append(dict(A=A[:dims[0]].copy(), b=b[:dims[0]].copy(), D=D[:dims[1]].copy(), f=f[:dims[1]].copy()))
+    return out
+
+
+Oracle.wbc_tasks = _wbc_tasks
 
 
 def batch_step(model_blob, settings_blob, nthreads, t0, horizon, x0, ref_t, ref_x, ev, modes, period, time):

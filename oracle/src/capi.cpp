@@ -153,6 +153,17 @@ int qmo_wbc(void* h, const double* xdes, const double* udes, const double* rbd, 
   return 0;
 }
 
+// the three priority levels of the last qmo_wbc call as (A, b, D, f) — what WbcBase hands to HoQp (HierarchicalWbc.cpp:18-44); dims = {rows A, rows D};
+// A / D row-major with 36 columns, caller buffers sized for 64 / 128 rows
+int qmo_wbc_task(void* h, int level, int* dims, double* A, double* b, double* D, double* f) {
+  Oracle* o = (Oracle*)h; if (level < 0 || level > 2) return -1; const Task& t = o->dbg.task[level];
+  if (t.A.r > 64 || t.D.r > 128) return -2;
+  dims[0] = t.A.r; dims[1] = t.D.r;
+  for (int i = 0; i < t.A.r; ++i) { for (int j = 0; j < QM_NWBC; ++j) A[i * QM_NWBC + j] = t.A(i, j); b[i] = t.b[i]; }
+  for (int i = 0; i < t.D.r; ++i) { for (int j = 0; j < QM_NWBC; ++j) D[i * QM_NWBC + j] = t.D(i, j); f[i] = t.f[i]; }
+  return 0;
+}
+
 // ---- batched-plant restatement (oracle/src/sim.h) ----
 void qmo_sim_params(void* h, const double* p) { SimParams& q = ((Oracle*)h)->simp; q.k_n = p[0]; q.d_n = p[1]; q.mu = p[2]; q.v_eps = p[3]; q.foot_radius = p[4]; q.delay = p[5]; q.saturate = p[6] != 0.0; }
 void qmo_sim_reset(void* h, const double* q, const double* v, double time) { Oracle* o = (Oracle*)h; o->sim = SimState(); for (int i = 0; i < QM_NQ; ++i) { o->sim.q[i] = q[i]; o->sim.v[i] = v[i]; } o->sim.time = time; }

@@ -214,8 +214,9 @@ inline HoLevel solveHoLevel(const Task& task, const HoLevel* prev, int nx) {
 // ------------------------------------------------------------------------------------------------
 // WbcBase restated
 // ------------------------------------------------------------------------------------------------
+struct WbcDebug;
 struct WbcState { Vec inputLast; WbcState() : inputLast(QM_NU, 0.0) {} };
-struct WbcDebug { Vec qMeas, vMeas, qDes, vDes, baseAcc, nle, x0, x1, x2; Mat Mq, J, dJ; int status[3]; int iters[3]; };
+struct WbcDebug { Vec qMeas, vMeas, qDes, vDes, baseAcc, nle, x0, x1, x2; Mat Mq, J, dJ; int status[3]; int iters[3]; Task task[3]; };   // task[k]: level k exactly as handed to HoQp (tests/test_hoqp_literal.py)
 
 inline Vec wbcUpdate(const Model& M, WbcState& S, const Vec& xDes, const Vec& uDes, const Vec& rbd, int mode, double period, double time, bool mpcVariant, WbcDebug* dbg) {
   const double* st = M.st; const int nq = QM_NQ, nv = QM_NWBC;
@@ -341,6 +342,6 @@ inline Vec wbcUpdate(const Model& M, WbcState& S, const Vec& xDes, const Vec& uD
   Vec out(QM_NWBC_OUT, 0.0);
   for (int i = 0; i < nv; ++i) out[i] = l2.x[i];
   for (int r = 0; r < QM_NJ; ++r) { double s = nle[6 + r]; for (int c = 0; c < nq; ++c) s += Mq(6 + r, c) * l2.x[c]; for (int c = 0; c < 12; ++c) s -= J(c, 6 + r) * l2.x[nq + c]; out[nv + r] = s; }
-  if (dbg) { dbg->qMeas = q; dbg->vMeas = v; dbg->qDes = qd; dbg->vDes = vd; dbg->baseAcc = baseAcc; dbg->nle = nle; dbg->Mq = Mq; dbg->J = J; dbg->dJ = dJ; dbg->x0 = l0.x; dbg->x1 = l1.x; dbg->x2 = l2.x; dbg->status[0] = l0.status; dbg->status[1] = l1.status; dbg->status[2] = l2.status; dbg->iters[0] = l0.iters; dbg->iters[1] = l1.iters; dbg->iters[2] = l2.iters; }
+  if (dbg) { dbg->task[0] = task0; dbg->task[1] = task1; dbg->task[2] = task2; dbg->qMeas = q; dbg->vMeas = v; dbg->qDes = qd; dbg->vDes = vd; dbg->baseAcc = baseAcc; dbg->nle = nle; dbg->Mq = Mq; dbg->J = J; dbg->dJ = dJ; dbg->x0 = l0.x; dbg->x1 = l1.x; dbg->x2 = l2.x; dbg->status[0] = l0.status; dbg->status[1] = l1.status; dbg->status[2] = l2.status; dbg->iters[0] = l0.iters; dbg->iters[1] = l1.iters; dbg->iters[2] = l2.iters; }
   return out;
 }

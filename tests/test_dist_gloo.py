@@ -17,7 +17,7 @@ def _worker(rank, world, port, q):
     blobs = scenarios.load_blobs()
     cfg_all = scenarios.make_config("C3", batch=5, n_intervals=12)        # 5 instances over 2 ranks: 3 + 2
     cfg = sharding.shard_config(cfg_all, rank, world)
-    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 1, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
+    bad, xf, uf, w = pyoracle.batch_step(*pyoracle.load_blobs(), 1, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
     dist.barrier()
     tmax = sharding.max_over_ranks(10.0 + rank, dist)
     pad = np.zeros((3, 54)); pad[:cfg["B"]] = w                            # all_gather needs equal shapes
@@ -44,6 +44,6 @@ def test_two_rank_sharding_over_gloo(blobs):
     # unsharded reference
     import pyoracle
     cfg = scenarios.make_config("C3", batch=5, n_intervals=12)
-    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 2, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
+    bad, xf, uf, w = pyoracle.batch_step(*pyoracle.load_blobs(), 2, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
     got = np.concatenate([allw[0:3], allw[3:5]])
     assert np.array_equal(got, w)                                            # sharding does not change any result

@@ -7,7 +7,7 @@ import os
 import sys
 import numpy as np
 import pytest
-from conftest import rel_err
+from conftest import assert_blocks, rel_err
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 pytestmark = pytest.mark.gpu
@@ -155,7 +155,7 @@ def test_closed_loop_with_gait_switch_and_velocity_command(blobs, oracle):
             r = oracle.mpc_step(t, t + horizon, x, warm=(k > 0)); n = len(r["t"])
             assert res["status"][b] == 0 and res["num_nodes"][b] == n, (b, k)
             assert np.array_equal(res["event"][b, :n], r["ev"]) and np.array_equal(res["mode"][b, :n], r["mode"]), (b, k)
-            assert rel_err(res["x"][b, :n], r["x"]) <= TOL and rel_err(res["u"][b, :n], r["u"]) <= TOL, (b, k)
+            assert_blocks(res["x"][b, :n], r["x"], "x", TOL, (b, k)); assert_blocks(res["u"][b, :n], r["u"], "u", TOL, (b, k))
         assert set(res["mode"][b, :n]) - {15} != set(), b       # the new gait is inside the horizon by the last call
     itf.close()
 

@@ -3,7 +3,7 @@ through the C ABI.  The oracle is too slow for 1024 instances, so the full batch
 properties of the domain, and a seeded sample of it against the oracle at the stated tolerance (1e-6 relative)."""
 import numpy as np
 import pytest
-from conftest import rel_err
+from conftest import assert_blocks, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -80,9 +80,9 @@ def test_sample_matches_oracle(full_run, blobs):
     import pyoracle
     r = full_run; cfg = r["cfg"]
     idx = np.array([0, 17, 255, 256, 511, 640, 901, 1023])
-    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 8, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx],
+    bad, xf, uf, w = pyoracle.batch_step(*pyoracle.load_blobs(), 8, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx],
                                          cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"])
     assert bad == 0
-    assert rel_err(r["xd"][idx], xf) <= TOL and rel_err(r["ud"][idx], uf) <= TOL
+    assert_blocks(r["xd"][idx], xf, "x", TOL, "policy x"); assert_blocks(r["ud"][idx], uf, "u", TOL, "policy u")
     for j, b in enumerate(idx):
-        assert rel_err(r["out"][b], w[j]) <= TOL and rel_err(r["out"][b, 36:], w[j, 36:]) <= TOL, b
+        assert_blocks(r["out"][b], w[j], "wbc", TOL, b)

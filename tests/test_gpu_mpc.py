@@ -5,7 +5,7 @@ contact-mode schedules / node event tags bit-exact.
 """
 import numpy as np
 import pytest
-from conftest import rel_err
+from conftest import assert_blocks, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -32,8 +32,8 @@ def _compare(res, b, r):
     assert np.array_equal(res["t"][b, :n], r["t"])                    # same f64 operations -> identical times
     assert np.array_equal(res["event"][b, :n], r["ev"])                # integer: bit-exact
     assert np.array_equal(res["mode"][b, :n], r["mode"])               # integer: bit-exact
-    assert rel_err(res["x"][b, :n], r["x"]) <= TOL
-    assert rel_err(res["u"][b, :n], r["u"]) <= TOL
+    assert_blocks(res["x"][b, :n], r["x"], "x", TOL, "x* instance %d" % b)
+    assert_blocks(res["u"][b, :n], r["u"], "u", TOL, "u* instance %d" % b)
     assert res["perf"][b, 8] == r["alpha"]
     assert rel_err(res["perf"][b, :8], r["perf"][:8]) <= 1e-6
 
@@ -109,7 +109,7 @@ def test_receding_horizon_closed_loop(blobs, oracle):
             r = oracle.mpc_step(t0, t0 + cfg["horizon"], x0, warm=(k > 0)); n = len(r["t"]); g = got[k]
             assert g["status"][b] == 0 and g["num_nodes"][b] == n
             assert np.array_equal(g["t"][b, :n], r["t"]) and np.array_equal(g["event"][b, :n], r["ev"]) and np.array_equal(g["mode"][b, :n], r["mode"])
-            assert rel_err(g["x"][b, :n], r["x"]) <= TOL and rel_err(g["u"][b, :n], r["u"]) <= TOL, (b, k)
+            assert_blocks(g["x"][b, :n], r["x"], "x", TOL, (b, k)); assert_blocks(g["u"][b, :n], r["u"], "u", TOL, (b, k))
     # the fused closed loop (MPC + policy + WBC per step) reproduces the step-by-step sequence bit for bit
     wbc.reset(); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
     mpc.closed_loop_resident(steps, dt_mpc, cfg["horizon"], cfg["period"], cfg["time"])
@@ -134,6 +134,6 @@ def test_multiple_sqp_iterations(blobs, oracle):
             r = oracle.mpc_step(t0, t0 + cfg["horizon"], cfg["x0"][b], warm="iterate")
         n = len(r["t"])
         assert got["status"][b] == 0 and got["num_nodes"][b] == n
-        assert rel_err(got["x"][b, :n], r["x"]) <= TOL and rel_err(got["u"][b, :n], r["u"]) <= TOL, b
+        assert_blocks(got["x"][b, :n], r["x"], "x", TOL, b); assert_blocks(got["u"][b, :n], r["u"], "u", TOL, b)
         assert rel_err(got["perf"][b, :8], r["perf"][:8]) <= 1e-5
     itf.close()

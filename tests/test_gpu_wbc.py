@@ -3,7 +3,7 @@ through the C ABI, against the CPU oracle.  Tolerance 1e-6 relative on torques /
 (BASELINE.json north_star); qp status must be 0 on both sides."""
 import numpy as np
 import pytest
-from conftest import rel_err
+from conftest import assert_blocks, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -46,8 +46,7 @@ def test_wbc_random_states(blobs, oracle, variant):
         ref, sto = oracle.wbc(c["xd"], c["ud"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant))
         assert list(sto) == [0, 0, 0], (b, sto)
         assert list(st[b]) == [0, 0, 0], (b, st[b])
-        assert rel_err(out[b], ref) <= TOL, b
-        assert rel_err(out[b, 36:], ref[36:]) <= TOL, b
+        assert_blocks(out[b], ref, "wbc", TOL, b)
     itf.close()
 
 
@@ -57,7 +56,7 @@ def test_control_step_vs_oracle(blobs, oracle, name, B, N):
     import pyoracle
     from qm_control_amd import api, scenarios
     cfg = scenarios.make_config(name, batch=B, n_intervals=N)
-    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 8, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
+    bad, xf, uf, w = pyoracle.batch_step(*pyoracle.load_blobs(), 8, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
     assert bad == 0
     itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=N + 40, max_ref_knots=2, max_events=cfg["ev"].shape[1])
     mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
@@ -66,11 +65,10 @@ def test_control_step_vs_oracle(blobs, oracle, name, B, N):
     mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
     out, st = wbc.download(B)
     xd, ud, mode = mpc.evaluatePolicy(cfg["t0"])
-    assert rel_err(xd, xf) <= TOL and rel_err(ud, uf) <= TOL
+    assert_blocks(xd, xf, "x", TOL, "policy x"); assert_blocks(ud, uf, "u", TOL, "policy u")
     assert (st == 0).all()
     for b in range(B):
-        assert rel_err(out[b], w[b]) <= TOL, b
-        assert rel_err(out[b, 36:], w[b, 36:]) <= TOL, b
+        assert_blocks(out[b], w[b], "wbc", TOL, b)
     itf.close()
 
 
@@ -81,7 +79,7 @@ def test_control_step_other_gaits(blobs, oracle, gait):
     from qm_control_amd import api, scenarios
     B, N = 8, 30
     cfg = scenarios.gait_config(gait, batch=B, n_intervals=N, seed=11)
-    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 8, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
+    bad, xf, uf, w = pyoracle.batch_step(*pyoracle.load_blobs(), 8, cfg["t0"], cfg["horizon"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["period"], cfg["time"])
     assert bad == 0
     itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=96, max_ref_knots=2, max_events=cfg["ev"].shape[1])
     mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
@@ -91,8 +89,7 @@ def test_control_step_other_gaits(blobs, oracle, gait):
     out, st = wbc.download(B)
     assert (st == 0).all()
     for b in range(B):
-        assert rel_err(out[b], w[b]) <= TOL, b
-        assert rel_err(out[b, 36:], w[b, 36:]) <= TOL, b
+        assert_blocks(out[b], w[b], "wbc", TOL, b)
     itf.close()
 
 
@@ -111,6 +108,7 @@ def test_degenerate_vertices_are_resolved(blobs, oracle, gait, inst):
     res = mpc.download(); out, st = wbc.download(B)
     assert (res["status"] == 0).all() and (st == 0).all()
     idx = np.array([inst])
-    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 1, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx], cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"])
-    assert bad == 0 and rel_err(out[inst], w[0]) <= TOL
+    bad, xf, uf, w = pyoracle.batch_step(*pyoracle.load_blobs(), 1, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx], cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"])
+    assert bad == 0
+    assert_blocks(out[inst], w[0], "wbc", TOL, inst)
     itf.close()

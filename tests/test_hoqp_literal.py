@@ -1,0 +1,95 @@
+"""Independent pin of the hierarchical-QP solve: the reference's cascade built literally (tests/hoqp_literal.py restates
+qm_wbc/src/HoQp.cpp:57-124 with z AND w present) and solved by a generic certified method, against
+  * the CPU oracle (oracle/src/wbc.h:solveHoLevel — slack eliminated, sqrt(rho) rows, QR active set)      [-m "not gpu"]
+  * the HIP product through the C ABI (csrc/kernels/k_wbc.h)                                              [-m gpu]
+on >= 50 random measured / desired states over stance, both trot phases and three-leg support, both hierarchies
+(HierarchicalWbc / HierarchicalMpcWbc), time 5 (arm-joint level 1, HierarchicalWbc.cpp:25-29) and 20, including fast states and a
+weak-actuator model (effort limits x 0.15) whose level-0 soft rows (torque limits, friction pyramids) are active and come back as
+hard rows at levels 1 and 2.  Tolerance 1e-8 per block (v̇, F, τ); 1e-5 on the stress families (weak actuators, 4 rad/s velocity noise), whose level-2
+problem is poorly conditioned (most of their cases still agree to 1e-8, asserted).  Observation recorded here: in this hierarchy the level-0 slack w* is always 0 (the floating base can
+always satisfy the equation of motion within the limits), so what the cascade exercises is ACTIVE soft rows with w = 0 and their
+hard copies f_prev − D_prev x + w* below."""
+import numpy as np
+import pytest
+from conftest import assert_blocks, block_errs
+from hoqp_literal import hoqp_literal
+from wbc_cases import MODES, hard_wbc_inputs, random_wbc_inputs
+
+TOL = 1e-8
+STRESS_TOL = 1e-5      # weak-actuator / 4 rad/s families: v̇ of O(100) rad/s² through a poorly conditioned level 2; the f64 solvers keep ~1e-7 of it, the literal solve is 80-bit
+
+
+def _cases(oracle, blobs, variant):
+    return random_wbc_inputs(oracle, blobs, 16, 21 + variant, 0.05, MODES) + hard_wbc_inputs(oracle, blobs, 16, 31 + variant)
+
+
+def _weak_blobs(blobs):
+    mb = blobs[0].copy(); mb[324:342] *= 0.15            # MB_TAUMAX
+    return mb, blobs[1]
+
+
+def _literal(oracle, c, variant):
+    """the oracle only FORMULATES the tasks here (WbcBase task rows); the cascade is solved literally"""
+    oracle.wbc_reset(); oracle.wbc(c["xd"], c["il"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant))
+    ref, st, d = oracle.wbc(c["xd"], c["ud"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant), debug=True)
+    x, levels = hoqp_literal(oracle.wbc_tasks())
+    tau = d["nle"][6:] + d["M"][6:] @ x[:24] - d["J"][:, 6:].T @ x[24:]              # updateCmd, WbcBase.cpp:548-563
+    return np.concatenate([x, tau]), ref, st, levels
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_oracle_cascade_equals_literal_hoqp(blobs, oracle, variant):
+    n_l0_active = n_hard_active = 0
+    for k, c in enumerate(_cases(oracle, blobs, variant)):
+        lit, ref, st, levels = _literal(oracle, c, variant)
+        assert list(st) == [0, 0, 0], (k, st)
+        assert_blocks(ref, lit, "wbc", TOL, "case %d mode %d" % (k, c["mode"]))
+        n_l0_active += levels[0]["n_active"] > 0; n_hard_active += levels[2]["n_active"] > 0
+    assert n_l0_active >= 16 and n_hard_active >= 16       # the families really put soft rows on their bounds, at level 0 and as hard rows below
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_oracle_cascade_equals_literal_hoqp_weak_actuators(blobs, oblobs, variant):
+    import pyoracle
+    wb = _weak_blobs(oblobs); o = pyoracle.Oracle(*wb)
+    tight = 0; cases = [(o, c) for c in random_wbc_inputs(o, wb, 12, 5, 0.3, MODES)]
+    cases += [(oracle_fast, c) for oracle_fast in [pyoracle.Oracle(*oblobs)] for c in random_wbc_inputs(oracle_fast, oblobs, 8, 41 + variant, 4.0, MODES)]   # 4 rad/s of velocity noise
+    for k, (orc, c) in enumerate(cases):
+        lit, ref, st, levels = _literal(orc, c, variant)
+        assert list(st) == [0, 0, 0], (k, st)
+        assert_blocks(ref, lit, "wbc", STRESS_TOL, "case %d mode %d" % (k, c["mode"]))
+        tight += max(block_errs(ref, lit, "wbc").values()) <= TOL
+    assert tight >= len(cases) - 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1])
+def test_product_cascade_equals_literal_hoqp(blobs, oblobs, oracle, variant):
+    from qm_control_amd import api
+    cases = _cases(oracle, blobs, variant)
+    B = len(cases)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=8, max_ref_knots=2, max_events=2)
+    wbc = api.HierarchicalWbc(itf, mpc_variant=bool(variant))
+    arr = lambda k: np.array([c[k] for c in cases])
+    wbc.reset()
+    wbc.update(arr("xd"), arr("il"), arr("rbd"), arr("mode"), 0.002, arr("time"))       # primes inputLast_
+    out, st = wbc.update(arr("xd"), arr("ud"), arr("rbd"), arr("mode"), 0.002, arr("time"))
+    for k, c in enumerate(cases):
+        lit, ref, sto, _ = _literal(oracle, c, variant)
+        assert list(st[k]) == [0, 0, 0], (k, st[k])
+        assert_blocks(out[k], lit, "wbc", TOL, "case %d mode %d" % (k, c["mode"]))
+    itf.close()
+    # weak-actuator model: a second context on modified blobs
+    import pyoracle
+    wb = _weak_blobs(oblobs); o = pyoracle.Oracle(*wb)
+    cases = random_wbc_inputs(o, wb, 12, 5, 0.3, MODES); B = len(cases)
+    itf = api.QMInterface(blobs=_weak_blobs(blobs), max_batch=B, max_nodes=8, max_ref_knots=2, max_events=2)
+    wbc = api.HierarchicalWbc(itf, mpc_variant=bool(variant))
+    wbc.reset()
+    wbc.update(arr("xd"), arr("il"), arr("rbd"), arr("mode"), 0.002, arr("time"))
+    out, st = wbc.update(arr("xd"), arr("ud"), arr("rbd"), arr("mode"), 0.002, arr("time"))
+    for k, c in enumerate(cases):
+        lit, ref, sto, _ = _literal(o, c, variant)
+        assert list(st[k]) == [0, 0, 0], (k, st[k])
+        assert_blocks(out[k], lit, "wbc", STRESS_TOL, "weak case %d mode %d" % (k, c["mode"]))
+    itf.close()

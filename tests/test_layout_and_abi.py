@@ -54,26 +54,39 @@ def test_missing_files_raise_like_the_reference():
         api.parse_model("/nonexistent/robot.urdf", "/nonexistent/task.info", "/nonexistent/reference.info")
 
 
-@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference inputs not present")
-def test_cpp_parsers_match_numpy_front_end(blobs):
-    """product C++ URDF/INFO ingestion vs the independent numpy front-end (committed blobs)"""
+DATA = os.path.join(ROOT, "tests", "data")
+INPUTS = [os.path.join(DATA, f) for f in ("robot.urdf", "task.info", "reference.info")]
+
+
+def test_product_blobs_come_from_the_product_parser(blobs):
+    """the blobs the product runs on (qm_control_amd/data) are bit-equal to what its own C++ ingestion (qmhip_parse_model) makes of the shipped input files"""
     from qm_control_amd import api
-    mb, st = api.parse_model(REFERENCE + "/qm_description/urdf/qudraputed_manipulator/robot.urdf", REFERENCE + "/qm_controllers/config/task.info", REFERENCE + "/qm_controllers/config/reference.info")
-    assert np.abs(mb - blobs[0]).max() <= 1e-14
-    assert np.abs(st - blobs[1]).max() <= 1e-14
+    mb, st = api.parse_model(*INPUTS)
+    assert np.array_equal(mb, blobs[0]) and np.array_equal(st, blobs[1])
     assert abs(mb[654] - 27.371574) < 1e-9                         # total mass (SURVEY.md §8(c))
     with pytest.raises(ValueError, match="URDF file not found"):
-        api.parse_model("/nonexistent/robot.urdf", REFERENCE + "/qm_controllers/config/task.info", REFERENCE + "/qm_controllers/config/reference.info")
+        api.parse_model("/nonexistent/robot.urdf", INPUTS[1], INPUTS[2])
 
 
-@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference inputs not present")
-def test_committed_blobs_are_current():
+def test_oracle_blobs_come_from_the_numpy_front_end_and_check_the_product(blobs, oblobs):
+    """the oracle's blobs (oracle/data) are bit-equal to a fresh run of the independent numpy front-end, and the two ingestions agree to round-off"""
     import front
+    mb, _ = front.build_model(INPUTS[0], INPUTS[2])
+    st = front.build_settings(INPUTS[1], mb)
+    assert np.array_equal(mb, oblobs[0]) and np.array_equal(st, oblobs[1])
+    assert np.abs(blobs[0] - oblobs[0]).max() <= 1e-13 and np.abs(blobs[1] - oblobs[1]).max() <= 1e-13
+    # everything the integer / event-time path reads from the settings is the same f64 in both
+    for k in ("SQP_DT", "PHASE_TRANS_STANCE", "TIME_HORIZON", "SWING_TIME_SCALE"):
+        assert blobs[1][front.ST[k]] == oblobs[1][front.ST[k]], k
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference not present")
+def test_shipped_inputs_and_gaits_are_the_reference_files():
+    import filecmp, front
     from qm_control_amd import scenarios
-    mb, _ = front.build_model(REFERENCE + "/qm_description/urdf/qudraputed_manipulator/robot.urdf", REFERENCE + "/qm_controllers/config/reference.info")
-    st = front.build_settings(REFERENCE + "/qm_controllers/config/task.info", mb)
-    cmb, cst = scenarios.load_blobs()
-    assert np.array_equal(mb, cmb) and np.array_equal(st, cst)
+    ref = [REFERENCE + "/qm_description/urdf/qudraputed_manipulator/robot.urdf", REFERENCE + "/qm_controllers/config/task.info", REFERENCE + "/qm_controllers/config/reference.info"]
+    for a, b in zip(INPUTS, ref):
+        assert filecmp.cmp(a, b, shallow=False), a
     times, modes = front.load_gait(REFERENCE + "/qm_controllers/config/gait.info", "trot")
     g = scenarios.load_gaits()["trot"]
     assert times == g["switchingTimes"] and modes == g["modeSequence"]

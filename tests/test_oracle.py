@@ -2,7 +2,7 @@
 SURVEY.md §8(c): reference data facts, finite differences, KKT / feasibility residuals, an independent dense solve."""
 import numpy as np
 import pytest
-from conftest import rel_err
+from conftest import assert_blocks, rel_err
 
 
 def test_known_answers_from_reference_data(blobs, oracle):
@@ -71,32 +71,58 @@ def test_constraint_jacobians_and_projection(oracle):
         assert np.abs(J[:, :12]).max() > 0.1 and np.abs(J[:, 30:42]).max() < 1e-9   # depends on momentum/base pose, not on forces
 
 
-def test_riccati_step_equals_dense_kkt_solution(oracle):
-    """independent cross-check: assemble the whole-horizon equality-constrained QP and solve its KKT system with numpy"""
-    from qm_control_amd import scenarios
-    cfg = scenarios.make_config("C1", n_intervals=6)
-    r = _solve(oracle, cfg); n = len(r["t"]); N = n - 1
-    dx, du = oracle.step(n)
-    nz = 30 * (N + 1) + 30 * N
+def _dense_kkt_step(oracle, n):
+    """the whole-horizon equality-constrained QP of the SQP iteration the oracle just ran, assembled from the UNPROJECTED node data
+    (A, B, b, Q, R, P, q, r, C, D, e; event nodes as identity jumps without input) and solved as one dense KKT system with numpy:
+    no projection, no Riccati recursion.  Returns dx[n][30], du[n-1][30]."""
+    N = n - 1; nz = 30 * (N + 1) + 30 * N
     H = np.zeros((nz, nz)); g = np.zeros(nz); rows = []; rhs = []
     xo = lambda i: 30 * i
     uo = lambda i: 30 * (N + 1) + 30 * i
+    n_event = n_eq = 0
     for i in range(N):
         q = oracle.node_lq(i); nc = q["nc"]
-        H[xo(i):xo(i) + 30, xo(i):xo(i) + 30] += q["Q"]; H[uo(i):uo(i) + 30, uo(i):uo(i) + 30] += q["R"]
-        g[xo(i):xo(i) + 30] += q["q"]; g[uo(i):uo(i) + 30] += q["r"]
-        E = np.zeros((30, nz)); E[:, xo(i):xo(i) + 30] = q["A"]; E[:, uo(i):uo(i) + 30] = q["B"]; E[:, xo(i + 1):xo(i + 1) + 30] = -np.eye(30)
+        E = np.zeros((30, nz)); E[:, xo(i):xo(i) + 30] = q["A"]; E[:, xo(i + 1):xo(i + 1) + 30] = -np.eye(30)
+        if q["event"]:                                       # PreEvent -> PostEvent: dx+ = dx + (x_i − x_{i+1}), the node has no input
+            U = np.zeros((30, nz)); U[:, uo(i):uo(i) + 30] = np.eye(30); rows.append(U); rhs.append(np.zeros(30)); n_event += 1
+            assert np.array_equal(q["A"], np.eye(30))
+        else:
+            H[xo(i):xo(i) + 30, xo(i):xo(i) + 30] += q["Q"]; H[uo(i):uo(i) + 30, uo(i):uo(i) + 30] += q["R"]
+            H[uo(i):uo(i) + 30, xo(i):xo(i) + 30] += q["P"]; H[xo(i):xo(i) + 30, uo(i):uo(i) + 30] += q["P"].T
+            g[xo(i):xo(i) + 30] += q["q"]; g[uo(i):uo(i) + 30] += q["r"]
+            E[:, uo(i):uo(i) + 30] = q["B"]
+            Cc = np.zeros((nc, nz)); Cc[:, xo(i):xo(i) + 30] = q["C"][:nc]; Cc[:, uo(i):uo(i) + 30] = q["D"][:nc]
+            rows.append(Cc); rhs.append(-q["e"][:nc]); n_eq += nc
         rows.append(E); rhs.append(-q["b"])
-        Cc = np.zeros((nc, nz)); Cc[:, xo(i):xo(i) + 30] = q["C"][:nc]; Cc[:, uo(i):uo(i) + 30] = q["D"][:nc]
-        rows.append(Cc); rhs.append(-q["e"][:nc])
     Qn, qn, _ = oracle.terminal()
     H[xo(N):xo(N) + 30, xo(N):xo(N) + 30] += Qn; g[xo(N):xo(N) + 30] += qn
     E0 = np.zeros((30, nz)); E0[:, :30] = np.eye(30); rows.append(E0); rhs.append(np.zeros(30))
     Aeq = np.vstack(rows); beq = np.concatenate(rhs)
     K = np.block([[H, Aeq.T], [Aeq, np.zeros((Aeq.shape[0],) * 2)]])
-    sol = np.linalg.lstsq(K, np.concatenate([-g, beq]), rcond=None)[0][:nz]
-    assert rel_err(sol[:30 * (N + 1)].reshape(N + 1, 30), dx) < 1e-7
-    assert rel_err(sol[30 * (N + 1):].reshape(N, 30), du) < 1e-7
+    sol = np.linalg.solve(K, np.concatenate([-g, beq]))[:nz]
+    return sol[:30 * (N + 1)].reshape(N + 1, 30), sol[30 * (N + 1):].reshape(N, 30), n_event, n_eq
+
+
+@pytest.mark.parametrize("name,N,b,what", [
+    ("C1", 6, 0, "stance, nc = 12"),
+    ("C2", 30, 0, "trot across a gait event: nc = 14 rows, PreEvent/PostEvent nodes"),
+    ("C5", 56, 1, "trot -> stance switch, EE target perturbed, arm near its joint limits: barriers active"),
+])
+def test_riccati_step_equals_dense_kkt_solution(blobs, oracle, name, N, b, what):
+    """independent cross-check of projection + Riccati: the SQP step must equal the dense KKT solution of the unprojected QP"""
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config(name, batch=8 if name == "C5" else 1, n_intervals=N)
+    if name == "C5":                                          # an instance whose arm starts within 0.1 rad of the joint-2/3 lower limits (scenarios.make_config)
+        lo = blobs[0][288 + 12:288 + 18]
+        near = [k for k in range(8) if cfg["x0"][k, 25] - lo[1] < 0.1001 and cfg["x0"][k, 26] - lo[2] < 0.1001]
+        assert near, "no near-limit instance in the first 8"
+        b = near[0]
+    r = _solve(oracle, cfg, b); n = len(r["t"])
+    dx, du = oracle.step(n)
+    kdx, kdu, n_event, n_eq = _dense_kkt_step(oracle, n)
+    if name != "C1":
+        assert n_event >= 1 and n_eq > 12 * (n - 1 - n_event)        # event nodes and swing-leg rows really are on this horizon
+    assert_blocks(dx, kdx, "x", 1e-7, what); assert_blocks(du, kdu, "u", 1e-7, what)
 
 
 def test_wbc_invariants(blobs, oracle):

@@ -16,7 +16,7 @@ for name, B, N, seed in cases:
     res = mpc.download(); out, qps = wbc.download(B)
     bad_m = np.nonzero(res["status"])[0]; bad_w = np.nonzero((qps != 0).any(1))[0]
     idx = np.random.default_rng(seed).choice(B, 6, replace=False)
-    bad, xf, uf, w = pyoracle.batch_step(blobs[0], blobs[1], 6, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx], cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"])
+    bad, xf, uf, w = pyoracle.batch_step(*pyoracle.load_blobs(), 6, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx], cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"])
     err = max(float(np.abs(out[b] - w[k]).max() / np.abs(w[k]).max()) for k, b in enumerate(idx)); worst = max(worst, err)
     print("%-20s B %5d N %3d seed %5d  mpc bad %d  wbc bad %d %s  finite %s  sample rel err %.1e (oracle bad %d)" % (name, B, N, seed, len(bad_m), len(bad_w), qps[bad_w[:3]].tolist(), bool(np.isfinite(out).all()), err, bad))
     itf.close()
