@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libqmhip.so")
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
-MB_SIZE, ST_SIZE = 685, 1030
+from . import layout as L
+MB_SIZE, ST_SIZE = L.MB_SIZE, L.ST_SIZE
 
 EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
            "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_solve_resident_warm",
@@ -111,12 +112,12 @@ class QMInterface:
 
     # getters named after the reference's
     def getInitialState(self):
-        return self.settings_blob[930:960].copy()
+        return self.settings_blob[L.ST_XINIT:L.ST_XINIT + 30].copy()
 
     def getCentroidalModelInfo(self):
         mb = self.model_blob
-        return dict(robotMass=mb[654], centroidalInertiaNominal=mb[655:664].reshape(3, 3).copy(), comToBasePositionNominal=mb[664:667].copy(),
-                    qPinocchioNominal=np.concatenate([np.zeros(6), mb[667:685]]), stateDim=30, inputDim=30, generalizedCoordinatesNum=24, actuatedDofNum=18, numThreeDofContacts=4)
+        return dict(robotMass=mb[L.MB_ROBOTMASS], centroidalInertiaNominal=mb[L.MB_INOM:L.MB_INOM + 9].reshape(3, 3).copy(), comToBasePositionNominal=mb[L.MB_RNOM:L.MB_RNOM + 3].copy(),
+                    qPinocchioNominal=np.concatenate([np.zeros(6), mb[L.MB_QNOM:L.MB_QNOM + 18]]), stateDim=30, inputDim=30, generalizedCoordinatesNum=24, actuatedDofNum=18, numThreeDofContacts=4)
 
     def set_setting(self, index, value):
         self._check(self.lib.qmhip_set_setting(self.h, C.c_int(index), C.c_double(value)), "qmhip_set_setting")

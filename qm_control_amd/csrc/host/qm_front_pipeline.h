@@ -52,7 +52,7 @@ struct QmFrontPipeline {
   }
   // getModeSchedule(t0 − T, t0 + 2T) of every instance -> the solver's ev / modes buffers
   void gait_schedule(QmMpcBuffers& d, int B, double horizon) {
-    QmGaitScheduleArgs a; a.T = table(); a.s = state(B); a.t0 = d.t0; a.horizon = horizon; a.nev = d.nev; a.ev_out = d.ev; a.modes_out = d.modes; a.solver_status = d.status;
+    QmGaitScheduleArgs a; a.T = table(); a.s = state(B); a.t0 = d.t0; a.horizon = horizon; a.nev = d.nev; a.ev_out = d.ev; a.modes_out = d.modes;
     bk.launch(qm_gait_schedule_kernel, (B + 63) / 64, 64, 0, a);
   }
   void target_reset(int B, const double* last_ee7) { std::vector<double> h((size_t)B * 7); for (int b = 0; b < B; ++b) for (int q = 0; q < 7; ++q) h[(size_t)b * 7 + q] = last_ee7[q]; bk.to_device(f.last_ee, h.data(), h.size() * 8); }

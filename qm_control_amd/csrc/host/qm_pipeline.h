@@ -48,6 +48,7 @@ struct QmMpcPipeline {
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
   bool ncap_pending = false;   // K0 has been launched and its count not been read yet
+  const int* front_status = nullptr; int front_B = 0;   // sticky status of the device-resident GaitSchedule driving batches of front_B instances (null: schedules come from the host)
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
   template <class T> T* A(size_t n) { T* p = (T*)bk.alloc(n * sizeof(T)); bk.zero(p, n * sizeof(T)); return p; }
@@ -101,7 +102,7 @@ struct QmMpcPipeline {
                 bk.launch(qm_save_grid_kernel, (d.nmax * B + 63) / 64, 64, 0, sg); }
     QmGridArgs g; g.mb = d.mb; g.st = d.st; g.B = B; g.nmax = d.nmax; g.nref = d.nref; g.nev = d.nev; g.t0 = d.t0; g.x0 = d.x0; g.ref_t = d.ref_t; g.ref_x = d.ref_x; g.ev = d.ev; g.modes = d.modes;
     g.horizon = horizon; g.n_nodes = d.n_nodes; g.node_t = d.node_t; g.node_ts = d.node_ts; g.node_dt = d.node_dt; g.node_ev = d.node_ev; g.node_mode = d.node_mode;
-    g.zvel = d.zvel; g.zpos = d.zpos; g.xref = d.xref; g.eeref = d.eeref; g.x = d.x; g.u = d.u; g.status = d.status;
+    g.zvel = d.zvel; g.zpos = d.zpos; g.xref = d.xref; g.eeref = d.eeref; g.x = d.x; g.u = d.u; g.status = d.status; g.front_status = (front_status && front_B == B) ? front_status : nullptr;
     if (ncap_pending) bk.wait_flag(d.host_ncap, -1);          // a grid whose count was never read: let it publish before the word is re-armed
     g.ncap_dev = d.ncap_dev; g.host_ncap = (volatile int*)d.host_ncap_dev; d.host_ncap[0] = -1; ncap = 0; ncap_pending = true;
     g.warm = warm ? 1 : 0; g.prev_n = d.prev_n; g.prev_t = d.prev_t; g.prev_ev = d.prev_ev; g.prev_xs = d.xs; g.prev_us = d.us;

@@ -1,6 +1,7 @@
 // qmhip.hip — libqmhip.so: HIP backend of the launch sequence (qm_pipeline.h) + the C ABI of include/qmhip.h.
 // gfx950 only.  One context = one device, one HIP stream, all buffers resident in HBM for max_batch instances.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -28,7 +29,7 @@ struct HipBackend {
   std::vector<Span> spans; std::vector<hipEvent_t> pool;
   std::map<std::string, std::pair<double, int>> acc;
   std::map<const void*, int> lds_set;
-  hipEvent_t ev() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; hipEventCreate(&e); return e; }
+  hipEvent_t ev() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e = nullptr; check(hipEventCreate(&e), "hipEventCreate"); return e; }
   void check(hipError_t e, const char* what) { if (e != hipSuccess && error.empty()) error = std::string(what) + ": " + hipGetErrorString(e); }
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
@@ -44,10 +45,10 @@ struct HipBackend {
     }
     const void* kp_ = (const void*)kernel;
     const bool span = profiling == 1 || (profiling == 2 && (kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_riccati_kernel || kp_ == (const void*)qm_wbc_kernel));
-    Span s; if (span) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); hipEventRecord(s.a, cur); }
+    Span s; if (span) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); check(hipEventRecord(s.a, cur), "hipEventRecord"); }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, cur, args);
     check(hipGetLastError(), "kernel launch");
-    if (span) { hipEventRecord(s.b, cur); spans.push_back(s); }
+    if (span) { check(hipEventRecord(s.b, cur), "hipEventRecord"); spans.push_back(s); }
   }
   void resolve() {
     if (spans.empty()) return;
@@ -65,19 +66,19 @@ struct HipBackend {
   // host-visible (pinned, mapped) memory for flags a kernel publishes: returns the device-side address, *host_view the host-side one
   hipEvent_t ev_order = nullptr;
   void stream_select(int s) { cur = s ? stream_b : stream; }
-  void stream_order(int a, int b) { if (!ev_order) hipEventCreateWithFlags(&ev_order, hipEventDisableTiming); hipEventRecord(ev_order, a ? stream_b : stream); hipStreamWaitEvent(b ? stream_b : stream, ev_order, 0); }
+  void stream_order(int a, int b) { if (!ev_order) check(hipEventCreateWithFlags(&ev_order, hipEventDisableTiming), "hipEventCreate"); check(hipEventRecord(ev_order, a ? stream_b : stream), "hipEventRecord"); check(hipStreamWaitEvent(b ? stream_b : stream, ev_order, 0), "hipStreamWaitEvent"); }
   void copy_dd(void* d, const void* s, size_t n) { check(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, cur), "D2D"); }
   void* alloc_mapped(size_t n, void** host_view) { void* h = nullptr; void* dv = nullptr; check(hipHostMalloc(&h, n ? n : 8, hipHostMallocMapped), "hipHostMalloc"); check(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer"); *host_view = h; return dv; }
   void free_mapped(void* host_view) { hipHostFree(host_view); }
   void wait_launched() { check(hipStreamSynchronize(cur), "sync"); }     // everything launched so far on the current stream has completed
   // spin on a host-visible word a kernel already launched on `stream` overwrites (anything but `pending`); falls back to a stream synchronisation
   void wait_flag(volatile int* word, int pending) {
-    for (long spin = 0; *word == pending; ++spin) if (spin > 50000000L) { check(hipStreamSynchronize(stream), "sync"); if (*word == pending && error.empty()) error = "a kernel did not publish its host-visible word"; return; }
+    for (long spin = 0; *word == pending; ++spin) if (spin > 50000000L) { check(hipStreamSynchronize(stream), "sync"); check(hipStreamSynchronize(cur), "sync"); if (*word == pending && error.empty()) error = "a kernel did not publish its host-visible word"; return; }
   }
   // WBC of the current step on stream_b: its inputs were produced on `stream` (ev_in); the next producers on `stream` wait for ev_wbc
-  void wbc_inputs_next() { if (wbc_pending) { hipStreamWaitEvent(stream, ev_wbc, 0); wbc_pending = false; } }
-  void wbc_begin() { hipEventRecord(ev_in, stream); hipStreamWaitEvent(stream_b, ev_in, 0); cur = stream_b; }
-  void wbc_end() { hipEventRecord(ev_wbc, stream_b); cur = stream; wbc_pending = true; }
+  void wbc_inputs_next() { if (wbc_pending) { check(hipStreamWaitEvent(stream, ev_wbc, 0), "hipStreamWaitEvent"); wbc_pending = false; } }
+  void wbc_begin() { check(hipEventRecord(ev_in, stream), "hipEventRecord"); check(hipStreamWaitEvent(stream_b, ev_in, 0), "hipStreamWaitEvent"); cur = stream_b; }
+  void wbc_end() { check(hipEventRecord(ev_wbc, stream_b), "hipEventRecord"); cur = stream; wbc_pending = true; }
 };
 
 struct qmhip_ctx {
@@ -108,9 +109,13 @@ __global__ void qm_bench_mfma_kernel(double* out, int iters) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
 }
 
+// settings whose value the kernels' loop bounds depend on (K0 walks t0 + k dt up to the horizon)
+static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT) return v > 0.0 && std::isfinite(v); return true; }
+
 static int create_common(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
   if (!out || max_batch <= 0 || max_nodes < 3 || max_nodes > RW_MAXNODES || max_ref < 1 || max_ev < 1) { g_create_error = "qmhip_create: bad argument (max_nodes must be in [3, 512])"; return QMHIP_ERR_ARG; }
   std::string err; if (!qmio::validateModelBlob(mb, err)) { g_create_error = err; return QMHIP_ERR_MODEL; }
+  if (!setting_ok(ST_SQP_DT, st[ST_SQP_DT])) { g_create_error = "settings blob: sqp.dt must be a positive finite number"; return QMHIP_ERR_MODEL; }
   int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (libqmhip has no CPU fallback)"; return QMHIP_ERR_HIP; }
   if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return QMHIP_ERR_ARG; }
   if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return QMHIP_ERR_HIP; }
@@ -139,9 +144,9 @@ int qmhip_parse_model(const char* urdf, const char* task, const char* ref, doubl
   return QMHIP_OK;
 }
 int qmhip_create(const char* urdf, const char* task, const char* ref, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
-  static double mb[MB_SIZE], st[ST_SIZE];
-  const int rc = qmhip_parse_model(urdf, task, ref, mb, st); if (rc != QMHIP_OK) return rc;
-  return create_common(mb, st, device, max_batch, max_nodes, max_ref, max_ev, out);
+  std::vector<double> mb(MB_SIZE), st(ST_SIZE);
+  const int rc = qmhip_parse_model(urdf, task, ref, mb.data(), st.data()); if (rc != QMHIP_OK) return rc;
+  return create_common(mb.data(), st.data(), device, max_batch, max_nodes, max_ref, max_ev, out);
 }
 int qmhip_create_from_blobs(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
   if (!mb || !st) { g_create_error = "qmhip_create_from_blobs: null blob"; return QMHIP_ERR_ARG; }
@@ -149,18 +154,21 @@ int qmhip_create_from_blobs(const double* mb, const double* st, int device, int 
 }
 void qmhip_destroy(qmhip_ctx* c) {
   if (!c) return; hipSetDevice(c->device); c->bk.sync(); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release();
-  for (auto e : c->bk.pool) hipEventDestroy(e); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
+  for (auto e : c->bk.pool) hipEventDestroy(e); if (c->bk.ev_order) hipEventDestroy(c->bk.ev_order); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
 }
 const char* qmhip_last_error(const qmhip_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
 int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
 int qmhip_set_setting(qmhip_ctx* c, int idx, double v) {
-  if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
+  if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
+  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt must be a positive finite number"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
 }
 
 int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) {
   if (!c) return QMHIP_ERR_ARG;
   if (B <= 0 || B > c->max_batch || n_ref != c->max_ref || n_ev != c->max_ev || !t0 || !x0 || !ref_t || !ref_x || !ev || !modes) { c->fail("qmhip_mpc_upload: bad argument (B <= max_batch, n_ref == max_ref_knots, n_events == max_events required)"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); c->mpc.solved_B = 0; c->lastB = B; c->have_solution = false; return c->hipstate();
+  hipSetDevice(c->device); c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); c->mpc.solved_B = 0; c->lastB = B; c->have_solution = false;
+ return c->hipstate();
 }
 int qmhip_mpc_solve_resident(qmhip_ctx* c, int B, double horizon) {
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident: bad argument"); return QMHIP_ERR_ARG; }
@@ -201,7 +209,7 @@ int qmhip_gait_reset(qmhip_ctx* c, int B, int n_events, const double* event_time
   if (!c || B <= 0 || B > c->max_batch || n_events < 1 || n_events > QM_GAIT_EVENT_SLOTS || !event_times || !mode_sequence || default_template < 0 || default_template >= c->front.f.n_gaits) {
     if (c) c->fail("qmhip_gait_reset: bad argument (templates must be set first; the initial schedule needs at least one event)"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->front.phase_transition_stance_time = c->st[ST_PHASE_TRANS_STANCE];
-  c->front.gait_reset(B, n_events, event_times, mode_sequence, default_template); c->front_B = B; return c->hipstate();
+  c->front.gait_reset(B, n_events, event_times, mode_sequence, default_template); c->front_B = B; c->mpc.front_status = c->front.f.gs_status; c->mpc.front_B = B; return c->hipstate();
 }
 int qmhip_gait_insert_template(qmhip_ctx* c, int B, const int32_t* template_id, const double* start_time, const double* final_time) {
   if (!c || B <= 0 || B != c->front_B || !template_id || !start_time || !final_time) { if (c) c->fail("qmhip_gait_insert_template: bad argument (B must be the batch of qmhip_gait_reset)"); return QMHIP_ERR_ARG; }
@@ -217,6 +225,7 @@ int qmhip_gait_download(qmhip_ctx* c, int B, int32_t* n_events, double* event_ti
 }
 int qmhip_schedule_download(qmhip_ctx* c, int B, double* ev, int32_t* modes) {
   if (!c || B <= 0 || B > c->max_batch || !ev || !modes) return QMHIP_ERR_ARG;
+  if (B != c->lastB && B != c->front_B) { c->fail("qmhip_schedule_download: B differs from the batch size the schedule buffers were filled for"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); c->bk.to_host(ev, c->mpc.d.ev, (size_t)B * c->max_ev * 8); c->bk.to_host(modes, c->mpc.d.modes, (size_t)B * (c->max_ev + 1) * 4); return c->hipstate();
 }
 int qmhip_target_reset(qmhip_ctx* c, int B, const double* last_ee_target) {
@@ -241,6 +250,7 @@ int qmhip_target_download(qmhip_ctx* c, int B, double* ref_t, double* ref_x, dou
 int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) {
   if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG;
   if (!c->have_solution) { c->fail("qmhip_mpc_download: no solution available"); return QMHIP_ERR_STATE; }
+  if (B != c->mpc.solved_B) { c->fail("qmhip_mpc_download: B differs from the batch size of the last solve (the solver buffers are strided by it)"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); const int nm = c->max_nodes; const QmMpcBuffers& d = c->mpc.d;
   std::vector<int> n_h(B), st_h(B); c->bk.to_host(n_h.data(), d.n_nodes, (size_t)B * 4); c->bk.to_host(st_h.data(), d.status, (size_t)B * 4);
   std::vector<double> si((size_t)B * 4); c->bk.to_host(si.data(), d.step_info, si.size() * 8);
@@ -267,6 +277,7 @@ int qmhip_mpc_step(qmhip_ctx* c, int B, const double* t0, const double* x0, int 
 int qmhip_policy_eval(qmhip_ctx* c, int B, const double* t, double* xd, double* ud, int32_t* mode) {
   if (!c || B <= 0 || B > c->max_batch || !t) return QMHIP_ERR_ARG;
   if (!c->have_solution) { c->fail("qmhip_policy_eval: no policy received yet"); return QMHIP_ERR_STATE; }
+  if (B != c->mpc.solved_B) { c->fail("qmhip_policy_eval: B differs from the batch size of the last solve"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); c->wbc.policy_eval(c->mpc.d, B, t);
   if (xd) c->bk.to_host(xd, c->wbc.w.x_des, (size_t)B * 30 * 8); if (ud) c->bk.to_host(ud, c->wbc.w.u_des, (size_t)B * 30 * 8); if (mode) c->bk.to_host(mode, c->wbc.w.mode, (size_t)B * 4);
   return c->hipstate();
@@ -301,7 +312,9 @@ int qmhip_sim_set_params(qmhip_ctx* c, const double* p, int n) {
 }
 int qmhip_sim_reset(qmhip_ctx* c, int B, const double* q, const double* v, const double* time) {
   if (!c || B <= 0 || B > c->max_batch || !q || !v || !time) { if (c) c->fail("qmhip_sim_reset: bad argument"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->sim.allocate(c->max_batch); c->sim.reset(B, q, v, time); c->sim_ticks = 0; c->sim.step(c->mpc.d.mb, B, 0.0, 0); return c->hipstate();   // rbd / contact of the reset state
+  hipSetDevice(c->device); c->sim.allocate(c->max_batch); c->sim.reset(B, q, v, time); c->sim_ticks = 0;
+  c->mpc.solved_B = 0; c->have_solution = false;      // a new episode starts cold, like the reference after "Simulation reset" (no warm start from the previous episode's trajectory)
+  c->sim.step(c->mpc.d.mb, B, 0.0, 0); return c->hipstate();   // rbd / contact of the reset state
 }
 int qmhip_sim_set_command(qmhip_ctx* c, int B, const double* pos_des, const double* vel_des, const double* kp, const double* kd, const double* ff) {
   if (!c || B <= 0 || B > c->max_batch || !pos_des || !vel_des || !kp || !kd || !ff) { if (c) c->fail("qmhip_sim_set_command: bad argument"); return QMHIP_ERR_ARG; }

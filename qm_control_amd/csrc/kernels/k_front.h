@@ -31,22 +31,26 @@ struct QmGaitState {
   double* ev;                   // [cap][B]
   int* mode;                    // [cap + 1][B]
   int* tpl;                     // [B] index into the table
-  int* status;                  // [B] 0 ok, -3 schedule capacity exceeded, -4 tiling start not after the last event (upstream throws), -5 empty schedule
+  int* status;                  // [B] 0 ok, -3 schedule capacity exceeded, -4 tiling start not after the last event (upstream throws), -5 empty schedule.
+                                //     STICKY: the first failure of an instance stays until qmhip_gait_reset; K0 copies it into the solver status of every
+                                //     later MPC call (a failed instance keeps solving on its last good schedule, but never reports status 0 again)
 };
+__device__ __forceinline__ void gait_fail(const QmGaitState& s, int b, int st) { if (s.status[b] == 0) s.status[b] = st; }
 
 // GaitSchedule::tileModeSequenceTemplate [upstream]: push startTime, then template phases until the last event >= finalTime, then STANCE.
 // On entry the instance holds n events and n + 1 modes (slots 0..n); on success s.n[b] is the new event count.
 __device__ __forceinline__ int gait_tile(const QmGaitTable& T, const QmGaitState& s, int b, int n, double startTime, double finalTime) {
   const int g = s.tpl[b]; const int np = T.n_phases[g];
   const double* tt = T.times + (size_t)g * (QM_GAIT_MAX_PHASES + 1); const int* tm = T.modes + (size_t)g * QM_GAIT_MAX_PHASES;
+  // on every failure the instance is left with a CONSISTENT schedule (n events, modes 0..n): what was tiled so far, closed by STANCE
   if (np == 0) { s.n[b] = n; return 0; }                                // "the last subsystem continues for ever": nothing appended
-  if (n > 0 && startTime <= s.ev[(size_t)(n - 1) * s.B + b]) return -4;
-  if (n >= s.cap) return -3;
+  if (n > 0 && startTime <= s.ev[(size_t)(n - 1) * s.B + b]) { s.n[b] = n; return -4; }
+  if (n >= s.cap) { s.n[b] = n; return -3; }
   s.ev[(size_t)n * s.B + b] = startTime; ++n;                              // events n, modes n
   double last = startTime;
   while (last < finalTime) {
     for (int i = 0; i < np; ++i) {
-      if (n >= s.cap) return -3;
+      if (n >= s.cap) { s.mode[(size_t)n * s.B + b] = QM_MODE_STANCE; s.n[b] = n; return -3; }
       s.mode[(size_t)n * s.B + b] = tm[i];
       last = last + (tt[i + 1] - tt[i]);                                   // eventTimes.back() + deltaTime: the reference's addition order
       s.ev[(size_t)n * s.B + b] = last; ++n;
@@ -88,17 +92,18 @@ __global__ void qm_gait_insert_kernel(QmGaitInsertArgs a) {
   double pts = a.phase_transition_stance_time;
   if (s.mode[(size_t)n * s.B + b] == QM_MODE_STANCE) pts = 0.0;           // modeSequence.back() (never empty: n + 1 >= 1 modes)
   if (pts > 0.0) {                                                        // intermediate stance phase
-    if (n >= s.cap) { s.status[b] = -3; return; }
+    if (n >= s.cap) { s.n[b] = n; gait_fail(s, b, -3); return; }
     s.ev[(size_t)n * s.B + b] = startTime; ++n; s.mode[(size_t)n * s.B + b] = QM_MODE_STANCE;
   }
   const int st = gait_tile(a.T, s, b, n, startTime + pts, a.final_t[b]);
-  if (st != 0) s.status[b] = st;
+  if (st != 0) gait_fail(s, b, st);
 }
 
 // GaitSchedule::getModeSchedule(lowerBoundTime, upperBoundTime) [upstream] with the bounds SwitchedModelReferenceManager::modifyReferences
 // asks for, [t0 − T, t0 + 2T] (T = finalTime − initTime), followed by the export of the schedule into the solver's buffers
 // ev[B][nev], modes[B][nev + 1] (unused slots: far-future events, STANCE — the layout scenarios/_pad_schedules uses).
-struct QmGaitScheduleArgs { QmGaitTable T; QmGaitState s; const double* t0; double horizon; int nev; double* ev_out; int* modes_out; int* solver_status; };
+// A failure (status != 0, sticky) leaves the solver's buffers on the last good schedule; K0 reports it (QmGridArgs::front_status).
+struct QmGaitScheduleArgs { QmGaitTable T; QmGaitState s; const double* t0; double horizon; int nev; double* ev_out; int* modes_out; };
 __global__ void qm_gait_schedule_kernel(QmGaitScheduleArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.s.B) return;
@@ -123,11 +128,11 @@ __global__ void qm_gait_schedule_kernel(QmGaitScheduleArgs a) {
     n -= 1;                                                                 // drop the trailing default STANCE phase (one event, one mode)
     st = gait_tile(a.T, s, b, n, tilingStart, upper);
   }
-  s.status[b] = st;
-  if (st != 0) { a.solver_status[b] = st; return; }
+  if (st != 0) { gait_fail(s, b, st); return; }
+  if (s.status[b] != 0) return;                                             // failed earlier: the export stays on the last good schedule
   n = s.n[b];
   double* eo = a.ev_out + (size_t)b * a.nev; int* mo = a.modes_out + (size_t)b * (a.nev + 1);
-  if (n > a.nev) { s.status[b] = -3; a.solver_status[b] = -3; return; }
+  if (n > a.nev) { gait_fail(s, b, -3); return; }
   for (int k = 0; k < n; ++k) eo[k] = s.ev[(size_t)k * B + b];
   for (int k = 0; k <= n; ++k) mo[k] = s.mode[(size_t)k * B + b];
   const double lastev = (n > 0) ? eo[n - 1] : upper;

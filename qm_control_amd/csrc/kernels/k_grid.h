@@ -37,7 +37,8 @@ struct QmGridArgs {
   double* x; double* u;   // [nmax][B][30] initial guess (cold start, or warm start from the previous primal solution)
   // warm start ([upstream ocs2_sqp multiple_shooting::initializeStateInputTrajectories]): previous grid + primal solution; warm == 0 -> cold
   int warm; const int* prev_n; const double* prev_t; const int* prev_ev; const double* prev_xs; const double* prev_us;
-  int* status;            // [B] 0 ok, -1 too many nodes, -2 swing phase not enclosed by stance
+  int* status;            // [B] 0 ok, -1 too many nodes / bad step or horizon, -2 swing phase not enclosed by stance, -3..-5 the gait front-end's sticky status
+  const int* front_status; // [B] or null: status of the device-resident GaitSchedule of this batch (k_front.h) — a failed schedule update must not be reported as 0
 };
 
 __device__ __forceinline__ int grid_find_index(const double* ev, int nev, double t) {   // std::lower_bound
@@ -73,19 +74,22 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
   const double t0 = a.t0[b], tf = t0 + a.horizon, dt = a.st[ST_SQP_DT];
   const double dtMin = 10.0 * QM_WEAK_EPS;   // steps shorter than this are merged: with [upstream]'s few-epsilon default a node within weakEpsilon before an event opens an
                                              // interval of negative adapted duration (a fixed-rate loop with events on the same raster hits that exactly)
-  int status = 0;
+  int status = a.front_status ? a.front_status[b] : 0;
   // ---- time discretisation with events ----
   a.node_t[0 * a.B + b] = t0; a.node_ev[0 * a.B + b] = QM_EV_NONE; n = 1;
   int k = grid_find_index(ev, a.nev, t0);
   double nt = t0; double backT = t0;
-  while (backT < tf) {
+  // a step that is not a positive finite number (or a NaN time) would never reach tf: one-node grid, status -1 (the solve kernels skip n < 2)
+  const bool sane = dt > 0.0 && dt < 1.0e300 && t0 == t0 && tf > t0 && tf < 1.0e300;
+  if (!sane) status = (status == 0) ? -1 : status;
+  while (sane && backT < tf) {
     nt = nt + dt; int nevt = QM_EV_NONE; bool post = false;
     if (k < a.nev && nt >= ev[k]) { nt = ev[k]; nevt = QM_EV_PRE; post = true; ++k; }
     if (nt >= tf) { nt = tf; nevt = QM_EV_NONE; post = false; }
-    if (nt > backT + dtMin) { if (n >= a.nmax) { status = -1; break; } a.node_t[n * a.B + b] = nt; a.node_ev[n * a.B + b] = nevt; ++n; }
+    if (nt > backT + dtMin) { if (n >= a.nmax) { status = (status == 0) ? -1 : status; break; } a.node_t[n * a.B + b] = nt; a.node_ev[n * a.B + b] = nevt; ++n; }
     else { a.node_t[(n - 1) * a.B + b] = nt; a.node_ev[(n - 1) * a.B + b] = nevt; }
     backT = nt;
-    if (post) { if (n >= a.nmax) { status = -1; break; } a.node_t[n * a.B + b] = nt; a.node_ev[n * a.B + b] = QM_EV_POST; ++n; }
+    if (post) { if (n >= a.nmax) { status = (status == 0) ? -1 : status; break; } a.node_t[n * a.B + b] = nt; a.node_ev[n * a.B + b] = QM_EV_POST; ++n; }
   }
   a.n_nodes[b] = n;
   a.status[b] = status;
@@ -190,7 +194,7 @@ __global__ void qm_grid_nodes_kernel(QmGridArgs a) {
       if (e != QM_EV_PRE && nst > 0) for (int c = 0; c < 4; ++c) if (mode_flag(mode, c)) a.u[nb * 30 + 3 * c + 2] = mass * 9.81 / nst;
     }
   }
-  if (status != 0) a.status[b] = status;
+  if (status != 0 && a.status[b] == 0) a.status[b] = status;       // (K0 wrote the instance's status before this launch; racing writers of the same instance all carry -2)
 }
 
 // keeps the grid of the solve that produced the current primal solution (xs, us) before K0 overwrites it: the warm start of the

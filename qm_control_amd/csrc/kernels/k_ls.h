@@ -179,8 +179,9 @@ __global__ void qm_ls_apply_kernel(QmLsArgs a) {
   a.xs[nb * 30 + q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
   // input of the primal solution: own node, or the closest earlier non-event node
   int j = (i == n - 1) ? n - 2 : i;
+  if (j < 0) j = 0;                                          // one-node grid (degenerate horizon, K0 status -1): no interval, no input
   while (j > 0 && a.node_ev[j * a.B + b] == QM_EV_PRE) --j;
-  const int jb = j * a.B + b; const bool evj = (a.node_ev[jb] == QM_EV_PRE);
+  const int jb = j * a.B + b; const bool evj = (a.node_ev[jb] == QM_EV_PRE) || n < 2;
   a.us[nb * 30 + q] = evj ? 0.0 : a.u[jb * 30 + q] + al * a.du[jb * 30 + q];
 }
 // commit the accepted step into the iterate (separate launch: apply reads neighbours' u)

@@ -29,7 +29,7 @@ struct QmWbcArgs {
   double* input_last;                         // [B][30] state (WbcBase.cpp:212-213)
   double* out;                                // [B][54]
   int* qp_status;                             // [B][3]  0 ok, 1 iteration limit (nWSR=100), 2 working set overflow
-  double* scratch; int sstride;               // unused by the wave kernel (kept so the pipeline ABI is stable)
+  double* scratch;                            // [B][WBC_SCRATCH] per-instance HBM scratch (WS_* below): tip records, arm Jacobian, cycle counters
   int stop;                                   // profiling only: 1 return after the rigid-body phase, 2/3/4 after level 0/1/2 (no outputs)
   double* dbg;                                // optional [B][WBC_DBG_SIZE]: qMeas vMeas qDes vDes baseAcc nle x0 x1 x2 M J dJv
 };

@@ -92,7 +92,7 @@ void emu_control_step(void* h, int B, double horizon, double period, double time
 }
 // reference / gait front-end (same calls as the qmhip_gait_* / qmhip_target_* entry points)
 void emu_gait_set_templates(void* h, int G, const int* n_phases, const double* times, const int* modes) { ((EmuCtx*)h)->front.set_templates(G, n_phases, times, modes); }
-void emu_gait_reset(void* h, int B, int n0, const double* ev0, const int* mode0, int tpl0) { ((EmuCtx*)h)->front.gait_reset(B, n0, ev0, mode0, tpl0); }
+void emu_gait_reset(void* h, int B, int n0, const double* ev0, const int* mode0, int tpl0) { EmuCtx* c = (EmuCtx*)h; c->front.gait_reset(B, n0, ev0, mode0, tpl0); c->mpc.front_status = c->front.f.gs_status; c->mpc.front_B = B; }   // as qmhip_gait_reset does
 void emu_gait_insert(void* h, int B, const int* tpl, const double* start, const double* final_t) { ((EmuCtx*)h)->front.gait_insert(B, tpl, start, final_t); }
 void emu_gait_update(void* h, int B, const double* t0, double horizon) { EmuCtx* c = (EmuCtx*)h; memcpy(c->mpc.d.t0, t0, (size_t)B * 8); c->front.gait_schedule(c->mpc.d, B, horizon); }
 void emu_gait_download(void* h, int B, int* n, double* ev, int* mode, int* tpl, int* status) { ((EmuCtx*)h)->front.gait_download(B, n, ev, mode, tpl, status); }

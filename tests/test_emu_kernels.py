@@ -1,6 +1,7 @@
 """The product's device kernels, executed by the host emulator (tests/emu), against the oracle — CPU-only parity.
 Same tolerances as the GPU tests: 1e-6 relative on trajectories / torques, integers bit-exact."""
 import numpy as np
+from qm_control_amd import layout as L
 import pytest
 from conftest import assert_blocks, rel_err
 
@@ -45,7 +46,7 @@ def test_line_search_backtracks_like_the_oracle(blobs, oblobs, oracle):
     """tighten g_max so the first trial is rejected and the filter line-search has to halve alpha"""
     import emu_harness, pyoracle
     from qm_control_amd import scenarios
-    st = blobs[1].copy(); st[994] = 1e-9; st[993] = 1e-12     # g_max, deltaTol
+    st = blobs[1].copy(); st[L.ST_G_MAX] = 1e-9; st[L.ST_DELTA_TOL] = 1e-12
     o2 = pyoracle.Oracle(oblobs[0], st)
     cfg = scenarios.make_config("C3", batch=1, n_intervals=10)
     cfg["x0"][0, 24:30] += 0.3

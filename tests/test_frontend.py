@@ -1,5 +1,6 @@
 """Reference / gait front-end on the CPU: the oracle against hand-computed known answers, and the product's
 front-end kernels (run by the host emulator, tests/emu) against the oracle.  Integers and event times: bit-exact.  Targets: 1e-12."""
+import ctypes as C
 import os
 import sys
 import numpy as np
@@ -119,6 +120,49 @@ def test_emulated_schedule_feeds_the_grid_kernel(emu):
     for b in range(B):
         oe, om = o[b].modify_references(t0[b], horizon)
         assert np.array_equal(ev[b, :len(oe)], np.array(oe)) and np.array_equal(mo[b, :len(om)], np.array(om))
+
+
+def test_failed_schedule_update_is_sticky_and_reaches_the_solver_status():
+    """a schedule that does not fit the solver's event slots (-3) used to be reset to 0 by K0; now the front-end status is sticky, the
+    instance keeps a CONSISTENT schedule state, the solver keeps its last good schedule and every later grid reports the failure"""
+    from emu_harness import Emu
+    mb, st = scenarios.load_blobs()
+    e = Emu(mb, st, 2, 64, 2, 6)                                  # 6 solver event slots: too few for [t − T, t + 2T] of pace at T = 1.5 s
+    e.gait_setup(GAITS, 2, default="pace")
+    cfg = scenarios.make_config("C2", batch=2, n_intervals=20)
+    ev = np.tile(np.array([0.5, 1e3, 2e3, 3e3, 4e3, 5e3]), (2, 1)); mo = np.full((2, 7), 15, np.int32)
+    good = dict(cfg, ev=ev, modes=mo, B=2)
+    e.grid_only(good)                                             # uploads a good (all-stance) schedule; the front-end has not failed yet
+    assert (e.buf("status", (2,), np.int32) == 0).all()
+    e.gait_update(np.array([1.0, 1.0]), 1.5)
+    d = e.gait_download()
+    assert (d["status"] == -3).all()
+    n = d["n"]; assert (n >= 1).all() and all(d["mode_sequence"][b, n[b]] == 15 for b in range(2))        # consistent: n events, n + 1 modes, closed by STANCE
+    ev2, mo2 = e.schedule_download()
+    assert np.array_equal(ev2, ev) and np.array_equal(mo2, mo)      # the solver's buffers stay on the last good schedule
+    e.lib.emu_grid(e.h, 2, C.c_double(0.3))
+    assert (e.buf("status", (2,), np.int32) == -3).all()            # ... and the MPC call reports the failure instead of 0
+    e.gait_update(np.array([1.01, 1.01]), 0.1)                      # a later update that would fit does not clear it
+    assert (e.gait_download()["status"] == -3).all()
+    e.lib.emu_grid(e.h, 2, C.c_double(0.3))
+    assert (e.buf("status", (2,), np.int32) == -3).all()
+    e.gait_setup(GAITS, 2, default="stance")                        # reset clears
+    e.gait_update(np.array([1.0, 1.0]), 0.1)
+    assert (e.gait_download()["status"] == 0).all()
+
+
+def test_degenerate_horizon_and_step_do_not_hang_or_read_out_of_bounds():
+    """sqp.dt <= 0 / NaN used to loop forever in K0, a one-node grid made the apply kernel read node -1"""
+    from emu_harness import Emu
+    mb, st = scenarios.load_blobs()
+    cfg = scenarios.make_config("C1", n_intervals=4)
+    for bad_dt in (0.0, -0.01, float("nan")):
+        st2 = st.copy(); st2[scenarios.ST_SQP_DT] = bad_dt
+        e = Emu(mb, st2, 1, 16, 2, cfg["ev"].shape[1])
+        e.grid_only(cfg)
+        assert e.buf("status", (1,), np.int32)[0] == -1 and e.buf("n_nodes", (1,), np.int32)[0] == 1
+        e.mpc_step(cfg)                                             # whole iteration on the one-node grid: must terminate, status stays -1
+        assert e.buf("status", (1,), np.int32)[0] == -1 and np.isfinite(e.node_arr("us", 30)[0, 0]).all()
 
 
 def test_emulated_targets_vs_oracle(emu):

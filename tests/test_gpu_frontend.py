@@ -197,6 +197,30 @@ def test_fused_closed_loop_refreshes_the_schedule(blobs):
     assert (r1["mode"][:, :r1["num_nodes"].min()] != 15).any()                          # the robots are trotting by the end
 
 
+def test_closed_loop_reports_a_failed_schedule_update(blobs):
+    """with too few solver event slots the schedule refresh inside the fused closed loop fails (-3); K0 used to reset the status to 0 and the
+    MPC silently solved on the stale schedule.  Now: sticky front-end status, non-zero MPC status for the failed instances, the others unaffected."""
+    from qm_control_amd import api, scenarios
+    gaits = scenarios.load_gaits()
+    B, N = 4, 20
+    horizon = N * blobs[1][scenarios.ST_SQP_DT]
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=64, max_ref_knots=2, max_events=8)      # stance fits, [t − T, t + 2T] of trot does not
+    mpc = api.SqpMpc(itf); mpc.B = B; wbc = api.HierarchicalWbc(itf); wbc.reset()
+    gs = api.GaitSchedule(itf, gaits, B); pub = api.TargetTrajectoriesPublisher(itf, B, time_to_target=2.0)
+    x0 = np.tile(itf.getInitialState(), (B, 1)); t0 = np.full(B, 0.1)
+    mpc.set_initial(t0, x0)
+    pub.publish(np.full(B, api.CMD_VEL, np.int32), np.zeros((B, 7)))
+    mpc.closed_loop_resident(2, 0.05, horizon, 0.002, 20.0)
+    assert (mpc.download()["status"] == 0).all() and (gs.download()["status"] == 0).all()            # standing: fine
+    gs.insertModeSequenceTemplate(["trot", None, "trot", None], 0.3, 5.0)                            # instances 0 and 2 switch to a long trot
+    mpc.closed_loop_resident(3, 0.05, horizon, 0.002, 20.0)
+    st = mpc.download()["status"]; fs = gs.download()["status"]
+    assert list(fs) == [-3, 0, -3, 0] and list(st) == [-3, 0, -3, 0], (fs, st)
+    mpc.closed_loop_resident(1, 0.05, horizon, 0.002, 20.0)                                          # ... and it stays reported
+    assert list(mpc.download()["status"]) == [-3, 0, -3, 0]
+    itf.close()
+
+
 def test_golden_front_end_stream(blobs):
     """the committed fixture tests/golden/frontend_stream.npz (tools/gen_golden_frontend.py) through the C ABI"""
     from qm_control_amd import api, scenarios

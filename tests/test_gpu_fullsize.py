@@ -2,6 +2,7 @@
 through the C ABI.  The oracle is too slow for 1024 instances, so the full batch is checked through size-independent
 properties of the domain, and a seeded sample of it against the oracle at the stated tolerance (1e-6 relative)."""
 import numpy as np
+from qm_control_amd import layout as L
 import pytest
 from conftest import assert_blocks, rel_err
 
@@ -53,7 +54,7 @@ def test_wbc_hard_constraints_hold_everywhere(full_run, blobs):
     """torque limits, friction pyramids and zero swing forces are the hard rows of WBC levels 1-2: they must hold for every instance"""
     mb, st = blobs; r = full_run
     out = r["out"]; F = out[:, 24:36].reshape(-1, 4, 3); tau = out[:, 36:54]
-    taumax = np.concatenate([np.tile(mb[324:327], 4), mb[336:342]]); mu = st[997]
+    taumax = np.concatenate([np.tile(mb[L.MB_TAUMAX:L.MB_TAUMAX + 3], 4), mb[L.MB_TAUMAX + 12:L.MB_TAUMAX + 18]]); mu = st[L.ST_WBC_FRIC]
     assert (np.abs(tau) <= taumax[None, :] * (1 + 1e-9) + 1e-9).all()
     flags = np.stack([(r["mode"] >> 3) & 1, (r["mode"] >> 2) & 1, (r["mode"] >> 1) & 1, r["mode"] & 1], axis=1).astype(bool)
     scale = max(1.0, np.abs(F).max())

@@ -4,6 +4,7 @@ Tolerance: BASELINE.json north_star — optimal state/input trajectories within 
 contact-mode schedules / node event tags bit-exact.
 """
 import numpy as np
+from qm_control_amd import layout as L
 import pytest
 from conftest import assert_blocks, rel_err
 
@@ -124,7 +125,7 @@ def test_multiple_sqp_iterations(blobs, oracle):
     B = 2
     cfg = scenarios.make_config("C3", batch=B, n_intervals=40)
     itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=80, max_ref_knots=cfg["ref_t"].shape[1], max_events=cfg["ev"].shape[1])
-    itf.set_setting(992, 3.0)                                   # ST_SQP_ITER
+    itf.set_setting(L.ST_SQP_ITER, 3.0)
     mpc = api.SqpMpc(itf)
     got = mpc.run(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"])
     for b in range(B):

@@ -9,25 +9,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-6
 
 
-def _random_wbc_inputs(oracle, blobs, n, seed, vel_scale):
-    mb, st = blobs
-    rng = np.random.default_rng(seed)
-    xbar = st[930:960]
-    cases = []
-    for k in range(n):
-        mode = [15, 9, 6, 15, 9, 6][k % 6]
-        q = xbar[6:30] + 0.1 * rng.normal(size=24); q[18:] = xbar[24:] + 0.05 * rng.normal(size=6)
-        v = vel_scale * rng.normal(size=24)
-        rbd = oracle.rbd_from_q(q, v)
-        xd = xbar + 0.05 * rng.normal(size=30); xd[24:] = xbar[24:] + 0.02 * rng.normal(size=6)
-        ud = np.zeros(30); fl = [(mode >> 3) & 1, (mode >> 2) & 1, (mode >> 1) & 1, mode & 1]
-        for c in range(4):
-            if fl[c]:
-                ud[3 * c:3 * c + 3] = [5 * rng.normal(), 5 * rng.normal(), mb[654] * 9.81 / sum(fl) + 10 * rng.normal()]
-        ud[12:] = vel_scale * rng.normal(size=18)
-        il = vel_scale * rng.normal(size=30)
-        cases.append(dict(mode=mode, rbd=rbd, xd=xd, ud=ud, il=il, time=20.0 if k % 4 != 3 else 5.0))
-    return cases
+from wbc_cases import random_wbc_inputs as _random_wbc_inputs
 
 
 @pytest.mark.parametrize("variant", [0, 1])

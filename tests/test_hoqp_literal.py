@@ -10,6 +10,7 @@ problem is poorly conditioned (most of their cases still agree to 1e-8, asserted
 always satisfy the equation of motion within the limits), so what the cascade exercises is ACTIVE soft rows with w = 0 and their
 hard copies f_prev − D_prev x + w* below."""
 import numpy as np
+from qm_control_amd import layout as L
 import pytest
 from conftest import assert_blocks, block_errs
 from hoqp_literal import hoqp_literal
@@ -24,7 +25,7 @@ def _cases(oracle, blobs, variant):
 
 
 def _weak_blobs(blobs):
-    mb = blobs[0].copy(); mb[324:342] *= 0.15            # MB_TAUMAX
+    mb = blobs[0].copy(); mb[L.MB_TAUMAX:L.MB_TAUMAX + 18] *= 0.15
     return mb, blobs[1]
 
 

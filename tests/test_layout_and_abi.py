@@ -3,6 +3,7 @@ import ctypes as C
 import os
 import re
 import numpy as np
+from qm_control_amd import layout as L
 import pytest
 from conftest import ROOT, REFERENCE
 
@@ -63,7 +64,7 @@ def test_product_blobs_come_from_the_product_parser(blobs):
     from qm_control_amd import api
     mb, st = api.parse_model(*INPUTS)
     assert np.array_equal(mb, blobs[0]) and np.array_equal(st, blobs[1])
-    assert abs(mb[654] - 27.371574) < 1e-9                         # total mass
+    assert abs(mb[L.MB_ROBOTMASS] - 27.371574) < 1e-9                         # total mass
     with pytest.raises(ValueError, match="URDF file not found"):
         api.parse_model("/nonexistent/robot.urdf", INPUTS[1], INPUTS[2])
 

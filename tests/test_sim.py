@@ -1,6 +1,7 @@
 """Batched rigid-body plant: the emulated kernel against the CPU oracle's restatement (oracle/src/sim.h) — command law with the
 delay buffer of QMHWSim::writeSim, forward dynamics, penalty contact — plus physical sanity checks of the oracle itself."""
 import numpy as np
+from qm_control_amd import layout as L
 import pytest
 from conftest import rel_err
 
@@ -47,11 +48,11 @@ def test_oracle_free_fall_and_static_stance(blobs, oracle):
     z0 = stand_height(oracle, st); q = nominal_q(st, z0 - 0.002)
     kp = np.concatenate([np.full(12, 300.0), np.full(6, 20.0)]); kd = np.concatenate([np.full(12, 3.0), np.full(6, 0.5)])   # explicit joint law: kd h must stay below 2 x the joint inertia (wrist: 5.8e-4)
     oracle.sim_reset(q, np.zeros(24), 0.0); oracle.sim_command(q[6:], 0.0, kp, kd, 0.0)
-    weight = mb[654] * 9.81; imp = 0.0; h = 0.001
+    weight = mb[L.MB_ROBOTMASS] * 9.81; imp = 0.0; h = 0.001
     for k in range(200):
         r = oracle.sim_step(h, 1); imp += (r["force"][2::3].sum() - weight) * h
         if k % 50 == 49:
-            M = oracle.wbc(st[930:960], np.zeros(30), oracle.rbd_from_q(r["q"], np.zeros(24)), 15, 0.002, 20.0, debug=True)[2]["M"]
+            M = oracle.wbc(st[L.ST_XINIT:L.ST_XINIT + 30], np.zeros(30), oracle.rbd_from_q(r["q"], np.zeros(24)), 15, 0.002, 20.0, debug=True)[2]["M"]
             assert abs((M @ r["v"])[2] - imp) < 0.02 * max(1.0, abs(imp)), (k, (M @ r["v"])[2], imp)
     assert r["status"] == 0 and r["contact"].all()
     assert abs(r["q"][2] - z0) < 0.01 and np.abs(r["q"][3:6]).max() < 0.05 and np.isfinite(r["v"]).all()

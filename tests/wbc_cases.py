@@ -1,5 +1,6 @@
 """tests/wbc_cases.py — random WBC inputs shared by the CPU and GPU parity tests."""
 import numpy as np
+from qm_control_amd import layout as L
 
 MODES = [15, 9, 6, 7, 15, 9, 6, 14]        # stance, the two trot phases, three-leg support (LF resp. RH in the air)
 
@@ -7,7 +8,7 @@ MODES = [15, 9, 6, 7, 15, 9, 6, 14]        # stance, the two trot phases, three-
 def random_wbc_inputs(oracle, blobs, n, seed, vel_scale, modes=(15, 9, 6, 15, 9, 6)):
     mb, st = blobs
     rng = np.random.default_rng(seed)
-    xbar = st[930:960]
+    xbar = st[L.ST_XINIT:L.ST_XINIT + 30]
     cases = []
     for k in range(n):
         mode = modes[k % len(modes)]
@@ -18,7 +19,7 @@ def random_wbc_inputs(oracle, blobs, n, seed, vel_scale, modes=(15, 9, 6, 15, 9,
         ud = np.zeros(30); fl = [(mode >> 3) & 1, (mode >> 2) & 1, (mode >> 1) & 1, mode & 1]
         for c in range(4):
             if fl[c]:
-                ud[3 * c:3 * c + 3] = [5 * rng.normal(), 5 * rng.normal(), mb[654] * 9.81 / sum(fl) + 10 * rng.normal()]
+                ud[3 * c:3 * c + 3] = [5 * rng.normal(), 5 * rng.normal(), mb[L.MB_ROBOTMASS] * 9.81 / sum(fl) + 10 * rng.normal()]
         ud[12:] = vel_scale * rng.normal(size=18)
         il = vel_scale * rng.normal(size=30)
         cases.append(dict(mode=mode, rbd=rbd, xd=xd, ud=ud, il=il, time=20.0 if k % 4 != 3 else 5.0))
