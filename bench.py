@@ -3,114 +3,248 @@
 One "step" = one multiple-shooting SQP iteration over the horizon + policy evaluation at t0 + one 3-level
 hierarchical WBC solve, for one instance.  Workload per GPU: configuration C3/C4 of
 BASELINE.md — trot gait, N=100, 1024 independent instances with random initial states (seeded), inputs resident
-in HBM before the timed region.  Instances are independent, so N GPUs run N shards with no data-path
-collective (weak scaling); torch.distributed (RCCL) only carries the barrier and the max-over-ranks time.
+in HBM before the timed region.  Instances are independent, so N GPUs run N contiguous shards with NO data-path
+collective (weak scaling); torch.distributed (RCCL) carries the barrier, the max-over-ranks time and a gathered
+per-rank timing vector.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
-        N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--no-secondary]
+        --gpus N > 1 without WORLD_SIZE in the environment: bench.py re-launches itself as N ranks under
+        `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (what the driver does itself).
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic FP64 work and HBM bytes per unit of each kernel (SURVEY.md §8(d) table; DESIGN.md §5 derives every figure)
-#   unit = one non-event shooting interval (lq, riccati) or one instance (wbc)
-KERNEL_MODEL = {
-    # K1b: LQ approximation + projection. bytes: stage record written (Ap Bp, the upper tiles of Qp, Pp Rp, the 12 non-zero rows of Px, vectors, swing blocks = 3533 doubles; Pu is not stored) + kin record / inputs read (~620)
-    "lq": {"flop": 190e3 + 410e3, "bytes": (3533 + 620) * 8.0, "unit": "interval"},
-    # K3: backward sweep reads [Ap|bp] Bp [Qp|qp] [Pp|rp] Rp (3282) and writes L W y (882); forward rollout reads the 12 momentum / base-pose rows of Ap Bp, W L,
-    #     the 12 non-zero rows of Px, vectors and the swing blocks (1952; joint rows are x_j + dt u_j, Pu is rebuilt from the contact mode), x/dx/du (120)
-    "riccati": {"flop": 250e3, "bytes": (3282 + 882 + 1952 + 120) * 8.0, "unit": "interval"},
-    # K5-K7: rigid-body pass + 3-level cascade; bytes: inputs/outputs + tip/Jacobian scratch (~0.9k doubles)
-    "wbc": {"flop": 2.0e6, "bytes": 900 * 8.0, "unit": "instance"},
-}
-FP64_PEAK_TFLOPS = 78.6                 # MI355X dense FP64 matrix peak = FP64 vector peak (AMD public figure; v_mfma_f64_16x16x4 micro-benchmark: 77.7, profiles/)
+# Per-unit work model of the three big kernels: unit = one non-event shooting interval (lq, riccati) or one instance (wbc).
+#   flop : ALGORITHMIC dense FP64 count of SURVEY.md §8(d) (LQ 190 k + projection 410 k; Riccati 250 k; WBC 2.0 M) — what a roofline is priced on;
+#          the flops the kernels actually ISSUE (tile padding, rank-1 MFMAs, ...) are measured with SQ PMC counters: profiles/flops_pmc.json,
+#          reported next to it as `issued_*` when that file is present (tools/gpu_round_profile.sh, tools/flops_pmc_digest.py)
+#   bytes: HBM bytes the design moves per unit (DESIGN.md §4 derives every figure; `doubles` below are f64 counts)
+
+def _kernel_model():
+    # K1b writes one compact stage record per interval (DESIGN.md §3) and reads the kin record + node inputs
+    from qm_control_amd import record_model as rm
+    return {
+        "lq": {"flop": 190e3 + 410e3, "bytes": (rm.LQ_WRITE_DOUBLES + rm.LQ_READ_DOUBLES) * 8.0, "unit": "interval"},
+        "riccati": {"flop": 250e3, "bytes": (rm.RICCATI_BWD_READ_DOUBLES + rm.RICCATI_BWD_WRITE_DOUBLES + rm.RICCATI_FWD_READ_DOUBLES + rm.RICCATI_FWD_IO_DOUBLES) * 8.0, "unit": "interval"},
+        "wbc": {"flop": 2.0e6, "bytes": rm.WBC_IO_DOUBLES * 8.0, "unit": "instance"},
+    }
+
+
+FP64_PEAK_TFLOPS = 78.6                 # MI355X dense FP64 matrix peak = FP64 vector peak (AMD public figure; measured on the device by this bench: fp64_peak_measured)
 HBM_PEAK_TBS = 8.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (≈6.3 TB/s achievable)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--n-intervals", type=int, default=100, help="horizon N (the metric is quoted at 100; other values are for tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-plant-loop", action="store_true", help="skip the secondary closed-loop-around-the-plant figure")
-    args = ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (closed loops, latency, C5)")
+    ap.add_argument("--no-plant-loop", action="store_true", help="skip only the closed-loop-around-the-plant figure")
+    return ap.parse_args(argv)
 
+
+def launch_ranks(n, argv):
+    """--gpus N given to a plain `python bench.py`: become N ranks, one per GPU, under torch.distributed.run (RCCL over xGMI)"""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class HipEngine:
+    """the product: libqmhip.so through the C ABI (qm_control_amd/api.py); inputs resident in HBM after construction"""
+    name = "hip"
+
+    def __init__(self, cfg, local_rank, max_nodes=None):
+        from qm_control_amd import api, scenarios
+        self.api = api; self.cfg = cfg; self.B = cfg["B"]
+        nm = max_nodes or (cfg["n_intervals"] + 28)
+        self.itf = api.QMInterface(blobs=scenarios.load_blobs(), device=local_rank, max_batch=self.B, max_nodes=nm, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+        self.mpc = api.SqpMpc(self.itf); self.wbc = api.HierarchicalWbc(self.itf)
+        self.upload(cfg)
+        for key in ("riccati_skip", "wbc_stop", "lq_prof"):      # profiling-only switches make results meaningless: they must all be off
+            assert self.itf.debug_get(key) == 0, key
+
+    def upload(self, cfg):
+        self.cfg = cfg
+        self.mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+
+    def step(self):
+        self.wbc.reset()
+        self.mpc.control_step_resident(self.cfg["horizon"], self.cfg["period"], self.cfg["time"])
+
+    def sync(self):
+        self.itf.synchronize()
+
+    def results(self):
+        res = self.mpc.download(); out, qps = self.wbc.download(self.cfg["B"])
+        n_intervals = int(sum(int(res["num_nodes"][b]) - 1 - int((res["event"][b, :res["num_nodes"][b]] == 1).sum()) for b in range(self.cfg["B"])))
+        return dict(ok=bool((res["status"] == 0).all() and (qps == 0).all()), out=out, n_intervals=n_intervals, ls_trials=int(res["ls_trials"]))
+
+    def close(self):
+        self.itf.close()
+
+
+def timed_region(engine, steps, dist, device):
+    """EXACTLY `steps` steps between barrier + device synchronisation on both sides; returns (max over ranks of the elapsed seconds, this rank's seconds)"""
+    from qm_control_amd import sharding
+    sharding.barrier(dist, device); engine.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        engine.step()
+    engine.sync(); sharding.barrier(dist, device)
+    mine = time.perf_counter() - t0
+    return sharding.max_over_ranks(mine, dist, device), mine
+
+
+def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
+    """the whole benchmark on this rank; returns the JSON line (dict) on rank 0, None elsewhere.  `make_engine`, `backend`, `device` exist so that the
+    world-size-2 gloo test (tests/test_dist_gloo.py) drives THIS code path with the host-emulated kernels."""
     import numpy as np
-    from qm_control_amd import api, scenarios, sharding
+    from qm_control_amd import scenarios, sharding
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1 or os.environ.get("QM_BENCH_FORCE_DIST"):      # (the env switch exercises the RCCL path on a single GPU)
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local)
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-        dist = dist_mod
-
-    def barrier():
-        if dist is not None:
-            import torch
-            dist.barrier(); torch.cuda.synchronize()
-
+    dist = sharding.init_distributed(backend, local) if (world > 1 or os.environ.get("QM_BENCH_FORCE_DIST")) else None     # (the env switch exercises the RCCL path on one GPU)
     B = args.batch
-    blobs = scenarios.load_blobs()
     # C4: seed 1235, contiguous shard of the global batch for this rank
-    cfg = sharding.shard_config(scenarios.make_config("C4", batch=B * world), rank, world)
-    itf = api.QMInterface(blobs=blobs, device=local, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
-    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])     # inputs resident in HBM from here on
+    cfg = sharding.shard_config(scenarios.make_config("C4", batch=B * world, n_intervals=args.n_intervals), rank, world)
+    eng = make_engine(cfg, local)
+    hip = getattr(eng, "name", "") == "hip"
+    itf = eng.itf if hip else None
 
-    def step():
-        wbc.reset()
-        mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
-
-    # roofline denominators measured on this very device before anything is timed (SURVEY.md §8(d): "microbenchmark it first"): FP64 matrix and
-    # vector FMA throughput, ≈ 0.6 s of sustained FP64 work (which also brings a freshly booted device to its sustained clocks)
-    peak_mfma = max(itf.microbench_fp64(True) for _ in range(12)); peak_fma = max(itf.microbench_fp64(False) for _ in range(6))
+    peak_mfma = peak_fma = None
+    if hip:
+        # roofline denominators measured on this very device before anything is timed (SURVEY.md §8(d): "microbenchmark it first"): FP64 matrix and
+        # vector FMA throughput, ≈ 0.6 s of sustained FP64 work (which also brings a freshly booted device to its sustained clocks)
+        peak_mfma = max(itf.microbench_fp64(True) for _ in range(12)); peak_fma = max(itf.microbench_fp64(False) for _ in range(6))
     for _ in range(args.warmup):
-        step()
-    itf.synchronize()
-    # per-kernel times of every kernel from a short untimed pass; inside the timed region only the three modelled kernels (lq, riccati, wbc — the roofline's
-    # avg_launch_ms) carry HIP-event spans: two event records cost about one launch, 22 of them per step would cost 2 % of the headline
-    itf.set_profiling(True); itf.reset_kernel_ms()
-    for _ in range(5):
-        step()
-    itf.synchronize(); itf.set_profiling(False)
-    kms_all = {k: itf.kernel_ms(k) for k in ("grid", "lq_kin", "lq", "riccati", "ls_eval", "ls_misc", "policy", "wbc")}
-    itf.set_profiling(2); itf.reset_kernel_ms()
-    barrier(); itf.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    itf.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dist, "cuda")
+        eng.step()
+    eng.sync()
+    kms_all = {}
+    if hip:
+        # per-kernel times of every kernel from a short untimed pass; inside the timed region only the three modelled kernels (lq, riccati, wbc — the roofline's
+        # avg_launch_ms) carry HIP-event spans: two event records cost about one launch, 22 of them per step would cost 2 % of the headline
+        itf.set_profiling(True); itf.reset_kernel_ms()
+        for _ in range(5):
+            eng.step()
+        eng.sync(); itf.set_profiling(False)
+        kms_all = {k: itf.kernel_ms(k) for k in ("grid", "lq_kin", "lq", "riccati", "ls_eval", "ls_misc", "policy", "wbc")}
+        itf.set_profiling(2); itf.reset_kernel_ms()
+    elapsed, mine = timed_region(eng, args.steps, dist, device)
+    kms = {}
+    if hip:
+        itf.set_profiling(False)      # per-kernel HIP-event times over the timed region (events recorded on the stream each kernel runs on)
+        kms = {k: itf.kernel_ms(k) for k in ("lq", "riccati", "wbc")}
+    res = eng.results()
+    avg = lambda k: (kms[k][0] / max(1, kms[k][1])) if k in kms else 0.0
+    # every rank's {seconds of the timed region, avg launch ms of the modelled kernels, all statuses ok, intervals per launch}: what RCCL is used for here
+    per_rank = sharding.gather_rows(np.array([[mine, avg("lq"), avg("riccati"), avg("wbc"), float(res["ok"]), float(res["n_intervals"])]]), dist, device)
 
-    # per-kernel HIP-event times over the timed region (events recorded on the stream the kernels run on)
-    itf.set_profiling(False)
-    kms = {k: itf.kernel_ms(k) for k in ("lq", "riccati", "wbc")}
-    res = mpc.download(); out, qps = wbc.download(B)
-    # secondary figure (SURVEY.md §8(f) rank 1, NOT the headline value): the same step run as a receding-horizon closed loop on the device —
-    # every MPC call warm-started from the previous primal solution, the observation advanced along the policy, no host data movement
+    # ---- secondary figures (NOT the headline value) ----
+    sec = {}
+    if hip and not args.no_secondary:
+        sec = secondary_figures(args, eng, cfg, dist, device, world, rank)
+
+    line = None
+    if rank == 0:
+        KM = _kernel_model()
+        n_intervals = res["n_intervals"]
+
+        def roof(name):
+            ms = avg(name); mdl = KM[name]; units = n_intervals if mdl["unit"] == "interval" else B
+            tf = mdl["flop"] * units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0; tb = mdl["bytes"] * units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            return {"kernel": "qm_%s_kernel" % name, "avg_launch_ms": ms, "units_per_launch": units, "unit": mdl["unit"], "flop_per_launch": mdl["flop"] * units, "bytes_per_launch": mdl["bytes"] * units,
+                    "tflops": tf, "frac_fp64": tf / FP64_PEAK_TFLOPS, "tbs": tb, "frac_hbm": tb / HBM_PEAK_TBS}
+        roofline = None; roofs = {}
+        if hip:
+            roofs = {k: roof(k) for k in KM}
+            dom = max(roofs, key=lambda k: roofs[k]["avg_launch_ms"]); rd = roofs[dom]      # the dominant kernel = the longest average launch among the modelled ones
+            if rd["frac_hbm"] >= rd["frac_fp64"]:
+                roofline = {"bound": "hbm", "kernel": rd["kernel"], "achieved": rd["tbs"] * 1e3, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": rd["frac_hbm"], "traffic": None}
+            else:
+                roofline = {"bound": "mfma", "kernel": rd["kernel"], "achieved": rd["tflops"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rd["frac_fp64"], "traffic": None}
+            roofline.update({"avg_launch_ms": rd["avg_launch_ms"], "flop_per_launch": rd["flop_per_launch"], "bytes_per_launch": rd["bytes_per_launch"],
+                             "flop_model": "algorithmic dense count, SURVEY.md §8(d) (not the issued instruction count: see issued_flops)"})
+            # measured HBM bytes per launch of that kernel: the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, digested into
+            # profiles/hbm_traffic.json by tools/digest_round_profile.sh (PMC collection cannot run inside the timed bench itself) — a STATIC file of the named profile round
+            try:
+                with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
+                    ht = json.load(fh)
+                roofline["traffic"] = ht["kernels"][rd["kernel"]]["traffic_bytes"]
+                roofline["traffic_source"] = "profiles/hbm_traffic.json, round %s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, B=1024; not measured in this run)" % ht.get("round", "r01 v18")
+            except (OSError, KeyError, ValueError):
+                pass
+            try:       # flops the kernels ISSUE, from the SQ instruction counters of the same command (profiles/flops_pmc.json): achieved-flops view of every modelled kernel
+                with open(os.path.join(ROOT, "profiles", "flops_pmc.json")) as fh:
+                    fp = json.load(fh)
+                for k, v in roofs.items():
+                    f = fp["kernels"].get(v["kernel"], {}).get("flops_per_launch")
+                    if f and v["avg_launch_ms"] > 0:
+                        v["issued_flops_per_launch"] = f; v["issued_tflops"] = f / (v["avg_launch_ms"] * 1e-3) / 1e12; v["issued_frac_fp64"] = v["issued_tflops"] / FP64_PEAK_TFLOPS
+                roofline["issued_flops_source"] = "profiles/flops_pmc.json, round %s (SQ_INSTS_VALU_*_F64 + MFMA MOPS, B=1024; not measured in this run)" % fp.get("round", "?")
+            except (OSError, KeyError, ValueError):
+                pass
+        total_steps = B * world * args.steps
+        line = {
+            "metric": "MPC+WBC control steps/sec (24-DoF quadruped-manipulator, SQP horizon N=100)", "value": total_steps / elapsed, "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3/C4: trot gait, horizon N=%d (dt 0.015), %d random initial states per GPU (seed 1235), cold start, 1 SQP iteration + policy eval + 3-level WBC; "
+                                   "back-to-back steps, the WBC of a step on its own stream beside the next step's MPC kernels (pipelined THROUGHPUT: the per-kernel times add up to more "
+                                   "than ms_per_step; the unpipelined step latency is latency_ms)" % (args.n_intervals, B),
+                       "instances_per_gpu": B, "parallelism": "shard%d" % world, "all_status_ok": bool(per_rank[:, 4].all()), "ls_trials": res["ls_trials"], "engine": getattr(eng, "name", "?")},
+            "per_rank": {"seconds": [float(v) for v in per_rank[:, 0]], "lq_ms": [float(v) for v in per_rank[:, 1]], "riccati_ms": [float(v) for v in per_rank[:, 2]],
+                         "wbc_ms": [float(v) for v in per_rank[:, 3]], "intervals_per_launch": [int(v) for v in per_rank[:, 5]]},
+        }
+        if hip:
+            line["roofline"] = roofline
+            line["fp64_peak_measured"] = {"mfma_f64_16x16x4": peak_mfma, "vector_fma": peak_fma, "unit": "TFLOP/s", "note": "roofline.peak stays the 78.6 TFLOP/s data-sheet figure"}
+            keys = ("avg_launch_ms", "tflops", "frac_fp64", "tbs", "frac_hbm", "issued_tflops", "issued_frac_fp64")
+            line["roofline_all"] = {k: {kk: v[kk] for kk in keys if kk in v} for k, v in roofs.items()}
+            line["kernel_ms_per_step"] = {k: v[0] / 5 for k, v in kms_all.items()}
+        line.update(sec)
+        if hip and not args.no_cpu_baseline and world == 1:      # the CPU baseline is a property of the box: reported on the single-GPU line only
+            line["cpu_baseline"] = cpu_baseline(cfg, res["out"], B)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return line
+
+
+def secondary_figures(args, eng, cfg, dist, device, world, rank):
+    import numpy as np
+    from qm_control_amd import api, scenarios, sharding
+    itf, mpc, wbc = eng.itf, eng.mpc, eng.wbc; B = cfg["B"]; out = {}
+    # (1) unpipelined step LATENCY: every step followed by a device synchronisation (no WBC(k) / MPC(k+1) overlap); B = 1024 here, B = 1 below
+    eng.sync(); t = time.perf_counter()
+    for _ in range(10):
+        eng.step(); eng.sync()
+    lat_b = (time.perf_counter() - t) / 10 * 1e3
+    # (2) SURVEY.md §8(f) rank 1: the same step run as a receding-horizon closed loop on the device — every MPC call warm-started from the previous
+    #     primal solution, the observation advanced along the policy, no host data movement
     cl_steps, cl_dt = 10, 0.01
     wbc.reset(); mpc.closed_loop_resident(2, cl_dt, cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
     tcl = time.perf_counter(); mpc.closed_loop_resident(cl_steps, cl_dt, cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize(); tcl = time.perf_counter() - tcl
     res_cl = mpc.download(); _, qps_cl = wbc.download(B)
-    closed_loop = {"value": B * cl_steps / tcl, "unit": "steps/s per GPU", "steps": cl_steps, "mpc_dt": cl_dt, "ms_per_step": tcl / cl_steps * 1e3,
-                   "all_status_ok": bool((res_cl["status"] == 0).all() and (qps_cl == 0).all()), "ls_trials_last": int(res_cl["ls_trials"])}
-    # secondary figure (SURVEY.md §8(f) rank 3, NOT the headline value): the whole controller around the batched rigid-body plant, device resident —
-    # per 1 ms tick [state estimate -> MPC every 10 ticks (warm) -> policy -> WBC -> updateControlLaw -> plant step with the 9 ms command delay]
-    plant = None
-    if not args.no_plant_loop:
+    out["closed_loop_warm_start"] = {"value": B * cl_steps / tcl, "unit": "steps/s per GPU", "steps": cl_steps, "mpc_dt": cl_dt, "ms_per_step": tcl / cl_steps * 1e3,
+                                     "all_status_ok": bool((res_cl["status"] == 0).all() and (qps_cl == 0).all()), "ls_trials_last": int(res_cl["ls_trials"])}
+    # (3) SURVEY.md §8(f) rank 3: the whole controller around the batched rigid-body plant, device resident — per 1 ms tick
+    #     [state estimate -> MPC every 10 ticks (warm) -> policy -> WBC -> updateControlLaw -> plant step with the 9 ms command delay]
+    if not args.no_plant_loop and world == 1:
         sim = api.QMHWSim(itf); t_shift = 20.0                                  # the reference switches the legs on at time > 10 (QMController.cpp:179)
         mpc.set_problem(cfg["t0"] + t_shift, cfg["x0"], cfg["ref_t"] + t_shift, cfg["ref_x"], cfg["ev"] + t_shift, cfg["modes"]); wbc.reset()
         q0 = np.array(cfg["x0"][:, 6:30]); q0[:, 0:2] = 0.0; q0[:, 2] = 0.385; q0[:, 3:6] = 0.0
@@ -118,62 +252,77 @@ def main():
         sim.closed_loop(10, 0.001, cfg["horizon"], n_substeps=2, mpc_every=10); itf.synchronize()
         n_ticks = 30; tp = time.perf_counter(); sim.closed_loop(n_ticks, 0.001, cfg["horizon"], n_substeps=2, mpc_every=10); itf.synchronize(); tp = time.perf_counter() - tp
         sp = sim.state(); res_p = mpc.download(); _, qps_p = wbc.download(B)
-        plant = {"value": B * n_ticks / tp, "unit": "plant + controller ticks/s per GPU (1 ms ticks, MPC every 10th)", "ticks": n_ticks, "ms_per_tick": tp / n_ticks * 1e3,
-                 "realtime_factor_per_instance": n_ticks * 0.001 / tp, "all_status_ok": bool((res_p["status"] == 0).all() and (qps_p == 0).all() and (sp["status"] == 0).all()),
-                 "all_finite": bool(np.isfinite(sp["q"]).all()), "base_height_range": [float(sp["q"][:, 2].min()), float(sp["q"][:, 2].max())]}
-    ok = bool((res["status"] == 0).all() and (qps == 0).all())
-    n_intervals = int(sum(int(res["num_nodes"][b]) - 1 - int((res["event"][b, :res["num_nodes"][b]] == 1).sum()) for b in range(B)))
-    # roofline of the dominant kernel (largest average launch duration among the modelled kernels), both ceilings priced
-    def roof(name):
-        ms = kms[name][0] / max(1, kms[name][1]); mdl = KERNEL_MODEL[name]; units = n_intervals if mdl["unit"] == "interval" else B
-        tf = mdl["flop"] * units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0; tb = mdl["bytes"] * units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {"kernel": "qm_%s_kernel" % name, "avg_launch_ms": ms, "units_per_launch": units, "unit": mdl["unit"], "flop_per_launch": mdl["flop"] * units, "bytes_per_launch": mdl["bytes"] * units,
-                "tflops": tf, "frac_fp64": tf / FP64_PEAK_TFLOPS, "tbs": tb, "frac_hbm": tb / HBM_PEAK_TBS}
-    roofs = {k: roof(k) for k in KERNEL_MODEL}
-    dom = max(roofs, key=lambda k: roofs[k]["avg_launch_ms"]); rd = roofs[dom]
-    if rd["frac_hbm"] >= rd["frac_fp64"]:
-        roofline = {"bound": "hbm", "kernel": rd["kernel"], "achieved": rd["tbs"] * 1e3, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": rd["frac_hbm"], "traffic": None}
-    else:
-        roofline = {"bound": "mfma", "kernel": rd["kernel"], "achieved": rd["tflops"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rd["frac_fp64"], "traffic": None}
-    roofline.update({"avg_launch_ms": rd["avg_launch_ms"], "flop_per_launch": rd["flop_per_launch"], "bytes_per_launch": rd["bytes_per_launch"]})
-    # measured HBM bytes per launch of that kernel: the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
-    # summarised in profiles/hbm_traffic.json (tools/gpu_round_profile.sh; PMC collection cannot run inside the timed bench itself)
-    try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
-            roofline["traffic"] = json.load(fh)["kernels"][rd["kernel"]]["traffic_bytes"]
-            roofline["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, B=1024)"
-    except (OSError, KeyError, ValueError):
-        pass
-
+        out["closed_loop_plant"] = {"value": B * n_ticks / tp, "unit": "plant + controller ticks/s per GPU (1 ms ticks, MPC every 10th)", "ticks": n_ticks, "ms_per_tick": tp / n_ticks * 1e3,
+                                    "realtime_factor_per_instance": n_ticks * 0.001 / tp, "all_status_ok": bool((res_p["status"] == 0).all() and (qps_p == 0).all() and (sp["status"] == 0).all()),
+                                    "all_finite": bool(np.isfinite(sp["q"]).all()), "base_height_range": [float(sp["q"][:, 2].min()), float(sp["q"][:, 2].max())]}
+    # (4) BASELINE.json config 5: EE-tracking task, trot -> stance -> trot, N = 150, arm near its joint limits, 512 instances per GPU (4096 over 8), seed 1236
+    B5 = min(512, B); steps5 = max(2, args.steps // 5)
+    cfg5 = sharding.shard_config(scenarios.make_config("C5", batch=B5 * world), rank, world)
+    e5 = HipEngine(cfg5, int(os.environ.get("LOCAL_RANK", "0")), max_nodes=192)
+    for _ in range(2):
+        e5.step()
+    el5, _ = timed_region(e5, steps5, dist, device); r5 = e5.results(); e5.close()
+    out["config_C5"] = {"workload": "C5: EE-tracking target, trot -> stance -> trot, N = 150, arm near joint limits, %d instances per GPU (seed 1236)" % B5, "value": B5 * world * steps5 / el5,
+                        "unit": "steps/s", "n_gpus": world, "steps": steps5, "ms_per_step": el5 / steps5 * 1e3, "all_status_ok": r5["ok"], "ls_trials": r5["ls_trials"]}
+    # (5) BASELINE.json config 2: a single instance (B = 1): the dependency-chain latency of one control step
     if rank == 0:
-        total_steps = B * world * args.steps
-        line = {
-            "metric": "MPC+WBC control steps/sec (24-DoF quadruped-manipulator, SQP horizon N=100)", "value": total_steps / elapsed, "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3/C4: trot gait, horizon N=100 (dt 0.015), %d random initial states per GPU (seed 1235), cold start, 1 SQP iteration + policy eval + 3-level WBC; back-to-back steps, the WBC of a step on its own stream beside the next step's MPC kernels" % B,
-                       "instances_per_gpu": B, "parallelism": "shard%d" % world, "all_status_ok": ok, "ls_trials": int(res["ls_trials"])},
-            "roofline": roofline,
-            "fp64_peak_measured": {"mfma_f64_16x16x4": peak_mfma, "vector_fma": peak_fma, "unit": "TFLOP/s", "note": "roofline.peak stays the 78.6 TFLOP/s data-sheet figure"},
-            "roofline_all": {k: {kk: v[kk] for kk in ("avg_launch_ms", "tflops", "frac_fp64", "tbs", "frac_hbm")} for k, v in roofs.items()},
-            "kernel_ms_per_step": {k: v[0] / 5 for k, v in kms_all.items()},
-            "closed_loop_warm_start": closed_loop,
-            "closed_loop_plant": plant,
-        }
-        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a property of the box: reported on the single-GPU line only
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import pyoracle
-            cores = min(os.cpu_count() or 1, 64); S = min(B, 128)
-            tb = time.perf_counter()
-            bad, _, _, w = pyoracle.batch_step(*pyoracle.load_blobs(), cores, cfg["t0"][:S], cfg["horizon"], cfg["x0"][:S], cfg["ref_t"][:S], cfg["ref_x"][:S], cfg["ev"][:S], cfg["modes"][:S], cfg["period"], cfg["time"])
-            tcpu = time.perf_counter() - tb
-            err = float(np.abs(out[:S] - w).max() / np.abs(w).max())
-            line["cpu_baseline"] = {"value": S / tcpu, "unit": "steps/s", "cores": cores, "kind": "port",
-                                    "sample": "first %d instances of the same batch, CPU oracle (C++ restatement, AD Jacobians), %d threads over instances; max rel diff of GPU torques on the sample %.1e" % (S, cores, err)}
+        cfg2 = scenarios.make_config("C2"); e2 = HipEngine(cfg2, int(os.environ.get("LOCAL_RANK", "0")), max_nodes=128)
+        for _ in range(3):
+            e2.step()
+        e2.sync(); t = time.perf_counter()
+        for _ in range(20):
+            e2.step(); e2.sync()
+        lat1 = (time.perf_counter() - t) / 20 * 1e3; r2 = e2.results(); e2.close()
+        out["latency_ms"] = {"B1_C2": lat1, "B%d_unpipelined" % B: lat_b, "note": "one control step with a device synchronisation after every step (no stream overlap between steps); "
+                             "B1_C2 = BASELINE.json config 2 (single instance, trot, N = 100): %.0f Hz" % (1e3 / lat1), "C2_status_ok": r2["ok"]}
+    return out
+
+
+def cpu_baseline(cfg, gpu_out, B):
+    """the oracle (C++ restatement of the reference's algorithm, kind "port") timed on this box's host cores, on a bounded sample of the same workload:
+    (i) batch mode: threads over instances; (ii) ONE instance the way the reference runs it: 1 thread and sqp.nThreads = 3 worker threads over the
+    shooting nodes (task.info:77), MPC iteration and WBC update timed separately (the two timers QMController prints, QMController.cpp:145-147, 321-323)"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from qm_control_amd import scenarios
+    ob = pyoracle.load_blobs()
+    cores = min(os.cpu_count() or 1, 64); S = min(B, 128)
+    tb = time.perf_counter()
+    bad, _, _, w = pyoracle.batch_step(*ob, cores, cfg["t0"][:S], cfg["horizon"], cfg["x0"][:S], cfg["ref_t"][:S], cfg["ref_x"][:S], cfg["ev"][:S], cfg["modes"][:S], cfg["period"], cfg["time"])
+    tcpu = time.perf_counter() - tb
+    err = float(np.abs(gpu_out[:S] - w).max() / np.abs(w).max())
+    # single instance = BASELINE.json config 2 (trot, N = 100)
+    o = pyoracle.Oracle(*ob); c2 = scenarios.make_config("C2")
+    o.set_schedule(c2["ev"][0], c2["modes"][0]); o.set_target(c2["ref_t"][0], c2["ref_x"][0])
+    single = {}
+    for nt in (1, 3):
+        o.set_threads(nt); best = 1e9; ph = None
+        for _ in range(3):
+            t = time.perf_counter(); o.mpc_step(c2["t0"][0], c2["t0"][0] + c2["horizon"], c2["x0"][0]); dt_ = (time.perf_counter() - t) * 1e3
+            if dt_ < best:
+                best = dt_; ph = o.phase_ms()
+        single["mpc_ms_%dthread%s" % (nt, "" if nt == 1 else "s")] = best
+        single["mpc_phases_ms_%dthread%s" % (nt, "" if nt == 1 else "s")] = {"lq_approximation": float(ph[0]), "riccati": float(ph[1]), "line_search": float(ph[2])}
+    o.set_threads(1)
+    xd, ud, mode = o.eval_policy(c2["t0"][0]); rbd = o.rbd_from_q(c2["x0"][0][6:30]); o.wbc_reset(); best = 1e9
+    for _ in range(5):
+        t = time.perf_counter(); o.wbc(xd, ud, rbd, mode, 0.002, 20.0); best = min(best, (time.perf_counter() - t) * 1e3)
+    single["wbc_ms_1thread"] = best
+    return {"value": S / tcpu, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "first %d instances of the same batch, %d threads over instances (thread count = min(os.cpu_count(), 64)); max rel diff of GPU torques on the sample %.1e" % (S, cores, err),
+            "single_instance_ms": single,
+            "note": "the oracle is a RESTATEMENT with forward-mode AD Jacobians (Dual<60>) and an O(n^4) Lagrangian mass matrix — much slower than the OCS2 / Pinocchio / HPIPM binary the "
+                    "reference runs (SURVEY.md a11: ~5-10 ms per MPC iteration on 3 cores); it is a reported baseline, never a speed-up claim"}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    line = run(args)
+    if line is not None:
         print(json.dumps(line))
-    itf.close()
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -185,6 +185,8 @@ int qmhip_last_ls_trials(const qmhip_ctx* ctx);
 int qmhip_debug_read(qmhip_ctx* ctx, const char* buffer, void* dst, size_t bytes);
 /* profiling-only switches (e.g. "riccati_skip" bit mask of kernel phases to skip; results are then meaningless) */
 int qmhip_debug_set(qmhip_ctx* ctx, const char* key, int value);
+/* read such a switch back (bench.py asserts they are all 0 before it times anything) */
+int qmhip_debug_get(const qmhip_ctx* ctx, const char* key, int* value);
 /* micro-benchmarks used to anchor the FP64 roofline: returns achieved TFLOP/s */
 int qmhip_microbench_fp64(qmhip_ctx* ctx, int use_mfma, double* tflops);
 

@@ -56,6 +56,14 @@ class Oracle:
         except Exception:
             pass
 
+    def set_threads(self, n):
+        """worker threads over shooting nodes (LQ approximation, line-search evaluation) — sqp.nThreads of task.info:77"""
+        self.lib.qmo_set_threads(C.c_int(n))
+
+    def phase_ms(self):
+        """wall time of the last mpc_step: [LQ approximation + projection, Riccati solve, line search] in ms"""
+        ms = np.zeros(3); self.lib.qmo_phase_ms(self.h, _p(ms)); return ms
+
     def set_setting(self, idx, v):
         self.lib.qmo_set_setting(self.h, C.c_int(idx), C.c_double(v))
 

@@ -21,6 +21,8 @@ void* qmo_create(const double* mb, const double* st) {
 }
 void qmo_destroy(void* h) { delete (Oracle*)h; }
 void qmo_set_setting(void* h, int idx, double v) { ((Oracle*)h)->M.st[idx] = v; }
+// worker threads over shooting nodes of the calling thread's later mpc_step calls (sqp.nThreads, task.info:77)
+void qmo_set_threads(int n) { n = n < 1 ? 1 : n; if (n != oracleThreads()) { oracleThreads() = n; nodePool().resize(n - 1); } }
 
 void qmo_flow_map(void* h, const double* x, const double* u, double* f, double* A, double* B) {
   Oracle* o = (Oracle*)h; Vec xv(x, x + QM_NX), uv(u, u + QM_NU), fv; Mat Am, Bm;
@@ -102,6 +104,7 @@ int qmo_get_step(void* h, double* dx, double* du) {
   return n;
 }
 int qmo_ls_trials(void* h) { return ((Oracle*)h)->R.lsTrials; }
+void qmo_phase_ms(void* h, double* ms3) { for (int i = 0; i < 3; ++i) ms3[i] = ((Oracle*)h)->R.phaseMs[i]; }
 // one more SQP iteration on the iterate the last call left (sqp.sqpIteration > 1, [upstream SqpSolver::runImpl loop]); same outputs as qmo_mpc_step
 int qmo_mpc_iterate(void* h, double t0, double tf, const double* x0, int maxn, int* n_nodes, double* node_t, int* node_ev, int* node_mode, double* xs, double* us, double* perf) {
   Oracle* o = (Oracle*)h; Vec x0v(x0, x0 + QM_NX);

@@ -4,6 +4,46 @@
 // SURVEY.md §8 a11 / Appendix B.1, B.6.  PARITY UNPINNED.
 #pragma once
 #include "ocp.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <functional>
+#include <thread>
+#include <pthread.h>
+#include <sched.h>
+
+// worker threads over shooting nodes for the LQ approximation and the line-search performance evaluation: what `sqp.nThreads 3`
+// (qm_controllers/config/task.info:77) does in [upstream ocs2_sqp SqpSolver] (the Riccati / HPIPM solve stays serial there too).
+// Results do not depend on the thread count: every node writes its own slot, sums are taken afterwards in node order.
+// A persistent pool (the way OCS2's ThreadPool lives for the solver's lifetime): on this class of host a thread that is created per call and
+// lives ~100 ms is often never migrated off its parent's core.
+struct NodePool {
+  std::vector<std::thread> th; std::mutex m; std::condition_variable cvWork, cvDone;
+  const std::function<void(int)>* fn = nullptr; int n = 0; std::atomic<int> next{0}; int gen = 0, busy = 0; bool stop = false;
+  void resize(int workers) {
+    { std::unique_lock<std::mutex> l(m); stop = true; ++gen; } cvWork.notify_all(); for (auto& t : th) t.join(); th.clear(); stop = false;
+    // each worker is pinned to its own allowed CPU (not the caller's): this host's scheduler otherwise leaves freshly woken workers stacked on the waker's core
+    cpu_set_t allowed; CPU_ZERO(&allowed); std::vector<int> cpus;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) { const int self = sched_getcpu(); for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &allowed) && c != self) cpus.push_back(c); }
+    const int g0 = gen;                                   // (a worker that reads `gen` itself could start after the first run() bumped it and sleep through that job)
+    for (int i = 0; i < workers; ++i) th.emplace_back([this, g0] { int seen = g0; for (;;) { std::unique_lock<std::mutex> l(m); cvWork.wait(l, [&] { return gen != seen; }); seen = gen; if (stop) return;
+                                                                   l.unlock(); for (int k = next++; k < n; k = next++) (*fn)(k); l.lock(); if (--busy == 0) cvDone.notify_one(); } });
+    if (!cpus.empty()) for (int i = 0; i < workers; ++i) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[i % cpus.size()], &one); pthread_setaffinity_np(th[i].native_handle(), sizeof(one), &one); }
+  }
+  void run(int count, const std::function<void(int)>& f) {
+    { std::unique_lock<std::mutex> l(m); fn = &f; n = count; next = 0; busy = (int)th.size(); ++gen; } cvWork.notify_all();
+    for (int k = next++; k < count; k = next++) f(k);
+    std::unique_lock<std::mutex> l(m); cvDone.wait(l, [&] { return busy == 0; });
+  }
+  ~NodePool() { resize(0); }
+};
+inline NodePool& nodePool() { static NodePool p; return p; }
+inline int& oracleThreads() { static int n = 1; return n; }          // process-wide (one solver at a time uses the pool; the batch driver runs with 1)
+inline void parallelFor(int n, const std::function<void(int)>& fn) {
+  if (oracleThreads() <= 1 || n <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+  nodePool().run(n, fn);
+}
 
 static const double kWeakEps = 1e-6;                       // numeric_traits::weakEpsilon<double>()
 static const double kLimitEps = 2.220446049250313e-16;     // numeric_traits::limitEpsilon<double>()
@@ -48,6 +88,7 @@ struct SqpResult {
   std::vector<Node> grid; std::vector<int> mode; std::vector<Vec> x, u;   // u has grid.size() entries (primal solution)
   std::vector<Vec> dx, du; std::vector<NodeLQ> lq; NodeLQ terminal;
   Performance baseline, after; double alpha = 0; int lsTrials = 0; double armijo = 0; int status = 0;
+  double phaseMs[3] = {0, 0, 0};   // wall time of the last iteration: LQ approximation + projection, Riccati solve, line search (the timers ocs2's benchmark prints)
 };
 
 // RK2 (Heun) flow value: x + dt/2 (k1 + k2)
@@ -115,20 +156,22 @@ inline void projectNode(NodeLQ& n) {
 // performance of a trajectory (computePerformance)
 inline Performance computePerformance(const Problem& P, const std::vector<Node>& g, const Vec& x0, const std::vector<Vec>& x, const std::vector<Vec>& u) {
   const Model& M = *P.M; const int N = (int)g.size() - 1; Performance p;
-  for (int i = 0; i < N; ++i) {
+  std::vector<double> dyn(N, 0.0), cost(N, 0.0), eq(N, 0.0);
+  parallelFor(N, [&](int i) {
     if (g[i].ev == QM_EV_PRE) {
       double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = x[i][k] - x[i + 1][k]; s += d * d; }
-      p.dynSSE += s;
+      dyn[i] = s;
     } else {
       const double ti = intervalStart(g[i]); const double dt = intervalEnd(g[i + 1]) - ti;
       Vec xe = rk2Step(M, x[i], u[i], dt);
       double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = xe[k] - x[i + 1][k]; s += d * d; }
-      p.dynSSE += dt * s;
-      CostQuad c; intermediateCost(P, ti, x[i], u[i], false, c); p.cost += c.f * dt;
+      dyn[i] = dt * s;
+      CostQuad c; intermediateCost(P, ti, x[i], u[i], false, c); cost[i] = c.f * dt;
       Vec e; Mat C, D; equalityConstraints(P, ti, x[i], u[i], false, e, C, D);
-      double se = 0; for (double v : e) se += v * v; p.eqSSE += dt * se;
+      double se = 0; for (double v : e) se += v * v; eq[i] = dt * se;
     }
-  }
+  });
+  for (int i = 0; i < N; ++i) { p.dynSSE += dyn[i]; if (g[i].ev != QM_EV_PRE) { p.cost += cost[i]; p.eqSSE += eq[i]; } }
   { CostQuad c; terminalCost(P, intervalStart(g[N]), x[N], false, c); p.cost += c.f; }
   { double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = x0[k] - x[0][k]; s += d * d; } p.dynSSE += s; }
   p.merit = p.cost;
@@ -167,27 +210,34 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
     }
   }
   // ---- setupQuadraticSubproblem ----
+  const auto tq0 = std::chrono::steady_clock::now();
   R.lq.assign(N, NodeLQ()); Performance base;
-  for (int i = 0; i < N; ++i) {
+  parallelFor(N, [&](int i) {
     NodeLQ& n = R.lq[i];
     if (R.grid[i].ev == QM_EV_PRE) {   // setupEventNode: identity jump map, no pre-jump cost/constraints (QMInterface.cpp:79-142)
       n.event = 1; n.m = 0; n.nc = 0; n.dt = 0;
       n.Ap = Mat::identity(QM_NX); n.A = n.Ap; n.bp.assign(QM_NX, 0.0);
       for (int k = 0; k < QM_NX; ++k) n.bp[k] = x[i][k] - x[i + 1][k];
       n.b = n.bp; n.Qp = Mat(QM_NX, QM_NX); n.Q = n.Qp; n.qp.assign(QM_NX, 0.0); n.q = n.qp; n.cp = n.c = 0;
-      double s = 0; for (double v : n.bp) s += v * v; base.dynSSE += s;
     } else {
       const double ti = intervalStart(R.grid[i]); const double dt = intervalEnd(R.grid[i + 1]) - ti;
       setupIntermediateNode(P, ti, dt, x[i], x[i + 1], u[i], n);
-      double s = 0; for (double v : n.b) s += v * v; base.dynSSE += dt * s;
-      base.cost += n.c;
-      double se = 0; for (double v : n.e) se += v * v; base.eqSSE += dt * se;
       projectNode(n);
+    }
+  });
+  for (int i = 0; i < N; ++i) {          // baseline performance, summed in node order (independent of the thread count)
+    const NodeLQ& n = R.lq[i];
+    if (n.event) { double s = 0; for (double v : n.bp) s += v * v; base.dynSSE += s; }
+    else {
+      double s = 0; for (double v : n.b) s += v * v; base.dynSSE += n.dt * s;
+      base.cost += n.c;
+      double se = 0; for (double v : n.e) se += v * v; base.eqSSE += n.dt * se;
     }
   }
   { CostQuad c; terminalCost(P, intervalStart(R.grid[N]), x[N], true, c); R.terminal.Qp = c.Q; R.terminal.qp = c.q; R.terminal.cp = c.f; base.cost += c.f; }
   { double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = x0[k] - x[0][k]; s += d * d; } base.dynSSE += s; }
   base.merit = base.cost; R.baseline = base;
+  const auto tq1 = std::chrono::steady_clock::now();
   // ---- QP solve: Riccati ----
   Mat S = R.terminal.Qp; Vec s = R.terminal.qp;
   for (int k = N - 1; k >= 0; --k) {
@@ -222,6 +272,7 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
   }
   armijo += vdot(R.terminal.qp, R.dx[N]);
   R.armijo = armijo;
+  const auto tq2 = std::chrono::steady_clock::now();
   // ---- takeStep: filter line-search ----
   const double gMax = st[ST_G_MAX], gMin = st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
   const double theta0 = std::sqrt(base.dynSSE + base.eqSSE);
@@ -245,6 +296,9 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
   for (int i = 0; i < N; ++i) { if (R.grid[i].ev == QM_EV_PRE && i > 0) R.u[i] = R.u[i - 1]; else R.u[i] = u[i]; }
   R.u[N] = R.u[N - 1];
   R.status = 0;
+  const auto tq3 = std::chrono::steady_clock::now();
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  R.phaseMs[0] = ms(tq0, tq1); R.phaseMs[1] = ms(tq1, tq2); R.phaseMs[2] = ms(tq2, tq3);
 }
 
 // a12: MPC_MRT_Interface::evaluatePolicy [upstream]: linear interpolation of the primal solution

@@ -372,6 +372,11 @@ int qmhip_reset_kernel_ms(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; c->bk.re
 int qmhip_synchronize(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
 int qmhip_last_ls_trials(const qmhip_ctx* c) { return c ? c->mpc.ls_trials_run : -1; }
 int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; } return QMHIP_ERR_ARG; }
+int qmhip_debug_get(const qmhip_ctx* c, const char* key, int* value) {
+  if (!c || !key || !value) return QMHIP_ERR_ARG;
+  if (!strcmp(key, "riccati_skip")) { *value = c->mpc.riccati_skip; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { *value = c->wbc.wbc_stop; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { *value = c->mpc.lq_prof; return QMHIP_OK; }
+  return QMHIP_ERR_ARG;
+}
 int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) {
   if (!c || !name || !dst) return QMHIP_ERR_ARG; hipSetDevice(c->device); const QmMpcBuffers& d = c->mpc.d; const void* p = nullptr;
 #define F(n) if (!strcmp(name, #n)) p = d.n;

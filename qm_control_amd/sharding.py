@@ -22,9 +22,32 @@ def shard_config(cfg_all, rank, world):
     return out
 
 
+def init_distributed(backend, local_rank=0):
+    """one process per GPU: join the process group torch.distributed.run described in the environment (backend "nccl" IS RCCL on ROCm;
+    "gloo" in the CPU tests); returns the torch.distributed module"""
+    import torch
+    import torch.distributed as dist
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def barrier(dist=None, device="cpu"):
+    """process-group barrier + device synchronisation (a no-op when not distributed)"""
+    if dist is None or not dist.is_initialized():
+        return
+    dist.barrier()
+    if device == "cuda":
+        import torch
+        torch.cuda.synchronize()
+
+
 def max_over_ranks(value, dist=None, device="cpu"):
     """max of a python float over all ranks (identity when not distributed)"""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(value)
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
@@ -34,7 +57,7 @@ def max_over_ranks(value, dist=None, device="cpu"):
 
 def gather_rows(local, dist=None, device="cpu"):
     """concatenate equally-shaped per-rank f64 arrays [b, k] on every rank in rank order (parity runs: torques)"""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return np.asarray(local)
     import torch
     t = torch.as_tensor(np.ascontiguousarray(local), dtype=torch.float64, device=device)
