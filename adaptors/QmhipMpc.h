@@ -1,0 +1,165 @@
+// adaptors/QmhipMpc.h — the ocs2::MPC_BASE the controller holds (qm_controllers/include/qm_controllers/QMController.h:78), backed by libqmhip.
+//
+// Seam: QMController::setupMpc installs `std::make_shared<SqpMpc>(mpcSettings, sqpSettings, problem, initializer)` into `std::shared_ptr<MPC_BASE> mpc_`
+// (QMController.cpp:286-306) and then only talks to it through MPC_BASE / SolverBase: getSolverPtr()->addSynchronizedModule(gaitReceiver),
+// getSolverPtr()->setReferenceManager(rosReferenceManager), and MPC_MRT_Interface(*mpc_) (QMController.cpp:302-303, 310).  Upstream's SqpMpc is a thin
+// MPC_BASE whose calculateController() forwards to SqpSolver::run(); this file has the same two layers:
+//   QmhipSolver : ocs2::SolverBase   run() (the base class: preSolverRun of the reference manager and of every synchronized module, runImpl, postSolverRun)
+//                                    -> runImpl(): one multiple-shooting SQP iteration (sqp.sqpIteration of them) on the device, warm-started from the previous call
+//   QmhipMpc    : ocs2::MPC_BASE     calculateController(t0, x0, tf) -> solver.run(t0, x0, tf)
+// so GaitReceiver, RosReferenceManager and MPC_MRT_Interface (policy buffer, evaluatePolicy) work unchanged.
+//
+// The primal solution handed back is exactly what [upstream] multiple_shooting::toPrimalSolution builds with useFeedbackPolicy false: time / state / input
+// trajectories on the solver's grid (pre-event inputs copied from the previous node, last input repeated — libqmhip already returns them that way),
+// post-event indices, the mode schedule and a FeedforwardController over (time, input).
+#pragma once
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "qmhip.h"
+#ifdef QMHIP_ADAPTOR_STUBS
+#include "stubs/reference_stubs.h"
+#else
+#include <ocs2_core/control/FeedforwardController.h>
+#include <ocs2_mpc/MPC_BASE.h>
+#include <ocs2_oc/oc_data/PrimalSolution.h>
+#include <ocs2_oc/oc_solver/SolverBase.h>
+#endif
+
+namespace qm {
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// the "primal-solution shim": C arrays of qmhip_mpc_download -> ocs2::PrimalSolution
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+inline void toPrimalSolution(int numNodes, const double* t, const int32_t* event, const double* x, const double* u, const ocs2::ModeSchedule& modeSchedule,
+                             ocs2::PrimalSolution& out) {
+  out.clear();
+  out.timeTrajectory_.reserve(numNodes); out.stateTrajectory_.reserve(numNodes); out.inputTrajectory_.reserve(numNodes);
+  for (int i = 0; i < numNodes; ++i) {
+    out.timeTrajectory_.push_back(t[i]);
+    ocs2::vector_t xi(QM_NX), ui(QM_NU);
+    for (int k = 0; k < QM_NX; ++k) xi(k) = x[(size_t)i * QM_NX + k];
+    for (int k = 0; k < QM_NU; ++k) ui(k) = u[(size_t)i * QM_NU + k];
+    out.stateTrajectory_.push_back(std::move(xi)); out.inputTrajectory_.push_back(std::move(ui));
+    if (event[i] == QM_EV_POST) out.postEventIndices_.push_back((size_t)i);      // index of the first node AFTER the jump, as upstream stores it
+  }
+  out.modeSchedule_ = modeSchedule;
+  out.controllerPtr_.reset(new ocs2::FeedforwardController(out.timeTrajectory_, out.inputTrajectory_));
+}
+
+class QmhipSolver final : public ocs2::SolverBase {
+ public:
+  struct Sizes { int maxNodes, maxRefKnots, maxEvents; };
+
+  QmhipSolver(qmhip_ctx* ctx, Sizes sizes, const ocs2::OptimalControlProblem* problemForGetters = nullptr)
+      : ctx_(ctx), sz_(sizes), problem_(problemForGetters), t_(sizes.maxNodes), x_((size_t)sizes.maxNodes * QM_NX), u_((size_t)sizes.maxNodes * QM_NU),
+        event_(sizes.maxNodes), mode_(sizes.maxNodes) {}
+
+  void reset() override { havePrevious_ = false; primal_.clear(); iterations_ = 0; log_.clear(); }
+  ocs2::scalar_t getFinalTime() const override { return primal_.timeTrajectory_.empty() ? 0.0 : primal_.timeTrajectory_.back(); }
+  void getPrimalSolution(ocs2::scalar_t /*finalTime*/, ocs2::PrimalSolution* out) const override { *out = primal_; }
+  size_t getNumIterations() const override { return iterations_; }
+  const ocs2::PerformanceIndex& getPerformanceIndeces() const override { return performance_; }
+  const std::vector<ocs2::PerformanceIndex>& getIterationsLog() const override { return log_; }
+  const ocs2::OptimalControlProblem& getOptimalControlProblem() const override {
+    if (!problem_) throw std::runtime_error("[QmhipSolver] no OptimalControlProblem was given for the getter (the device solver does not use one)");
+    return *problem_;
+  }
+  // quantities the multiple-shooting SQP solver of upstream does not provide either ([upstream] SqpSolver throws in the same getters)
+  ocs2::ScalarFunctionQuadraticApproximation getValueFunction(ocs2::scalar_t, const ocs2::vector_t&) const override { throw std::runtime_error("[QmhipSolver] getValueFunction() not available"); }
+  ocs2::ScalarFunctionQuadraticApproximation getHamiltonian(ocs2::scalar_t, const ocs2::vector_t&, const ocs2::vector_t&) override { throw std::runtime_error("[QmhipSolver] getHamiltonian() not available"); }
+  ocs2::vector_t getStateInputEqualityConstraintLagrangian(ocs2::scalar_t, const ocs2::vector_t&) const override { throw std::runtime_error("[QmhipSolver] getStateInputEqualityConstraintLagrangian() not available"); }
+
+  int lastStatus() const { return status_; }                          // 0 ok; see include/qmhip.h (qmhip_mpc_step) for the codes
+  const double* lastPerformance() const { return perf_; }             // baseline{merit,cost,dynSSE,eqSSE}, after{...}, alpha, armijo
+
+ private:
+  void runImpl(ocs2::scalar_t initTime, const ocs2::vector_t& initState, ocs2::scalar_t finalTime) override {
+    // SolverBase::run has just executed preSolverRun: the reference manager holds the mode schedule (GaitSchedule::getModeSchedule(t − T, t + 2T) through
+    // SwitchedModelReferenceManager::modifyReferences) and the target trajectories for this call
+    const ocs2::ModeSchedule& ms = this->getReferenceManager().getModeSchedule();
+    const ocs2::TargetTrajectories& tt = this->getReferenceManager().getTargetTrajectories();
+    if (initState.size() != QM_NX) throw std::runtime_error("[QmhipSolver] state dimension must be 30");
+    packSchedule(ms); packTargets(tt, initTime);
+    const double t0 = initTime, horizon = finalTime - initTime;
+    int rc;
+    // upload (it drops a previous solution only when the batch layout changes; the warm start below uses the one kept from the last call)
+    const bool warm = havePrevious_;
+    if (!warm) {
+      rc = qmhip_mpc_upload(ctx_, 1, &t0, initState.data(), sz_.maxRefKnots, refT_.data(), refX_.data(), sz_.maxEvents, ev_.data(), modes_.data());
+      check(rc, "qmhip_mpc_upload");
+      rc = qmhip_mpc_solve_resident(ctx_, 1, horizon);                  // cold start: QMInitializer (mpc.coldStart false only concerns later calls, task.info:142)
+      check(rc, "qmhip_mpc_solve_resident");
+    } else {
+      // schedule / targets may have changed since the last call: refresh them WITHOUT dropping the previous primal solution, then warm start from it
+      rc = qmhip_mpc_update_references(ctx_, 1, sz_.maxRefKnots, refT_.data(), refX_.data(), sz_.maxEvents, ev_.data(), modes_.data());
+      check(rc, "qmhip_mpc_update_references");
+      rc = qmhip_mpc_set_initial(ctx_, 1, &t0, initState.data());      // MPC_MRT_Interface::setCurrentObservation -> MPC_BASE::run(t, x)
+      check(rc, "qmhip_mpc_set_initial");
+      rc = qmhip_mpc_solve_resident_warm(ctx_, 1, horizon);
+      check(rc, "qmhip_mpc_solve_resident_warm");
+    }
+    int32_t n = 0;
+    rc = qmhip_mpc_download(ctx_, 1, &n, t_.data(), event_.data(), mode_.data(), x_.data(), u_.data(), perf_, &status_);
+    check(rc, "qmhip_mpc_download");
+    if (status_ != 0) throw std::runtime_error("[QmhipSolver] MPC iteration failed with status " + std::to_string(status_));   // caught by mpcThread_, QMController.cpp:327-330
+    toPrimalSolution(n, t_.data(), event_.data(), x_.data(), u_.data(), ms, primal_);
+    performance_.merit = perf_[4]; performance_.cost = perf_[5]; performance_.dynamicsViolationSSE = perf_[6]; performance_.equalityConstraintsSSE = perf_[7];
+    log_.assign(1, performance_); iterations_ = 1; havePrevious_ = true;
+  }
+  void runImpl(ocs2::scalar_t initTime, const ocs2::vector_t& initState, ocs2::scalar_t finalTime, const ocs2::ControllerBase* /*externalControllerPtr*/) override {
+    runImpl(initTime, initState, finalTime);                            // like [upstream] SqpSolver: the external controller is not used as an initial guess
+  }
+
+  // mode schedule -> fixed-size arrays: unused event slots are far-future events in STANCE (the layout K0 expects; qm_control_amd/scenarios.py::_pad_schedules)
+  void packSchedule(const ocs2::ModeSchedule& ms) {
+    const int n = (int)ms.eventTimes.size();
+    if (n > sz_.maxEvents) throw std::runtime_error("[QmhipSolver] mode schedule has more events than max_events");
+    if (n == 0) throw std::runtime_error("[QmhipSolver] empty mode schedule");
+    ev_.assign(sz_.maxEvents, 0.0); modes_.assign(sz_.maxEvents + 1, QM_MODE_STANCE);
+    for (int k = 0; k < n; ++k) ev_[k] = ms.eventTimes[k];
+    for (int k = 0; k <= n; ++k) modes_[k] = (int32_t)ms.modeSequence[k];
+    for (int k = n; k < sz_.maxEvents; ++k) ev_[k] = ms.eventTimes[n - 1] + 1.0e3 * (double)(k - n + 1);
+  }
+  // target trajectories (37-dim states: 30 + EE position + quaternion xyzw) -> fixed number of knots; spare knots hold the last one
+  void packTargets(const ocs2::TargetTrajectories& tt, double initTime) {
+    const int n = (int)tt.timeTrajectory.size();
+    if (n < 1 || n > sz_.maxRefKnots) throw std::runtime_error("[QmhipSolver] target trajectories must have 1..max_ref_knots knots");
+    refT_.assign(sz_.maxRefKnots, 0.0); refX_.assign((size_t)sz_.maxRefKnots * QM_NREF, 0.0);
+    for (int k = 0; k < sz_.maxRefKnots; ++k) {
+      const int s = k < n ? k : n - 1;
+      if (tt.stateTrajectory[s].size() != QM_NREF) throw std::runtime_error("[QmhipSolver] target state must have 37 entries (QMController.cpp:106-111)");
+      refT_[k] = k < n ? tt.timeTrajectory[k] : tt.timeTrajectory[n - 1] + 1.0e3 * (double)(k - n + 1);
+      for (int q = 0; q < QM_NREF; ++q) refX_[(size_t)k * QM_NREF + q] = tt.stateTrajectory[s](q);
+    }
+    (void)initTime;
+  }
+  void check(int rc, const char* what) const { if (rc != QMHIP_OK) throw std::runtime_error(std::string("[QmhipSolver] ") + what + ": " + qmhip_last_error(ctx_)); }
+
+  qmhip_ctx* ctx_; Sizes sz_; const ocs2::OptimalControlProblem* problem_;
+  std::vector<double> t_, x_, u_, ev_, refT_, refX_; std::vector<int32_t> event_, mode_, modes_;
+  double perf_[10] = {0}; int32_t status_ = 0; bool havePrevious_ = false;
+  ocs2::PrimalSolution primal_; ocs2::PerformanceIndex performance_; std::vector<ocs2::PerformanceIndex> log_; size_t iterations_ = 0;
+};
+
+class QmhipMpc final : public ocs2::MPC_BASE {
+ public:
+  QmhipMpc(ocs2::mpc::Settings mpcSettings, qmhip_ctx* ctx, QmhipSolver::Sizes sizes, const ocs2::OptimalControlProblem* problemForGetters = nullptr)
+      : MPC_BASE(std::move(mpcSettings)), solver_(ctx, sizes, problemForGetters) {}
+  ~QmhipMpc() override = default;
+  QmhipSolver* getSolverPtr() override { return &solver_; }
+  const QmhipSolver* getSolverPtr() const override { return &solver_; }
+
+ protected:
+  void calculateController(ocs2::scalar_t initTime, const ocs2::vector_t& initState, ocs2::scalar_t finalTime) override {
+    if (settings().coldStart_) solver_.reset();                       // [upstream] SqpMpc::calculateController
+    solver_.run(initTime, initState, finalTime);
+  }
+
+ private:
+  QmhipSolver solver_;
+};
+
+}  // namespace qm

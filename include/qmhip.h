@@ -73,6 +73,11 @@ int qmhip_mpc_download(qmhip_ctx* ctx, int B, int32_t* out_num_nodes, double* ou
  *      closed_loop_resident: n_steps x [advance (not on the first step), warm solve, policy at t0, WBC on the state built from x0]; when the gait
  *      front-end below has been reset for this batch, every step first refreshes the mode schedule (qmhip_gait_update_resident). */
 int qmhip_mpc_set_initial(qmhip_ctx* ctx, int B, const double* t0, const double* x0 /*[B][30]*/);
+/*      update_references: new target trajectories and / or mode schedule for the NEXT call, the previous primal solution kept for its warm start — what
+ *      ReferenceManager::preSolverRun leaves behind before every MPC_BASE::run (RosReferenceManager's target subscriber, GaitReceiver's template insertion,
+ *      QMController.cpp:296-303).  Either pair may be NULL (left as is).  B must be the batch of the last upload. */
+int qmhip_mpc_update_references(qmhip_ctx* ctx, int B, int n_ref, const double* ref_t /*[B][n_ref]*/, const double* ref_x /*[B][n_ref][37]*/,
+                                int n_events, const double* event_times /*[B][n_events]*/, const int32_t* modes /*[B][n_events+1]*/);
 int qmhip_mpc_solve_resident_warm(qmhip_ctx* ctx, int B, double horizon);
 int qmhip_mpc_advance_resident(qmhip_ctx* ctx, int B, double dt);
 int qmhip_closed_loop_resident(qmhip_ctx* ctx, int B, int n_steps, double mpc_dt, double horizon, double period, double time0);

@@ -19,7 +19,7 @@ from . import layout as L
 MB_SIZE, ST_SIZE = L.MB_SIZE, L.ST_SIZE
 
 EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
-           "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_solve_resident_warm",
+           "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_update_references", "qmhip_mpc_solve_resident_warm",
            "qmhip_mpc_advance_resident", "qmhip_closed_loop_resident", "qmhip_mpc_download", "qmhip_policy_eval",
            "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
            "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_debug_get", "qmhip_microbench_fp64",
@@ -185,6 +185,16 @@ class SqpMpc:
         """new observation (MPC_MRT_Interface::setCurrentObservation); references, schedule and the previous solution stay resident"""
         t0 = _f(t0, (self.B,)); x0 = _f(x0, (self.B, 30))
         self.itf._check(self.lib.qmhip_mpc_set_initial(self.itf.h, self.B, _p(t0), _p(x0)), "qmhip_mpc_set_initial")
+
+    def update_references(self, ref_t=None, ref_x=None, event_times=None, modes=None):
+        """new targets and / or mode schedule for the next call; the previous primal solution stays (warm start) — ReferenceManager::preSolverRun"""
+        B = self.B
+        rt = rx = ev = mo = None; n_ref = self.itf.max_ref_knots; n_ev = self.itf.max_events
+        if ref_t is not None:
+            rt = _f(ref_t, (B, n_ref)); rx = _f(ref_x, (B, n_ref, 37))
+        if event_times is not None:
+            ev = _f(event_times, (B, n_ev)); mo = np.ascontiguousarray(modes, dtype=np.int32); assert mo.shape == (B, n_ev + 1)
+        self.itf._check(self.lib.qmhip_mpc_update_references(self.itf.h, B, n_ref, _p(rt), _p(rx), n_ev, _p(ev), _pi(mo)), "qmhip_mpc_update_references")
 
     def advance(self, dt):
         """perfect-tracking plant on the device: t0 += dt, x0 <- policy state at the new t0"""

@@ -178,6 +178,15 @@ int qmhip_mpc_set_initial(qmhip_ctx* c, int B, const double* t0, const double* x
   if (!c || B <= 0 || B > c->max_batch || !t0 || !x0) { if (c) c->fail("qmhip_mpc_set_initial: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->bk.to_device(c->mpc.d.t0, t0, (size_t)B * 8); c->bk.to_device(c->mpc.d.x0, x0, (size_t)B * 30 * 8); return c->hipstate();
 }
+int qmhip_mpc_update_references(qmhip_ctx* c, int B, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) {
+  if (!c) return QMHIP_ERR_ARG;
+  if (B <= 0 || B != c->lastB || (!ref_t != !ref_x) || (!ev != !modes) || (ref_t && n_ref != c->max_ref) || (ev && n_ev != c->max_ev)) {
+    c->fail("qmhip_mpc_update_references: bad argument (B == batch of the last upload, n_ref == max_ref_knots, n_events == max_events required; arrays come in pairs)"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device);
+  if (ref_t) { c->bk.to_device(c->mpc.d.ref_t, ref_t, (size_t)B * n_ref * 8); c->bk.to_device(c->mpc.d.ref_x, ref_x, (size_t)B * n_ref * QM_NREF * 8); }
+  if (ev) { c->bk.to_device(c->mpc.d.ev, ev, (size_t)B * n_ev * 8); c->bk.to_device(c->mpc.d.modes, modes, (size_t)B * (n_ev + 1) * 4); }
+  return c->hipstate();
+}
 int qmhip_mpc_solve_resident_warm(qmhip_ctx* c, int B, double horizon) {
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident_warm: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->mpc.grid(B, horizon, true); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true; return c->hipstate();

@@ -119,6 +119,36 @@ def test_receding_horizon_closed_loop(blobs, oracle):
     itf.close()
 
 
+def test_update_references_keeps_the_warm_start(blobs, oracle):
+    """what the MPC_BASE adaptor does on every call after the first (adaptors/QmhipMpc.h): new targets / schedule from preSolverRun, new observation,
+    warm-started iteration from the PREVIOUS primal solution — qmhip_mpc_update_references must not drop it (qmhip_mpc_upload would)"""
+    from qm_control_amd import api, scenarios
+    B = 3
+    cfg = scenarios.make_config("C3", batch=B, n_intervals=30)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=64, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"]); mpc.solve_resident(cfg["horizon"])
+    first = mpc.download()
+    ref_x2 = cfg["ref_x"].copy(); ref_x2[:, 1, 6] += 0.2; ref_x2[:, 1, 30] += 0.05                 # the operator moved the base and the EE goal
+    t1 = cfg["t0"] + 0.03; x1, _, _ = mpc.evaluatePolicy(t1)
+    mpc.update_references(ref_t=cfg["ref_t"], ref_x=ref_x2)                                        # schedule left as is
+    mpc.set_initial(t1, x1); mpc.solve_resident(cfg["horizon"], warm=True)
+    got = mpc.download()
+    for b in range(B):
+        oracle.set_schedule(cfg["ev"][b], cfg["modes"][b]); oracle.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+        r0 = oracle.mpc_step(cfg["t0"][b], cfg["t0"][b] + cfg["horizon"], cfg["x0"][b]); n0 = len(r0["t"])
+        assert_blocks(first["x"][b, :n0], r0["x"], "x", TOL, b)
+        xo, _, _ = oracle.eval_policy(t1[b])
+        oracle.set_target(cfg["ref_t"][b], ref_x2[b])
+        r = oracle.mpc_step(t1[b], t1[b] + cfg["horizon"], xo, warm=True); n = len(r["t"])
+        assert got["status"][b] == 0 and got["num_nodes"][b] == n and np.array_equal(got["mode"][b, :n], r["mode"])
+        assert_blocks(got["x"][b, :n], r["x"], "x", TOL, b); assert_blocks(got["u"][b, :n], r["u"], "u", TOL, b)
+        # a cold start from the same observation is a different iterate: the warm start really was used
+        rc = oracle.mpc_step(t1[b], t1[b] + cfg["horizon"], xo)
+        assert np.abs(rc["u"] - r["u"]).max() > 1e-3
+    itf.close()
+
+
 def test_multiple_sqp_iterations(blobs, oracle):
     """sqp.sqpIteration = 3 through qmhip_set_setting: three SQP iterations per MPC call, against the oracle iterating on its own iterate"""
     from qm_control_amd import api, scenarios
