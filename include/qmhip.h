@@ -159,6 +159,11 @@ int qmhip_wbc_download(qmhip_ctx* ctx, int B, double* out /*[B][54]*/, int32_t* 
  *        command delay [s], saturate efforts (0/1)}; Gazebo's ODE contact solver is not part of the reference's sources, the contact model is this library's own.
  *      sim_get_state: q, v, time, contact forces [B][12] (world frame) of the last sub-step, status [B] (0 ok, 1 mass matrix not positive definite); any may be null. */
 int qmhip_sim_set_params(qmhip_ctx* ctx, const double* params, int n);
+/*      sim_set_controller: which controller plugin the closed loops below run — 0 qm::QMController (HierarchicalWbc; updateControlLaw QMController.cpp:177-190),
+ *        1 qm::QMMpcController (HierarchicalMpcWbc, QMController.cpp:410-414; updateControlLaw QMController.cpp:431-445: legs commanded on every tick, the arm as
+ *        position commands q_meas + velDes / 100 re-published when more than 1/100 s have passed — arm_kp / arm_kd of the loop calls are then the gains of the arm's
+ *        position controllers and no arm torque is fed forward).  Takes effect at the next qmhip_sim_reset. */
+int qmhip_sim_set_controller(qmhip_ctx* ctx, int controller);
 int qmhip_sim_reset(qmhip_ctx* ctx, int B, const double* q /*[B][24]*/, const double* v /*[B][24]*/, const double* time /*[B]*/);
 int qmhip_sim_set_command(qmhip_ctx* ctx, int B, const double* pos_des /*[B][18]*/, const double* vel_des, const double* kp, const double* kd, const double* ff);
 int qmhip_sim_step(qmhip_ctx* ctx, int B, double period, int n_substeps, double* rbd /*[B][55]*/, int32_t* contact /*[B][4]*/);

@@ -25,7 +25,7 @@ EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_la
            "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_debug_get", "qmhip_microbench_fp64",
            "qmhip_gait_set_templates", "qmhip_gait_reset", "qmhip_gait_insert_template", "qmhip_gait_update_resident", "qmhip_gait_download", "qmhip_schedule_download",
            "qmhip_target_reset", "qmhip_target_from_command", "qmhip_target_download",
-           "qmhip_sim_set_params", "qmhip_sim_reset", "qmhip_sim_set_command", "qmhip_sim_step", "qmhip_sim_get_state", "qmhip_closed_loop_sim", "qmhip_closed_loop_sim_pipelined"]
+           "qmhip_sim_set_params", "qmhip_sim_set_controller", "qmhip_sim_reset", "qmhip_sim_set_command", "qmhip_sim_step", "qmhip_sim_get_state", "qmhip_closed_loop_sim", "qmhip_closed_loop_sim_pipelined"]
 
 
 class QmhipError(RuntimeError):
@@ -286,6 +286,10 @@ class QMHWSim:
         B = self.B; rbd = np.zeros((B, 55)) if download else None; contact = np.zeros((B, 4), np.int32) if download else None
         self.itf._check(self.lib.qmhip_sim_step(self.itf.h, B, C.c_double(period), int(n_substeps), _p(rbd), _pi(contact)), "qmhip_sim_step")
         return rbd, contact
+
+    def set_controller(self, kind):
+        """0: qm::QMController, 1: qm::QMMpcController (HierarchicalMpcWbc + arm position commands at 100 Hz); call before reset()"""
+        self.itf._check(self.lib.qmhip_sim_set_controller(self.itf.h, int(kind)), "qmhip_sim_set_controller")
 
     def closed_loop(self, n_ticks, period, horizon, n_substeps=2, mpc_every=10, arm_kp=0.0, arm_kd=0.5, pipelined=False):
         """n_ticks of [state estimate -> MPC every mpc_every ticks -> policy -> WBC -> updateControlLaw -> simulation step] on the device (QMController::update);

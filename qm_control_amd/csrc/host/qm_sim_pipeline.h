@@ -9,6 +9,7 @@ struct QmSimBuffers {
   int Bmax = 0;
   double* q = nullptr; double* v = nullptr; double* time = nullptr; double* cmd = nullptr; double* ring = nullptr; int* ring_n = nullptr;
   double* rbd = nullptr; int* contact = nullptr; double* force = nullptr; int* status = nullptr;
+  double* arm_hold = nullptr; double* arm_last = nullptr;     // QMMpcController: held arm position commands and last_time_ per joint ([B][6])
   // published policy (pipelined loop): what evaluatePolicy reads while the MPC writes its next solution — OCS2 guards this buffer with a mutex, here it is a copy
   int p_nmax = 0, p_nev = 0; double* p_xs = nullptr; double* p_us = nullptr; double* p_node_t = nullptr; int* p_node_ev = nullptr; int* p_n_nodes = nullptr; double* p_ev = nullptr; int* p_modes = nullptr;
   bool p_valid = false;
@@ -17,6 +18,7 @@ struct QmSimBuffers {
 template <class BK>
 struct QmSimPipeline {
   BK& bk; QmSimBuffers s; QmSimParams p;
+  int controller = 0;       // 0: QMController (HierarchicalWbc, arm torque + PD), 1: QMMpcController (HierarchicalMpcWbc, arm position commands at 100 Hz)
   explicit QmSimPipeline(BK& b) : bk(b) { p.k_n = 4.0e4; p.d_n = 200.0; p.mu = 0.8; p.v_eps = 1.0e-2; p.foot_radius = 0.02; p.delay = 0.009; p.saturate = 1; }
   template <class T> T* A(size_t n) { T* ptr = (T*)bk.alloc(n * sizeof(T)); bk.zero(ptr, n * sizeof(T)); return ptr; }
   void allocate(int Bmax) {
@@ -24,13 +26,15 @@ struct QmSimPipeline {
     s.Bmax = Bmax; s.q = A<double>((size_t)Bmax * 24); s.v = A<double>((size_t)Bmax * 24); s.time = A<double>(Bmax); s.cmd = A<double>((size_t)Bmax * (QM_SIM_CMD - 1));
     s.ring = A<double>((size_t)Bmax * QM_SIM_SLOTS * QM_SIM_CMD); s.ring_n = A<int>((size_t)Bmax * 2); s.rbd = A<double>((size_t)Bmax * QM_NRBD); s.contact = A<int>((size_t)Bmax * 4);
     s.force = A<double>((size_t)Bmax * 12); s.status = A<int>(Bmax);
+    s.arm_hold = A<double>((size_t)Bmax * 6); s.arm_last = A<double>((size_t)Bmax * 6);
   }
-  void release() { void* ps[] = {s.q, s.v, s.time, s.cmd, s.ring, s.ring_n, s.rbd, s.contact, s.force, s.status, s.p_xs, s.p_us, s.p_node_t, s.p_node_ev, s.p_n_nodes, s.p_ev, s.p_modes}; for (void* ptr : ps) if (ptr) bk.free(ptr); s = QmSimBuffers(); }
+  void release() { void* ps[] = {s.q, s.v, s.time, s.cmd, s.ring, s.ring_n, s.rbd, s.contact, s.force, s.status, s.arm_hold, s.arm_last, s.p_xs, s.p_us, s.p_node_t, s.p_node_ev, s.p_n_nodes, s.p_ev, s.p_modes}; for (void* ptr : ps) if (ptr) bk.free(ptr); s = QmSimBuffers(); }
   // "Simulation reset" of QMHWSim::writeSim: state set, delay buffer and held command cleared
   void reset(int B, const double* q_host, const double* v_host, const double* time_host) {
     s.p_valid = false;
     bk.to_device(s.q, q_host, (size_t)B * 24 * 8); bk.to_device(s.v, v_host, (size_t)B * 24 * 8); bk.to_device(s.time, time_host, (size_t)B * 8);
     bk.zero(s.ring_n, (size_t)s.Bmax * 2 * sizeof(int)); bk.zero(s.cmd, (size_t)s.Bmax * (QM_SIM_CMD - 1) * 8);
+    QmArmResetArgs r; r.B = B; r.q = s.q; r.time = s.time; r.arm_hold = s.arm_hold; r.arm_last = s.arm_last; bk.launch(qm_arm_reset_kernel, (B * 6 + 63) / 64, 64, 0, r);
   }
   void set_command(int B, const double* cmd_host) { bk.to_device(s.cmd, cmd_host, (size_t)B * (QM_SIM_CMD - 1) * 8); }
   // copy of the solver's primal solution + grid + mode schedule into the published-policy buffers
@@ -47,6 +51,7 @@ struct QmSimPipeline {
   // hybrid joint command from the evaluated policy and the WBC torques
   void command(int B, const double* x_des, const double* u_des, const double* wbc_out, double arm_kp, double arm_kd) {
     QmCommandArgs c; c.B = B; c.x_des = x_des; c.u_des = u_des; c.wbc_out = wbc_out; c.time = s.time; c.arm_kp = arm_kp; c.arm_kd = arm_kd; c.cmd = s.cmd;
+    c.controller = controller; c.rbd = s.rbd; c.arm_hold = s.arm_hold; c.arm_last = s.arm_last;
     bk.launch(qm_command_kernel, (B * QM_NJ + 63) / 64, 64, 0, c);
   }
   // rbd state / contact flags of the current plant state without advancing it (nsub = 0 is not a step: the delay buffer is left alone)
@@ -74,7 +79,7 @@ void qm_closed_loop_sim_ticks(BK& bk, QmMpcPipeline<BK>& mpc, QmWbcPipeline<BK>&
     // first tick after a reset: inputLast_ primed with the planned input (the reference's WBC has been running since time 0 when the legs are switched on at
     // time 10): zero joint acceleration
     if (sim_ticks == 0) bk.copy_dd(wbc.w.input_last, wbc.w.u_des, (size_t)B * 30 * 8);
-    wbc.step(mpc.d, B, period, 0, sim.s.rbd, sim.s.time);
+    wbc.step(mpc.d, B, period, sim.controller == 1 ? 1 : 0, sim.s.rbd, sim.s.time);      // QMMpcController::setupWbc installs HierarchicalMpcWbc (QMController.cpp:410-414)
     sim.command(B, wbc.w.x_des, wbc.w.u_des, wbc.w.out, arm_kp, arm_kd);
     sim.step(mpc.d.mb, B, period, n_substeps);
     ++sim_ticks;
@@ -96,7 +101,7 @@ void qm_closed_loop_sim_pipelined(BK& bk, QmMpcPipeline<BK>& mpc, QmWbcPipeline<
       QmPolicyArgs pa = wbc.pargs(mpc.d, B, sim.s.time); pa.n_nodes = sim.s.p_n_nodes; pa.node_t = sim.s.p_node_t; pa.node_ev = sim.s.p_node_ev; pa.xs = sim.s.p_xs; pa.us = sim.s.p_us; pa.ev = sim.s.p_ev; pa.modes = sim.s.p_modes;
       bk.launch(qm_policy_kernel, (B + 63) / 64, 64, 0, pa);
       if (sim_ticks == 0) bk.copy_dd(wbc.w.input_last, wbc.w.u_des, (size_t)B * 30 * 8);
-      wbc.step(mpc.d, B, period, 0, sim.s.rbd, sim.s.time);
+      wbc.step(mpc.d, B, period, sim.controller == 1 ? 1 : 0, sim.s.rbd, sim.s.time);
       sim.command(B, wbc.w.x_des, wbc.w.u_des, wbc.w.out, arm_kp, arm_kd);
       sim.step(mpc.d.mb, B, period, n_substeps);
       ++sim_ticks;

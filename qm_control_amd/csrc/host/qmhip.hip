@@ -319,6 +319,10 @@ int qmhip_sim_set_params(qmhip_ctx* c, const double* p, int n) {
   if (!(q.k_n >= 0) || !(q.d_n >= 0) || !(q.mu >= 0) || !(q.v_eps > 0) || !(q.delay >= 0)) { c->fail("qmhip_sim_set_params: negative parameter"); return QMHIP_ERR_ARG; }
   return QMHIP_OK;
 }
+int qmhip_sim_set_controller(qmhip_ctx* c, int controller) {
+  if (!c || (controller != 0 && controller != 1)) { if (c) c->fail("qmhip_sim_set_controller: 0 (QMController) or 1 (QMMpcController)"); return QMHIP_ERR_ARG; }
+  c->sim.controller = controller; return QMHIP_OK;
+}
 int qmhip_sim_reset(qmhip_ctx* c, int B, const double* q, const double* v, const double* time) {
   if (!c || B <= 0 || B > c->max_batch || !q || !v || !time) { if (c) c->fail("qmhip_sim_reset: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->sim.allocate(c->max_batch); c->sim.reset(B, q, v, time); c->sim_ticks = 0;

@@ -52,6 +52,7 @@ struct QmRiccatiArgs {
 #define RF_W   3000               /* [18][31] W  */
 #define RF_L   3558               /* [18][19] L (diagonal holds 1/L_jj) */
 #define RF_V   3900               /* bp(30) qp(30) rp(18) Pe(30) | y(18) | pad(2) swing blocks [4][6] (128..151) mode (152) dt (153) */
+#define RF_DUMP (RF_V + 156)      /* write-only slot for the lanes past the end of the fetch list */
 /* backward prefetch buffer (global_load_lds): a flat copy of record fields [0, 3204) = Ap Bp Qp Pp Rp and [4644, 4722) = bp qp rp of the
    NEXT regular stage, landing while the current stage computes; lives behind the 1200-double Cholesky / transposition buffer */
 #define RP_REC   1200
@@ -356,10 +357,15 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   if (l < 19) buf[RF_PU + l] = 0.0;
   int pu_mode = -1, pu_col = 0, pu_kind = 0, pu_off = 128;     // (Pu ut) source of this lane's du row, cached per contact mode
   double pf[RF_NLOAD];
+  // the lane's 31 (record offset, LDS slot) pairs do not depend on the stage: computed once (the select chains of rf_src / rf_dst cost ≈ 40 integer
+  // instructions per element — more than the rest of a stage's forward arithmetic when evaluated per stage)
+  int fsrc[RF_NLOAD], fdst[RF_NLOAD];
+#pragma unroll
+  for (int t = 0; t < RF_NLOAD; ++t) { const int e = t * 64 + l; const bool in = e < RF_TOTAL; fsrc[t] = in ? rf_src(e) : 0; fdst[t] = in ? rf_dst(e) : RF_DUMP; }
   auto fetch = [&](int k) {
     const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
 #pragma unroll
-    for (int t = 0; t < RF_NLOAD; ++t) { const int e = t * 64 + l; pf[t] = (e < RF_TOTAL) ? rec[rf_src(e)] : 0.0; }
+    for (int t = 0; t < RF_NLOAD; ++t) pf[t] = rec[fsrc[t]];
   };
   { int k0 = 0; while (k0 < n - 1 && evlist(k0) == QM_EV_PRE) ++k0; if (k0 < n - 1 && !(a.skip & 4)) fetch(k0); }
   long long tfw[6] = {0, 0, 0, 0, 0, 0}; long long tfl = (long long)__builtin_readcyclecounter();
@@ -376,7 +382,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     qm_wave_sync();
     RFT(0)
 #pragma unroll
-    for (int t = 0; t < RF_NLOAD; ++t) { const int e = t * 64 + l; if (e < RF_TOTAL) buf[rf_dst(e)] = pf[t]; }
+    for (int t = 0; t < RF_NLOAD; ++t) buf[fdst[t]] = pf[t];          // lanes past the end of the list write a dump slot
     qm_wave_sync();
     RFT(1)
     { int kn = k + 1; while (kn < n - 1 && evlist(kn) == QM_EV_PRE) ++kn; if (kn < n - 1) fetch(kn); }

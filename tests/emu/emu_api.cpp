@@ -67,6 +67,7 @@ void emu_sim_params(void* h, const double* p) { QmSimParams& q = ((EmuCtx*)h)->s
 void emu_sim_reset(void* h, int B, const double* q, const double* v, const double* time) { EmuCtx* c = (EmuCtx*)h; c->sim.allocate(c->mpc.d.Bmax); c->sim.reset(B, q, v, time); }
 void emu_sim_command(void* h, int B, const double* cmd90) { ((EmuCtx*)h)->sim.set_command(B, cmd90); }
 static long g_emu_sim_ticks = 0;
+void emu_sim_set_controller(void* h, int kind) { ((EmuCtx*)h)->sim.controller = kind; }
 void emu_closed_loop_sim(void* h, int B, int n_ticks, double period, int nsub, int mpc_every, double horizon, double arm_kp, double arm_kd, int restart) {
   EmuCtx* c = (EmuCtx*)h; if (restart) { g_emu_sim_ticks = 0; c->sim.step(c->mpc.d.mb, B, 0.0, 0); }
   qm_closed_loop_sim_ticks(c->bk, c->mpc, c->wbc, c->sim, g_emu_sim_ticks, B, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, 1, []() {});

@@ -173,6 +173,9 @@ class Emu:
         B = self.simB; cmd = np.concatenate([np.ascontiguousarray(np.broadcast_to(x, (B, 18)), float) for x in (pos, vel, kp, kd, ff)], axis=1)
         cmd = np.ascontiguousarray(cmd); self.lib.emu_sim_command(self.h, C.c_int(B), _p(cmd))
 
+    def sim_set_controller(self, kind):
+        self.lib.emu_sim_set_controller(self.h, C.c_int(kind))
+
     def closed_loop_sim(self, n_ticks, period, horizon, nsub=2, mpc_every=10, arm_kp=0.0, arm_kd=0.5, restart=False, pipelined=False):
         (self.lib.emu_closed_loop_sim_pipelined if pipelined else self.lib.emu_closed_loop_sim)(self.h, C.c_int(self.simB), C.c_int(n_ticks), C.c_double(period), C.c_int(nsub), C.c_int(mpc_every), C.c_double(horizon), C.c_double(arm_kp), C.c_double(arm_kd), C.c_int(int(restart)))
 

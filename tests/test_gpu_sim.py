@@ -90,6 +90,34 @@ def test_closed_loop_around_the_plant_vs_oracle(blobs, oracle, gait):
     itf.close()
 
 
+def test_mpc_controller_loop_vs_oracle(blobs, oracle):
+    """qmhip_sim_set_controller(1): the QMMpcController loop (HierarchicalMpcWbc, legs commanded on every tick, arm position commands at 100 Hz) against
+    the oracle-built loop; 30 ticks at time < 10"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    from qm_control_amd import api
+    mb, st = blobs
+    B = 2; horizon = 0.6; t_start = 5.3; c = setup("trot", B, horizon, t_start=t_start)
+    q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    sim.set_controller(1)
+    mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset()
+    sim.reset(np.tile(q0, (B, 1)), np.zeros((B, 24)), t_start)
+    n_ticks = 30; dev = []; arm_kp, arm_kd = 60.0, 2.0
+    for k in range(n_ticks):
+        sim.closed_loop(1, 0.001, horizon, n_substeps=2, mpc_every=10, arm_kp=arm_kp, arm_kd=arm_kd); s = sim.state(); out, st3 = wbc.download(B); s["tau"] = out[:, 36:]; s["wbc_status"] = st3; s["mpc_status"] = mpc.download()["status"]; dev.append(s)
+    log = oracle_closed_loop(oracle, mb, c, q0, n_ticks, 0.001, 2, 10, horizon, arm_kp, arm_kd, t_start, controller=1)
+    for k in range(n_ticks):
+        assert (dev[k]["mpc_status"] == 0).all() and (dev[k]["wbc_status"] == 0).all() and log[k]["wbc_status"] == [0, 0, 0], k
+        for b in range(B):
+            assert rel_err(dev[k]["tau"][b], log[k]["tau"]) < 1e-5 and rel_err(dev[k]["q"][b], log[k]["q"]) < 1e-7 and rel_err(dev[k]["v"][b], log[k]["v"]) < 1e-5, (k, b)
+    assert dev[-1]["q"][0][2] > 0.36
+    itf.close()
+
+
 def test_plant_and_closed_loop_match_the_goldens(blobs):
     """qmhip_sim_* and qmhip_closed_loop_sim against the committed fixtures (tests/golden/sim_*.npz, tools/gen_golden_sim.py)"""
     import os, sys

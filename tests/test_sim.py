@@ -108,23 +108,31 @@ def centroidal_from_rbd(mb, rbd):
     return x
 
 
-def oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0, pipelined=False):
+def oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0, pipelined=False, controller=0):
     """QMController::update around the oracle's plant, same order of operations as qmhip_closed_loop_sim; pipelined: as qmhip_closed_loop_sim_pipelined — the MPC
     triggered at a tick observes the plant there, its solution is used from the next MPC period on (the first one is synchronous)"""
     oracle.set_schedule(cfg["ev"][0], cfg["modes"][0]); oracle.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
     oracle.wbc_reset(); oracle.sim_params(); oracle.sim_reset(q0, np.zeros(24), time0); oracle.sim_command(0, 0, 0, 0, 0)
     st = dict(rbd=oracle.rbd_from_q(q0, np.zeros(24)), time=time0, k=0); log = []
     pos = np.zeros(18); vel = np.zeros(18); kp = np.zeros(18); kd = np.zeros(18); ff = np.zeros(18)
+    arm_hold = np.array(q0[18:24], float); arm_last = np.full(6, float(time0))      # QMMpcController: held position commands, last_time_ (QMController.cpp:127)
 
     def tick():
         time, rbd = st["time"], st["rbd"]
         xd, ud, mode = oracle.eval_policy(time)
         if st["k"] == 0:
             oracle.wbc_set_input_last(ud)          # inputLast_ primed with the planned input at the first tick (qmhip_closed_loop_sim)
-        out, wst = oracle.wbc(xd, ud, rbd, mode, period, time)
-        if time > 10.0:
+        out, wst = oracle.wbc(xd, ud, rbd, mode, period, time, mpc_variant=(controller == 1))
+        if controller == 1:                        # QMMpcController::updateControlLaw (QMController.cpp:431-445)
             pos[:12] = xd[12:24]; vel[:12] = ud[12:24]; kp[:12] = 0.0; kd[:12] = 3.0; ff[:12] = out[36:48]
-        pos[12:] = xd[24:30]; vel[12:] = 0.0; kp[12:] = arm_kp; kd[12:] = arm_kd; ff[12:] = out[48:54]
+            for j in range(6):
+                if time - arm_last[j] > 1.0 / 100.0:
+                    arm_hold[j] = rbd[18 + j] + ud[24 + j] * 1.0 / 100.0; arm_last[j] = time
+            pos[12:] = arm_hold; vel[12:] = 0.0; kp[12:] = arm_kp; kd[12:] = arm_kd; ff[12:] = 0.0
+        else:
+            if time > 10.0:
+                pos[:12] = xd[12:24]; vel[:12] = ud[12:24]; kp[:12] = 0.0; kd[:12] = 3.0; ff[:12] = out[36:48]
+            pos[12:] = xd[24:30]; vel[12:] = 0.0; kp[12:] = arm_kp; kd[12:] = arm_kd; ff[12:] = out[48:54]
         oracle.sim_command(pos, vel, kp, kd, ff)
         r = oracle.sim_step(period, nsub); st["rbd"] = r["rbd"]; st["time"] = r["time"]; st["k"] += 1
         log.append(dict(q=r["q"].copy(), v=r["v"].copy(), tau=out[36:].copy(), wbc_status=list(wst), mode=mode))
@@ -167,6 +175,33 @@ def test_emulated_closed_loop_around_the_plant_vs_oracle(blobs, oracle):
     for k in range(n_ticks):
         assert dev[k]["mpc_status"][0] == 0 and list(dev[k]["wbc_status"][0]) == [0, 0, 0], k
         assert rel_err(dev[k]["tau"][0], log[k]["tau"]) < 1e-6 and rel_err(dev[k]["q"][0], log[k]["q"]) < 1e-9 and rel_err(dev[k]["v"][0], log[k]["v"]) < 1e-7, k
+
+
+def test_emulated_mpc_controller_loop_vs_oracle(blobs, oracle):
+    """the QMMpcController variant of the loop (HierarchicalMpcWbc; legs commanded on every tick, the arm as position commands re-published at 100 Hz:
+    QMController.cpp:410-414, 431-445) on the host emulator against the same loop built from the oracle's pieces; time < 10, so the QMController law
+    would NOT command the legs here — 24 ticks cover two arm publications"""
+    import os, sys, emu_harness
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sim_closed_loop_demo import setup
+    mb, st = blobs
+    horizon = 0.45; t_start = 5.2; c = setup("trot", 1, horizon, t_start=t_start)
+    q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
+    e = emu_harness.Emu(mb, st, 1, 64, 2, c["ev"].shape[1])
+    c["horizon"] = horizon; c["B"] = 1; e.grid_only(c, batch=1)
+    e.sim_set_controller(1)
+    e.lib.emu_wbc_reset(e.h); e.sim_params(); e.sim_reset(q0[None], np.zeros((1, 24)), t_start); e.sim_command(0, 0, 0, 0, 0)
+    n_ticks = 24; dev = []; arm_kp, arm_kd = 60.0, 2.0
+    for k in range(n_ticks):
+        e.closed_loop_sim(1, 0.001, horizon, nsub=2, mpc_every=8, arm_kp=arm_kp, arm_kd=arm_kd, restart=(k == 0)); dev.append(e.sim_state())
+    log = oracle_closed_loop(oracle, mb, c, q0, n_ticks, 0.001, 2, 8, horizon, arm_kp, arm_kd, t_start, controller=1)
+    for k in range(n_ticks):
+        assert dev[k]["mpc_status"][0] == 0 and list(dev[k]["wbc_status"][0]) == [0, 0, 0], k
+        assert rel_err(dev[k]["tau"][0], log[k]["tau"]) < 1e-6 and rel_err(dev[k]["q"][0], log[k]["q"]) < 1e-9 and rel_err(dev[k]["v"][0], log[k]["v"]) < 1e-7, k
+    # the legs really were driven (time < 10): the plant did not simply collapse as it would under the QMController law before the legs are switched on
+    assert dev[-1]["q"][0][2] > 0.36
+    e.sim_set_controller(0)
 
 
 def test_oracle_reproduces_the_plant_goldens(blobs, oracle):

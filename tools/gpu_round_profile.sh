@@ -19,3 +19,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write -- $B --steps 
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 --kernel-trace -d gpurun_out/pmc_flops_a -- $B --steps 3 --warmup 1 > gpurun_out/pmc_flops_a.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_MFMA SQ_WAVES --kernel-trace -d gpurun_out/pmc_flops_b -- $B --steps 3 --warmup 1 > gpurun_out/pmc_flops_b.log 2>&1
 ls -R gpurun_out | head -60
+rm -rf gpurun_out/pmc_sq
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d gpurun_out/pmc_sq -- $B --steps 3 --warmup 1 > gpurun_out/pmc_sq.log 2>&1
+tail -3 gpurun_out/pmc_sq.log
