@@ -122,7 +122,7 @@ struct QmMpcPipeline {
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof; q.ncap = ncap;
-    bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, 0, q);
+    bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, LQ_KIN_LDS_BYTES, q);
     bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node; an empty workgroup costs the dispatcher as much as a full one
     QmLsArgs l = ls_args(B);
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
@@ -131,7 +131,7 @@ struct QmMpcPipeline {
     ls_trials_run = 0;
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;
-      bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, 0, l);
+      bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching
       ++ls_trials_run;
       bk.wait_launched();                                  // the last block of the launch has published the count in host-visible memory

@@ -34,7 +34,7 @@ struct HipBackend {
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
     if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel) return "riccati";
-    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy";
+    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy";
     return "ls_misc";
   }
   template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {

@@ -93,6 +93,7 @@ struct QmLqArgs {
 #define LW_PD    (LW_K2 + KW_SIZE)      /* Pu column descriptors: first source row i0 as double [32], weights [32][3] */
 #define LW_LDS_DOUBLES (LW_PD + 128)
 #define LQ_LDS_BYTES (LW_LDS_DOUBLES * 8)
+#define LQ_KIN_LDS_BYTES (2 * 64 * 31 * 8)  /* K1a: two 31-double rows per thread (the input u, a flow-map value) */
 
 // value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column
 __device__ __forceinline__ void lw_set_col30(qm_d4 (&F)[2][2], const double* v) {
@@ -229,7 +230,10 @@ __global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
   const int nb = i * a.B + b; const bool terminal = (i == nn - 1);
   if (!terminal && a.node_ev[nb] == QM_EV_PRE) return;
   double* rec = a.kin + (size_t)nb * KR_SIZE; const double* mb = qm_table(a.mb);
-  double x[30], u[30], K[KW_SIZE];
+  // x and the kinematics workspace K live in registers; the input u — read-only here — sits in a per-thread LDS row (31-double pitch: conflict free):
+  // x + u + K + two flow values do not fit 512 registers, and what does not fit would otherwise be spilled to scratch memory
+  extern __shared__ double qm_smem[];                  // LQ_KIN_LDS_BYTES
+  double x[30], K[KW_SIZE]; double* u = qm_smem + (threadIdx.x & 63) * 31;
   _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q];
   const double* ee = a.eeref + nb * 7;
   if (terminal) {
@@ -244,9 +248,9 @@ __global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
   kin_base(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x, u, K); kin_arm(mb, x, K);
   _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
   { double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq); _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q]; }
-  double f1[30], x2[30], f2[30];
+  double x2[30]; double* f1 = qm_smem + 64 * 31 + (threadIdx.x & 63) * 31; double* f2 = f1;      // the flow values pass through the thread's second LDS row
   flow_from_kin(mb, x, u, K, f1);
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) { x2[q] = x[q] + dt * f1[q]; rec[KR_F1 + q] = f1[q]; rec[KR_X2 + q] = x2[q]; }
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double fq = f1[q]; x2[q] = x[q] + dt * fq; rec[KR_F1 + q] = fq; rec[KR_X2 + q] = x2[q]; }
   kin_base(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x2, u, K);
   flow_from_kin(mb, x2, u, K, f2);
   _Pragma("unroll") for (int q = 0; q < KW_ARM; ++q) rec[KR_K2 + q] = K[q];

@@ -32,16 +32,16 @@ struct QmLsArgs {
   volatile int* host_open;              // [QM_LS_MAX_TRIALS] host-visible copy of open_cnt[t], written by the last block of trial t (the host never copies flags)
 };
 #define QM_LS_MAX_TRIALS 16
+#define LS_EVAL_LDS_BYTES (3 * 64 * 31 * 8)   /* qm_ls_eval_kernel: three 31-double rows per thread */
 
 // cost value of one intermediate node (a2 + a6 + a7 + a5), not yet × dt; K must hold base, legs and arm
 __device__ __forceinline__ double node_cost_value(const double* mb, const double* st, const double* x, const double* u, const double* K, int mode,
-                                                   const double* xref, const double* eeref, double muPos, double muOri, bool intermediate) {
+                                                   const double* xref, const double* eeref, double muPos, double muOri, bool intermediate, double* du /* [30] workspace (a per-thread LDS row) */) {
   double c = 0.0;
   if (intermediate) {
     int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
-    double du[30];
-    for (int i = 0; i < 30; ++i) { const double d = x[i] - xref[i]; c += 0.5 * st[ST_Q + i] * d * d; du[i] = u[i]; }
-    if (nst > 0) for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) du[3 * k + 2] -= mb[MB_ROBOTMASS] * 9.81 / nst;
+    _Pragma("unroll") for (int i = 0; i < 30; ++i) { const double d = x[i] - xref[i]; c += 0.5 * st[ST_Q + i] * d * d; du[i] = u[i]; }
+    if (nst > 0) { _Pragma("unroll") for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) du[3 * k + 2] -= mb[MB_ROBOTMASS] * 9.81 / nst; }
     for (int i = 0; i < 30; ++i) { double s = 0.0; for (int j = 0; j < 30; ++j) s += st[ST_R + 30 * i + j] * du[j]; c += 0.5 * du[i] * s; }
     for (int i = 0; i < 6; ++i) {
       const double lo = mb[MB_QLO + 12 + i], hi = mb[MB_QHI + 12 + i], z = x[24 + i], mu = st[ST_JPOS_MU], de = st[ST_JPOS_DELTA];
@@ -82,13 +82,14 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   if (i >= n || a.done[b] != 0) return;
   const int nb = i * a.B + b; const double al = a.alpha[b];
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
-  double x[30], u[30], K[KW_SIZE];
+  extern __shared__ double qm_smem[]; double* qm_ls_u = qm_smem;   // LS_EVAL_LDS_BYTES: [0] the trial input, [1] u − u_nominal of the input cost: the trial input of this thread's node: a per-thread LDS row instead of registers (see qm_lq_kin_kernel)
+  double x[30], K[KW_SIZE]; double* u = qm_ls_u + (threadIdx.x & 63) * 31;
   _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
   double* pf = a.perf + (size_t)nb * PF_SIZE;
   const int ev = a.node_ev[nb];
   if (i == n - 1) {
     kin_base(mb, x, K); kin_arm(mb, x, K);
-    pf[0] = node_cost_value(mb, st, x, nullptr, K, 0, nullptr, a.eeref + nb * 7, st[ST_MU_EEF_POS], st[ST_MU_EEF_ORI], false); pf[1] = 0.0; pf[2] = 0.0;
+    pf[0] = node_cost_value(mb, st, x, nullptr, K, 0, nullptr, a.eeref + nb * 7, st[ST_MU_EEF_POS], st[ST_MU_EEF_ORI], false, u); pf[1] = 0.0; pf[2] = 0.0;
     return;
   }
   const int nbn = (i + 1) * a.B + b;
@@ -102,9 +103,9 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   // a zero-length interval contributes neither cost nor constraint residual and needs no second Heun stage; besides skipping work, the guards
   // split this straight-line kernel into basic blocks, which bounds the live ranges the scheduler builds (measured: 20 % faster)
   double cost = 0.0, eq = 0.0;
-  if (dt > 0.0) cost = node_cost_value(mb, st, x, u, K, mode, a.xref + nb * 30, a.eeref + nb * 7, st[ST_MU_EE_POS], st[ST_MU_EE_ORI], true);
+  if (dt > 0.0) cost = node_cost_value(mb, st, x, u, K, mode, a.xref + nb * 30, a.eeref + nb * 7, st[ST_MU_EE_POS], st[ST_MU_EE_ORI], true, qm_ls_u + 64 * 31 + (threadIdx.x & 63) * 31);
   if (dt > 0.0) eq = node_eq_sse(st, x, u, K, mode, a.zvel + nb * 4, a.zpos + nb * 4);
-  double f1[30], x2[30], f2[30];
+  double x2[30], f2[30]; double* f1 = qm_ls_u + 2 * 64 * 31 + (threadIdx.x & 63) * 31;      // first Heun stage's flow value: the thread's third LDS row
   flow_from_kin(mb, x, u, K, f1);
   _Pragma("unroll") for (int q = 0; q < 30; ++q) { x2[q] = x[q] + dt * f1[q]; f2[q] = f1[q]; }
   if (dt > 0.0) {

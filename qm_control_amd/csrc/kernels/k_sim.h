@@ -48,7 +48,8 @@ struct QmSimArgs {
 #define SL_F     1116                   /* [12] */
 #define SL_TAU   1128                   /* [18] */
 #define SL_JDUM  1146                   /* [6][24] sink of the arm Jacobian (not needed by the plant) */
-#define SL_TOTAL 1290
+#define SL_COMP  1290                   /* [19 x 6][6] per-joint subtree composites of the six chain lanes (lane interleaved; registers would spill) */
+#define SL_TOTAL (SL_COMP + 19 * 6 * 6)
 #define SIM_LDS_BYTES (SL_TOTAL * 8)
 
 // measured pass of one chain per lane (lanes 0-3 legs, 4 arm, 5 root body) + base block: M, nle, foot Jacobians, tips
@@ -63,7 +64,8 @@ __device__ __forceinline__ void sim_dynamics_terms(const double* mb, double* S, 
       const bool leg = l < 4; const int contact = leg ? chain_to_contact(l) : 4;
       RbdJsink Jt; Jt.rows = leg ? Jf + 3 * contact * QM_NQ : S + SL_JDUM; Jt.nrows = leg ? 3 : 6; Jt.dummy = 0.0;
       RbdTip tip;
-      rbd_chain<6, double*, RbdJsink>(mb, leg ? 3 * l : 12, contact, q, v, Bb, M, nle, want_m, cm, ch, cI, F, NO, (RbdSums*)nullptr, tip, Jt, want_m && leg, leg ? 3 : 6);
+      RbdCompLds comp; comp.base = S + SL_COMP + l; comp.stride = 6;
+      rbd_chain<6, double*, RbdJsink, RbdCompLds>(mb, leg ? 3 * l : 12, contact, q, v, Bb, M, nle, want_m, cm, ch, cI, F, NO, (RbdSums*)nullptr, tip, Jt, want_m && leg, leg ? 3 : 6, comp);
       if (leg) {
         if (want_m) {
           double* Jr = Jt.rows;

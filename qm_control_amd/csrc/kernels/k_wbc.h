@@ -82,6 +82,10 @@ struct QmWbcArgs {
 #define WL_ACC    (WL_G + 18 * 16)                /* chain accumulators: 3 passes x 6 slots x 20 (inside G, after the momentum sums) */
 #define WL_MISC   (WL_WLIST + 12)                 /* q v qd vd w2 (5 x 24), baseAcc(6) */
 #define WL_TOTAL  (WL_MISC + 5 * 24 + 8)
+/* rigid-body phase only: per-joint subtree composites of the 18 chain lanes (19 x 6 doubles each, lane interleaved), behind the arm Jacobian that is
+   being built at the head of the Zp region; spans Zp .. R, all of which the cascade (re)initialises itself — the region is cleared again after the passes */
+#define WL_RBDWS  (WL_ZP + 144)
+#define WL_RBDWS_SIZE (RBD_COMP * 6 * 18)
 // per-instance HBM scratch (doubles): cycle counters, arm Jacobian, the ten tip records (read a handful of times while the tasks are built)
 #define WS_TIME   0
 #define WS_JARM   16                              /* [6][24] */
@@ -271,7 +275,12 @@ __device__ __forceinline__ void wv_apply_Q(const double* V, const double* beta, 
 }
 
 struct WbcCtx {   // everything the D0 block and the torque map need (all wave-uniform)
-  const double* M; const double* Jf; const double* nle; double tauMax[18]; int nc; int contactOf[4]; double mu; int nIneq; bool fl[4];
+  const double* M; const double* Jf; const double* nle; int nc; int mode; double mu; int nIneq;     // no arrays: a runtime-indexed member array would live in the private segment (scratch)
+  __device__ __forceinline__ bool fl(int k) const { return mode_flag(mode, k); }
+  // contact index (LF RF LH RH) of the j-th stance foot
+  __device__ __forceinline__ int contactOf(int j) const { int cnt = 0, res = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const bool f = mode_flag(mode, k); res = (f && cnt == j) ? k : res; cnt += f ? 1 : 0; } return res; }
 };
 // out = D0 x ; lanes cooperate, tau scratch in LDS
 __device__ __forceinline__ void wv_d0_apply(const WbcCtx& c, const double* x, double* tau, double* out) {
@@ -279,14 +288,14 @@ __device__ __forceinline__ void wv_d0_apply(const WbcCtx& c, const double* x, do
   if (l < 18) { double s = 0.0; for (int k = 0; k < 24; ++k) s += c.M[(6 + l) * 24 + k] * x[k]; for (int k = 0; k < 12; ++k) s -= c.Jf[k * 24 + 6 + l] * x[24 + k]; tau[l] = s; out[l] = s; out[18 + l] = -s; }
   if (l >= 36 && l < c.nIneq) {
     const int r = l - 36; double v = 0.0;
-    if (r < 5 * c.nc) { const int j = r / 5, q = r - 5 * j; const double* F = x + 24 + 3 * c.contactOf[j]; v = (q == 0) ? -F[2] : (q == 1) ? F[0] - c.mu * F[2] : (q == 2) ? -F[0] - c.mu * F[2] : (q == 3) ? F[1] - c.mu * F[2] : -F[1] - c.mu * F[2]; }
+    if (r < 5 * c.nc) { const int j = r / 5, q = r - 5 * j; const double* F = x + 24 + 3 * c.contactOf(j); v = (q == 0) ? -F[2] : (q == 1) ? F[0] - c.mu * F[2] : (q == 2) ? -F[0] - c.mu * F[2] : (q == 3) ? F[1] - c.mu * F[2] : -F[1] - c.mu * F[2]; }
     out[l] = v;
   }
   qm_wave_sync();
 }
 __device__ __forceinline__ double wbc_d0_entry(const WbcCtx& c, int i, int k) {   // D0[i][k]
   if (i < 36) { const int r = (i < 18) ? i : i - 18; const double sg = (i < 18) ? 1.0 : -1.0; return (k < 24) ? sg * c.M[(6 + r) * 24 + k] : -sg * c.Jf[(k - 24) * 24 + 6 + r]; }
-  if (i < 36 + 5 * c.nc) { const int j = (i - 36) / 5, q = (i - 36) - 5 * j; const int k0 = 24 + 3 * c.contactOf[j]; if (k < k0 || k >= k0 + 3) return 0.0; const int a = k - k0;
+  if (i < 36 + 5 * c.nc) { const int j = (i - 36) / 5, q = (i - 36) - 5 * j; const int k0 = 24 + 3 * c.contactOf(j); if (k < k0 || k >= k0 + 3) return 0.0; const int a = k - k0;
     if (q == 0) return a == 2 ? -1.0 : 0.0; if (a == 2) return -c.mu; if (q == 1) return a == 0 ? 1.0 : 0.0; if (q == 2) return a == 0 ? -1.0 : 0.0; if (q == 3) return a == 1 ? 1.0 : 0.0; return a == 1 ? -1.0 : 0.0; }
   return 0.0;
 }
@@ -299,10 +308,11 @@ __device__ __forceinline__ void wv_Z_times(const double* Zp, int n, const double
 
 // min |R z − c|² s.t. E z = e (me working-set rows in WL_EROWS / WL_ERHS), null-space method.  Rc = [R | c] (n x (n+1), ld WTLD,
 // upper triangle valid) is the once-per-level QR factor of G0 = [AZ; sqrt(rho) I | g0]; T (n x (n+1), ld WTLD) is scratch.  lam: multipliers.
+template <bool PROF>
 __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* T, int n, int me, double* zout, long long* tf) {
   const int l = threadIdx.x & 63;
-  long long tl_ = (long long)__builtin_readcyclecounter();
-#define WF(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tf[k] += now_ - tl_; tl_ = now_; }
+  long long tl_ = PROF ? (long long)__builtin_readcyclecounter() : 0;
+#define WF(k) { if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tf[k] += now_ - tl_; tl_ = now_; } }
   if (me == 0) { wv_backsub_tri<WVLD>(Rc, WTLD, n, zout); return; }
   double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
   WF(0)
@@ -376,11 +386,11 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
 // R is never needed.  Reflector k is stored SHIFTED (Vs[k][i] = v_k[k + i], zero padded to MAXN), so neither sweep needs an index
 // bound: Q2 = H_0 … H_{r-1} [0; I] is accumulated backwards with one column of Q2 per lane in a register window that moves down one
 // row per reflector (the row that enters is a zero of [0; I]).
-template <int MAXN>
+template <int MAXN, bool PROF>
 __device__ __forceinline__ int wv_null_space(double* S, int ra, int n, long long* tn) {
   const int l = threadIdx.x & 63;
-  long long tl_ = (long long)__builtin_readcyclecounter();
-#define WN(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tn[k] += now_ - tl_; tl_ = now_; }
+  long long tl_ = PROF ? (long long)__builtin_readcyclecounter() : 0;
+#define WN(k) { if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tn[k] += now_ - tl_; tl_ = now_; } }
   double* Vs = S + WL_G; double* Zp = S + WL_ZP; const double* AZ = S + WL_AZ; double* bet = S + WL_R; double* vd = S + WL_R + 40;   // Vs: [rank][MAXN] (<= 18 x 36); bet, vd: 2 / (v·v) and the pivot entry of each reflector
   double col[MAXN];
 #pragma unroll
@@ -491,13 +501,16 @@ __device__ __forceinline__ void tip_store(double* dst, const RbdTip& t) { for (i
 #define TIP_A(t) ((t) + 18)
 #define TIP_AL(t) ((t) + 21)
 
-__global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
+// PROF: in-kernel cycle counters of the phases (tools/wbc_prof.py; a.stop < 0 selects which set is written out).  The production instance carries none of
+// them: 31 64-bit accumulators live across the whole cascade were the kernel's last private-segment spills.
+template <bool PROF>
+__device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
   extern __shared__ double qm_smem[];
   double* S = qm_smem;
   const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
-  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tfine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tnull[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = (long long)__builtin_readcyclecounter();
-#define WT(k) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; }
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tfine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tnull[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? (long long)__builtin_readcyclecounter() : 0;
+#define WT(k) { if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } }
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   const double* xDes = a.x_des + (size_t)b * 30; const double* uDes = a.u_des + (size_t)b * 30; const double* rbd = a.rbd + (size_t)b * QM_NRBD;
   const int mode = a.mode[b]; const double time = a.time[b];
@@ -505,22 +518,23 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   qm_wave_sync();
   double* M = S + WL_M; double* nle = S + WL_NLE; double* Jf = S + WL_JF;
   double* gs = a.scratch + (size_t)b * WBC_SCRATCH; double* Jarm = S + WL_ZP; double* tips = gs + WS_TIPS;   // Jarm: built in the (still unused) Zp region, parked in HBM scratch for level 1
-  WbcCtx C; C.nc = 0; for (int k = 0; k < 4; ++k) { C.fl[k] = mode_flag(mode, k); if (C.fl[k]) C.contactOf[C.nc++] = k; }
+  WbcCtx C; C.mode = mode; C.nc = 0; for (int k = 0; k < 4; ++k) C.nc += mode_flag(mode, k) ? 1 : 0;
   C.mu = st[ST_WBC_FRIC]; C.nIneq = 36 + 5 * C.nc + 3 * (4 - C.nc); C.M = M; C.Jf = Jf; C.nle = nle;
-  for (int q2 = 0; q2 < 4; ++q2) for (int k = 0; k < 3; ++k) C.tauMax[3 * q2 + k] = mb[MB_TAUMAX + k]; for (int k = 0; k < 6; ++k) C.tauMax[12 + k] = mb[MB_TAUMAX + 12 + k];
   // ---- generalized coordinates of the three passes: measured (q,v), desired (qd,vd), joint-acceleration (qd, w2) ----
   double* q = S + WL_MISC; double* v = q + 24; double* qd = v + 24; double* vd = qd + 24; double* w2 = vd + 24; double* baseAcc = w2 + 24;
   if (l < 3) { q[l] = rbd[3 + l]; q[3 + l] = rbd[l]; v[l] = rbd[27 + l]; }
   if (l == 3) { const double z = rbd[0], y = rbd[1]; const double sz = sin(z), cz = cos(z), sy = sin(y), cy = cos(y); const double wx = rbd[24], wy = rbd[25], wz = rbd[26]; const double tmp = cz * wx / cy + sz * wy / cy; v[3] = sy * tmp + wz; v[4] = -sz * wx + cz * wy; v[5] = tmp; }
   if (l >= 6 && l < 24) { q[l] = rbd[l]; v[l] = rbd[24 + l]; }
   if (l >= 32 && l < 56) qd[l - 32] = xDes[6 + (l - 32)];
-  double Kd[KW_SIZE];                                  // SRBD quantities at the desired state (every lane: cheap, avoids a broadcast)
-  kin_base(mb, xDes, Kd);
-  if (l == 0) { double wr[3]; v3_cross(Kd + KW_OM, Kd + KW_RW, wr); for (int k = 0; k < 3; ++k) { vd[k] = xDes[k] + wr[k]; vd[3 + k] = Kd[KW_THD + k]; } }
+  {
+    double Kd[KW_LEG];                                 // SRBD quantities at the desired state (every lane: cheap, avoids a broadcast); NOT kept across the
+    kin_base(mb, xDes, Kd);                            // rigid-body passes (21 of them are needed again for baseAccDesired: recomputed there, 42 registers less here)
+    if (l == 0) { double wr[3]; v3_cross(Kd + KW_OM, Kd + KW_RW, wr); for (int k = 0; k < 3; ++k) { vd[k] = xDes[k] + wr[k]; vd[3 + k] = Kd[KW_THD + k]; } }
+  }
   if (l >= 6 && l < 24) { vd[l] = uDes[6 + l]; const double* il = a.input_last + (size_t)b * 30; w2[l] = (uDes[6 + l] - il[6 + l]) / a.period; }
   qm_wave_sync();
   if (l < 30) a.input_last[(size_t)b * 30 + l] = uDes[l];
-  { const long long now_ = (long long)__builtin_readcyclecounter(); tnull[4] = now_ - tlast; }
+  if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tnull[4] = now_ - tlast; }
   // ---- rigid-body passes: lanes 0-5 measured, 8-13 desired, 16-21 joint-acceleration; slot 0-3 legs, 4 arm, 5 root body ----
   {
     const int pass = l >> 3, slot = l & 7;
@@ -528,37 +542,41 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       const double* qq = (pass == 0) ? q : qd; const double* vv = (pass == 0) ? v : (pass == 1 ? vd : w2);
       RbdBase Bb; rbd_base(qq, vv, Bb);
       double cm = 0.0, ch[3] = {0, 0, 0}, cI[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, F[3] = {0, 0, 0}, NO[3] = {0, 0, 0};
-      RbdSums Sm; Sm.mass = 0.0; for (int i = 0; i < 3; ++i) { Sm.mc[i] = Sm.hl[i] = Sm.hO[i] = Sm.Fb[i] = Sm.NbO[i] = 0.0; }
+      RbdSums* Sm = S + WL_G + (pass * 6 + slot) * 16;          // momentum sums of this slot, accumulated in place in LDS (G is free at this point and was cleared at the
+                                                                // start; a private array of 16 is not promoted to registers by the compiler and would live in scratch memory)
       RbdTip tip; const bool meas = (pass == 0);
       if (slot < 5) {
         // legs (3 joints) and the arm (6 joints) share one instruction stream: slot 4 runs all six joint slots, the legs mask the last three
         const bool leg = slot < 4; const int contact = leg ? chain_to_contact(slot) : 4;
         RbdJsink Jt; Jt.rows = leg ? Jf + 3 * contact * QM_NQ : Jarm; Jt.nrows = leg ? 3 : 6; Jt.dummy = 0.0;   // Jacobian columns land in place (LDS was cleared at the start)
-        rbd_chain<6, double*, RbdJsink>(mb, leg ? 3 * slot : 12, contact, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, &Sm, tip, Jt, meas, leg ? 3 : 6);
+        RbdCompLds comp; comp.base = S + WL_RBDWS + (pass * 6 + slot); comp.stride = 18;
+        rbd_chain<6, double*, RbdJsink, RbdCompLds>(mb, leg ? 3 * slot : 12, contact, qq, vv, Bb, M, nle, meas, cm, ch, cI, F, NO, Sm, tip, Jt, meas, leg ? 3 : 6, comp);
         if (meas) {
           double* Jr = Jt.rows;
+#pragma unroll
           for (int r = 0; r < 3; ++r) Jr[r * QM_NQ + r] = 1.0;
+#pragma unroll
           for (int k = 0; k < 3; ++k) { const double e[3] = {Bb.E[k], Bb.E[3 + k], Bb.E[6 + k]}, d[3] = {tip.p[0] - Bb.p[0], tip.p[1] - Bb.p[1], tip.p[2] - Bb.p[2]}; double cr[3]; v3_cross(e, d, cr);
+#pragma unroll
             for (int r = 0; r < 3; ++r) { Jr[r * QM_NQ + 3 + k] = cr[r]; if (!leg) Jr[(3 + r) * QM_NQ + 3 + k] = e[r]; } }
         }
         if (pass < 2) tip_store(tips + 27 * (5 * pass + contact), tip);
       } else {
         const double zero3[3] = {0.0, 0.0, 0.0}; double c[3], Iw[9], vc[3], ac[3];
         body_state(mb, 0, Bb.R, Bb.p, Bb.vlin, Bb.w, zero3, Bb.al, c, Iw, vc, ac);
-        add_body(mb[MB_MASS], c, Iw, vc, Bb.w, ac, Bb.al, cm, ch, cI, F, NO, &Sm);
+        add_body(mb[MB_MASS], c, Iw, vc, Bb.w, ac, Bb.al, cm, ch, cI, F, NO, Sm);
       }
       double* acc = S + WL_ACC + (pass * 6 + slot) * 20;       // cm ch(3) cI(9) F(3) NO(3)
       acc[0] = cm; for (int i = 0; i < 3; ++i) { acc[1 + i] = ch[i]; acc[13 + i] = F[i]; acc[16 + i] = NO[i]; } for (int i = 0; i < 9; ++i) acc[4 + i] = cI[i];
-      double* sm = S + WL_G + (pass * 6 + slot) * 16;          // momentum sums of this slot (G is free at this point)
-      sm[0] = Sm.mass; for (int i = 0; i < 3; ++i) { sm[1 + i] = Sm.mc[i]; sm[4 + i] = Sm.hl[i]; sm[7 + i] = Sm.hO[i]; sm[10 + i] = Sm.Fb[i]; sm[13 + i] = Sm.NbO[i]; }
     }
   }
   qm_wave_sync();
   for (int i = l; i < 144; i += 64) gs[WS_JARM + i] = Jarm[i];
   Jarm = gs + WS_JARM;
+  for (int i = l; i < WL_RBDWS_SIZE; i += 64) S[WL_RBDWS + i] = 0.0;      // the cascade expects its work arrays as the kernel's initial clear left them
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    // the tip records and the arm Jacobian go through HBM scratch (same CU: no L2 maintenance needed)
   qm_wave_sync();
-  { const long long now_ = (long long)__builtin_readcyclecounter(); tnull[8] = now_ - tlast; }
+  if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tnull[8] = now_ - tlast; }
   RbdBase Bm; rbd_base(q, v, Bm);                        // measured root state (every lane)
   // base block of M and base rows of nle from the whole-tree composite (lane d = base dof)
   {
@@ -583,6 +601,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
     double cF[3], cH[3]; v3_cross(com, Sd + 10, cF); v3_cross(com, Sa + 4, cH);
     for (int i = 0; i < 3; ++i) { rate[i] -= Sd[10 + i] + Sa[4 + i]; rate[3 + i] -= (Sd[13 + i] - cF[i]) + (Sa[7 + i] - cH[i]); }
     const double ra3[3] = {rate[3], rate[4], rate[5]}; double wdd[3], thdd[3], t[3];
+    double Kd[KW_LEG]; kin_base(mb, xDes, Kd);
     m3_mulv(Kd + KW_IINV, ra3, wdd); m3_mulv(Kd + KW_EINV, wdd, thdd); v3_cross(Kd + KW_RW, wdd, t);
     for (int i = 0; i < 3; ++i) { baseAcc[i] = rate[i] / m - t[i]; baseAcc[3 + i] = thdd[i]; }
   }
@@ -593,9 +612,12 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
   double* A = S + WL_AZ; double* bb = S + WL_BB; double* AZ = S + WL_AZ; double* Zp = S + WL_ZP; double* x = S + WL_X; double* z = S + WL_Z; double* zn = S + WL_ZN; double* p = S + WL_P;
   double* f0 = S + WL_F0; double* w0 = S + WL_W0; double* fb = S + WL_FB; double* Dz = S + WL_DZ; double* Dp = S + WL_DP; double* tau = S + WL_TAU; double* g0 = S + WL_G0RHS; double* G = S + WL_G;
   double* Zz = S + WL_ZZ; double* Zpv = S + WL_ZPV; double* lam = S + WL_LAM;
-  if (l < 18) { f0[l] = C.tauMax[l] - nle[6 + l]; f0[18 + l] = C.tauMax[l] + nle[6 + l]; }
+  if (l < 18) { const double tmax = a.mb[MB_TAUMAX + ((l < 12) ? (l % 3) : l)];      // torque limits: the first leg's three for every leg (WbcBase.cpp:565-578), the arm's own; lane-indexed: a plain global load
+                f0[l] = tmax - nle[6 + l]; f0[18 + l] = tmax + nle[6 + l]; }
   qm_wave_sync();
-  int nz = WNV; int status[3] = {0, 0, 0};
+  int nz = WNV; int status0 = 0, status1 = 0, status2 = 0;      // per-level qp status (three scalars: an array indexed by `level` would live in scratch memory)
+  auto get_status = [&](int lv) { return lv == 0 ? status0 : (lv == 1 ? status1 : status2); };
+  auto set_status = [&](int lv, int v) { status0 = (lv == 0) ? v : status0; status1 = (lv == 1) ? v : status1; status2 = (lv == 2) ? v : status2; };
   for (int level = 0; level < 3; ++level) {
     // ---- the level's equality task ----
     A = (level == 0) ? AZ : S + WL_A;                       // level 0: Zp = I, the task rows are A Zp
@@ -606,8 +628,8 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
       for (int idx = l; idx < 6 * 36; idx += 64) { const int r = idx / 36, k = idx - 36 * r; A[r * WNV + k] = (k < 24) ? M[r * 24 + k] : -Jf[(k - 24) * 24 + r]; }
       if (l < 6) bb[l] = -nle[l];
       ra = 6;
-      for (int k = 0; k < 4; ++k) if (C.fl[k]) { for (int idx = l; idx < 72; idx += 64) { const int r = idx / 24, c2 = idx - 24 * r; A[(ra + r) * WNV + c2] = Jf[(3 * k + r) * 24 + c2]; } if (l < 3) bb[ra + l] = -TIP_A(tipsM + 27 * k)[l]; ra += 3; }
-      for (int k = 0; k < 4; ++k) if (!C.fl[k]) { if (l < 3) { A[(ra + l) * WNV + 24 + 3 * k + l] = 1.0; bb[ra + l] = 0.0; } ra += 3; }
+      for (int k = 0; k < 4; ++k) if (C.fl(k)) { for (int idx = l; idx < 72; idx += 64) { const int r = idx / 24, c2 = idx - 24 * r; A[(ra + r) * WNV + c2] = Jf[(3 * k + r) * 24 + c2]; } if (l < 3) bb[ra + l] = -TIP_A(tipsM + 27 * k)[l]; ra += 3; }
+      for (int k = 0; k < 4; ++k) if (!C.fl(k)) { if (l < 3) { A[(ra + l) * WNV + 24 + 3 * k + l] = 1.0; bb[ra + l] = 0.0; } ra += 3; }
     } else if (level == 1) {
       const bool init = (a.variant == 0 && time < 10.0);
       if (init) { if (l < 6) { A[l * WNV + 18 + l] = 1.0; bb[l] = st[ST_KP_ARM_J + l] * (qd[18 + l] - q[18 + l]) + st[ST_KD_ARM_J + l] * (vd[18 + l] - v[18 + l]); } ra = 6; }
@@ -632,7 +654,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
           if (l < 2) { A[(ra + l) * WNV + l] = 1.0; bb[ra + l] = baseAcc[l] + st[ST_KP_BASE_LIN] * (qd[l] - q[l]) + st[ST_KD_BASE_LIN] * (vd[l] - v[l]); }
           ra += 2;
         }
-        for (int k = 0; k < 4; ++k) if (!C.fl[k]) {   // swing legs, x100
+        for (int k = 0; k < 4; ++k) if (!C.fl(k)) {   // swing legs, x100
           const double* fM = tipsM + 27 * k; const double* fD = tipsD + 27 * k;
           for (int idx = l; idx < 72; idx += 64) { const int r = idx / 24, c2 = idx - 24 * r; A[(ra + r) * WNV + c2] = 100.0 * Jf[(3 * k + r) * 24 + c2]; }
           if (l < 3) bb[ra + l] = 100.0 * (st[ST_KP_SWING] * (TIP_P(fD)[l] - TIP_P(fM)[l]) + st[ST_KD_SWING] * (TIP_V(fD)[l] - TIP_V(fM)[l]) - TIP_A(fM)[l]);
@@ -714,7 +736,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
         const double zs = fmax(1.0, wv_max((l < n) ? fabs(z[l]) : 0.0));
         if (pn <= 1e-12 * zs) break;
       }
-      if (it >= 100) status[0] = 1;
+      if (it >= 100) status0 = 1;
       wv_Z_times(Zp, n, z, Zz); wv_d0_apply(C, Zz, tau, Dz);
       if (l < C.nIneq) w0[l] = fmax(0.0, Dz[l] - fb[l]);
       qm_wave_sync();
@@ -765,7 +787,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
 #pragma unroll
           for (int k = 0; k < WVLD; ++k) dz[k] = (k < n) ? sg * tmp[rr * WVLD + k] : 0.0;
         } else if (l < 36 + 5 * C.nc) {                   // friction pyramid rows touch one force triple
-          const int k0 = 24 + 3 * C.contactOf[(l - 36) / 5];
+          const int k0 = 24 + 3 * C.contactOf((l - 36) / 5);
           for (int a3 = 0; a3 < 3; ++a3) { const double e = wbc_d0_entry(C, l, k0 + a3); if (e != 0.0) {
 #pragma unroll
             for (int k = 0; k < WVLD; ++k) if (k < n) dz[k] += e * Zp[(k0 + a3) * n + k]; } }
@@ -784,7 +806,7 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
         }
         qm_wave_sync();
         WT(10)
-        wv_eq_ls_R(S, G, Tm, n, nw, zn, tfine);
+        wv_eq_ls_R<PROF>(S, G, Tm, n, nw, zn, tfine);
         WT(9)
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
@@ -831,33 +853,33 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
             else if (nw >= n) { if (al <= 1e-12) vertex = true; }   // n rows are active already (the working-set rows are numerically dependent, else p would vanish): the set
                                                                  // cannot grow beyond the dimension.  A step blocked at once means z is a degenerate vertex: decide by the multipliers
                                                                  // (drop by Bland's rule).  After a partial step the same rows are solved again and the remainder ends up here.
-            else { status[level] = 2; qm_wave_sync(); break; }
+            else { set_status(level, 2); qm_wave_sync(); break; }
           }
           qm_wave_sync();
         }
       }
-      if (it >= 100 && status[level] == 0) status[level] = 1;
-      if (a.stop == -4 && l == 0) gs[WS_TIME + 12 + level] = (double)it;      // profiling: active-set iterations of this level
+      if (it >= 100 && get_status(level) == 0) set_status(level, 1);
+      if (PROF && a.stop == -4 && l == 0) gs[WS_TIME + 12 + level] = (double)it;      // profiling: active-set iterations of this level
     }
     wv_Z_times(Zp, n, z, Zz);
     if (l < WNV) { x[l] += Zz[l]; if (a.dbg) a.dbg[(size_t)b * WBC_DBG_SIZE + 126 + level * WNV + l] = x[l]; }
     qm_wave_sync();
     if (a.stop == 2 + level) return;
     WT(10)
-    if (level < 2) nz = (level == 0) ? wv_null_space<WNV>(S, ra, n, tnull) : wv_null_space<WVLD>(S, ra, n, tnull + 5);
+    if (level < 2) nz = (level == 0) ? wv_null_space<WNV, PROF>(S, ra, n, tnull) : wv_null_space<WVLD, PROF>(S, ra, n, tnull + 5);
     WT(7)
-    if (level > 0 && status[level] == 0 && status[level - 1] != 0) status[level] = status[level - 1];
+    if (level > 0 && get_status(level) == 0 && get_status(level - 1) != 0) set_status(level, get_status(level - 1));
   }
   // ---- updateCmd (WbcBase.cpp:548-563) ----
   wv_d0_apply(C, x, tau, Dz);
   double* out = a.out + (size_t)b * QM_NWBC_OUT;
   if (l < WNV) out[l] = x[l];
   if (l < 18) out[WNV + l] = tau[l] + nle[6 + l];
-  if (l < 3) a.qp_status[b * 3 + l] = status[l];
+  if (l < 3) a.qp_status[b * 3 + l] = get_status(l);
   WT(11)
-  if (a.stop < 0 && l == 0) for (int k = 0; k < 12; ++k) gs[WS_TIME + k] = (double)tacc[k];
-  if (a.stop == -2 && l == 0) for (int k = 0; k < 9; ++k) gs[WS_TIME + k] = (double)tfine[k];
-  if (a.stop == -3 && l == 0) for (int k = 0; k < 10; ++k) gs[WS_TIME + k] = (double)tnull[k];
+  if (PROF && a.stop < 0 && l == 0) for (int k = 0; k < 12; ++k) gs[WS_TIME + k] = (double)tacc[k];
+  if (PROF && a.stop == -2 && l == 0) for (int k = 0; k < 9; ++k) gs[WS_TIME + k] = (double)tfine[k];
+  if (PROF && a.stop == -3 && l == 0) for (int k = 0; k < 10; ++k) gs[WS_TIME + k] = (double)tnull[k];
 #undef WT
   if (a.dbg) {
     double* d = a.dbg + (size_t)b * WBC_DBG_SIZE;
@@ -868,3 +890,5 @@ __global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) {
     if (l < 12) d[1098 + l] = TIP_A(tipsM + 27 * (l / 3))[l % 3];
   }
 }
+__global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) { qm_wbc_body<false>(a); }
+__global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_prof_kernel(QmWbcArgs a) { qm_wbc_body<true>(a); }      // profiling only (a.stop < 0)

@@ -43,6 +43,9 @@ __device__ __forceinline__ void kin_base(const double* mb, const double* x, doub
 // one serial chain hanging off the base: joints j0..j0+nj-1, tip frame `frame`.
 // a,o: world axes / joint origins [nj][3]; p: tip position; Rend (optional): tip rotation;
 // s (optional, needs u): joint-induced tip velocity Σ qd_j a_j × (p − o_j)
+// HAS_S / HAS_REND are compile-time (not `if (s)` / `if (Rend)`): the outputs usually point into a thread-private workspace, and comparing such an address
+// with null keeps the whole workspace out of registers (address 0 is a valid private address on this target, the test cannot be folded)
+template <bool HAS_S, bool HAS_REND>
 __device__ __forceinline__ void kin_chain(const double* mb, int j0, int nj, int frame, const double* x, const double* u, const double* K,
                                           double* a, double* o, double* p, double* s, double* Rend) {
   double Rp[9], pp[3], Rj[9], Rq[9], Rn[9];
@@ -60,8 +63,8 @@ __device__ __forceinline__ void kin_chain(const double* mb, int j0, int nj, int 
   }
   double t[3]; m3_mulv(Rp, mb + MB_FP + 3 * frame, t);
   for (int i = 0; i < 3; ++i) p[i] = pp[i] + t[i];
-  if (Rend) m3_mul(Rp, mb + MB_FR + 9 * frame, Rend);
-  if (s) {
+  if (HAS_REND) m3_mul(Rp, mb + MB_FR + 9 * frame, Rend);
+  if (HAS_S) {
     s[0] = s[1] = s[2] = 0.0;
     for (int jj = 0; jj < nj; ++jj) {
       double d[3] = {p[0] - o[3 * jj], p[1] - o[3 * jj + 1], p[2] - o[3 * jj + 2]}, c[3];
@@ -73,11 +76,13 @@ __device__ __forceinline__ void kin_chain(const double* mb, int j0, int nj, int 
 }
 __device__ __forceinline__ void kin_leg(const double* mb, int chain, const double* x, const double* u, double* K) {
   double* L = K + KW_LEG + KW_LEGSZ * chain;
-  kin_chain(mb, 3 * chain, 3, chain_to_contact(chain), x, u, K, L, L + 9, L + 18, u ? L + 21 : nullptr, nullptr);
+  // u must not be null (no `u ? … : nullptr` here: comparing the address of a thread-private array with null keeps the whole array out of registers,
+  // address 0 being a valid private address on this target)
+  kin_chain<true, false>(mb, 3 * chain, 3, chain_to_contact(chain), x, u, K, L, L + 9, L + 18, L + 21, nullptr);
 }
 __device__ __forceinline__ void kin_arm(const double* mb, const double* x, double* K) {
   double* A = K + KW_ARM;
-  kin_chain(mb, 12, 6, 4, x, nullptr, K, A, A + 18, A + 36, nullptr, A + 39);
+  kin_chain<false, true>(mb, 12, 6, 4, x, nullptr, K, A, A + 18, A + 36, nullptr, A + 39);
 }
 __device__ __forceinline__ const double* kin_foot(const double* K, int contact) { return K + KW_LEG + KW_LEGSZ * contact_to_chain(contact) + 18; }
 
@@ -93,7 +98,7 @@ __device__ __forceinline__ void flow_from_kin(const double* mb, const double* x,
   }
   double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
   for (int k = 0; k < 3; ++k) { f[k] = lin[k] * im; f[3 + k] = ang[k] * im; f[6 + k] = x[k] + wr[k]; f[9 + k] = K[KW_THD + k]; }
-  for (int j = 0; j < QM_NJ; ++j) f[12 + j] = u[12 + j];
+  _Pragma("unroll") for (int j = 0; j < QM_NJ; ++j) f[12 + j] = u[12 + j];      // (static indices: f / u stay in registers)
 }
 // One Heun stage of one node on thread-private data with the legs in a ROLLED loop (small code, few live registers, so that
 // several waves fit a SIMD): x and u may point to global memory.  Kb[KW_LEG] receives the base block, leg(c, L) is called with
@@ -106,7 +111,7 @@ template <class LegFn> __device__ __forceinline__ void kin_stage(const double* m
   for (int c = 0; c < 4; ++c) {
     double L[KW_LEGSZ];
     const int contact = chain_to_contact(c);
-    kin_chain(mb, 3 * c, 3, contact, x, u, Kb, L, L + 9, L + 18, L + 21, nullptr);
+    kin_chain<true, false>(mb, 3 * c, 3, contact, x, u, Kb, L, L + 9, L + 18, L + 21, nullptr);
     leg(c, L);
     const double F[3] = {u[3 * contact], u[3 * contact + 1], u[3 * contact + 2]};
     const double d[3] = {L[18] - Kb[KW_COM], L[19] - Kb[KW_COM + 1], L[20] - Kb[KW_COM + 2]};
@@ -119,7 +124,7 @@ template <class LegFn> __device__ __forceinline__ void kin_stage(const double* m
 }
 // arm block A[KW_SIZE - KW_ARM] = {a[6][3], o[6][3], p, R} from the base block
 __device__ __forceinline__ void kin_arm_block(const double* mb, const double* x, const double* Kb, double* A) {
-  kin_chain(mb, 12, 6, 4, x, nullptr, Kb, A, A + 18, A + 36, nullptr, A + 39);
+  kin_chain<false, true>(mb, 12, 6, 4, x, nullptr, Kb, A, A + 18, A + 36, nullptr, A + 39);
 }
 // foot velocity v_i = h_lin + ω × d_i + s_i   (LOCAL_WORLD_ALIGNED linear velocity of the foot frame under the SRBD map)
 __device__ __forceinline__ void foot_velocity(const double* x, const double* K, int contact, double* v) {

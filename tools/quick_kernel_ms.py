@@ -8,7 +8,10 @@ cfg = scenarios.make_config("C4", batch=B)
 itf = api.QMInterface(blobs=scenarios.load_blobs(), max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
 mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
 mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
-def step(): wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+MPC_ONLY = bool(os.environ.get("QM_MPC_ONLY"))
+def step():
+    if MPC_ONLY: mpc.solve_resident(cfg["horizon"])       # no WBC on the second stream: per-kernel times without cross-stream waiting
+    else: wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
 for _ in range(12): itf.microbench_fp64(True)
 for _ in range(5): step()
 itf.synchronize(); itf.set_profiling(True); itf.reset_kernel_ms()
@@ -19,4 +22,5 @@ itf.synchronize(); t = time.perf_counter()
 for _ in range(30): step()
 itf.synchronize(); dt = (time.perf_counter() - t) / 30
 res = mpc.download(); out, qps = wbc.download(B)
+if MPC_ONLY: qps = qps * 0
 print(json.dumps({"B": B, "ms_per_step": round(dt * 1e3, 4), "steps_per_s": round(B / dt), "ok": bool((res["status"] == 0).all() and (qps == 0).all()), "kernel_ms": ms, "tau_checksum": float(np.abs(out[:, 36:]).sum())}))
