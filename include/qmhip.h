@@ -197,6 +197,9 @@ int qmhip_debug_read(qmhip_ctx* ctx, const char* buffer, void* dst, size_t bytes
 int qmhip_debug_set(qmhip_ctx* ctx, const char* key, int value);
 /* read such a switch back (bench.py asserts they are all 0 before it times anything) */
 int qmhip_debug_get(const qmhip_ctx* ctx, const char* key, int* value);
+/* profiling only: a latency-bound filler kernel on the second stream (co-residency experiments, tools/coresidency_probe.py) */
+int qmhip_debug_filler(qmhip_ctx* ctx, int waves, int iters, int wait, double* ms);
+int qmhip_debug_lq_with_filler(qmhip_ctx* ctx, int B, double horizon, int waves, int iters, double* ms /*[3]: LQ kernel, filler, Riccati kernel (ms)*/);
 /* micro-benchmarks used to anchor the FP64 roofline: returns achieved TFLOP/s */
 int qmhip_microbench_fp64(qmhip_ctx* ctx, int use_mfma, double* tflops);
 

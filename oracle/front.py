@@ -33,7 +33,7 @@ ST = dict(Q=0, R=30, XINIT=930, MU_EE_POS=960, MU_EE_ORI=961, MU_EEF_POS=962, MU
           TIME_HORIZON=996, WBC_FRIC=997, KP_SWING=998, KD_SWING=999, KP_BASE_H=1000,
           KD_BASE_H=1001, KP_BASE_LIN=1002, KD_BASE_LIN=1003, KP_BASE_ANG=1004, KD_BASE_ANG=1005,
           KP_ARM_J=1006, KD_ARM_J=1012, KP_EE_LIN=1018, KD_EE_LIN=1021, KP_EE_ANG=1024,
-          KD_EE_ANG=1027, SIZE=1030)
+          KD_EE_ANG=1027, SOLVER=1030, DDP_MIN_STEP=1031, DDP_MAX_STEP=1032, DDP_PENALTY=1033, SIZE=1034)
 
 FOOT_FRAMES = ["LF_FOOT", "RF_FOOT", "LH_FOOT", "RH_FOOT"]   # ModelSettings.h:38 (contact order)
 MODE_NAMES = {"FLY": 0, "RH": 1, "LH": 2, "LH_RH": 3, "RF": 4, "RF_RH": 5, "RF_LH": 6,
@@ -395,6 +395,11 @@ def build_settings(task_info_path, model_blob):
     s[ST['KD_EE_LIN']: ST['KD_EE_LIN'] + 3] = w['kd_ee_linear']
     s[ST['KP_EE_ANG']: ST['KP_EE_ANG'] + 3] = w['kp_ee_angular']
     s[ST['KD_EE_ANG']: ST['KD_EE_ANG'] + 3] = w['kd_ee_angular']
+    # discrete iLQR: the controller instantiates SqpMpc whatever `ddp.algorithm` says (QMController.cpp:287-288) -> solver 0
+    s[ST['SOLVER']] = 0.0
+    s[ST['DDP_MIN_STEP']] = g('ddp.lineSearch.minStepLength')
+    s[ST['DDP_MAX_STEP']] = g('ddp.lineSearch.maxStepLength')
+    s[ST['DDP_PENALTY']] = g('ddp.constraintPenaltyInitialValue')
     return s
 
 

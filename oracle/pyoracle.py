@@ -139,6 +139,17 @@ class Oracle:
         return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf,
                     alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h))
 
+    def ilqr_step(self, t0, tf, x0, warm=False):
+        """one discrete iLQR iteration (oracle/src/ilqr.h): same result dict as mpc_step"""
+        x0 = np.ascontiguousarray(x0, float); n = C.c_int(0)
+        nt = np.zeros(self.MAXN); ne = np.zeros(self.MAXN, np.int32); nm = np.zeros(self.MAXN, np.int32)
+        xo = np.zeros((self.MAXN, 30)); uo = np.zeros((self.MAXN, 30)); perf = np.zeros(10)
+        rc = self.lib.qmo_ilqr_step(self.h, C.c_int(int(bool(warm))), C.c_double(t0), C.c_double(tf), _p(x0), C.c_int(self.MAXN), C.byref(n), _p(nt), _pi(ne), _pi(nm), _p(xo), _p(uo), _p(perf))
+        if rc != 0:
+            raise RuntimeError("oracle ilqr_step failed rc=%d" % rc)
+        k = n.value
+        return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf, alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h))
+
     def node_lq(self, i):
         z = lambda *s: np.zeros(s)
         d = dict(A=z(30, 30), B=z(30, 30), b=z(30), Q=z(30, 30), R=z(30, 30), P=z(30, 30), q=z(30), r=z(30), scal=z(4), C=z(16, 30), D=z(16, 30), e=z(16))

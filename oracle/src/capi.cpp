@@ -1,6 +1,7 @@
 // oracle/src/capi.cpp — TEST INFRASTRUCTURE (CPU oracle): C entry points for ctypes (tests/, bench.py
 // cpu_baseline leg, __graft_entry__.smoke()).  Nothing under qm_control_amd/ may link or load this.
 #include "sqp.h"
+#include "ilqr.h"
 #include "wbc.h"
 #include "sim.h"
 #include <cstdio>
@@ -127,6 +128,19 @@ int qmo_mpc_step_warm(void* h, double t0, double tf, const double* x0, int maxn,
   SqpResult prev = o->R; o->R = SqpResult();
   try { sqpIteration(o->P, t0, tf, x0v, nullptr, nullptr, o->R, &prev); } catch (const std::exception&) { return -2; }
   const SqpResult& R = o->R; const int n = (int)R.grid.size(); if (n > maxn) return -1;
+  *n_nodes = n;
+  for (int i = 0; i < n; ++i) { node_t[i] = R.grid[i].t; node_ev[i] = R.grid[i].ev; node_mode[i] = R.mode[i]; std::memcpy(xs + QM_NX * i, R.x[i].data(), QM_NX * 8); std::memcpy(us + QM_NU * i, R.u[i].data(), QM_NU * 8); }
+  const Performance* pf[2] = {&R.baseline, &R.after};
+  for (int k = 0; k < 2; ++k) { perf[4 * k] = pf[k]->merit; perf[4 * k + 1] = pf[k]->cost; perf[4 * k + 2] = pf[k]->dynSSE; perf[4 * k + 3] = pf[k]->eqSSE; }
+  perf[8] = R.alpha; perf[9] = R.armijo;
+  return 0;
+}
+// one discrete iLQR iteration (oracle/src/ilqr.h); warm != 0: inputs from this oracle's previous solution; same outputs as qmo_mpc_step
+int qmo_ilqr_step(void* h, int warm, double t0, double tf, const double* x0, int maxn, int* n_nodes, double* node_t, int* node_ev, int* node_mode, double* xs, double* us, double* perf) {
+  Oracle* o = (Oracle*)h; Vec x0v(x0, x0 + QM_NX);
+  SqpResult prev = o->R; o->R = SqpResult();
+  try { ilqrIteration(o->P, t0, tf, x0v, o->R, warm ? &prev : nullptr); } catch (const std::exception&) { return -2; }
+  const SqpResult& R = o->R; if (R.status != 0) return R.status; const int n = (int)R.grid.size(); if (n > maxn) return -1;
   *n_nodes = n;
   for (int i = 0; i < n; ++i) { node_t[i] = R.grid[i].t; node_ev[i] = R.grid[i].ev; node_mode[i] = R.mode[i]; std::memcpy(xs + QM_NX * i, R.x[i].data(), QM_NX * 8); std::memcpy(us + QM_NU * i, R.u[i].data(), QM_NU * 8); }
   const Performance* pf[2] = {&R.baseline, &R.after};

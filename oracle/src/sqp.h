@@ -180,6 +180,47 @@ inline Performance computePerformance(const Problem& P, const std::vector<Node>&
 
 inline double trajectoryNorm(const std::vector<Vec>& v) { double s = 0; for (auto& a : v) for (double z : a) s += z * z; return std::sqrt(s); }
 
+// QP sub-problem of the projected LQ model: Riccati backward sweep (feedback gains K, feed-forward kff per node) and the LINEAR forward rollout
+// (dx, du, Armijo descent metric).  Shared by the SQP iteration and the discrete iLQR iteration.  
+inline bool riccatiSolve(SqpResult& R, const Vec& x0, const std::vector<Vec>& x) {
+  const int N = (int)R.grid.size() - 1;
+  // ---- QP solve: Riccati (SURVEY.md B.6 step 4) ----
+  Mat S = R.terminal.Qp; Vec s = R.terminal.qp;
+  for (int k = N - 1; k >= 0; --k) {
+    NodeLQ& n = R.lq[k];
+    Vec Sb = matvec(S, n.bp); Vec spSb = vadd(s, Sb);
+    Mat SA = matmul(S, n.Ap);
+    if (n.event) { S = matmulTN(n.Ap, SA); s = matvecT(n.Ap, spSb); }
+    else {
+      Mat BtS = matmulTN(n.Bp, S);
+      Mat Huu = add(n.Rp, matmul(BtS, n.Bp));
+      Mat Hux = add(n.Pp, matmul(BtS, n.Ap));
+      Vec hu = vadd(n.rp, matvecT(n.Bp, spSb));
+      for (int i = 0; i < Huu.r; ++i) for (int j = i + 1; j < Huu.c; ++j) { const double a = 0.5 * (Huu(i, j) + Huu(j, i)); Huu(i, j) = Huu(j, i) = a; }
+      Mat L; if (!cholesky(Huu, L)) { R.status = -2; return false; }
+      n.K = scaled(cholSolve(L, Hux), -1.0); n.kff = vscaled(cholSolve(L, hu), -1.0);
+      Mat Snew = add(add(n.Qp, matmulTN(n.Ap, SA)), matmulTN(Hux, n.K));
+      for (int i = 0; i < QM_NX; ++i) for (int j = i + 1; j < QM_NX; ++j) { const double a = 0.5 * (Snew(i, j) + Snew(j, i)); Snew(i, j) = Snew(j, i) = a; }
+      s = vadd(vadd(n.qp, matvecT(n.Ap, spSb)), matvecT(Hux, n.kff));
+      S = Snew;
+    }
+  }
+  R.dx.assign(N + 1, Vec(QM_NX, 0.0)); R.du.assign(N, Vec(QM_NU, 0.0));
+  for (int k = 0; k < QM_NX; ++k) R.dx[0][k] = x0[k] - x[0][k];
+  double armijo = 0;
+  for (int k = 0; k < N; ++k) {
+    NodeLQ& n = R.lq[k];
+    if (n.event) { R.dx[k + 1] = vadd(matvec(n.Ap, R.dx[k]), n.bp); armijo += vdot(n.qp, R.dx[k]); continue; }
+    Vec ut = vadd(matvec(n.K, R.dx[k]), n.kff);
+    R.dx[k + 1] = vadd(vadd(matvec(n.Ap, R.dx[k]), matvec(n.Bp, ut)), n.bp);
+    armijo += vdot(n.qp, R.dx[k]) + vdot(n.rp, ut);
+    R.du[k] = vadd(vadd(n.Pe, matvec(n.Px, R.dx[k])), matvec(n.Pu, ut));   // remapProjectedInput
+  }
+  armijo += vdot(R.terminal.qp, R.dx[N]);
+  R.armijo = armijo;
+  return true;
+}
+
 struct SqpResult;
 inline void evaluatePolicy(const SqpResult& R, const ModeSchedule& ms, double t, Vec& x, Vec& u, int& mode);
 
@@ -238,40 +279,8 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
   { double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = x0[k] - x[0][k]; s += d * d; } base.dynSSE += s; }
   base.merit = base.cost; R.baseline = base;
   const auto tq1 = std::chrono::steady_clock::now();
-  // ---- QP solve: Riccati (SURVEY.md B.6 step 4) ----
-  Mat S = R.terminal.Qp; Vec s = R.terminal.qp;
-  for (int k = N - 1; k >= 0; --k) {
-    NodeLQ& n = R.lq[k];
-    Vec Sb = matvec(S, n.bp); Vec spSb = vadd(s, Sb);
-    Mat SA = matmul(S, n.Ap);
-    if (n.event) { S = matmulTN(n.Ap, SA); s = matvecT(n.Ap, spSb); }
-    else {
-      Mat BtS = matmulTN(n.Bp, S);
-      Mat Huu = add(n.Rp, matmul(BtS, n.Bp));
-      Mat Hux = add(n.Pp, matmul(BtS, n.Ap));
-      Vec hu = vadd(n.rp, matvecT(n.Bp, spSb));
-      for (int i = 0; i < Huu.r; ++i) for (int j = i + 1; j < Huu.c; ++j) { const double a = 0.5 * (Huu(i, j) + Huu(j, i)); Huu(i, j) = Huu(j, i) = a; }
-      Mat L; if (!cholesky(Huu, L)) { R.status = -2; return; }
-      n.K = scaled(cholSolve(L, Hux), -1.0); n.kff = vscaled(cholSolve(L, hu), -1.0);
-      Mat Snew = add(add(n.Qp, matmulTN(n.Ap, SA)), matmulTN(Hux, n.K));
-      for (int i = 0; i < QM_NX; ++i) for (int j = i + 1; j < QM_NX; ++j) { const double a = 0.5 * (Snew(i, j) + Snew(j, i)); Snew(i, j) = Snew(j, i) = a; }
-      s = vadd(vadd(n.qp, matvecT(n.Ap, spSb)), matvecT(Hux, n.kff));
-      S = Snew;
-    }
-  }
-  R.dx.assign(N + 1, Vec(QM_NX, 0.0)); R.du.assign(N, Vec(QM_NU, 0.0));
-  for (int k = 0; k < QM_NX; ++k) R.dx[0][k] = x0[k] - x[0][k];
-  double armijo = 0;
-  for (int k = 0; k < N; ++k) {
-    NodeLQ& n = R.lq[k];
-    if (n.event) { R.dx[k + 1] = vadd(matvec(n.Ap, R.dx[k]), n.bp); armijo += vdot(n.qp, R.dx[k]); continue; }
-    Vec ut = vadd(matvec(n.K, R.dx[k]), n.kff);
-    R.dx[k + 1] = vadd(vadd(matvec(n.Ap, R.dx[k]), matvec(n.Bp, ut)), n.bp);
-    armijo += vdot(n.qp, R.dx[k]) + vdot(n.rp, ut);
-    R.du[k] = vadd(vadd(n.Pe, matvec(n.Px, R.dx[k])), matvec(n.Pu, ut));   // remapProjectedInput
-  }
-  armijo += vdot(R.terminal.qp, R.dx[N]);
-  R.armijo = armijo;
+  if (!riccatiSolve(R, x0, x)) return;
+  const double armijo = R.armijo;
   const auto tq2 = std::chrono::steady_clock::now();
   // ---- takeStep: filter line-search ----
   const double gMax = st[ST_G_MAX], gMin = st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;

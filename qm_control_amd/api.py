@@ -22,7 +22,7 @@ EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_la
            "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_update_references", "qmhip_mpc_solve_resident_warm",
            "qmhip_mpc_advance_resident", "qmhip_closed_loop_resident", "qmhip_mpc_download", "qmhip_policy_eval",
            "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
-           "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_debug_get", "qmhip_microbench_fp64",
+           "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_debug_get", "qmhip_debug_filler", "qmhip_debug_lq_with_filler", "qmhip_microbench_fp64",
            "qmhip_gait_set_templates", "qmhip_gait_reset", "qmhip_gait_insert_template", "qmhip_gait_update_resident", "qmhip_gait_download", "qmhip_schedule_download",
            "qmhip_target_reset", "qmhip_target_from_command", "qmhip_target_download",
            "qmhip_sim_set_params", "qmhip_sim_set_controller", "qmhip_sim_reset", "qmhip_sim_set_command", "qmhip_sim_step", "qmhip_sim_get_state", "qmhip_closed_loop_sim", "qmhip_closed_loop_sim_pipelined"]
@@ -146,6 +146,16 @@ class QMInterface:
 
     def debug_set(self, key, value):
         self._check(self.lib.qmhip_debug_set(self.h, key.encode(), C.c_int(value)), "qmhip_debug_set")
+
+    def debug_filler(self, waves, iters, wait=True):
+        ms = C.c_double(0)
+        self._check(self.lib.qmhip_debug_filler(self.h, int(waves), int(iters), int(bool(wait)), C.byref(ms)), "qmhip_debug_filler")
+        return ms.value
+
+    def debug_lq_with_filler(self, B, horizon, waves, iters):
+        ms = (C.c_double * 3)()
+        self._check(self.lib.qmhip_debug_lq_with_filler(self.h, int(B), C.c_double(horizon), int(waves), int(iters), ms), "qmhip_debug_lq_with_filler")
+        return list(ms)
 
     def debug_get(self, key):
         v = C.c_int(0)

@@ -12,11 +12,13 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <vector>
 #include "../kernels/k_grid.h"
 #include "../kernels/k_lq.h"
 #include "../kernels/k_riccati.h"
 #include "../kernels/k_ls.h"
+#include "../kernels/k_ilqr.h"
 
 struct QmMpcBuffers {
   int Bmax = 0, nmax = 0, nref = 0, nev = 0;
@@ -31,6 +33,7 @@ struct QmMpcBuffers {
   double* x = nullptr; double* u = nullptr; double* dx = nullptr; double* du = nullptr; double* stage = nullptr; double* lqdbg = nullptr; double* kin = nullptr;
   double* perf = nullptr; double* base_sum = nullptr; double* perf_sum = nullptr; double* step_info = nullptr;
   double* alpha = nullptr; int* done = nullptr; double* xs = nullptr; double* us = nullptr; double* out_perf = nullptr;
+  double* xt = nullptr; double* ut = nullptr;   // iLQR trial rollouts [nmax][B][30] (allocated on first use)
   // grid of the solve that produced (xs, us): the warm start of the next solve interpolates on it
   int* prev_n = nullptr; double* prev_t = nullptr; int* prev_ev = nullptr;
   // line search: instances still searching after trial t (device counters + their host-visible copy)
@@ -45,9 +48,11 @@ struct QmMpcPipeline {
   int ls_trials_run = 0;
   int riccati_skip = 0;   // profiling only
   int lq_prof = 0;        // profiling only
+  int solver = 0;         // 0: multiple-shooting SQP (the reference's SqpMpc), 1: discrete iLQR (settings slot ST_SOLVER)
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
   bool ncap_pending = false;   // K0 has been launched and its count not been read yet
+  std::function<void()> before_lq;   // profiling only (co-residency probe): called right before the LQ kernel is launched
   const int* front_status = nullptr; int front_B = 0;   // sticky status of the device-resident GaitSchedule driving batches of front_B instances (null: schedules come from the host)
   explicit QmMpcPipeline(BK& b) : bk(b) {}
 
@@ -73,7 +78,7 @@ struct QmMpcPipeline {
   }
   void release() {
     void* ps[] = {d.mb, d.st, d.t0, d.x0, d.ref_t, d.ref_x, d.ev, d.modes, d.n_nodes, d.node_t, d.node_ts, d.node_dt, d.node_ev, d.node_mode, d.zvel, d.zpos, d.xref, d.eeref, d.status,
-                  d.x, d.u, d.dx, d.du, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev, d.open_cnt, d.tickets, d.ncap_dev};
+                  d.x, d.u, d.dx, d.du, d.xt, d.ut, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev, d.open_cnt, d.tickets, d.ncap_dev};
     for (void* p : ps) if (p) bk.free(p);
     if (d.host_open) bk.free_mapped((void*)d.host_open);
     if (d.host_ncap) bk.free_mapped((void*)d.host_ncap);
@@ -90,7 +95,7 @@ struct QmMpcPipeline {
   QmLsArgs ls_args(int B) {
     QmLsArgs a; a.mb = d.mb; a.st = d.st; a.B = B; a.nmax = d.nmax; a.n_nodes = d.n_nodes; a.node_ts = d.node_ts; a.node_dt = d.node_dt; a.node_ev = d.node_ev; a.node_mode = d.node_mode;
     a.zvel = d.zvel; a.zpos = d.zpos; a.xref = d.xref; a.eeref = d.eeref; a.x0 = d.x0; a.x = d.x; a.u = d.u; a.dx = d.dx; a.du = d.du; a.alpha = d.alpha; a.done = d.done;
-    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.with_alpha = 0; a.open_cnt = d.open_cnt; a.tickets = d.tickets; a.host_open = (volatile int*)d.host_open_dev;
+    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.with_alpha = 0; a.open_cnt = d.open_cnt; a.tickets = d.tickets; a.host_open = (volatile int*)d.host_open_dev; a.xt = nullptr; a.ut = nullptr; a.ilqr = 0;
     return a;
   }
 
@@ -117,20 +122,27 @@ struct QmMpcPipeline {
   // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min).  `last`: no further iteration of this solve
   // follows, so the accepted step only has to reach the primal solution (xs, us), not the iterate (x, u) — the next solve starts from xs / us or cold
   void sqp_iteration(int B, int max_trials = 14, bool last = false) {
+    const bool ilqr = solver == 1;
+    if (ilqr && !d.xt) { d.xt = A<double>((size_t)d.nmax * d.Bmax * 30); d.ut = A<double>((size_t)d.nmax * d.Bmax * 30); }
+    QmRolloutArgs ro; ro.mb = d.mb; ro.st = d.st; ro.B = B; ro.nmax = d.nmax; ro.mode = 0; ro.trial = 0; ro.n_nodes = d.n_nodes; ro.node_dt = d.node_dt; ro.node_ev = d.node_ev; ro.x0 = d.x0;
+    ro.x = d.x; ro.u = d.u; ro.stage = d.stage; ro.alpha = d.alpha; ro.done = d.done; ro.xt = d.xt; ro.ut = d.ut;
+    if (ilqr) bk.launch(qm_ilqr_rollout_kernel, (B + 63) / 64, 64, 0, ro);      // single shooting: the nominal states are the rollout of the initial inputs
     if (ncap == 0) { if (ncap_pending) bk.wait_flag(d.host_ncap, -1); ncap = ncap_pending ? d.host_ncap[0] : d.nmax; ncap_pending = false; if (ncap < 1 || ncap > d.nmax) ncap = d.nmax; }   // K0 ran first in the stream: published long before K1a is done
     const int nodes_threads = ncap * B;
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof; q.ncap = ncap;
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, LQ_KIN_LDS_BYTES, q);
+    if (before_lq) before_lq();
     bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node; an empty workgroup costs the dispatcher as much as a full one
-    QmLsArgs l = ls_args(B);
+    QmLsArgs l = ls_args(B); if (ilqr) { l.xt = d.xt; l.ut = d.ut; l.ilqr = 1; }
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
     r.perf = d.perf; r.base_sum = d.base_sum; r.alpha = d.alpha; r.done = d.done; r.out_perf = d.out_perf; r.open_cnt = d.open_cnt; r.tickets = d.tickets;   // baseline merit + arming of the line search
     bk.launch(qm_riccati_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // one wavefront per instance
     ls_trials_run = 0;
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;
+      if (ilqr) { ro.mode = 1; ro.trial = t; bk.launch(qm_ilqr_rollout_kernel, (B + 63) / 64, 64, 0, ro); }      // nonlinear rollout with feedback at the instance's step length
       bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching
       ++ls_trials_run;

@@ -34,7 +34,7 @@ struct HipBackend {
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
     if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel) return "riccati";
-    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy";
+    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_ilqr_rollout_kernel) return "rollout"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy";
     return "ls_misc";
   }
   template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {
@@ -112,6 +112,24 @@ __global__ void qm_bench_mfma_kernel(double* out, int iters) {
 // settings whose value the kernels' loop bounds depend on (K0 walks t0 + k dt up to the horizon)
 static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT) return v > 0.0 && std::isfinite(v); return true; }
 
+// ---- co-residency probe (profiling only): a latency-bound stand-in for a narrow (<= 256 VGPR, <= 20 KB LDS) one-wave-per-instance solver wave — chains of
+// dependent f64 MFMAs and FMAs with an LDS round trip per step, ≈ 40 % issue utilisation like qm_riccati_kernel — launched on the second stream beside the
+// MPC kernels to measure what sharing SIMDs with the issue-bound LQ kernel is worth before restructuring the real kernel (tools/coresidency_probe.py)
+__global__ void __launch_bounds__(64, 2) qm_filler_kernel(double* out, int iters) {
+  extern __shared__ double qm_smem[];
+  const int l = threadIdx.x & 63;
+  qm_d4 acc = {0.0, 0.0, 0.0, 0.0}; double a = 1.0 + l * 1e-9, b = 1e-9, f = 1.0;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0); a = acc[0] * 1e-30 + 1.0; }      // dependent matrix-core chain
+#pragma unroll
+    for (int k = 0; k < 12; ++k) f = fma(f, 1.0000001, acc[k & 3] * 1e-30);                                                     // dependent vector chain
+    qm_smem[(l * 7 + i) & 2047] = f; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    f += qm_smem[(l * 13 + i + 1) & 2047];                                                                                     // LDS round trip
+  }
+  out[blockIdx.x * 64 + l] = f + acc[1];
+}
+
 static int create_common(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
   if (!out || max_batch <= 0 || max_nodes < 3 || max_nodes > RW_MAXNODES || max_ref < 1 || max_ev < 1) { g_create_error = "qmhip_create: bad argument (max_nodes must be in [3, 512])"; return QMHIP_ERR_ARG; }
   std::string err; if (!qmio::validateModelBlob(mb, err)) { g_create_error = err; return QMHIP_ERR_MODEL; }
@@ -123,7 +141,7 @@ static int create_common(const double* mb, const double* st, int device, int max
   memcpy(c->mb, mb, sizeof(c->mb)); memcpy(c->st, st, sizeof(c->st));
   if (hipStreamCreate(&c->bk.stream) != hipSuccess || hipStreamCreate(&c->bk.stream_b) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
   c->bk.cur = c->bk.stream; hipEventCreateWithFlags(&c->bk.ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->bk.ev_wbc, hipEventDisableTiming);
-  c->mpc.allocate(c->mb, c->st, max_batch, max_nodes, max_ref, max_ev, false);
+  c->mpc.allocate(c->mb, c->st, max_batch, max_nodes, max_ref, max_ev, false); c->mpc.solver = ((int)st[ST_SOLVER] == 1) ? 1 : 0;
   c->wbc.allocate(max_batch);
   c->front.allocate(max_batch);
   c->bk.sync();
@@ -161,6 +179,7 @@ int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { if (!c) ret
 int qmhip_set_setting(qmhip_ctx* c, int idx, double v) {
   if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
   if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt must be a positive finite number"); return QMHIP_ERR_ARG; }
+  if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP) or 1 (discrete iLQR)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
   hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
 }
 
@@ -385,6 +404,46 @@ int qmhip_reset_kernel_ms(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; c->bk.re
 int qmhip_synchronize(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
 int qmhip_last_ls_trials(const qmhip_ctx* c) { return c ? c->mpc.ls_trials_run : -1; }
 int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; } return QMHIP_ERR_ARG; }
+// profiling only: `waves` filler waves of `iters` steps on the second stream (see qm_filler_kernel); *ms (may be null) = its duration when waited for
+// profiling only: one MPC iteration of the resident batch with the filler started on the second stream right when the LQ kernel starts; ms[0] = LQ kernel,
+// ms[1] = filler, ms[2] = both (first start to last end), all from HIP events
+int qmhip_debug_lq_with_filler(qmhip_ctx* c, int B, double horizon, int waves, int iters, double* ms) {
+  if (!c || B <= 0 || B > c->max_batch || !ms) return QMHIP_ERR_ARG; hipSetDevice(c->device);
+  static double* out = nullptr; static int cap = 0;
+  if (waves > 0 && cap < waves) { if (out) hipFree(out); if (hipMalloc(&out, (size_t)waves * 64 * 8) != hipSuccess) return QMHIP_ERR_HIP; cap = waves; }
+  hipEvent_t a0, a1, b0, b1; hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
+  c->bk.sync();
+  c->mpc.before_lq = [&]() {
+    hipEventRecord(a0, c->bk.stream); hipStreamWaitEvent(c->bk.stream_b, a0, 0);      // the filler starts when everything before the LQ kernel is done
+    hipEventRecord(b0, c->bk.stream_b);
+    if (waves > 0) hipLaunchKernelGGL(qm_filler_kernel, dim3(waves), dim3(64), 20 * 1024, c->bk.stream_b, out, iters);
+    hipEventRecord(b1, c->bk.stream_b);
+    c->mpc.before_lq = [&]() {};                                                       // (re-armed below: the hook fires once per sqp iteration)
+  };
+  auto lq_done = [&]() {};
+  c->mpc.grid(B, horizon);
+  // one iteration; a1 is recorded by wrapping: the Riccati launch follows the LQ launch on the same stream, so record right after sqp_iteration's LQ launch is not
+  // reachable from here — use kernel spans instead
+  const int prof = c->bk.profiling; c->bk.resolve(); c->bk.acc.clear(); c->bk.profiling = 1;
+  c->mpc.sqp_iteration(B, 14, true);
+  c->bk.sync(); c->bk.resolve(); c->bk.profiling = prof; c->mpc.before_lq = nullptr;
+  float fb = 0; hipEventElapsedTime(&fb, b0, b1);
+  ms[0] = c->bk.acc["lq"].first; ms[1] = fb; ms[2] = c->bk.acc["riccati"].first;
+  hipEventDestroy(a0); hipEventDestroy(a1); hipEventDestroy(b0); hipEventDestroy(b1); (void)lq_done;
+  return c->hipstate();
+}
+int qmhip_debug_filler(qmhip_ctx* c, int waves, int iters, int wait, double* ms) {
+  if (!c || waves <= 0 || iters <= 0) return QMHIP_ERR_ARG; hipSetDevice(c->device);
+  static double* out = nullptr; static int cap = 0;
+  if (cap < waves) { if (out) hipFree(out); if (hipMalloc(&out, (size_t)waves * 64 * 8) != hipSuccess) return QMHIP_ERR_HIP; cap = waves; }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, c->bk.stream_b);
+  hipLaunchKernelGGL(qm_filler_kernel, dim3(waves), dim3(64), 20 * 1024, c->bk.stream_b, out, iters);
+  hipEventRecord(e1, c->bk.stream_b);
+  if (wait) { hipEventSynchronize(e1); float f = 0; hipEventElapsedTime(&f, e0, e1); if (ms) *ms = f; }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  return c->hipstate();
+}
 int qmhip_debug_get(const qmhip_ctx* c, const char* key, int* value) {
   if (!c || !key || !value) return QMHIP_ERR_ARG;
   if (!strcmp(key, "riccati_skip")) { *value = c->mpc.riccati_skip; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { *value = c->wbc.wbc_stop; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { *value = c->mpc.lq_prof; return QMHIP_OK; }

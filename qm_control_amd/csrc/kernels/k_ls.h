@@ -30,6 +30,9 @@ struct QmLsArgs {
   int with_alpha;                       // perf_sum: 1 = initial-state defect of the trial iterate, 0 = of the base iterate
   int* open_cnt; int* tickets;          // [QM_LS_MAX_TRIALS] instances still searching after trial t / blocks that have passed; zeroed by the baseline sum
   volatile int* host_open;              // [QM_LS_MAX_TRIALS] host-visible copy of open_cnt[t], written by the last block of trial t (the host never copies flags)
+  // discrete iLQR (k_ilqr.h): the trial trajectory is a nonlinear ROLLOUT held in xt / ut (null for the SQP, whose trial point is x + alpha dx, u + alpha du);
+  // merit = cost + rho sqrt(eqSSE), accepted when merit(a) < merit(0) + 1e-4 a armijo, a halved down to ddp.lineSearch.minStepLength
+  const double* xt; const double* ut; int ilqr;
 };
 #define QM_LS_MAX_TRIALS 16
 #define LS_EVAL_LDS_BYTES (3 * 64 * 31 * 8)   /* qm_ls_eval_kernel: three 31-double rows per thread */
@@ -84,7 +87,8 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   extern __shared__ double qm_smem[]; double* qm_ls_u = qm_smem;   // LS_EVAL_LDS_BYTES: [0] the trial input, [1] u − u_nominal of the input cost: the trial input of this thread's node: a per-thread LDS row instead of registers (see qm_lq_kin_kernel)
   double x[30], K[KW_SIZE]; double* u = qm_ls_u + (threadIdx.x & 63) * 31;
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
+  if (a.xt) { _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.xt[nb * 30 + q]; }
+  else { _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q]; }
   double* pf = a.perf + (size_t)nb * PF_SIZE;
   const int ev = a.node_ev[nb];
   if (i == n - 1) {
@@ -94,10 +98,11 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   }
   const int nbn = (i + 1) * a.B + b;
   if (ev == QM_EV_PRE) {
-    double s = 0.0; _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double d = x[q] - (a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]); s += d * d; }
+    double s = 0.0; _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double xnq = a.xt ? a.xt[nbn * 30 + q] : a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]; const double d = x[q] - xnq; s += d * d; }
     pf[0] = 0.0; pf[1] = s; pf[2] = 0.0; return;
   }
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q] + al * a.du[nb * 30 + q];
+  if (a.ut) { _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.ut[nb * 30 + q]; }
+  else { _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q] + al * a.du[nb * 30 + q]; }
   const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
   kin_base(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x, u, K); kin_arm(mb, x, K);
   // a zero-length interval contributes neither cost nor constraint residual and needs no second Heun stage; besides skipping work, the guards
@@ -113,7 +118,7 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
     flow_from_kin(mb, x2, u, K, f2);
   }
   double s = 0.0;
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double d = x[q] + 0.5 * dt * f1[q] + 0.5 * dt * f2[q] - (a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]); s += d * d; }
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double xnq = a.xt ? a.xt[nbn * 30 + q] : a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]; const double d = x[q] + 0.5 * dt * f1[q] + 0.5 * dt * f2[q] - xnq; s += d * d; }
   pf[0] = cost * dt; pf[1] = dt * s; pf[2] = dt * eq;
 }
 
@@ -128,7 +133,7 @@ __device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b,
   const int n = a.n_nodes[b]; double c = 0.0, d = 0.0, e = 0.0;
   for (int i = l; i < n; i += 64) { const double* pf = a.perf + (size_t)(i * a.B + b) * PF_SIZE; c += pf[0]; d += pf[1]; e += pf[2]; }
   const double al0 = with_alpha ? a.alpha[b] : 0.0;
-  if (l < 30) { const double dd = a.x0[(size_t)b * 30 + l] - (a.x[b * 30 + l] + al0 * a.dx[b * 30 + l]); d += dd * dd; }
+  if (l < 30) { const double x0t = (with_alpha && a.xt) ? a.xt[b * 30 + l] : a.x[b * 30 + l] + al0 * a.dx[b * 30 + l]; const double dd = a.x0[(size_t)b * 30 + l] - x0t; d += dd * dd; }
   c = qm_wave_sum(c); d = qm_wave_sum(d); e = qm_wave_sum(e);
   if (l != 0) return false;
   a.perf_sum[b * 4] = c; a.perf_sum[b * 4 + 1] = c; a.perf_sum[b * 4 + 2] = d; a.perf_sum[b * 4 + 3] = e;
@@ -139,6 +144,15 @@ __device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b,
     return false;
   }
   if (a.trial == 0) a.out_perf[b * 10 + 9] = a.step_info[b * 4];
+  if (a.ilqr) {
+    const double rho = a.st[ST_DDP_PENALTY]; const double* bs0 = a.base_sum + b * 4; const double armijo0 = a.step_info[b * 4];
+    const double m0 = bs0[1] + rho * sqrt(bs0[3]), mt = c + rho * sqrt(e);
+    if (a.trial == 0) { a.out_perf[b * 10] = m0; a.out_perf[b * 10 + 4] = m0; }                       // (the Riccati prologue wrote the SQP's merit = cost)
+    if (mt < m0 + 1e-4 * al0 * armijo0) { a.done[b] = 1; a.out_perf[b * 10 + 4] = mt; a.out_perf[b * 10 + 5] = c; a.out_perf[b * 10 + 6] = d; a.out_perf[b * 10 + 7] = e; a.out_perf[b * 10 + 8] = al0; return false; }
+    const double an = al0 * 0.5;
+    if (!(an >= a.st[ST_DDP_MIN_STEP])) { a.done[b] = 2; a.alpha[b] = 0.0; return false; }
+    a.alpha[b] = an; return true;
+  }
   const double gMax = a.st[ST_G_MAX], gMin = a.st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
   const double* bs = a.base_sum + b * 4; const double ps[4] = {c, c, d, e};
   const double theta0 = sqrt(bs[2] + bs[3]), theta = sqrt(ps[2] + ps[3]);
@@ -176,14 +190,14 @@ __global__ void qm_ls_apply_kernel(QmLsArgs a) {
   const int i = nb / a.B, b = nb - i * a.B;
   if (i >= a.nmax) return;
   const int n = a.n_nodes[b]; if (i >= n) return;
-  const double al = (a.done[b] == 1) ? a.alpha[b] : 0.0;
-  a.xs[nb * 30 + q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
+  const double al = (a.done[b] == 1) ? a.alpha[b] : 0.0; const bool tr = a.xt && a.done[b] == 1;       // iLQR: the accepted rollout IS the new trajectory
+  a.xs[nb * 30 + q] = tr ? a.xt[nb * 30 + q] : a.x[nb * 30 + q] + al * a.dx[nb * 30 + q];
   // input of the primal solution: own node, or the closest earlier non-event node
   int j = (i == n - 1) ? n - 2 : i;
   if (j < 0) j = 0;                                          // one-node grid (degenerate horizon, K0 status -1): no interval, no input
   while (j > 0 && a.node_ev[j * a.B + b] == QM_EV_PRE) --j;
   const int jb = j * a.B + b; const bool evj = (a.node_ev[jb] == QM_EV_PRE) || n < 2;
-  a.us[nb * 30 + q] = evj ? 0.0 : a.u[jb * 30 + q] + al * a.du[jb * 30 + q];
+  a.us[nb * 30 + q] = evj ? 0.0 : (tr ? a.ut[jb * 30 + q] : a.u[jb * 30 + q] + al * a.du[jb * 30 + q]);
 }
 // commit the accepted step into the iterate (separate launch: apply reads neighbours' u)
 __global__ void qm_ls_commit_kernel(QmLsArgs a) {
@@ -194,5 +208,6 @@ __global__ void qm_ls_commit_kernel(QmLsArgs a) {
   const int n = a.n_nodes[b]; if (i >= n) return;
   const double al = (a.done[b] == 1) ? a.alpha[b] : 0.0;
   const bool hasu = (i < n - 1) && a.node_ev[nb] != QM_EV_PRE;
+  if (a.xt) { if (a.done[b] == 1) { a.x[nb * 30 + q] = a.xt[nb * 30 + q]; if (hasu) a.u[nb * 30 + q] = a.ut[nb * 30 + q]; } return; }
   a.x[nb * 30 + q] += al * a.dx[nb * 30 + q]; if (hasu) a.u[nb * 30 + q] += al * a.du[nb * 30 + q];
 }
