@@ -86,6 +86,9 @@ struct qmhip_ctx {
   double mb[MB_SIZE], st[ST_SIZE];
   HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc; QmFrontPipeline<HipBackend> front; QmSimPipeline<HipBackend> sim;
   std::string error; int lastB = 0; bool have_solution = false; int front_B = 0; long sim_ticks = 0;
+  double* filler_out = nullptr; int filler_cap = 0;      // output of the profiling-only filler kernel (co-residency probe)
+  bool filler_buffer(int waves) { if (filler_cap >= waves) return true; if (filler_out) hipFree(filler_out); filler_out = nullptr; filler_cap = 0;
+                                  if (hipMalloc(&filler_out, (size_t)waves * 64 * 8) != hipSuccess) return false; filler_cap = waves; return true; }
   qmhip_ctx() : mpc(bk), wbc(bk), front(bk), sim(bk) {}
   void fail(const std::string& m) { error = m; }
   // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
@@ -171,7 +174,7 @@ int qmhip_create_from_blobs(const double* mb, const double* st, int device, int 
   return create_common(mb, st, device, max_batch, max_nodes, max_ref, max_ev, out);
 }
 void qmhip_destroy(qmhip_ctx* c) {
-  if (!c) return; hipSetDevice(c->device); c->bk.sync(); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release();
+  if (!c) return; hipSetDevice(c->device); c->bk.sync(); if (c->filler_out) hipFree(c->filler_out); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release();
   for (auto e : c->bk.pool) hipEventDestroy(e); if (c->bk.ev_order) hipEventDestroy(c->bk.ev_order); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
 }
 const char* qmhip_last_error(const qmhip_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
@@ -409,8 +412,8 @@ int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { if (!c || !key) 
 // ms[1] = filler, ms[2] = both (first start to last end), all from HIP events
 int qmhip_debug_lq_with_filler(qmhip_ctx* c, int B, double horizon, int waves, int iters, double* ms) {
   if (!c || B <= 0 || B > c->max_batch || !ms) return QMHIP_ERR_ARG; hipSetDevice(c->device);
-  static double* out = nullptr; static int cap = 0;
-  if (waves > 0 && cap < waves) { if (out) hipFree(out); if (hipMalloc(&out, (size_t)waves * 64 * 8) != hipSuccess) return QMHIP_ERR_HIP; cap = waves; }
+  if (waves > 0 && !c->filler_buffer(waves)) { c->fail("hipMalloc of the filler buffer failed"); return QMHIP_ERR_HIP; }
+  double* out = c->filler_out;
   hipEvent_t a0, a1, b0, b1; hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
   c->bk.sync();
   c->mpc.before_lq = [&]() {
@@ -434,8 +437,8 @@ int qmhip_debug_lq_with_filler(qmhip_ctx* c, int B, double horizon, int waves, i
 }
 int qmhip_debug_filler(qmhip_ctx* c, int waves, int iters, int wait, double* ms) {
   if (!c || waves <= 0 || iters <= 0) return QMHIP_ERR_ARG; hipSetDevice(c->device);
-  static double* out = nullptr; static int cap = 0;
-  if (cap < waves) { if (out) hipFree(out); if (hipMalloc(&out, (size_t)waves * 64 * 8) != hipSuccess) return QMHIP_ERR_HIP; cap = waves; }
+  if (!c->filler_buffer(waves)) { c->fail("hipMalloc of the filler buffer failed"); return QMHIP_ERR_HIP; }
+  double* out = c->filler_out;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, c->bk.stream_b);
   hipLaunchKernelGGL(qm_filler_kernel, dim3(waves), dim3(64), 20 * 1024, c->bk.stream_b, out, iters);

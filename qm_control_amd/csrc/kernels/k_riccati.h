@@ -151,6 +151,49 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsel[I][r] = 1.0;
     RWT(2)
+    if constexpr (MT == 1) {
+      // ---- m <= 16: BLOCKED elimination, four pivots at a time.  Rows 4b .. 4b+3 of a D-layout tile are register b of the four lane groups, i.e. exactly the four
+      // k-slots of an MFMA B operand.  Per block: the 4 x 4 diagonal block is read with v_readlane and factored as L~ Δ L~ᵀ in wave-uniform scalars (one reciprocal chain
+      // per pivot); then ONE MFMA per tile replaces the block rows by L~⁻¹ (block rows) (A = L~⁻¹ − I on the block's rows) and ONE more subtracts
+      // Σ_k (R'[k][row] / d_k) R'[k] from the trailing rows (A = −R'ᵀ Δ⁻¹ masked to rows behind the block) — 6 MFMAs with all four k-slots live instead of the
+      // 12 single-slot rank-1 MFMAs of four consecutive pivots, and one dependent chain per block instead of four.  Same representation as the pivot loop below:
+      // row j ends up as L_jj · (row j of Lᵀ resp. W).  Padding rows (>= m) get a unit diagonal: their pivots are 1, their rows stay zero.
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (g + 4 * r >= m && c == g + 4 * r) Huu[0][0][r] = 1.0;
+      auto recip = [](double d) { double x = __builtin_amdgcn_rcp(d); const double e = fma(-d, x, 1.0); return fma(fma(e, e, e), x, x); };   // 2^-24 estimate + one third-order step
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int c0 = 4 * b;
+        const double D00 = qm_bcast(Huu[0][0][b], c0), D01 = qm_bcast(Huu[0][0][b], c0 + 1), D02 = qm_bcast(Huu[0][0][b], c0 + 2), D03 = qm_bcast(Huu[0][0][b], c0 + 3);
+        const double D11 = qm_bcast(Huu[0][0][b], 16 + c0 + 1), D12 = qm_bcast(Huu[0][0][b], 16 + c0 + 2), D13 = qm_bcast(Huu[0][0][b], 16 + c0 + 3);
+        const double D22 = qm_bcast(Huu[0][0][b], 32 + c0 + 2), D23 = qm_bcast(Huu[0][0][b], 32 + c0 + 3), D33 = qm_bcast(Huu[0][0][b], 48 + c0 + 3);
+        const double d0 = D00, rd0 = recip(d0);
+        const double l10 = D01 * rd0, l20 = D02 * rd0, l30 = D03 * rd0;
+        const double d1 = fma(-l10, D01, D11), rd1 = recip(d1);
+        const double t12 = fma(-l20, D01, D12), t13 = fma(-l30, D01, D13);            // D12 − l20 l10 d0, D13 − l30 l10 d0
+        const double l21 = t12 * rd1, l31 = t13 * rd1;
+        const double d2 = fma(-l21, t12, fma(-l20, D02, D22)), rd2 = recip(d2);
+        const double t23 = fma(-l31, t12, fma(-l30, D02, D23));                        // D23 − l30 l20 d0 − l31 l21 d1
+        const double l32 = t23 * rd2;
+        const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, D03, D33))), rd3 = recip(d3);
+        if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) chol_fail = 1;
+        // L~⁻¹ (unit lower): strictly lower entries
+        const double M10 = -l10, M21 = -l21, M32 = -l32, M20 = fma(l21, l10, -l20), M31 = fma(l32, l21, -l31), M30 = -(l30 + l31 * M10 + l32 * M20);
+        const int ri = c - c0;                                                           // A[i = c][k = g]: row i of the tile against block row k
+        const double a1 = (ri == 1) ? ((g == 0) ? M10 : 0.0) : ((ri == 2) ? ((g == 0) ? M20 : ((g == 1) ? M21 : 0.0)) : ((ri == 3) ? ((g == 0) ? M30 : ((g == 1) ? M31 : ((g == 2) ? M32 : 0.0))) : 0.0));
+        Huu[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Huu[0][0][b], Huu[0][0], 0, 0, 0);
+        Hux[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Hux[0][0][b], Hux[0][0], 0, 0, 0);
+        Hux[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Hux[0][1][b], Hux[0][1], 0, 0, 0);
+        const double dg = (g == 0) ? d0 : ((g == 1) ? d1 : ((g == 2) ? d2 : d3)), rdg = (g == 0) ? rd0 : ((g == 1) ? rd1 : ((g == 2) ? rd2 : rd3));
+        dsel[0][b] = dg;
+        if (b < 3) {                                                                     // the last block has no trailing rows
+          const double a2 = (c > c0 + 3) ? -rdg * Huu[0][0][b] : 0.0;                    // −R'[k][row] / d_k for the rows behind the block
+          Huu[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Huu[0][0][b], Huu[0][0], 0, 0, 0);
+          Hux[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Hux[0][0][b], Hux[0][0], 0, 0, 0);
+          Hux[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Hux[0][1][b], Hux[0][1], 0, 0, 0);
+        }
+      }
+    } else {
     // The pivots run one step AHEAD of the matrix cores: d_{j+1} = H[j+1][j+1] − H[j][j+1]² / d_j is formed from two entries of the
     // not-yet-updated fragments, so its reciprocal chain overlaps the MFMAs of step j instead of waiting for their result.
     double djj = qm_bcast(Huu[0][0][0], 0);
@@ -193,6 +236,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
           Hux[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], Hux[0][1][r], Hux[1][1], 0, 0, 0);
         }
       }
+    }
     }
     double invr[MT][4];                                              // 1/L_jj = d_j^(-1/2) for this lane's rows: four independent chains
 #pragma unroll
