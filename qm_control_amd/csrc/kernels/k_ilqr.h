@@ -58,10 +58,10 @@ __global__ void __launch_bounds__(64) qm_ilqr_rollout_kernel(QmRolloutArgs a) {
     const double* rec = a.stage + ((size_t)b * a.nmax + i) * SR_SIZE;
     const int m = (int)rec[SR_SCAL]; const int md = (int)rec[SR_MODEF];
     double dxi[30]; for (int q = 0; q < 30; ++q) dxi[q] = xc[q] - a.x[nb * 30 + q];
-    // t = W dx + a y ;  Lᵀ v = t (the record holds Lᵀ's upper triangle, its diagonal as 1 / L_jj) ;  ũ = −v
-    double v[QM_MMAX];
-    for (int r = 0; r < QM_MMAX; ++r) { double s = 0.0; if (r < m) { s = al * rec[SR_KFF + r]; for (int q = 0; q < 30; ++q) s += rec[SR_PP + r * 30 + q] * dxi[q]; } v[r] = s; }
-    for (int r = QM_MMAX - 1; r >= 0; --r) if (r < m) { double s = v[r]; for (int c = r + 1; c < QM_MMAX; ++c) if (c < m) s -= rec[SR_RP + r * QM_MMAX + c] * v[c]; v[r] = s * rec[SR_RP + r * QM_MMAX + r]; }
+    // t = W dx + a y ;  v = L⁻ᵀ t (the record holds L⁻¹, lower triangle) ;  ũ = −v
+    double tv[QM_MMAX], v[QM_MMAX];
+    for (int r = 0; r < QM_MMAX; ++r) { double s = 0.0; if (r < m) { s = al * rec[SR_KFF + r]; for (int q = 0; q < 30; ++q) s += rec[SR_PP + r * 30 + q] * dxi[q]; } tv[r] = s; }
+    for (int r = 0; r < QM_MMAX; ++r) { double s = 0.0; for (int q = r; q < QM_MMAX; ++q) if (q < m) s += rec[SR_RP + q * QM_MMAX + r] * tv[q]; v[r] = s; }
     for (int r = 0; r < QM_MMAX; ++r) v[r] = (r < m) ? -v[r] : 0.0;
     // du = a Pe + Px dx + Pu ũ : Px has the 12 leg-joint-velocity rows; Pu's columns are unit vectors (stance force components, arm joint velocities) and one
     // 3 x 2 null-space block per swing leg (SR_SWG), in the column order K1b's projector uses (k_riccati.h forward rollout)

@@ -21,7 +21,7 @@
 // The operands of the NEXT stage are copied global -> LDS asynchronously (global_load_lds_dwordx4, 1 KB per wave instruction, no
 // VGPRs) while the current stage computes; a stage starts by pulling its fragments out of that buffer.
 //
-// The backward sweep leaves Lᵀ (in SR_RP; upper triangle, diagonal = 1/L_jj), W (in SR_PP) and y (in SR_KFF) in the stage record; the forward rollout
+// The backward sweep leaves L⁻¹ (in SR_RP; lower triangle), W (in SR_PP) and y (in SR_KFF) in the stage record; the forward rollout
 //   ut = −L⁻ᵀ (W dx + y),  dx+ = Ap dx + Bp ut + bp,  du = Px dx + Pu ut + Pe,  Armijo metric += qp·dx + rp·ut
 // streams the records once more with one matrix row per lane.
 #pragma once
@@ -44,15 +44,19 @@ struct QmRiccatiArgs {
 
 #define RW_BLOCK 64
 #define RW_TLD 34                 /* transposition buffer [32][34] */
-/* forward staging (aliases the backward buffers): rows padded so that one-row-per-lane reads are bank-conflict free */
-#define RF_A   0                  /* [30][31] Ap */
-#define RF_B   930                /* [30][19] Bp */
-#define RF_PX  1500               /* [12][31] Px rows 12..23 (the only non-zero ones: leg joint velocities) + one zero row */
-#define RF_PU  2430               /* [19] zeros (Pu itself is not fetched: identity columns and the swing blocks of RF_V) */
-#define RF_W   3000               /* [18][31] W  */
-#define RF_L   3558               /* [18][19] L (diagonal holds 1/L_jj) */
-#define RF_V   3900               /* bp(30) qp(30) rp(18) Pe(30) | y(18) | pad(2) swing blocks [4][6] (128..151) mode (152) dt (153) */
-#define RF_DUMP (RF_V + 156)      /* write-only slot for the lanes past the end of the fetch list */
+/* forward staging (aliases the backward buffers): two flat copies (double buffer) of the fields of a stage record the rollout reads, in the order of the fetch
+   list below, written by global_load_lds (no VGPR staging, 1 KB per wave instruction) one stage ahead of their use */
+#define RF_F0   0                 /* buffer of the even regular stages */
+#define RF_F1   1952              /* buffer of the odd ones */
+#define RF_ZERO 3904              /* [32] zeros: the row the lanes without a Px / Bp row read */
+#define RF_PUD  3936              /* [30][18] Pu as a dense matrix: unit columns per contact mode, the swing legs' 3x2 blocks refreshed per stage */
+/* offsets inside one buffer */
+#define RFO_A   0                 /* [12][30] Ap rows 0..11 */
+#define RFO_B   360               /* [12][18] Bp rows 0..11 */
+#define RFO_W   576               /* [18][30] W  */
+#define RFO_L   1116              /* [18][18] L⁻¹ (lower triangle) */
+#define RFO_PX  1440              /* [12][30] Px rows 12..23 (the only non-zero ones: leg joint velocities) */
+#define RFO_V   1800              /* bp(30) qp(30) rp(18) Pe(30) | y(18) | swing blocks [4][6] (126..149) mode (150) dt (151) */
 /* backward prefetch buffer (global_load_lds): a flat copy of record fields [0, 3204) = Ap Bp Qp Pp Rp and [4644, 4722) = bp qp rp of the
    NEXT regular stage, landing while the current stage computes; lives behind the 1200-double Cholesky / transposition buffer */
 #define RP_REC   1200
@@ -62,7 +66,7 @@ struct QmRiccatiArgs {
 #define RW_MAXNODES 512
 #define RW_LDS_DOUBLES (RF_LIST + RW_MAXNODES / 2)
 #define RW_LDS_BYTES (RW_LDS_DOUBLES * 8)
-#define RF_NLOAD 31               /* ceil((360 + 216 + 864 + 360 + 108 + 18 + 24 + 2) / 64) */
+#define RF_NLOAD 16               /* ceil((360 + 216 + 864 + 360 + 108 + 18 + 24 + 2) / 128): sixteen-byte units, 64 per wave instruction */
 
 template <int KT, int IT, int JT>
 __device__ __forceinline__ void rw_gemm_tn(const qm_d4 (&Z)[KT][IT], const qm_d4 (&Y)[KT][JT], qm_d4 (&P)[IT][JT], int ksteps, bool neg) { qm_gemm_tn<KT, IT, JT>(Z, Y, P, 0, ksteps, neg); }
@@ -151,92 +155,68 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsel[I][r] = 1.0;
     RWT(2)
-    if constexpr (MT == 1) {
-      // ---- m <= 16: BLOCKED elimination, four pivots at a time.  Rows 4b .. 4b+3 of a D-layout tile are register b of the four lane groups, i.e. exactly the four
-      // k-slots of an MFMA B operand.  Per block: the 4 x 4 diagonal block is read with v_readlane and factored as L~ Δ L~ᵀ in wave-uniform scalars (one reciprocal chain
-      // per pivot); then ONE MFMA per tile replaces the block rows by L~⁻¹ (block rows) (A = L~⁻¹ − I on the block's rows) and ONE more subtracts
-      // Σ_k (R'[k][row] / d_k) R'[k] from the trailing rows (A = −R'ᵀ Δ⁻¹ masked to rows behind the block) — 6 MFMAs with all four k-slots live instead of the
-      // 12 single-slot rank-1 MFMAs of four consecutive pivots, and one dependent chain per block instead of four.  Same representation as the pivot loop below:
-      // row j ends up as L_jj · (row j of Lᵀ resp. W).  Padding rows (>= m) get a unit diagonal: their pivots are 1, their rows stay zero.
+    // ---- BLOCKED elimination, four pivots at a time.  Rows 4b .. 4b+3 of a D-layout tile are register b of the four lane groups, i.e. exactly the four k-slots
+    // of an MFMA B operand.  Per block: the 4 x 4 diagonal block is read with v_readlane and factored as L~ Δ L~ᵀ in wave-uniform scalars (one reciprocal chain per
+    // pivot); then ONE MFMA per tile replaces the block rows by L~⁻¹ (block rows) (A = L~⁻¹ − I on the block's rows) and ONE more subtracts
+    // Σ_k (R'[k][row] / d_k) R'[k] from the trailing rows (A = −R'ᵀ Δ⁻¹ masked to the rows behind the block) — MFMAs with all four k-slots live instead of the
+    // single-slot rank-1 MFMAs of four consecutive pivots, and one dependent chain per block instead of four.  Row j ends up as L_jj · (row j of Lᵀ resp. W).
+    // The same row operations run on an identity tile E, which therefore ends as L~⁻¹: scaled by Δ^(-1/2) it is L⁻¹, what the forward rollout multiplies with
+    // (a triangular SOLVE there is an 18-step dependent chain on a lone wave; a product with L⁻ᵀ is not).
+    // Padding rows (>= m) get a unit diagonal: their pivots are 1, their rows stay zero.
+    qm_d4 E[MT][MT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (g + 4 * r >= m && c == g + 4 * r) Huu[0][0][r] = 1.0;
-      auto recip = [](double d) { double x = __builtin_amdgcn_rcp(d); const double e = fma(-d, x, 1.0); return fma(fma(e, e, e), x, x); };   // 2^-24 estimate + one third-order step
+    for (int I = 0; I < MT; ++I)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int c0 = 4 * b;
-        const double D00 = qm_bcast(Huu[0][0][b], c0), D01 = qm_bcast(Huu[0][0][b], c0 + 1), D02 = qm_bcast(Huu[0][0][b], c0 + 2), D03 = qm_bcast(Huu[0][0][b], c0 + 3);
-        const double D11 = qm_bcast(Huu[0][0][b], 16 + c0 + 1), D12 = qm_bcast(Huu[0][0][b], 16 + c0 + 2), D13 = qm_bcast(Huu[0][0][b], 16 + c0 + 3);
-        const double D22 = qm_bcast(Huu[0][0][b], 32 + c0 + 2), D23 = qm_bcast(Huu[0][0][b], 32 + c0 + 3), D33 = qm_bcast(Huu[0][0][b], 48 + c0 + 3);
-        const double d0 = D00, rd0 = recip(d0);
-        const double l10 = D01 * rd0, l20 = D02 * rd0, l30 = D03 * rd0;
-        const double d1 = fma(-l10, D01, D11), rd1 = recip(d1);
-        const double t12 = fma(-l20, D01, D12), t13 = fma(-l30, D01, D13);            // D12 − l20 l10 d0, D13 − l30 l10 d0
-        const double l21 = t12 * rd1, l31 = t13 * rd1;
-        const double d2 = fma(-l21, t12, fma(-l20, D02, D22)), rd2 = recip(d2);
-        const double t23 = fma(-l31, t12, fma(-l30, D02, D23));                        // D23 − l30 l20 d0 − l31 l21 d1
-        const double l32 = t23 * rd2;
-        const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, D03, D33))), rd3 = recip(d3);
-        if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) chol_fail = 1;
-        // L~⁻¹ (unit lower): strictly lower entries
-        const double M10 = -l10, M21 = -l21, M32 = -l32, M20 = fma(l21, l10, -l20), M31 = fma(l32, l21, -l31), M30 = -(l30 + l31 * M10 + l32 * M20);
-        const int ri = c - c0;                                                           // A[i = c][k = g]: row i of the tile against block row k
-        const double a1 = (ri == 1) ? ((g == 0) ? M10 : 0.0) : ((ri == 2) ? ((g == 0) ? M20 : ((g == 1) ? M21 : 0.0)) : ((ri == 3) ? ((g == 0) ? M30 : ((g == 1) ? M31 : ((g == 2) ? M32 : 0.0))) : 0.0));
-        Huu[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Huu[0][0][b], Huu[0][0], 0, 0, 0);
-        Hux[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Hux[0][0][b], Hux[0][0], 0, 0, 0);
-        Hux[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Hux[0][1][b], Hux[0][1], 0, 0, 0);
-        const double dg = (g == 0) ? d0 : ((g == 1) ? d1 : ((g == 2) ? d2 : d3)), rdg = (g == 0) ? rd0 : ((g == 1) ? rd1 : ((g == 2) ? rd2 : rd3));
-        dsel[0][b] = dg;
-        if (b < 3) {                                                                     // the last block has no trailing rows
-          const double a2 = (c > c0 + 3) ? -rdg * Huu[0][0][b] : 0.0;                    // −R'[k][row] / d_k for the rows behind the block
-          Huu[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Huu[0][0][b], Huu[0][0], 0, 0, 0);
-          Hux[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Hux[0][0][b], Hux[0][0], 0, 0, 0);
-          Hux[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Hux[0][1][b], Hux[0][1], 0, 0, 0);
+      for (int J = 0; J < MT; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool diag = (I == J) && (c == g + 4 * r);
+          E[I][J][r] = diag ? 1.0 : 0.0;
+          if (diag && 16 * I + g + 4 * r >= m) Huu[I][I][r] = 1.0;
         }
-      }
-    } else {
-    // The pivots run one step AHEAD of the matrix cores: d_{j+1} = H[j+1][j+1] − H[j][j+1]² / d_j is formed from two entries of the
-    // not-yet-updated fragments, so its reciprocal chain overlaps the MFMAs of step j instead of waiting for their result.
-    double djj = qm_bcast(Huu[0][0][0], 0);
-    double rd = __builtin_amdgcn_rcp(djj);                           // 1/d_j: hardware estimate (2^-24) + one third-order correction
-    { const double e = fma(-djj, rd, 1.0); rd = fma(fma(e, e, e), rd, rd); }
+    auto recip = [](double d) { double x = __builtin_amdgcn_rcp(d); const double e = fma(-d, x, 1.0); return fma(fma(e, e, e), x, x); };   // 2^-24 estimate + one third-order step
+    constexpr int NBLK = (MT == 1) ? 4 : 5;                              // m <= 16: rows 0..15;  m = 17, 18: one more block in the second tile row
 #pragma unroll
-    for (int j = 0; j < QM_MMAX; ++j) if (j < 16 * MT && j < m) {
-      const int I = j >> 4, r = (j & 15) >> 2, gj = j & 3;
-      if (!(djj > 0.0)) chol_fail = 1;
-      double hd = 1.0, hj = 0.0;
-      if (j + 1 < 16 * MT) {
-        const int I1 = (j + 1) >> 4, r1 = ((j + 1) & 15) >> 2, g1 = (j + 1) & 3;
-        hd = qm_bcast(Huu[I1][I1][r1], 16 * g1 + ((j + 1) & 15)); hj = qm_bcast(Huu[I][I1][r], 16 * gj + ((j + 1) & 15));
-      }
-      if (g == gj) dsel[I][r] = djj;
-      // program order pinned by hand: the reciprocal chain of the NEXT pivot (≈ 7 dependent f64 ops) is cut into three pieces that
-      // issue right behind one MFMA each, i.e. while the matrix core is busy with it
-      double av[MT];
+    for (int b = 0; b < NBLK; ++b) {
+      const int I = b >> 2, rb = b & 3, c0 = 4 * rb;
+      const qm_d4& Hd = Huu[I][I];
+      const double D00 = qm_bcast(Hd[rb], c0), D01 = qm_bcast(Hd[rb], c0 + 1), D02 = qm_bcast(Hd[rb], c0 + 2), D03 = qm_bcast(Hd[rb], c0 + 3);
+      const double D11 = qm_bcast(Hd[rb], 16 + c0 + 1), D12 = qm_bcast(Hd[rb], 16 + c0 + 2), D13 = qm_bcast(Hd[rb], 16 + c0 + 3);
+      const double D22 = qm_bcast(Hd[rb], 32 + c0 + 2), D23 = qm_bcast(Hd[rb], 32 + c0 + 3), D33 = qm_bcast(Hd[rb], 48 + c0 + 3);
+      const double d0 = D00, rd0 = recip(d0);
+      const double l10 = D01 * rd0, l20 = D02 * rd0, l30 = D03 * rd0;
+      const double d1 = fma(-l10, D01, D11), rd1 = recip(d1);
+      const double t12 = fma(-l20, D01, D12), t13 = fma(-l30, D01, D13);            // D12 − l20 l10 d0, D13 − l30 l10 d0
+      const double l21 = t12 * rd1, l31 = t13 * rd1;
+      const double d2 = fma(-l21, t12, fma(-l20, D02, D22)), rd2 = recip(d2);
+      const double t23 = fma(-l31, t12, fma(-l30, D02, D23));                        // D23 − l30 l20 d0 − l31 l21 d1
+      const double l32 = t23 * rd2;
+      const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, D03, D33))), rd3 = recip(d3);
+      if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) chol_fail = 1;
+      // L~⁻¹ of the block (unit lower): its strictly lower entries
+      const double M10 = -l10, M21 = -l21, M32 = -l32, M20 = fma(l21, l10, -l20), M31 = fma(l32, l21, -l31), M30 = -(l30 + l31 * M10 + l32 * M20);
+      const int ri = c - c0;                                                           // A[i = c][k = g]: row i of the tile against block row k
+      const double a1 = (ri == 1) ? ((g == 0) ? M10 : 0.0) : ((ri == 2) ? ((g == 0) ? M20 : ((g == 1) ? M21 : 0.0)) : ((ri == 3) ? ((g == 0) ? M30 : ((g == 1) ? M31 : ((g == 2) ? M32 : 0.0))) : 0.0));
 #pragma unroll
-      for (int Ip = I; Ip < MT; ++Ip) av[Ip] = (g == gj && 16 * Ip + c > j) ? -rd * Huu[I][Ip][r] : 0.0;     // −H[j][row] / d_j for rows > j
-      const double rcur = rd;
-      __builtin_amdgcn_sched_barrier(0);
-      Huu[I][I] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], Huu[I][I][r], Huu[I][I], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      djj = fma(-rcur * hj, hj, hd);
-      double r0 = __builtin_amdgcn_rcp(djj);
-      __builtin_amdgcn_sched_barrier(0);
-      Hux[I][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], Hux[I][0][r], Hux[I][0], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      double e0 = fma(-djj, r0, 1.0); e0 = fma(e0, e0, e0);         // r0 (1 + e + e²): the 2^-24 hardware estimate to ≈ 1 ulp in one third-order step
-      __builtin_amdgcn_sched_barrier(0);
-      Hux[I][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], Hux[I][1][r], Hux[I][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      rd = fma(e0, r0, r0);
-      if (MT == 2) {                                                 // 17/18 inputs: the remaining tiles (second tile row / column)
-        if (I == 0) {
-          Huu[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], Huu[0][1][r], Huu[0][1], 0, 0, 0);
-          Huu[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], Huu[0][1][r], Huu[1][1], 0, 0, 0);
-          Hux[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], Hux[0][0][r], Hux[1][0], 0, 0, 0);
-          Hux[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], Hux[0][1][r], Hux[1][1], 0, 0, 0);
-        }
+      for (int J = I; J < MT; ++J) Huu[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Huu[I][J][rb], Huu[I][J], 0, 0, 0);
+#pragma unroll
+      for (int J = 0; J < 2; ++J) Hux[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Hux[I][J][rb], Hux[I][J], 0, 0, 0);
+#pragma unroll
+      for (int J = 0; J <= I; ++J) E[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, E[I][J][rb], E[I][J], 0, 0, 0);
+      const double dg = (g == 0) ? d0 : ((g == 1) ? d1 : ((g == 2) ? d2 : d3)), rdg = (g == 0) ? rd0 : ((g == 1) ? rd1 : ((g == 2) ? rd2 : rd3));
+      dsel[I][rb] = dg;
+      // trailing rows: behind the block in its own tile row, and every later tile row
+#pragma unroll
+      for (int I2 = I; I2 < MT; ++I2) {
+        if (I2 == I && rb == 3) continue;                                              // the tile row's last block has nothing behind it there
+        const double a2 = (I2 == I) ? ((c > c0 + 3) ? -rdg * Huu[I][I][rb] : 0.0) : -rdg * Huu[I][I2][rb];       // −R'[k][row] / d_k
+#pragma unroll
+        for (int J = I2; J < MT; ++J) Huu[I2][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Huu[I][J][rb], Huu[I2][J], 0, 0, 0);
+#pragma unroll
+        for (int J = 0; J < 2; ++J) Hux[I2][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Hux[I][J][rb], Hux[I2][J], 0, 0, 0);
+#pragma unroll
+        for (int J = 0; J <= I; ++J) E[I2][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, E[I][J][rb], E[I2][J], 0, 0, 0);
       }
-    }
     }
     double invr[MT][4];                                              // 1/L_jj = d_j^(-1/2) for this lane's rows: four independent chains
 #pragma unroll
@@ -248,7 +228,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
         invr[I][r] = inv;
       }
     RWT(3)
-    // Lᵀ (upper triangle, the diagonal keeps 1/L_jj), W and y go to the stage record for the forward rollout
+    // L⁻¹ (lower triangle), W and y go to the stage record for the forward rollout
 #pragma unroll
     for (int I = 0; I < MT; ++I)
 #pragma unroll
@@ -259,10 +239,12 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
           const int col = 16 * J + c; const double w = Hux[I][J][r] * sc; W[I][J][r] = w;
           if (row < m) { if (col < 30) rec[SR_PP + row * 30 + col] = w; else if (col == 30) rec[SR_KFF + row] = w; }
         }
+        // L⁻¹ = Δ^(-1/2) L~⁻¹ (its diagonal: 1 / L_jj), written as a FULL block over the tiles: exact zeros above the diagonal, unit rows for the padding rows
+        // (row >= m) — the forward rollout multiplies with the block as it is, without per-entry masks
 #pragma unroll
-        for (int J = I; J < MT; ++J) {
+        for (int J = 0; J < MT; ++J) {
           const int col = 16 * J + c;
-          if (row < m && col >= row && col < m) rec[SR_RP + row * QM_MMAX + col] = (col == row) ? sc : Huu[I][J][r] * sc;
+          if (row < QM_MMAX && col < QM_MMAX) rec[SR_RP + row * QM_MMAX + col] = (J <= I) ? E[I][J][r] * sc : 0.0;
         }
       }
   } else rw_zero<MT, 2>(W);
@@ -306,7 +288,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 #undef RWT
 }
 
-// flat, fully coalesced fetch of everything the forward rollout needs from one stage record: element e of the concatenation
+// flat fetch of everything the forward rollout needs from one stage record: element e of the concatenation
 // [Ap rows 0..11 | Bp rows 0..11 | W L | Px rows 12..23 | bp qp rp Pe | y | swing blocks | mode dt] lives at record offset rf_src(e).
 // Only the momentum / base-pose rows of the projected dynamics are read: a joint row of the Heun-discretised flow map is exactly
 // x_j+ = x_j + dt u_j (its rows of A_d, B_d are unit rows resp. dt times unit rows), so dx_j+ = dx_j + dt (du_j − Pe_j) + bp_j comes from the
@@ -316,16 +298,6 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 __device__ __forceinline__ int rf_src(int e) {
   return (e < 360) ? e : ((e < 576) ? e + (SR_BP - 360) : ((e < 1440) ? e + (SR_PP - 576) : ((e < 1800) ? e + (SR_PX + 360 - 1440) : ((e < 1908) ? e + (SR_BPV - 1800) :
          ((e < 1926) ? e + (SR_KFF - 1908) : ((e < 1950) ? e + (SR_SWG - 1926) : e + (SR_MODEF - 1950)))))));
-}
-// ... and goes to this (row-padded) LDS slot
-__device__ __forceinline__ int rf_dst(int e) {
-  if (e < 360) return RF_A + (e / 30) * 31 + e % 30;
-  if (e < 576) { const int f = e - 360; return RF_B + (f / QM_MMAX) * 19 + f % QM_MMAX; }
-  if (e < 1116) { const int f = e - 576; return RF_W + (f / 30) * 31 + f % 30; }
-  if (e < 1440) { const int f = e - 1116; return RF_L + (f % QM_MMAX) * 19 + f / QM_MMAX; }     // the record holds Lᵀ
-  if (e < 1800) { const int f = e - 1440; return RF_PX + (f / 30) * 31 + f % 30; }
-  if (e < 1926) return RF_V + (e - 1800);
-  return RF_V + 128 + (e - 1926);
 }
 #define RF_TOTAL 1952
 
@@ -391,78 +363,68 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   const long long tback = (long long)__builtin_readcyclecounter();
   // L, W, y were stored by other lanes than the ones that read them back below
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // same wave, same CU: ordering only, no L2 write-back
-  // ---- forward rollout.  Each stage record is fetched flat (512 B per wave instruction) one stage ahead into registers, dropped
-  //      into row-padded LDS, and consumed one matrix row per lane: lanes 0..29 rows of [Ap Bp bp], lanes 32..61 rows of
-  //      [Px Pu Pe] (only rows 12..23 of Px exist), lanes 0..m-1 also row i of W and column i of L; lane c carries dx[c] ----
+  // ---- forward rollout.  The fields of a stage record the rollout reads are copied global -> LDS by the DMA path (global_load_lds, 16 B per lane, no VGPRs) one
+  //      regular stage AHEAD into the other half of a double buffer, and consumed one matrix row per lane: lanes 0..29 rows of [Ap Bp bp], lanes 32..61 rows of
+  //      [Px Pu Pe] (only rows 12..23 of Px exist), lanes 0..m-1 also row i of W and column i of L⁻¹; lane c carries dx[c].
+  //      A stage's dx / du go to HBM one stage LATE, right behind the wait for the stage's operands and in front of the next copy: the wait (vmcnt(0)) then only
+  //      ever sees a copy issued a whole stage earlier and two stores older than that, never a store's round trip ----
   double dxl = (l < 30) ? a.x0[(size_t)b * 30 + l] - a.x[(0 * a.B + b) * 30 + l] : 0.0;
   double armijo = 0.0, dx2 = 0.0, du2 = 0.0;
   const int half = l >> 5, r = l & 31;
-  if (l < 31) buf[RF_PX + 12 * 31 + l] = 0.0;              // the zero row of the Px block (no stage writes it; a wave sync precedes its first use)
-  if (l < 19) buf[RF_PU + l] = 0.0;
-  int pu_mode = -1, pu_col = 0, pu_kind = 0, pu_off = 128;     // (Pu ut) source of this lane's du row, cached per contact mode
-  double pf[RF_NLOAD];
-  // the lane's 31 (record offset, LDS slot) pairs do not depend on the stage: computed once (the select chains of rf_src / rf_dst cost ≈ 40 integer
-  // instructions per element — more than the rest of a stage's forward arithmetic when evaluated per stage)
-  int fsrc[RF_NLOAD], fdst[RF_NLOAD];
+  if (l < 32) buf[RF_ZERO + l] = 0.0;                       // the zero row (no stage writes it; a wave sync precedes its first use)
+  int pu_mode = -1, pu_col = 0, pu_kind = 0, pu_off = 126;     // (Pu ut) source of this lane's du row, cached per contact mode
+  // the lane's record offsets do not depend on the stage: computed once (the select chain of rf_src costs ≈ 20 integer instructions per element)
+  int fsrc[RF_NLOAD];
 #pragma unroll
-  for (int t = 0; t < RF_NLOAD; ++t) { const int e = t * 64 + l; const bool in = e < RF_TOTAL; fsrc[t] = in ? rf_src(e) : 0; fdst[t] = in ? rf_dst(e) : RF_DUMP; }
-  auto fetch = [&](int k) {
-    const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
+  for (int t = 0; t < RF_NLOAD; ++t) { const int e = 2 * (t * 64 + l); fsrc[t] = (e < RF_TOTAL) ? rf_src(e) : -1; }
+  auto fetch = [&](int k, int which) {
+    const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE; double* F = buf + (which ? RF_F1 : RF_F0);
 #pragma unroll
-    for (int t = 0; t < RF_NLOAD; ++t) pf[t] = rec[fsrc[t]];
+    for (int t = 0; t < RF_NLOAD; ++t) if (fsrc[t] >= 0) qm_dma16(rec + fsrc[t], F + 128 * t);
   };
-  { int k0 = 0; while (k0 < n - 1 && evlist(k0) == QM_EV_PRE) ++k0; if (k0 < n - 1 && !(a.skip & 4)) fetch(k0); }
+  int cur = 0;
+  { int k0 = 0; while (k0 < n - 1 && evlist(k0) == QM_EV_PRE) ++k0; if (k0 < n - 1 && !(a.skip & 4)) fetch(k0, 0); }
   long long tfw[6] = {0, 0, 0, 0, 0, 0}; long long tfl = (long long)__builtin_readcyclecounter();
 #define RFT(i) { if (a.skip & 32) { const long long now_ = (long long)__builtin_readcyclecounter(); tfw[i] += now_ - tfl; tfl = now_; } }
+  double du_pend = 0.0; int nb_pend = -1;                   // du of the last regular stage, not yet stored
   for (int k = 0; k < n - 1; ++k) {
     if (a.skip & 4) break;
     const int nb = k * a.B + b;
-    if (l < 30) { a.dx[nb * 30 + l] = dxl; dx2 += dxl * dxl; }
     if (evlist(k) == QM_EV_PRE) {
-      if (l < 30) { a.du[nb * 30 + l] = 0.0; dxl += a.x[nb * 30 + l] - a.x[((k + 1) * a.B + b) * 30 + l]; }
+      if (l < 30) { a.dx[nb * 30 + l] = dxl; dx2 += dxl * dxl; a.du[nb * 30 + l] = 0.0; dxl += a.x[nb * 30 + l] - a.x[((k + 1) * a.B + b) * 30 + l]; }
       continue;
     }
     const int m = mlist(k);
-    qm_wave_sync();
+    qm_dma_wait();                                            // this stage's operands have landed
     RFT(0)
-#pragma unroll
-    for (int t = 0; t < RF_NLOAD; ++t) buf[fdst[t]] = pf[t];          // lanes past the end of the list write a dump slot
-    qm_wave_sync();
+    if (l < 30) { a.dx[nb * 30 + l] = dxl; dx2 += dxl * dxl; }
+    if (nb_pend >= 0 && half && r < 30) a.du[nb_pend * 30 + r] = du_pend;
     RFT(1)
-    { int kn = k + 1; while (kn < n - 1 && evlist(kn) == QM_EV_PRE) ++kn; if (kn < n - 1) fetch(kn); }
+    { int kn = k + 1; while (kn < n - 1 && evlist(kn) == QM_EV_PRE) ++kn; if (kn < n - 1) fetch(kn, cur ^ 1); }
     RFT(2)
+    const double* F = buf + (cur ? RF_F1 : RF_F0); cur ^= 1;
     const int rr = (r < 30) ? r : 29, lw = (l < m) ? l : 0;          // idle lanes read a valid row and drop the result
     const int ra = (rr < 12) ? rr : 0;                                 // lanes 12..29 (joint rows) do not use their products: any valid row
-    const double* rowA = half ? buf + RF_PX + ((rr >= 12 && rr < 24) ? rr - 12 : 12) * 31 : buf + RF_A + ra * 31;      // row 12 of the Px block: zeros
-    const double* rowB = half ? buf + RF_PU : buf + RF_B + ra * 19;                 // input-space rows: a row of zeros, Pu ut is assembled below
-    const double* rowW = buf + RF_W + lw * 31; const double* vecs = buf + RF_V;
-    double acc = vecs[half ? 78 + rr : rr];
+    // lanes 12..29 compute THEIR OWN copy of du row l (the same row lane l + 32 holds for the store): a joint row's dx+ then needs no cross-lane traffic
+    const bool durow = half ? (r < 30) : (l >= 12 && l < 30);
+    const int pr = (rr >= 12 && rr < 24) ? rr - 12 : -1;                                  // row of the Px block, if the du row has one
+    const double* rowA = (!half && l < 12) ? F + RFO_A + l * 30 : ((durow && pr >= 0) ? F + RFO_PX + pr * 30 : buf + RF_ZERO);
+    const double* rowB = (!half && l < 12) ? F + RFO_B + l * QM_MMAX : (durow ? buf + RF_PUD + rr * QM_MMAX : buf + RF_ZERO);
+    const double* rowW = F + RFO_W + lw * 30; const double* vecs = F + RFO_V;
+    double acc = vecs[(half || l >= 12) ? 78 + rr : rr];                                    // Pe of a du row, bp of a dynamics row
     double t = vecs[108 + lw];
     const double qv = (l < 30) ? vecs[30 + l] : 0.0, rp = (l < m) ? vecs[60 + l] : 0.0;
+    const double mdv = vecs[150]; double c1 = vecs[pu_off], c2 = vecs[pu_off + 3];          // the swing block entries of this lane's du row (if its leg swings in the mode seen last)
     { double ap[3] = {0.0, 0.0, 0.0}, tp[3] = {0.0, 0.0, 0.0};          // three partial sums each: a 30-long dependent FMA chain is what a lone wave waits on
 #pragma unroll
       for (int q = 0; q < 30; ++q) { const double dq = qm_bcast(dxl, q); ap[q % 3] += rowA[q] * dq; tp[q % 3] += rowW[q] * dq; }
       acc += (ap[0] + ap[1]) + ap[2]; t += (tp[0] + tp[1]) + tp[2]; }
     RFT(3)
-    // Lᵀ v = t (lane i keeps v_i), ut = −v.  Everything that does not depend on t is prepared BEFORE the dependent chain: the lane's 18 entries of L
-    // (independent LDS reads, masked once) are scaled by the pivots' reciprocals 1/L_qq (the stored diagonal, broadcast off the chain), so that one step of the
-    // chain is only broadcast t_q -> fused multiply-add:  t_i -= (L[q][i] / L_qq) t_q  for i < q;  v_q = t_q / L_qq falls out at the end on lane q.
-    double Lr[QM_MMAX], mydiag = 0.0;
-    { const int lc = (l < QM_MMAX) ? l : 0;
-#pragma unroll
-      for (int q = 0; q < QM_MMAX; ++q) { const double e = buf[RF_L + q * 19 + lc]; Lr[q] = (l <= q && l < m && q < m) ? e : 0.0; }   // L[q][l] (row q = l: 1/L_qq)
-#pragma unroll
-      for (int q = 0; q < QM_MMAX; ++q) { const double dq = qm_bcast(Lr[q], q); if (l == q) mydiag = Lr[q]; Lr[q] = (l < q) ? Lr[q] * dq : 0.0; } }
-#pragma unroll
-    for (int q = QM_MMAX - 1; q >= 1; --q) t -= Lr[q] * qm_bcast(t, q);     // steps q >= m are no-ops (Lr[q] == 0 on every lane): no uniform branch in the chain
-    const double v = t * mydiag;                                              // lanes >= m: mydiag == 0
-    const double ut = -v;
-    RFT(4)
-    // (Pu ut)[row] for the lanes that hold a row of du: a stance force component or an arm joint velocity IS one entry of ut, a swing leg's
-    // joint velocity combines the two null-space coordinates of its leg, swing forces get nothing (Pe carries −F)
-    double puut;
-    { const int md = (int)vecs[152];
-      if (md != pu_mode) {                                   // the lane's source columns only change with the contact mode (wave-uniform test, a few times per sweep)
+    // Pu as a dense matrix in LDS, one row per du row (written by the row's lane in the upper half): a stance force component or an arm joint velocity IS one
+    // entry of ut (a unit entry, constant per contact mode), a swing leg's joint velocity combines the two null-space coordinates of its leg (two entries per
+    // stage), swing forces get nothing (Pe carries −F).  Pu ut then is one more row-times-ut product, with nothing of it on the chain behind ut
+    { const int md = (int)mdv;
+      if (md != pu_mode) {                                   // the lane's columns only change with the contact mode (wave-uniform test, a few times per sweep)
         pu_mode = md;
         int nst = 0;
 #pragma unroll
@@ -475,22 +437,42 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
         const bool st = mode_flag(md, kk);
         pu_col = (row < 12) ? 3 * before_st + r3 : ((row < 24) ? 3 * nst + 2 * before_sw : 3 * nst + 2 * (4 - nst) + r3);
         pu_kind = !(half && r < 30) ? 0 : ((row < 12) ? (st ? 1 : 0) : ((row < 24) ? (st ? 0 : 2) : 1));      // 0: nothing, 1: one entry of ut, 2: a swing leg's 3x2 block
-        pu_off = 128 + 6 * kk + r3;
+        pu_off = 126 + 6 * kk + r3;
+        if (half && r < 30) {
+#pragma unroll
+          for (int q = 0; q < QM_MMAX; ++q) buf[RF_PUD + rr * QM_MMAX + q] = (pu_kind == 1 && q == pu_col) ? 1.0 : 0.0;
+        }
+        c1 = vecs[pu_off]; c2 = vecs[pu_off + 3];
       }
-      const double c1 = (pu_kind == 2) ? vecs[pu_off] : ((pu_kind == 1) ? 1.0 : 0.0), c2 = (pu_kind == 2) ? vecs[pu_off + 3] : 0.0;
-      const double u1 = __shfl(ut, pu_col & 63, 64), u2 = __shfl(ut, (pu_col + 1) & 63, 64);
-      puut = c1 * u1 + c2 * u2; }
+      if (pu_kind == 2) { buf[RF_PUD + rr * QM_MMAX + pu_col] = c1; buf[RF_PUD + rr * QM_MMAX + pu_col + 1] = c2; }
+      qm_wave_sync(); }
+    // v = L⁻ᵀ t (lane i keeps v_i = Σ_{q >= i} L⁻¹[q][i] t_q), ut = −v: a product with the inverse factor the backward sweep left in the record — 18 independent
+    // broadcast + FMA pairs in three partial sums instead of the 18-step dependent chain of a back substitution
+    double v;
+    { const int lc = (l < QM_MMAX) ? l : 0; double vp[3] = {0.0, 0.0, 0.0};
+      t = (l < m) ? t : 0.0;                                  // t_q = 0 for q >= m: the padding rows of the block contribute nothing
+#pragma unroll
+      for (int q = 0; q < 16; ++q) vp[q % 3] += F[RFO_L + q * QM_MMAX + lc] * qm_bcast(t, q);
+      if (m > 16) {                                           // rows 16, 17 of the block are only written by the two-tile stages
+#pragma unroll
+        for (int q = 16; q < QM_MMAX; ++q) vp[q % 3] += F[RFO_L + q * QM_MMAX + lc] * qm_bcast(t, q);
+      }
+      v = (vp[0] + vp[1]) + vp[2]; v = (l < m) ? v : 0.0; }
+    const double ut = -v;
+    RFT(4)
     armijo += qv * dxl + rp * ut;
     { double bp[3] = {0.0, 0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < QM_MMAX; ++q) bp[q % 3] += rowB[q] * qm_bcast(ut, q);          // ut == 0 on lanes >= m: no bound needed
-      acc += ((bp[0] + bp[1]) + bp[2]) + puut; }
-    if (half && r < 30) { a.du[nb * 30 + r] = acc; du2 += acc * acc; }
-    const double duj = __shfl(acc, (l + 32) & 63, 64);                 // joint rows: dx_j+ = dx_j + dt (du_j − Pe_j) + bp_j
-    if (l >= 12) acc = vecs[rr] + dxl + vecs[153] * (duj - vecs[78 + rr]);
+      acc += (bp[0] + bp[1]) + bp[2]; }
+    if (half && r < 30) du2 += acc * acc;
+    du_pend = acc; nb_pend = nb;
+    if (l >= 12) acc = vecs[rr] + dxl + vecs[151] * (acc - vecs[78 + rr]);      // joint rows: dx_j+ = dx_j + dt (du_j − Pe_j) + bp_j  (lanes >= 32: dropped)
     dxl = (l < 30) ? acc : 0.0;
+    qm_lds_drain();                                           // every read of this buffer has returned before the copy after next overwrites it
     RFT(5)
   }
+  if (nb_pend >= 0 && half && r < 30) a.du[nb_pend * 30 + r] = du_pend;
   {
     const int nb = (n - 1) * a.B + b; const double* rec = a.stage + ((size_t)b * a.nmax + (n - 1)) * SR_SIZE;
     if (l < 30) { a.dx[nb * 30 + l] = dxl; a.du[nb * 30 + l] = 0.0; dx2 += dxl * dxl; armijo += rec[SR_QPV + l] * dxl; }
