@@ -24,9 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # Per-unit work model of the three big kernels: unit = one non-event shooting interval (lq, riccati) or one instance (wbc).
-#   flop : ALGORITHMIC dense FP64 count of SURVEY.md §8(d) (LQ 190 k + projection 410 k; Riccati 250 k; WBC 2.0 M) — what a roofline is priced on;
-#          the flops the kernels actually ISSUE (tile padding, rank-1 MFMAs, ...) are measured with SQ PMC counters: profiles/flops_pmc.json,
-#          reported next to it as `issued_*` when that file is present (tools/gpu_round_profile.sh, tools/flops_pmc_digest.py)
+#   flop : the survey's dense FP64 ESTIMATE of SURVEY.md §8(d) (LQ 190 k + projection 410 k; Riccati 250 k; WBC 2.0 M) — only the fall-back: the flops the kernels
+#          actually ISSUE are measured with SQ PMC counters (tools/gpu_round_profile.sh, tools/flops_pmc_digest.py -> profiles/flops_pmc.json) and replace the
+#          estimate whenever that file is present; the estimate stays in the line as `survey_dense_*`
 #   bytes: HBM bytes the design moves per unit (DESIGN.md §4 derives every figure; `doubles` below are f64 counts)
 
 def _kernel_model():
@@ -172,30 +172,36 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
         roofline = None; roofs = {}
         if hip:
             roofs = {k: roof(k) for k in KM}
+            # flops the kernels ISSUE, from the SQ instruction counters of this same command (tools/gpu_round_profile.sh -> profiles/flops_pmc.json: a STATIC file of the
+            # named profile round, PMC collection cannot run inside the timed bench).  When present it REPLACES the survey's dense estimate as the kernel's flop count:
+            # frac_fp64 then is an achieved-flops figure (tile padding and masked MFMA slots included, i.e. still an upper bound of the useful flops)
+            flop_src = "SURVEY.md §8(d) dense estimate (profiles/flops_pmc.json not found)"
+            try:
+                with open(os.path.join(ROOT, "profiles", "flops_pmc.json")) as fh:
+                    fp = json.load(fh)
+                for k, v in roofs.items():
+                    f = fp["kernels"].get(v["kernel"], {}).get("flops_per_launch")
+                    if f and v["avg_launch_ms"] > 0 and B == 1024 and args.n_intervals == 100:      # the counters were collected on the default workload
+                        v["survey_dense_flop_per_launch"] = v["flop_per_launch"]; v["survey_dense_frac_fp64"] = v["frac_fp64"]
+                        v["flop_per_launch"] = f; v["tflops"] = f / (v["avg_launch_ms"] * 1e-3) / 1e12; v["frac_fp64"] = v["tflops"] / FP64_PEAK_TFLOPS
+                if B == 1024 and args.n_intervals == 100: flop_src = "instrumented: SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 + SQ_INSTS_VALU_MFMA_MOPS_F64 per launch, profiles/flops_pmc.json round %s (same command, B=1024; not measured in this run)" % fp.get("round", "?")
+            except (OSError, KeyError, ValueError):
+                pass
             dom = max(roofs, key=lambda k: roofs[k]["avg_launch_ms"]); rd = roofs[dom]      # the dominant kernel = the longest average launch among the modelled ones
             if rd["frac_hbm"] >= rd["frac_fp64"]:
                 roofline = {"bound": "hbm", "kernel": rd["kernel"], "achieved": rd["tbs"] * 1e3, "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": rd["frac_hbm"], "traffic": None}
             else:
                 roofline = {"bound": "mfma", "kernel": rd["kernel"], "achieved": rd["tflops"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rd["frac_fp64"], "traffic": None}
-            roofline.update({"avg_launch_ms": rd["avg_launch_ms"], "flop_per_launch": rd["flop_per_launch"], "bytes_per_launch": rd["bytes_per_launch"],
-                             "flop_model": "algorithmic dense count, SURVEY.md §8(d) (not the issued instruction count: see issued_flops)"})
+            roofline.update({"avg_launch_ms": rd["avg_launch_ms"], "flop_per_launch": rd["flop_per_launch"], "bytes_per_launch": rd["bytes_per_launch"], "flop_model": flop_src,
+                             "frac_hbm": rd["frac_hbm"], "frac_fp64": rd["frac_fp64"],
+                             "note": "bound = the nearer of the two roofs for this kernel; neither is close: the kernel is limited by instruction issue (DESIGN.md §4)"})
             # measured HBM bytes per launch of that kernel: the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, digested into
-            # profiles/hbm_traffic.json by tools/digest_round_profile.sh (PMC collection cannot run inside the timed bench itself) — a STATIC file of the named profile round
+            # profiles/hbm_traffic.json by tools/digest_round_profile.sh — a STATIC file of the named profile round
             try:
                 with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
                     ht = json.load(fh)
                 roofline["traffic"] = ht["kernels"][rd["kernel"]]["traffic_bytes"]
                 roofline["traffic_source"] = "profiles/hbm_traffic.json, round %s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, B=1024; not measured in this run)" % ht.get("round", "r01 v18")
-            except (OSError, KeyError, ValueError):
-                pass
-            try:       # flops the kernels ISSUE, from the SQ instruction counters of the same command (profiles/flops_pmc.json): achieved-flops view of every modelled kernel
-                with open(os.path.join(ROOT, "profiles", "flops_pmc.json")) as fh:
-                    fp = json.load(fh)
-                for k, v in roofs.items():
-                    f = fp["kernels"].get(v["kernel"], {}).get("flops_per_launch")
-                    if f and v["avg_launch_ms"] > 0:
-                        v["issued_flops_per_launch"] = f; v["issued_tflops"] = f / (v["avg_launch_ms"] * 1e-3) / 1e12; v["issued_frac_fp64"] = v["issued_tflops"] / FP64_PEAK_TFLOPS
-                roofline["issued_flops_source"] = "profiles/flops_pmc.json, round %s (SQ_INSTS_VALU_*_F64 + MFMA MOPS, B=1024; not measured in this run)" % fp.get("round", "?")
             except (OSError, KeyError, ValueError):
                 pass
         total_steps = B * world * args.steps
@@ -213,7 +219,7 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
         if hip:
             line["roofline"] = roofline
             line["fp64_peak_measured"] = {"mfma_f64_16x16x4": peak_mfma, "vector_fma": peak_fma, "unit": "TFLOP/s", "note": "roofline.peak stays the 78.6 TFLOP/s data-sheet figure"}
-            keys = ("avg_launch_ms", "tflops", "frac_fp64", "tbs", "frac_hbm", "issued_tflops", "issued_frac_fp64")
+            keys = ("avg_launch_ms", "flop_per_launch", "tflops", "frac_fp64", "survey_dense_flop_per_launch", "survey_dense_frac_fp64", "bytes_per_launch", "tbs", "frac_hbm")
             line["roofline_all"] = {k: {kk: v[kk] for kk in keys if kk in v} for k, v in roofs.items()}
             line["kernel_ms_per_step"] = {k: v[0] / 5 for k, v in kms_all.items()}
         line.update(sec)
