@@ -151,7 +151,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
       for (int J = 0; J < MT; ++J)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; const double* src = T + ci0[J] * LW_TLD + row; Bp[I][J][r] = cw[J][0] * src[0] + cw[J][1] * src[LW_TLD] + cw[J][2] * src[2 * LW_TLD]; }
-    qm_frag_store<2, MT>(Bp, rec + SR_BP, QM_MMAX, 30, m); }
+    qm_frag_store<2, MT>(Bp, rec + SR_BP, QM_MMAX, 12, m); }        // rows 0..11 only: a joint row is dt Pu[j], K3 rebuilds it (k_riccati.h)
   // [R Px | R Pe + r]: Px rows 12..23 (k-steps 3..5); Pe also has rows 0..11 (column 30 only -> tile column 1, k-steps 0..2)
   qm_d4 RPx[2][2]; qm_frag_zero<2, 2>(RPx);
   qm_gemm_tn<2, 2, 2>(Rm, PxA, RPx, 3, 6, false);
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
       qm_gemm_tn<2, 2, 1>(Bdt, Y1, P1, 0, 3, false);
 #pragma unroll
       for (int I = 0; I < 2; ++I) ApA[I][1] = P1[I][0]; }
-    qm_frag_store<2, 2>(ApA, rec + SR_AP, 30, 30, 30);
+    qm_frag_store<2, 2>(ApA, rec + SR_AP, 30, 12, 30);               // rows 0..11 only: a joint row is e_j + dt Px[j], K3 rebuilds it (k_riccati.h)
     const int gg2 = l >> 4;
 #pragma unroll
     for (int I = 0; I < 2; ++I)

@@ -57,11 +57,20 @@ struct QmRiccatiArgs {
 #define RFO_L   1116              /* [18][18] L⁻¹ (lower triangle) */
 #define RFO_PX  1440              /* [12][30] Px rows 12..23 (the only non-zero ones: leg joint velocities) */
 #define RFO_V   1800              /* bp(30) qp(30) rp(18) Pe(30) | y(18) | swing blocks [4][6] (126..149) mode (150) dt (151) */
-/* backward prefetch buffer (global_load_lds): a flat copy of record fields [0, 3204) = Ap Bp Qp Pp Rp and [4644, 4722) = bp qp rp of the
-   NEXT regular stage, landing while the current stage computes; lives behind the 1200-double Cholesky / transposition buffer */
+/* backward prefetch buffer (global_load_lds): the fields of the NEXT regular stage's record the backward sweep reads, landing while the current stage computes;
+   lives behind the 1200-double Cholesky / transposition buffer.  Six segments, each padded to whole 1 KB wave instructions so that an instruction's source
+   offset is a compile-time constant.  The joint rows of the projected dynamics are NOT in the record: a joint row of the Heun-discretised flow map is exactly
+   x_j+ = x_j + dt u_j, so  Ap[j] = e_j + dt Px[j],  Bp[j] = dt Pu[j]  (j >= 12) are rebuilt from Px, the contact mode and the swing legs' 3x2 blocks */
 #define RP_REC   1200
-#define RP_VEC   (RP_REC + 3204)
-#define RP_END   (RP_VEC + 80)
+#define RPO_A    0                 /* [12][30] Ap rows 0..11                     <- SR_AP            360 */
+#define RPO_B    384               /* [12][18] Bp rows 0..11                     <- SR_BP            216 */
+#define RPO_Q    640               /* Qp [30][30], Pp [18][30], Rp [18][18]      <- SR_QP           1764 */
+#define RPO_PP   (RPO_Q + 900)
+#define RPO_RP   (RPO_Q + 1440)
+#define RPO_PX   2432              /* [12][30] Px rows 12..23                    <- SR_PX + 360      360 */
+#define RPO_VEC  2816              /* bp(30) qp(30) rp(18)                       <- SR_BPV            78 */
+#define RPO_SWG  2944              /* swing blocks [4][6], mode, dt              <- SR_SWG            26 */
+#define RP_END   (RP_REC + 3072)
 #define RF_LIST  4496             /* int list[RW_MAXNODES]: m | event tag << 8 per node (behind both the prefetch buffer and the forward staging) */
 #define RW_MAXNODES 512
 #define RW_LDS_DOUBLES (RF_LIST + RW_MAXNODES / 2)
@@ -101,30 +110,104 @@ __device__ __forceinline__ void rw_load(qm_d4 (&T)[IT][JT], const double* src, i
       }
 }
 
-// asynchronous copy of the backward operands of one stage record into the LDS prefetch buffer
-__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds) {
-  // 3204 doubles = 1602 sixteen-byte units + 39 units of vectors, 1 KB per wave instruction
-  const int l = threadIdx.x & 63;
+// asynchronous copy of the backward operands of one stage record into the LDS prefetch buffer: 24 wave instructions of (up to) 1 KB
+template <int SRC, int DST, int LEN>
+__device__ __forceinline__ void rw_prefetch_seg(const double* rec, double* lds, int l) {
 #pragma unroll
-  for (int t = 0; t < 26; ++t) { const int unit = t * 64 + l; if (unit < 1602) qm_dma16(rec + 2 * unit, lds + RP_REC + 128 * t); }
-  if (l < 39) qm_dma16(rec + SR_BPV + 2 * l, lds + RP_VEC);
+  for (int t = 0; t * 128 < LEN; ++t) if (128 * t + 2 * l < LEN) qm_dma16(rec + SRC + 128 * t + 2 * l, lds + RP_REC + DST + 128 * t);
+}
+__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds) {
+  const int l = threadIdx.x & 63;
+  rw_prefetch_seg<SR_AP, RPO_A, 360>(rec, lds, l);
+  rw_prefetch_seg<SR_BP, RPO_B, 216>(rec, lds, l);
+  rw_prefetch_seg<SR_QP, RPO_Q, 1764>(rec, lds, l);
+  rw_prefetch_seg<SR_PX + 360, RPO_PX, 360>(rec, lds, l);
+  rw_prefetch_seg<SR_BPV, RPO_VEC, 78>(rec, lds, l);
+  rw_prefetch_seg<SR_SWG, RPO_SWG, 26>(rec, lds, l);
+}
+// [Ap | bp] as D-layout fragments: rows 0..11 from the record, rows 12..23 = e_j + dt Px[j], rows 24..29 = e_j (arm joints), column 30 = bp.
+// Unconditional loads + selects: a read at column 30 / 31 of a 30-wide row lands in the next row (inside the buffer) and is replaced afterwards — the exec-mask
+// bookkeeping of conditional loads (save / branch / restore per element) costs more here than the selects
+__device__ __forceinline__ void rw_load_A(qm_d4 (&A)[2][2], const double* PA, const double* PX, const double* bp, double dt) {
+  const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r, col = 16 * J + c; double v;     // (I, r) decides the row class at compile time: rows 0..11 are I = 0, r < 3
+        if (I == 0 && r < 3) v = PA[row * 30 + col];
+        else if (I == 0 || r < 2) v = fma(dt, PX[(row - 12) * 30 + col], (row == col) ? 1.0 : 0.0);
+        else v = (row == col) ? 1.0 : 0.0;
+        if (J == 1) { const double bv = bp[row]; v = (c == 14) ? bv : ((c == 15) ? 0.0 : v); }      // bp is followed by qp in the buffer: rows 30, 31 read in bounds
+        if (I == 1 && r == 3) v = (g < 2) ? v : 0.0;                                               // rows 30, 31
+        A[I][J][r] = v;
+      }
+}
+// per contact mode: where the entries of  Bp[j] = dt Pu[j]  (j >= 12) of this lane's five row slots come from.  Leg joint rows: the two null-space columns of the
+// joint's leg if it swings (code = index into the swing blocks), nothing if it stands; arm joint rows: a unit entry in the arm's column.  The swing blocks in LDS are
+// followed by mode, dt and the constants 1.0 (index 26) and 0.0 (index 27), so every entry is dt * SWG[code] without a select.  Five 5-bit codes per column tile in one int
+struct RwPuCodes { int mode; int pk[2]; };
+__device__ __forceinline__ void rw_pu_codes(RwPuCodes& pc, int md) {
+  const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+  pc.mode = md;
+  int nst = 0;
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) nst += mode_flag(md, kq);
+#pragma unroll
+  for (int J = 0; J < 2; ++J) {
+    int pk = 0;
+#pragma unroll
+    for (int sl = 0; sl < 5; ++sl) {
+      const int row = 12 + g + 4 * sl, col = 16 * J + c; int code = 27;        // slots: (I = 0, r = 3), (I = 1, r = 0 .. 3) -> rows 12 + g + 4 sl
+      if (row < 24) {
+        const int chain = (row - 12) / 3, r3 = (row - 12) % 3, kk = chain_to_contact(chain);
+        int before_sw = 0;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) if (kq < kk) before_sw += !mode_flag(md, kq);
+        const int t = col - (3 * nst + 2 * before_sw);
+        if (!mode_flag(md, kk) && (t == 0 || t == 1)) code = 6 * kk + 3 * t + r3;
+      } else if (row < 30) { if (col == 3 * nst + 2 * (4 - nst) + (row - 24)) code = 26; }
+      pk |= code << (5 * sl);
+    }
+    pc.pk[J] = pk;
+  }
+}
+// Bp (30 x m) as D-layout fragments: rows 0..11 from the record, rows 12..29 = dt Pu
+template <int MT>
+__device__ __forceinline__ void rw_load_B(qm_d4 (&Bm)[2][MT], const double* PB, const double* SWG, const RwPuCodes& pc, double dt, int m) {
+  const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < MT; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r, col = 16 * J + c; double v = 0.0;
+        if (I == 0 && r < 3) { const double e = PB[row * QM_MMAX + col]; v = (col < m) ? e : 0.0; }      // unconditional read (in bounds), then the select
+        else v = dt * SWG[(pc.pk[J] >> (5 * (4 * I + r - 3))) & 31];
+        Bm[I][J][r] = v;
+      }
 }
 // one regular stage of the backward sweep; MT = number of 16-row tiles covering the m reduced inputs
 template <int MT>
-__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip, int& chol_fail, long long (&tacc)[8]) {
+__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip, int& chol_fail, long long (&tacc)[8], RwPuCodes& pc, int md) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
   const bool prof = (skip & 32) != 0; long long tq_ = prof ? (long long)__builtin_readcyclecounter() : 0;
 #define RWT(i) { if (prof) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[i] += t_ - tq_; tq_ = t_; } }
   qm_d4 A[2][2], Bm[2][MT], Hux[MT][2], Huu[MT][MT], Sn[2][2];
   {
     // this stage's operands were copied into LDS (asynchronously, global_load_lds) while the previous stage computed
-    const double* P = buf + RP_REC; const double* PV = buf + RP_VEC;
+    const double* P = buf + RP_REC; const double* PV = P + RPO_VEC;
+    if (md != pc.mode) rw_pu_codes(pc, md);                       // wave-uniform (the mode comes from the node list): a few times per sweep, ahead of the wait
     qm_dma_wait();
-    rw_load<2, 2>(A, P + SR_AP, 30, 30, 30, PV);                    // [Ap | bp]
-    rw_load<2, MT>(Bm, P + SR_BP, QM_MMAX, 30, m, nullptr);
-    rw_load<MT, 2>(Hux, P + SR_PP, 30, m, 30, PV + 60);             // [Pp | rp]
-    rw_load<MT, MT>(Huu, P + SR_RP, QM_MMAX, m, m, nullptr);
-    rw_load<2, 2>(Sn, P + SR_QP, 30, 30, 30, PV + 30);              // [Qp | qp]
+    const double dt = P[RPO_SWG + 25];
+    rw_load_A(A, P + RPO_A, P + RPO_PX, PV, dt);                    // [Ap | bp]
+    rw_load_B<MT>(Bm, P + RPO_B, P + RPO_SWG, pc, dt, m);
+    rw_load<MT, 2>(Hux, P + RPO_PP, 30, m, 30, PV + 60);            // [Pp | rp]
+    rw_load<MT, MT>(Huu, P + RPO_RP, QM_MMAX, m, m, nullptr);
+    rw_load<2, 2>(Sn, P + RPO_Q, 30, 30, 30, PV + 30);              // [Qp | qp]
     qm_lds_drain();
     if (nrec) rw_prefetch(nrec, buf);                               // next regular stage: flies during this stage's products and Cholesky
   }
@@ -306,7 +389,8 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   double* buf = qm_smem;
   int* nlist = (int*)(qm_smem + RF_LIST);
 #define mlist(k) (nlist[k] & 255)
-#define evlist(k) (nlist[k] >> 8)
+#define evlist(k) ((nlist[k] >> 8) & 255)
+#define modelist(k) (nlist[k] >> 16)
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15, b = blockIdx.x;
   if (b >= a.B) return;
   const int n = a.n_nodes[b];
@@ -322,9 +406,12 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     }
     if (b == 0 && l < 16) { a.open_cnt[l] = 0; a.tickets[l] = 0; }
   }
-  for (int k = l; k < n; k += 64) { const int ev = a.node_ev[k * a.B + b]; const int mk = (ev == QM_EV_PRE) ? 0 : (int)a.stage[((size_t)b * a.nmax + k) * SR_SIZE + SR_SCAL]; nlist[k] = (mk & 255) | (ev << 8); }
+  for (int k = l; k < n; k += 64) { const int ev = a.node_ev[k * a.B + b]; const double* rk = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE; const bool reg = (ev != QM_EV_PRE) && k < n - 1;
+    const int mk = reg ? (int)rk[SR_SCAL] : 0, mdk = reg ? (int)rk[SR_MODEF] : 0; nlist[k] = (mk & 255) | (ev << 8) | (mdk << 16); }      // m, event tag, contact mode of the interval
   qm_wave_sync();
   int chol_fail = 0;
+  RwPuCodes pc; pc.mode = -1; pc.pk[0] = pc.pk[1] = 0;
+  if (l == 0) { buf[RP_REC + RPO_SWG + 26] = 1.0; buf[RP_REC + RPO_SWG + 27] = 0.0; }      // constants behind the swing blocks (the copies never touch them)
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long tstart = (long long)__builtin_readcyclecounter();
   qm_d4 S[2][2], sv[2];
   {   // terminal value function
@@ -357,8 +444,8 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     int kn = k - 1; while (kn >= 0 && evlist(kn) == QM_EV_PRE) --kn;      // next regular stage: its operands are prefetched into LDS
     const double* nrec = (kn >= 0) ? a.stage + ((size_t)b * a.nmax + kn) * SR_SIZE : nullptr;
     const int m = mlist(k);
-    if (m <= 16) rw_stage<1>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc);
-    else rw_stage<2>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc);
+    if (m <= 16) rw_stage<1>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
+    else rw_stage<2>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
   }
   const long long tback = (long long)__builtin_readcyclecounter();
   // L, W, y were stored by other lanes than the ones that read them back below
@@ -489,3 +576,4 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
 }
 #undef mlist
 #undef evlist
+#undef modelist

@@ -253,8 +253,8 @@ __device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* 
 // ---- per-node stage record written by K1 (LQ + projection) and read by K3 (Riccati); doubles ----
 // dimensions: nx = 30, projected input dim m <= 18 (stance 18, trot 16); row-major, fixed strides
 #define QM_MMAX 18
-#define SR_AP   0                      /* [30][30]  A + B Px            */
-#define SR_BP   900                    /* [30][18]  B Pu                */
+#define SR_AP   0                      /* [30][30]  A + B Px : rows 0..11 written (joint rows: e_j + dt Px[j]) */
+#define SR_BP   900                    /* [30][18]  B Pu     : rows 0..11 written (joint rows: dt Pu[j])       */
 #define SR_QP   1440                   /* [30][30]                      */
 #define SR_PP   2340                   /* [18][30]  Puᵀ(P + R Px)       */
 #define SR_RP   2880                   /* [18][18]  Puᵀ R Pu            */

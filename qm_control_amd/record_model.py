@@ -4,10 +4,10 @@ tools/hbm_traffic_digest.py use (unit: one non-event shooting interval for K1b /
 Stage record written by K1b and read by K3 (csrc/kernels/qm_dev_common.h, SR_*): only what is structurally non-zero is moved.
 """
 # ---- K1b qm_lq_kernel ----
-LQ_WRITE_DOUBLES = 3533      # Ap 900, Bp 540, the upper 16x16 tiles of Qp 676+..., Pp 540, Rp 324, the 12 non-zero rows of Px 360, vectors 108+30, swing blocks 24+2 (Pu is implied by the contact mode)
+LQ_WRITE_DOUBLES = 2669      # rows 0..11 of Ap 360 and Bp 216 (joint rows are e_j + dt Px[j] resp. dt Pu[j]: rebuilt by K3), the upper 16x16 tiles of Qp 676+..., Pp 540, Rp 324, the 12 non-zero rows of Px 360, vectors 108+30, swing blocks 24+2 (Pu is implied by the contact mode)
 LQ_READ_DOUBLES = 620        # kin record (504) + x, u, references, node descriptors
 # ---- K3 qm_riccati_kernel ----
-RICCATI_BWD_READ_DOUBLES = 3282    # [Ap|bp] 930, Bp 540, [Qp|qp] 930, [Pp|rp] 558, Rp 324
+RICCATI_BWD_READ_DOUBLES = 2804    # rows 0..11 of Ap 360 and Bp 216, Qp 900, Pp 540, Rp 324, rows 12..23 of Px 360, bp qp rp 78, swing blocks + mode + dt 26
 RICCATI_BWD_WRITE_DOUBLES = 882    # W 540, L 324, y 18
 RICCATI_FWD_READ_DOUBLES = 1952    # rows 0..11 of Ap (360) and Bp (216), W 540, L 324, rows 12..23 of Px 360, bp qp rp Pe 108, y 18, swing blocks + mode + dt 26
 RICCATI_FWD_IO_DOUBLES = 120       # x (2 nodes' worth of defect reads at events amortised), dx 30 + du 30 written, x0
