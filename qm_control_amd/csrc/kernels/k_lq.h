@@ -518,9 +518,9 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     qm_frag_store<2, 2>(ApA, rec + SR_AP, 30, 12, 30);               // rows 0..11 only: a joint row is e_j + dt Px[j], K3 rebuilds it (k_riccati.h)
     const int gg2 = l >> 4;
 #pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = 16 * I + gg2 + 4 * r; if (c == 14 && row < 30) rec[SR_BPV + row] = ApA[I][1][r]; }
+    for (int r = 0; r < 4; ++r) { const int row = gg2 + 4 * r; if (c == 14) rec[SR_BPV + row] = ApA[0][1][r]; }
+    // rows 16..29 are joint rows: bp_j = b_j + dt Pe_j, the one non-zero term of the product (the second tile row of [Ap | bp] is never formed)
+    if (l >= 16 && l < 30) rec[SR_BPV + l] = fma(dt, S[LW_V_PE + l], S[LW_V_B + l]);
   }
   LQT()
   // ---- phase III: cost quadratic model (x dt) ----
