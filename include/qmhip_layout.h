@@ -96,11 +96,20 @@
 #define ST_KP_EE_ANG  1024  /* [3] */
 #define ST_KD_EE_ANG  1027  /* [3] */
 /* discrete iLQR behind the same MPC entry points (settings block `ddp`, task.info:33-71, loaded at QMInterface.cpp:70) */
-#define ST_SOLVER     1030  /* 0: multiple-shooting SQP (what QMController instantiates, QMController.cpp:287-288), 1: discrete iLQR; set through qmhip_set_setting */
+#define ST_SOLVER     1030  /* 0: multiple-shooting SQP (what QMController instantiates, QMController.cpp:287-288), 1: discrete iLQR, 2: multiple-shooting IPM (the `ipm` block); set through qmhip_set_setting */
 #define ST_DDP_MIN_STEP 1031 /* ddp.lineSearch.minStepLength (task.info:66)                              */
 #define ST_DDP_MAX_STEP 1032 /* ddp.lineSearch.maxStepLength (task.info:67)                              */
 #define ST_DDP_PENALTY  1033 /* ddp.constraintPenaltyInitialValue (task.info:56)                         */
-#define ST_SIZE       1034
+/* `ipm` block (task.info:94-125, loaded at QMInterface.cpp:72, never instantiated).  This OCP has NO hard inequality constraints — friction cones and joint limits enter as
+   relaxed-barrier soft costs (QMInterface.cpp:79-142) — so there are no slack / dual variables and an interior-point iteration is the equality-constrained multiple-shooting
+   step with the filter line search, run with THIS block's dt, iteration count and line-search thresholds (they differ from `sqp`: g_max 10 against 1e-2) */
+#define ST_IPM_DT        1034 /* ipm.dt                                                                   */
+#define ST_IPM_ITER      1035 /* ipm.ipmIteration                                                         */
+#define ST_IPM_DELTA_TOL 1036 /* ipm.deltaTol                                                             */
+#define ST_IPM_G_MAX     1037 /* ipm.g_max                                                                */
+#define ST_IPM_G_MIN     1038 /* ipm.g_min                                                                */
+#define ST_IPM_MU        1039 /* ipm.initialBarrierParameter (carried; no inequality rows to apply it to) */
+#define ST_SIZE       1040
 
 /* contact-mode ids: 8*LF + 4*RF + 2*LH + 1*RH (ocs2_legged_robot MotionPhaseDefinition) */
 #define QM_MODE_STANCE 15

@@ -33,7 +33,8 @@ ST = dict(Q=0, R=30, XINIT=930, MU_EE_POS=960, MU_EE_ORI=961, MU_EEF_POS=962, MU
           TIME_HORIZON=996, WBC_FRIC=997, KP_SWING=998, KD_SWING=999, KP_BASE_H=1000,
           KD_BASE_H=1001, KP_BASE_LIN=1002, KD_BASE_LIN=1003, KP_BASE_ANG=1004, KD_BASE_ANG=1005,
           KP_ARM_J=1006, KD_ARM_J=1012, KP_EE_LIN=1018, KD_EE_LIN=1021, KP_EE_ANG=1024,
-          KD_EE_ANG=1027, SOLVER=1030, DDP_MIN_STEP=1031, DDP_MAX_STEP=1032, DDP_PENALTY=1033, SIZE=1034)
+          KD_EE_ANG=1027, SOLVER=1030, DDP_MIN_STEP=1031, DDP_MAX_STEP=1032, DDP_PENALTY=1033,
+          IPM_DT=1034, IPM_ITER=1035, IPM_DELTA_TOL=1036, IPM_G_MAX=1037, IPM_G_MIN=1038, IPM_MU=1039, SIZE=1040)
 
 FOOT_FRAMES = ["LF_FOOT", "RF_FOOT", "LH_FOOT", "RH_FOOT"]   # ModelSettings.h:38 (contact order)
 MODE_NAMES = {"FLY": 0, "RH": 1, "LH": 2, "LH_RH": 3, "RF": 4, "RF_RH": 5, "RF_LH": 6,
@@ -400,6 +401,9 @@ def build_settings(task_info_path, model_blob):
     s[ST['DDP_MIN_STEP']] = g('ddp.lineSearch.minStepLength')
     s[ST['DDP_MAX_STEP']] = g('ddp.lineSearch.maxStepLength')
     s[ST['DDP_PENALTY']] = g('ddp.constraintPenaltyInitialValue')
+    # `ipm` block (task.info:94-125, loaded at QMInterface.cpp:72, never instantiated): the multiple-shooting parameter set of solver 2
+    for k, key in (('IPM_DT', 'ipm.dt'), ('IPM_ITER', 'ipm.ipmIteration'), ('IPM_DELTA_TOL', 'ipm.deltaTol'), ('IPM_G_MAX', 'ipm.g_max'), ('IPM_G_MIN', 'ipm.g_min'), ('IPM_MU', 'ipm.initialBarrierParameter')):
+        s[ST[k]] = g(key)
     return s
 
 

@@ -48,6 +48,19 @@ inline void parallelFor(int n, const std::function<void(int)>& fn) {
 static const double kWeakEps = 1e-6;                       // numeric_traits::weakEpsilon<double>()
 static const double kLimitEps = 2.220446049250313e-16;     // numeric_traits::limitEpsilon<double>()
 
+// parameter set of the multiple-shooting solver selected by ST_SOLVER: 2 = the `ipm` block (task.info:94-125) — with no hard inequality constraints in this OCP
+// (friction cones / joint limits are soft costs, QMInterface.cpp:79-142) an interior-point iteration has no slack / dual variables and is the SQP step on these parameters
+enum class MsParam { Dt, Iterations, DeltaTol, GMax, GMin };
+inline double msParam(const double* st, MsParam p) {
+  const bool ipm = st[ST_SOLVER] == 2.0;
+  switch (p) {
+    case MsParam::Dt: return ipm ? st[ST_IPM_DT] : st[ST_SQP_DT];
+    case MsParam::Iterations: return ipm ? st[ST_IPM_ITER] : st[ST_SQP_ITER];
+    case MsParam::DeltaTol: return ipm ? st[ST_IPM_DELTA_TOL] : st[ST_DELTA_TOL];
+    case MsParam::GMax: return ipm ? st[ST_IPM_G_MAX] : st[ST_G_MAX];
+    default: return ipm ? st[ST_IPM_G_MIN] : st[ST_G_MIN];
+  }
+}
 struct Node { double t; int ev; };
 inline double intervalStart(const Node& n) { return n.ev == QM_EV_POST ? n.t + kWeakEps : n.t; }
 inline double intervalEnd(const Node& n) { return n.ev == QM_EV_PRE ? n.t - kWeakEps : n.t; }
@@ -231,7 +244,7 @@ inline void evaluatePolicy(const SqpResult& R, const ModeSchedule& ms, double t,
 inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, const std::vector<Vec>* xInit, const std::vector<Vec>* uInit, SqpResult& R, const SqpResult* prev = nullptr);
 inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, const std::vector<Vec>* xInit, const std::vector<Vec>* uInit, SqpResult& R, const SqpResult* prev) {
   const Model& M = *P.M; const double* st = M.st;
-  R.grid = timeDiscretizationWithEvents(t0, tf, st[ST_SQP_DT], P.ms.ev);
+  R.grid = timeDiscretizationWithEvents(t0, tf, msParam(st, MsParam::Dt), P.ms.ev);
   const int N = (int)R.grid.size() - 1;
   R.mode.resize(N + 1); for (int i = 0; i <= N; ++i) R.mode[i] = P.ms.modeAt(intervalStart(R.grid[i]));
   // initializeStateInputTrajectories, cold start: QMInitializer::compute (QMInitializer.cpp:33-41)
@@ -283,7 +296,7 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
   const double armijo = R.armijo;
   const auto tq2 = std::chrono::steady_clock::now();
   // ---- takeStep: filter line-search ----
-  const double gMax = st[ST_G_MAX], gMin = st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
+  const double gMax = msParam(st, MsParam::GMax), gMin = msParam(st, MsParam::GMin), gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
   const double theta0 = std::sqrt(base.dynSSE + base.eqSSE);
   const double duNorm = trajectoryNorm(R.du), dxNorm = trajectoryNorm(R.dx);
   double alpha = 1.0; bool accepted = false; std::vector<Vec> xn(N + 1), un(N); Performance pn; R.lsTrials = 0;
@@ -297,7 +310,7 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
     else accepted = pn.merit < (base.merit - gammaC * theta0) || theta < (1.0 - gammaC) * theta0;
     if (accepted) break;
     alpha *= alphaDecay;
-    if (alpha * duNorm < st[ST_DELTA_TOL] && alpha * dxNorm < st[ST_DELTA_TOL]) break;
+    if (alpha * duNorm < msParam(st, MsParam::DeltaTol) && alpha * dxNorm < msParam(st, MsParam::DeltaTol)) break;
   } while (alpha >= alphaMin);
   if (accepted) { x = xn; u = un; R.alpha = alpha; R.after = pn; } else { R.alpha = 0.0; R.after = base; }
   // ---- toPrimalSolution: u at PreEvent nodes copied from the previous node, last u repeated

@@ -274,9 +274,11 @@ bool buildSettingsBlob(const std::string& taskInfo, const double* mb, double* st
                    {"swing_trajectory_config.liftOffVelocity", ST_LIFTOFF_VEL}, {"swing_trajectory_config.touchDownVelocity", ST_TOUCHDOWN_VEL}, {"swing_trajectory_config.swingHeight", ST_SWING_HEIGHT},
                    {"swing_trajectory_config.swingTimeScale", ST_SWING_TIME_SCALE}, {"sqp.dt", ST_SQP_DT}, {"sqp.sqpIteration", ST_SQP_ITER}, {"sqp.deltaTol", ST_DELTA_TOL}, {"sqp.g_max", ST_G_MAX}, {"sqp.g_min", ST_G_MIN},
                    {"mpc.timeHorizon", ST_TIME_HORIZON}, {"frictionConeTask.frictionCoefficient", ST_WBC_FRIC},
-                   {"ddp.lineSearch.minStepLength", ST_DDP_MIN_STEP}, {"ddp.lineSearch.maxStepLength", ST_DDP_MAX_STEP}, {"ddp.constraintPenaltyInitialValue", ST_DDP_PENALTY}};
+                   {"ddp.lineSearch.minStepLength", ST_DDP_MIN_STEP}, {"ddp.lineSearch.maxStepLength", ST_DDP_MAX_STEP}, {"ddp.constraintPenaltyInitialValue", ST_DDP_PENALTY},
+                   {"ipm.dt", ST_IPM_DT}, {"ipm.ipmIteration", ST_IPM_ITER}, {"ipm.deltaTol", ST_IPM_DELTA_TOL}, {"ipm.g_max", ST_IPM_G_MAX}, {"ipm.g_min", ST_IPM_G_MIN}, {"ipm.initialBarrierParameter", ST_IPM_MU}};
   for (const KV& e : kv) if (!infoScalar(t, e.key, st[e.idx], err)) return false;
   if (!(st[ST_SQP_DT] > 0.0) || !(st[ST_SQP_DT] < 1.0e300)) { err = "INFO: sqp.dt must be a positive finite number"; return false; }   // K0 walks t0 + k dt up to the horizon
+  if (!(st[ST_IPM_DT] > 0.0) || !(st[ST_IPM_DT] < 1.0e300)) { err = "INFO: ipm.dt must be a positive finite number"; return false; }
   st[ST_FRIC_REG] = 25.0; st[ST_FRIC_SHIFT] = 1e-6;     // [upstream] FrictionConeConstraint::Config defaults
   st[ST_SOLVER] = 0.0;                                  // the controller instantiates SqpMpc whatever `ddp.algorithm` says (QMController.cpp:287-288)
   if (!infoMatrix(t, "jointVelocityLimits.lowerBound.arm", 6, 1, lo, err) || !infoMatrix(t, "jointVelocityLimits.upperBound.arm", 6, 1, hi, err)) return false;

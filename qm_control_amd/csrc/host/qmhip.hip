@@ -93,7 +93,7 @@ struct qmhip_ctx {
   void fail(const std::string& m) { error = m; }
   // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
   // them (an instance whose line search finds no step just keeps its iterate)
-  int sqp_iterations() const { const int n = (int)st[ST_SQP_ITER]; return n < 1 ? 1 : (n > 50 ? 50 : n); }
+  int sqp_iterations() const { const int n = (int)qm_ms_param(st, ST_SQP_ITER); return n < 1 ? 1 : (n > 50 ? 50 : n); }      // ipm.ipmIteration with solver 2
   int hipstate() { if (!bk.error.empty()) { error = bk.error; bk.error.clear(); return QMHIP_ERR_HIP; } return QMHIP_OK; }
 };
 
@@ -113,7 +113,7 @@ __global__ void qm_bench_mfma_kernel(double* out, int iters) {
 }
 
 // settings whose value the kernels' loop bounds depend on (K0 walks t0 + k dt up to the horizon)
-static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT) return v > 0.0 && std::isfinite(v); return true; }
+static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT || idx == ST_IPM_DT) return v > 0.0 && std::isfinite(v); return true; }
 
 // ---- co-residency probe (profiling only): a latency-bound stand-in for a narrow (<= 256 VGPR, <= 20 KB LDS) one-wave-per-instance solver wave — chains of
 // dependent f64 MFMAs and FMAs with an LDS round trip per step, ≈ 40 % issue utilisation like qm_riccati_kernel — launched on the second stream beside the
@@ -144,7 +144,7 @@ static int create_common(const double* mb, const double* st, int device, int max
   memcpy(c->mb, mb, sizeof(c->mb)); memcpy(c->st, st, sizeof(c->st));
   if (hipStreamCreate(&c->bk.stream) != hipSuccess || hipStreamCreate(&c->bk.stream_b) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
   c->bk.cur = c->bk.stream; hipEventCreateWithFlags(&c->bk.ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->bk.ev_wbc, hipEventDisableTiming);
-  c->mpc.allocate(c->mb, c->st, max_batch, max_nodes, max_ref, max_ev, false); c->mpc.solver = ((int)st[ST_SOLVER] == 1) ? 1 : 0;
+  c->mpc.allocate(c->mb, c->st, max_batch, max_nodes, max_ref, max_ev, false); c->mpc.solver = (st[ST_SOLVER] == 1.0) ? 1 : ((st[ST_SOLVER] == 2.0) ? 2 : 0);
   c->wbc.allocate(max_batch);
   c->front.allocate(max_batch);
   c->bk.sync();
@@ -181,8 +181,8 @@ const char* qmhip_last_error(const qmhip_ctx* c) { return c ? c->error.c_str() :
 int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
 int qmhip_set_setting(qmhip_ctx* c, int idx, double v) {
   if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
-  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt must be a positive finite number"); return QMHIP_ERR_ARG; }
-  if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP) or 1 (discrete iLQR)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
+  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number"); return QMHIP_ERR_ARG; }
+  if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR) or 2 (multiple-shooting IPM)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
   hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
 }
 

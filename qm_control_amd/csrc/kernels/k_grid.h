@@ -71,7 +71,7 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
   int n = 0;
   if (b < a.B) {
   const double* ev = a.ev + (size_t)b * a.nev; const int* modes = a.modes + (size_t)b * (a.nev + 1);
-  const double t0 = a.t0[b], tf = t0 + a.horizon, dt = a.st[ST_SQP_DT];
+  const double t0 = a.t0[b], tf = t0 + a.horizon, dt = qm_ms_param(a.st, ST_SQP_DT);
   const double dtMin = 10.0 * QM_WEAK_EPS;   // steps shorter than this are merged: with [upstream]'s few-epsilon default a node within weakEpsilon before an event opens an
                                              // interval of negative adapted duration (a fixed-rate loop with events on the same raster hits that exactly)
   int status = a.front_status ? a.front_status[b] : 0;

@@ -153,7 +153,7 @@ __device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b,
     if (!(an >= a.st[ST_DDP_MIN_STEP])) { a.done[b] = 2; a.alpha[b] = 0.0; return false; }
     a.alpha[b] = an; return true;
   }
-  const double gMax = a.st[ST_G_MAX], gMin = a.st[ST_G_MIN], gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
+  const double gMax = qm_ms_param(a.st, ST_G_MAX), gMin = qm_ms_param(a.st, ST_G_MIN), gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
   const double* bs = a.base_sum + b * 4; const double ps[4] = {c, c, d, e};
   const double theta0 = sqrt(bs[2] + bs[3]), theta = sqrt(ps[2] + ps[3]);
   double al = al0; const double armijo = a.step_info[b * 4];
@@ -164,7 +164,7 @@ __device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b,
   if (acc) { a.done[b] = 1; for (int q = 0; q < 4; ++q) a.out_perf[b * 10 + 4 + q] = ps[q]; a.out_perf[b * 10 + 8] = al; return false; }
   al *= alphaDecay;
   const double dxn = sqrt(a.step_info[b * 4 + 1]), dun = sqrt(a.step_info[b * 4 + 2]);
-  if ((al * dun < a.st[ST_DELTA_TOL] && al * dxn < a.st[ST_DELTA_TOL]) || !(al >= alphaMin)) { a.done[b] = 2; a.alpha[b] = 0.0; return false; }
+  if ((al * dun < qm_ms_param(a.st, ST_DELTA_TOL) && al * dxn < qm_ms_param(a.st, ST_DELTA_TOL)) || !(al >= alphaMin)) { a.done[b] = 2; a.alpha[b] = 0.0; return false; }
   a.alpha[b] = al;
   return true;
 }

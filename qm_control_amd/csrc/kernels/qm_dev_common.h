@@ -250,6 +250,10 @@ __device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* 
       for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < rows && col < cols) dst[row * ld + col] = T[I][J][r]; }
 }
 
+// parameter of the multiple-shooting transcription / filter line search for the selected solver: the `ipm` block's value with ST_SOLVER == 2, the `sqp` block's otherwise
+// (the iLQR shares the SQP's grid).  sqp_slot is one of ST_SQP_DT, ST_SQP_ITER, ST_DELTA_TOL, ST_G_MAX, ST_G_MIN — contiguous, in the order of the ipm slots
+__host__ __device__ __forceinline__ double qm_ms_param(const double* st, int sqp_slot) { return (st[ST_SOLVER] == 2.0) ? st[ST_IPM_DT + (sqp_slot - ST_SQP_DT)] : st[sqp_slot]; }
+
 // ---- per-node stage record written by K1 (LQ + projection) and read by K3 (Riccati); doubles ----
 // dimensions: nx = 30, projected input dim m <= 18 (stance 18, trot 16); row-major, fixed strides
 #define QM_MMAX 18

@@ -137,3 +137,27 @@ def test_ilqr_iteration_vs_oracle(blobs, oracle, name, N):
     e.mpc_step_warm(np.array([t1]), x1[None], cfg["horizon"])
     assert e.buf("n_nodes", (1,), np.int32)[0] == n2 and e.buf("out_perf", (10,))[8] == r2["alpha"]
     assert_blocks(e.node_arr("xs", 30)[:n2, 0], r2["x"], "x", TOL); assert_blocks(e.node_arr("us", 30)[:n2, 0], r2["u"], "u", TOL)
+
+
+def test_ipm_slot_runs_the_multiple_shooting_step_on_the_ipm_block(blobs, oblobs):
+    """ST_SOLVER = 2 (the `ipm` block the reference loads and never uses, task.info:94-125): this OCP has no hard inequality rows, so the interior-point iteration is
+    the multiple-shooting step on the ipm block's dt and line-search thresholds.  Grid, iterate and line-search outcome against the oracle run on the same settings;
+    the ipm block's own values (g_max 10 against the sqp block's 1e-2) change the line search of a perturbed start"""
+    import emu_harness, pyoracle
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config("C3", batch=1, n_intervals=10)
+    cfg["x0"][0, 24:30] += 0.3
+    out = {}
+    for solver, dt in ((0, None), (2, None), (2, 0.02)):
+        st = blobs[1].copy(); st[L.ST_SOLVER] = float(solver)
+        if dt: st[L.ST_IPM_DT] = dt
+        o2 = pyoracle.Oracle(oblobs[0], st)
+        r = _oracle(o2, cfg); n = len(r["t"])
+        e = emu_harness.Emu(blobs[0], st, 1, n + 3, 2, cfg["ev"].shape[1])
+        trials = e.mpc_step(cfg); perf = e.buf("out_perf", (10,))
+        assert trials == r["ls_trials"] and perf[8] == r["alpha"]
+        assert e.node_arr("node_t", 1)[:n, 0].tolist() == list(r["t"])
+        assert_blocks(e.node_arr("xs", 30)[:n, 0], r["x"], "x", TOL); assert_blocks(e.node_arr("us", 30)[:n, 0], r["u"], "u", TOL)
+        out[(solver, dt)] = (n, r["alpha"], r["ls_trials"])
+    assert blobs[1][L.ST_IPM_G_MAX] == 10.0 and blobs[1][L.ST_G_MAX] == 1e-2 and blobs[1][L.ST_IPM_DT] == blobs[1][L.ST_SQP_DT]
+    assert out[(2, 0.02)][0] < out[(2, None)][0] == out[(0, None)][0]                 # a coarser ipm.dt gives a shorter grid; equal dt, equal grid
