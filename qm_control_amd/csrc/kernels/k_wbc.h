@@ -131,9 +131,9 @@ __device__ __forceinline__ bool qm_house_scalars(double nrm2, double g, double& 
 // Row k of [R | Qᵀ rhs] is written to Rout[k * ldR + l], k <= l <= n.  With Vout the reflectors are kept:
 // Vout[k * ldV + k + i] = v_k[i] (zero above the pivot), beta[k] = 2 / (v·v) (0 for a null column).
 template <int MR>
-__device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, double* hv, double* Rout, int ldR, double* Vout, int ldV, double* beta) {
+__device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, double* hv, double* Rout, int ldR, double* Vout, int ldV, double* beta, int kstart = 0) {
   const int l = threadIdx.x & 63;
-  for (int k = 0; k < nsteps; ++k) {
+  for (int k = kstart; k < nsteps; ++k) {      // kstart > 0: the registers have already moved up kstart rows (wv_qr_Et_append)
     // the pivot column reaches every lane through v_readlane (MR <= 18 values fit the scalar registers): no LDS round trip in the chain
     double v[MR];
 #pragma unroll
@@ -265,6 +265,33 @@ __device__ __forceinline__ void wv_qr_Et(const double* E, int me, int n, double*
   for (int idx = l; idx < me * WVLD; idx += 64) V[idx] = 0.0;             // reflector entries above the pivot must read as zero
   rq_house<WVLD>(col, me, me - 1, hv, R, WMAXACT, V, WVLD, beta);
 }
+// The same factorisation after ONE more row has been appended to E (row m = me − 1): the reflectors of the first m columns of Eᵀ do not depend on later columns, so
+// they are applied to the new column — in the lane that holds it, with the arithmetic of rq_house (same partial sums, same order: the result is bit-identical to a
+// factorisation from scratch) — and one Householder step follows.  Costs m reflections of one vector + 1 step instead of me steps over all columns.
+__device__ __forceinline__ void wv_qr_Et_append(const double* E, int me, int n, double* V, double* beta, double* R, double* hv) {
+  const int l = threadIdx.x & 63, m = me - 1;
+  double col[WVLD];
+#pragma unroll
+  for (int i = 0; i < WVLD; ++i) col[i] = (l == m && i < n) ? E[m * WVLD + i] : 0.0;
+  for (int k = 0; k < m; ++k) {
+    const double* vs = V + k * WVLD + k; const double b2 = beta[k];
+    double v[WVLD];
+#pragma unroll
+    for (int i = 0; i < WVLD; ++i) v[i] = vs[i];                          // v[0] = vk; entries past the row end are the zeros rq_house left there
+    double dq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 1; i < WVLD; ++i) dq[i & 3] += v[i] * col[i];
+    const double dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
+    const double s = (dot + v[0] * col[0]) * b2;
+    if (l == m) R[k * WMAXACT + m] = col[0] - s * v[0];
+#pragma unroll
+    for (int i = 1; i < WVLD; ++i) col[i - 1] = col[i] - s * v[i];
+    col[WVLD - 1] = 0.0;
+  }
+  if (l < m) V[m * WVLD + l] = 0.0;                                      // reflector entries above the pivot must read as zero
+  qm_wave_sync();
+  rq_house<WVLD>(col, me, me - 1, hv, R, WMAXACT, V, WVLD, beta, m);
+}
 __device__ __forceinline__ void wv_apply_Qt(const double* V, const double* beta, int me, int n, double* x) {   // x <- Qᵀ x
   const int l = threadIdx.x & 63;
   for (int k = 0; k < me; ++k) { const double* v = V + k * WVLD; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
@@ -309,25 +336,36 @@ __device__ __forceinline__ void wv_Z_times(const double* Zp, int n, const double
 // min |R z − c|² s.t. E z = e (me working-set rows in WL_EROWS / WL_ERHS), null-space method.  Rc = [R | c] (n x (n+1), ld WTLD,
 // upper triangle valid) is the once-per-level QR factor of G0 = [AZ; sqrt(rho) I | g0]; T (n x (n+1), ld WTLD) is scratch.  lam: multipliers.
 template <bool PROF>
-__device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* T, int n, int me, double* zout, long long* tf) {
+__device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* T, int n, int me, double* zout, long long* tf, int& nfact, double (&g)[WVLD]) {
   const int l = threadIdx.x & 63;
   long long tl_ = PROF ? (long long)__builtin_readcyclecounter() : 0;
 #define WF(k) { if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tf[k] += now_ - tl_; tl_ = now_; } }
-  if (me == 0) { wv_backsub_tri<WVLD>(Rc, WTLD, n, zout); return; }
+  if (me == 0) { nfact = -1; wv_backsub_tri<WVLD>(Rc, WTLD, n, zout); return; }
   double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
   WF(0)
-  wv_qr_Et(S + WL_EROWS, me, n, V, beta, R, S + WL_HV);
+  // nfact = number of leading working rows whose factor data (reflectors V / beta, R_E, y1 and this lane's row g of [R | c] Q) are still valid: the active-set loop
+  // appends one row per step most of the time, and everything that belongs to the earlier rows is unchanged by an append (a drop invalidates: nfact = -1)
+  const bool append = (nfact == me - 1);
+  if (append) wv_qr_Et_append(S + WL_EROWS, me, n, V, beta, R, S + WL_HV);
+  else if (nfact != me) wv_qr_Et(S + WL_EROWS, me, n, V, beta, R, S + WL_HV);
   WF(1)
-  { const double y1 = wv_solve_lower<WVLD>([&](int j, int i) { return R[i * WMAXACT + j]; }, me, (l < me) ? e[l] : 0.0);   // R_Eᵀ y1 = e
+  if (append) {                                                          // R_Eᵀ y1 = e: only the new entry (lane m repeats wv_solve_lower's row arithmetic)
+    const int m = me - 1; double rj = (l == m) ? e[m] : 0.0;
+    for (int i = 0; i < m; ++i) rj -= ((l == m) ? R[i * WMAXACT + m] : 0.0) * y[i];
+    if (l == m) y[m] = rj * (1.0 / R[m * WMAXACT + m]);
+  } else if (nfact != me) {
+    const double y1 = wv_solve_lower<WVLD>([&](int j, int i) { return R[i * WMAXACT + j]; }, me, (l < me) ? e[l] : 0.0);   // R_Eᵀ y1 = e
     if (l < me) y[l] = y1; }
   WF(2)
   // T <- T Q (row-wise reflections; lane = row), rhs column untouched
   qm_wave_sync();
   {
-    double g[WVLD];                                          // row l of [R | c] in registers; V is zero above each pivot, so no index bounds are needed
+    // row l of [R | c] Q in registers, kept across the iterations; V is zero above each pivot, so no index bounds are needed
+    if (!append && nfact != me) {
 #pragma unroll
-    for (int i = 0; i < WVLD; ++i) g[i] = (l < n && i >= l && i < n) ? Rc[l * WTLD + i] : 0.0;
-    for (int k = 0; k < me; ++k) {
+      for (int i = 0; i < WVLD; ++i) g[i] = (l < n && i >= l && i < n) ? Rc[l * WTLD + i] : 0.0;
+    }
+    for (int k = append ? me - 1 : ((nfact == me) ? me : 0); k < me; ++k) {
       const double* v = V + k * WVLD; double sq[2] = {0.0, 0.0};
 #pragma unroll
       for (int i = 0; i < WVLD; ++i) sq[i & 1] += g[i] * v[i];
@@ -335,6 +373,7 @@ __device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* 
 #pragma unroll
       for (int i = 0; i < WVLD; ++i) g[i] -= sacc * v[i];
     }
+    nfact = me;
     double rhs = (l < n) ? Rc[l * WTLD + n] : 0.0;
 #pragma unroll
     for (int i = 0; i < WVLD; ++i) if (i < me) rhs -= g[i] * y[i];
@@ -798,6 +837,9 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
       WT(8)
       int* Wi = (int*)(S + WL_WLIST);                    // working-set list lives in LDS (wave-uniform reads)
       unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false, vertex = false; double pscale = 0.0; int myslot = -1;   // position of this lane's row in the working set
+      int nfact = -1; double grow[WVLD];                 // factor data of the working set carried from one iteration to the next (wv_eq_ls_R)
+#pragma unroll
+      for (int k = 0; k < WVLD; ++k) grow[k] = 0.0;
       for (; it < 100; ++it) {
         if (myslot >= 0) {
 #pragma unroll
@@ -806,7 +848,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
         }
         qm_wave_sync();
         WT(10)
-        wv_eq_ls_R<PROF>(S, G, Tm, n, nw, zn, tfine);
+        wv_eq_ls_R<PROF>(S, G, Tm, n, nw, zn, tfine, nfact, grow);
         WT(9)
         if (l < n) p[l] = zn[l] - z[l];
         qm_wave_sync();
@@ -826,6 +868,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
           if (worst < 0) break;
           wmask &= ~(1ull << Wi[worst]);
           if (myslot == worst) myslot = -1; else if (myslot > worst) --myslot;
+          nfact = -1;                                       // the rows behind the dropped one move up: factor again
           const int nxt = (l + 1 < nw) ? Wi[l + 1] : 0;
           qm_wave_sync();
           if (l >= worst && l + 1 < nw) Wi[l] = nxt;

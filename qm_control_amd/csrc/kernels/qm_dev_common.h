@@ -10,6 +10,9 @@
 //    Fragment maps (cdna_hip_programming.md §3): A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
 //    D[row=(l>>4)+4r][col=l&15].
 #pragma once
+#ifndef QM_MAX_VGPRS
+#define QM_MAX_VGPRS(n) __attribute__((amdgpu_waves_per_eu(512 / (n), 512 / (n))))      /* cap a kernel's vector registers through the occupancy it asks for (the host emulator defines this away) */
+#endif
 #include <hip/hip_runtime.h>
 #include "../../../include/qmhip_layout.h"
 

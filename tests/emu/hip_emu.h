@@ -24,6 +24,7 @@
 #define __shared__
 #define __restrict__
 #define __launch_bounds__(...)
+#define QM_MAX_VGPRS(n)            /* register caps mean nothing on the host */
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)   /* instruction-scheduling fence: no meaning on the host */
 #define QM_TABLE_OPAQUE(p)            /* device-only register constraint */
 
