@@ -15,8 +15,8 @@
 //   S A = Sᵀ A,  S B = Sᵀ B,  Hux = Bᵀ (S A),  Huu = Bᵀ (S B),  Aᵀ (S A),  Wᵀ W
 // so results chain from MFMA to MFMA without any layout conversion.  The vectors ride in the padding column 30 of the 32-wide
 // tiles: A|b, (S A | S b + s), (P | r), (Q | q), (W | y) — the mat-vecs cost nothing extra.
-// The Cholesky factorisation of Huu and the forward substitution of [Hux | hu] stay in fragment layout as well: the rank-1 update of
-// one elimination step is an MFMA with a single live k-slot (see rw_stage).  Only the symmetrisation of S' takes a wave-local LDS
+// The Cholesky factorisation of Huu and the forward substitution of [Hux | hu] stay in fragment layout as well: four pivots per block,
+// two MFMAs per tile and block with all four k-slots live (see rw_stage).  Only the symmetrisation of S' takes a wave-local LDS
 // round trip.  (On gfx950 f64 MFMA and f64 VALU share one rate and do not overlap: the MFMA buys the data movement, not flops.)
 // The operands of the NEXT stage are copied global -> LDS asynchronously (global_load_lds_dwordx4, 1 KB per wave instruction, no
 // VGPRs) while the current stage computes; a stage starts by pulling its fragments out of that buffer.
@@ -224,12 +224,11 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
     rw_gemm_tn_upper<2>(A, SA, Sn, 8, false);                        // [Q + Aᵀ S A | q + Aᵀ (S b + s)], upper tiles  (row 30 is garbage, masked below)
   }
   RWT(1)
-  // ---- Cholesky of Huu and forward substitution of [Hux | hu] IN FRAGMENT LAYOUT (right-looking, one pivot per step).
+  // ---- Cholesky of Huu and forward substitution of [Hux | hu] IN FRAGMENT LAYOUT (right-looking).
   // Row j of a D-layout matrix is register (j&15)>>2 of lane group g = j&3, i.e. it already is k-slot j&3 of an MFMA B operand, and
-  // — Huu being symmetric — the same register read as an A operand supplies column j.  The rank-1 update of the trailing rows of
-  // [Huu | Hux hu] is therefore one MFMA per 16x16 tile with a single live k-slot: no LDS staging and no layout change, and
-  // W = L⁻¹[Hux | hu] comes out as fragments, ready for Wᵀ W.  Only the upper triangle of Huu is ever read (pivot row, columns > j);
-  // rows <= j are masked out of the update, so at the end row j still holds its value at elimination time: L_jj · (row j of Lᵀ resp. W).
+  // — Huu being symmetric — the same register read as an A operand supplies column j: the updates of the trailing rows of
+  // [Huu | Hux hu] are MFMAs on the fragments as they are, no LDS staging and no layout change, and W = L⁻¹[Hux | hu] comes out as
+  // fragments, ready for Wᵀ W.  Only the upper triangle of Huu is ever read; a row keeps its value at elimination time: L_jj · (row j of Lᵀ resp. W).
   qm_d4 W[MT][2];
   if (!(skip & 1)) {
     double dsel[MT][4];                                              // pivot d_row of this lane's rows (1 on padding rows)
