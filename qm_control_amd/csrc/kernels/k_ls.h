@@ -35,7 +35,7 @@ struct QmLsArgs {
   const double* xt; const double* ut; int ilqr;
 };
 #define QM_LS_MAX_TRIALS 16
-#define LS_EVAL_LDS_BYTES (3 * 64 * 31 * 8)   /* qm_ls_eval_kernel: three 31-double rows per thread */
+#define LS_EVAL_LDS_BYTES (2 * 64 * 31 * 8)   /* qm_ls_eval_kernel: two 31-double rows per thread = 31 KB per wave: FOUR waves fit a CU's 160 KB (three rows were 46.5 KB: three waves per CU, a SIMD idle) */
 
 // cost value of one intermediate node (a2 + a6 + a7 + a5), not yet × dt; K must hold base, legs and arm
 __device__ __forceinline__ double node_cost_value(const double* mb, const double* st, const double* x, const double* u, const double* K, int mode,
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   double cost = 0.0, eq = 0.0;
   if (dt > 0.0) cost = node_cost_value(mb, st, x, u, K, mode, a.xref + nb * 30, a.eeref + nb * 7, st[ST_MU_EE_POS], st[ST_MU_EE_ORI], true, qm_ls_u + 64 * 31 + (threadIdx.x & 63) * 31);
   if (dt > 0.0) eq = node_eq_sse(st, x, u, K, mode, a.zvel + nb * 4, a.zpos + nb * 4);
-  double x2[30], f2[30]; double* f1 = qm_ls_u + 2 * 64 * 31 + (threadIdx.x & 63) * 31;      // first Heun stage's flow value: the thread's third LDS row
+  double x2[30], f2[30]; double* f1 = qm_ls_u + 64 * 31 + (threadIdx.x & 63) * 31;      // first Heun stage's flow value: the thread's second LDS row again (the input cost's u − u_nominal is dead by now)
   flow_from_kin(mb, x, u, K, f1);
   _Pragma("unroll") for (int q = 0; q < 30; ++q) { x2[q] = x[q] + dt * f1[q]; f2[q] = f1[q]; }
   if (dt > 0.0) {
