@@ -1,0 +1,47 @@
+"""Register / LDS budgets the schedule of the control step relies on, read from the built library's gfx950 code object (no GPU needed).
+These are the numbers behind DESIGN.md's occupancy notes; crossing an allocation granule here has cost more than most kernel changes gained:
+  * a WBC wavefront holds ceil(vgpr / 8) * 8 of its SIMD's 512 registers while the next step's grid kernels run on the other stream — they must fit beside it;
+  * the one-wave-per-instance kernels and the LQ kernel must not touch the private segment (rocprofv3's ScratchBytesPerLane);
+  * the LQ kernel runs two waves per SIMD, the thread-per-node kernels four waves per CU (their LDS rows decide that)."""
+import os, re, struct, subprocess, tempfile, ctypes as C
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "qm_control_amd", "libqmhip.so")
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def _kernels():
+    blob = open(LIB, "rb").read(); i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__"); assert i >= 0, "no offload bundle in libqmhip.so"
+    n = struct.unpack_from("<Q", blob, i + 24)[0]; p = i + 32; co = None
+    for _ in range(n):
+        off, size, tl = struct.unpack_from("<QQQ", blob, p); p += 24; triple = blob[p:p + tl].decode(); p += tl
+        if "gfx950" in triple: co = blob[i + off:i + off + size]
+    assert co, "no gfx950 code object"
+    with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+        f.write(co); f.flush(); notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for blk in notes.split("  - .agpr_count:")[1:]:
+        g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+        name = re.search(r"\.name:\s+_Z\d+(qm_\w+_kernel)", blk)
+        if name: out[name.group(1)] = dict(vgpr=g("vgpr_count"), lds=g("group_segment_fixed_size"), scratch=g("private_segment_fixed_size"))
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(READELF)), reason="libqmhip.so / llvm-readelf not available")
+def test_register_and_scratch_budgets():
+    k = _kernels(); alloc = lambda name: (k[name]["vgpr"] + 7) // 8 * 8
+    for name in ("qm_wbc_kernel", "qm_sim_kernel", "qm_riccati_kernel", "qm_lq_kernel"):
+        assert k[name]["scratch"] == 0, (name, k[name])
+    assert alloc("qm_wbc_kernel") + alloc("qm_grid_nodes_kernel") <= 512 and alloc("qm_wbc_kernel") + alloc("qm_grid_kernel") <= 512, (k["qm_wbc_kernel"], k["qm_grid_nodes_kernel"])
+    assert alloc("qm_wbc_kernel") + alloc("qm_policy_kernel") <= 512
+    assert 2 * alloc("qm_lq_kernel") <= 512, k["qm_lq_kernel"]
+    assert k["qm_lq_kin_kernel"]["scratch"] <= 64 and k["qm_ls_eval_kernel"]["scratch"] <= 192       # what is left of the thread-per-node kernels' spills
+
+
+def test_lds_budgets_fit_the_intended_waves_per_cu():
+    import emu_harness
+    lib = C.CDLL(emu_harness.build())
+    cu = 160 * 1024
+    lq, ric, kin, ev, wbc, sim = (lib.emu_sizes(i) for i in (3, 4, 6, 7, 8, 9))
+    assert 8 * lq <= cu and 4 * ric <= cu and 4 * kin <= cu and 4 * ev <= cu and 4 * wbc <= cu and 4 * sim <= cu, (lq, ric, kin, ev, wbc, sim)
