@@ -127,7 +127,7 @@ struct QmMpcPipeline {
     if (ilqr && !d.xt) { d.xt = A<double>((size_t)d.nmax * d.Bmax * 30); d.ut = A<double>((size_t)d.nmax * d.Bmax * 30); }
     QmRolloutArgs ro; ro.mb = d.mb; ro.st = d.st; ro.B = B; ro.nmax = d.nmax; ro.mode = 0; ro.trial = 0; ro.n_nodes = d.n_nodes; ro.node_dt = d.node_dt; ro.node_ev = d.node_ev; ro.x0 = d.x0;
     ro.x = d.x; ro.u = d.u; ro.stage = d.stage; ro.alpha = d.alpha; ro.done = d.done; ro.xt = d.xt; ro.ut = d.ut;
-    if (ilqr) bk.launch(qm_ilqr_rollout_kernel, (B + 63) / 64, 64, 0, ro);      // single shooting: the nominal states are the rollout of the initial inputs
+    if (ilqr) bk.launch(qm_ilqr_rollout_kernel, B, 64, 0, ro);      // single shooting: the nominal states are the rollout of the initial inputs
     if (ncap == 0) { if (ncap_pending) bk.wait_flag(d.host_ncap, -1); ncap = ncap_pending ? d.host_ncap[0] : d.nmax; ncap_pending = false; if (ncap < 1 || ncap > d.nmax) ncap = d.nmax; }   // K0 ran first in the stream: published long before K1a is done
     const int nodes_threads = ncap * B;
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
@@ -143,7 +143,7 @@ struct QmMpcPipeline {
     ls_trials_run = 0;
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;
-      if (ilqr) { ro.mode = 1; ro.trial = t; bk.launch(qm_ilqr_rollout_kernel, (B + 63) / 64, 64, 0, ro); }      // nonlinear rollout with feedback at the instance's step length
+      if (ilqr) { ro.mode = 1; ro.trial = t; bk.launch(qm_ilqr_rollout_kernel, B, 64, 0, ro); }      // nonlinear rollout with feedback at the instance's step length
       bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching
       ++ls_trials_run;
