@@ -194,7 +194,10 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
                 roofline = {"bound": "mfma", "kernel": rd["kernel"], "achieved": rd["tflops"], "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rd["frac_fp64"], "traffic": None}
             roofline.update({"avg_launch_ms": rd["avg_launch_ms"], "flop_per_launch": rd["flop_per_launch"], "bytes_per_launch": rd["bytes_per_launch"], "flop_model": flop_src,
                              "frac_hbm": rd["frac_hbm"], "frac_fp64": rd["frac_fp64"],
-                             "note": "bound = the nearer of the two roofs for this kernel; neither is close: the kernel is limited by instruction issue (DESIGN.md §4)"})
+                             "note": "bound = the nearer of the two roofs for this kernel; neither is close: the kernel is limited by instruction issue (DESIGN.md §4)",
+                             # K1b and K3 take the same time to within the run-to-run spread: which of them is `the longest` flips from run to run, so both are named here
+                             "co_dominant": {v["kernel"]: {"avg_launch_ms": v["avg_launch_ms"], "frac_hbm": v["frac_hbm"], "frac_fp64": v["frac_fp64"]}
+                                             for v in roofs.values() if v["avg_launch_ms"] >= 0.97 * rd["avg_launch_ms"]}})
             # measured HBM bytes per launch of that kernel: the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, digested into
             # profiles/hbm_traffic.json by tools/digest_round_profile.sh — a STATIC file of the named profile round
             try:
