@@ -427,11 +427,11 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     if (mode_flag(mode, k)) { double M3[9]; for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) M3[3 * r + q] = Dt[(row0[k] + r) * LW_TLD + jc + q]; m3_inv(M3, gg); }
     else {
       const double gv[3] = {Dt[(row0[k] + 3) * LW_TLD + jc], Dt[(row0[k] + 3) * LW_TLD + jc + 1], Dt[(row0[k] + 3) * LW_TLD + jc + 2]};
-      const double n2 = gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2], nrm = sqrt(n2);
-      for (int r = 0; r < 3; ++r) gg[r] = gv[r] / n2;
+      const double n2 = gv[0] * gv[0] + gv[1] * gv[1] + gv[2] * gv[2], nrm = sqrt(n2), in2 = qm_frcp(n2);
+      for (int r = 0; r < 3; ++r) gg[r] = gv[r] * in2;
       // Householder H = I - 2 v vᵀ/(vᵀ v), v = g - alpha e1, alpha = -sign(g0)|g| : H e1 || g, columns 2,3 of H span g-perp
-      const double alpha = gv[0] > 0.0 ? -nrm : nrm; const double v[3] = {gv[0] - alpha, gv[1], gv[2]}; const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-      for (int r = 0; r < 3; ++r) { gg[3 + r] = ((r == 1) ? 1.0 : 0.0) - 2.0 * v[r] * v[1] / vv; gg[6 + r] = ((r == 2) ? 1.0 : 0.0) - 2.0 * v[r] * v[2] / vv; }
+      const double alpha = gv[0] > 0.0 ? -nrm : nrm; const double v[3] = {gv[0] - alpha, gv[1], gv[2]}; const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2], ivv = qm_frcp(vv);
+      for (int r = 0; r < 3; ++r) { gg[3 + r] = ((r == 1) ? 1.0 : 0.0) - 2.0 * v[r] * v[1] * ivv; gg[6 + r] = ((r == 2) ? 1.0 : 0.0) - 2.0 * v[r] * v[2] * ivv; }
     }
   }
   qm_wave_sync();
@@ -564,16 +564,16 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     const double lo = pos ? mb[MB_QLO + 12 + k] : st[ST_JVEL_LO + k], hi = pos ? mb[MB_QHI + 12 + k] : st[ST_JVEL_HI + k], z = pos ? X[24 + k] : U[24 + k];
     const double h1 = boxv ? z - lo : (boxc ? -lo : (fon ? muf * Fz - Tn : 1.0)), h2 = boxv ? hi - z : (boxc ? hi : 1.0);
     const double v1 = barrier_val(mu, de, h1), v2 = barrier_val(mu, de, h2);
-    const double p1 = barrier_d1(mu, de, h1), q1 = barrier_d1(mu, de, h2), p2 = barrier_d2(mu, de, h1), q2 = barrier_d2(mu, de, h2);
+    double p1, p2, q1, q2; barrier_d12(mu, de, h1, p1, p2); barrier_d12(mu, de, h2, q1, q2);
     cost += boxv ? v1 + v2 : (boxc ? -(v1 + v2) : (fon ? v1 : 0.0));
     if (boxv) { const double g1 = p1 - q1, g2 = p2 + q2; if (pos) { S[LW_V_QV + 24 + k] += g1; QD[24 + k] += g2; } else { S[LW_V_RV + 24 + k] += g1; RD[24 + k] += g2; } }
     else if (fric) {                                                     // one lane per contact (disjoint 3x3 blocks)
       double* fr = FR + 16 * kf; double ds = 0.0;
       for (int q = 0; q < 13; ++q) fr[q] = 0.0;
       if (fon) {
-        const double shift = st[ST_FRIC_SHIFT], T3 = Tn * Tn * Tn;
-        const double dh[3] = {-Fx / Tn, -Fy / Tn, muf};
-        const double ddh[9] = {-(Fy * Fy + reg) / T3, Fx * Fy / T3, 0.0, Fx * Fy / T3, -(Fx * Fx + reg) / T3, 0.0, 0.0, 0.0, 0.0};
+        const double shift = st[ST_FRIC_SHIFT], iTn = qm_frcp(Tn), iT3 = iTn * iTn * iTn;
+        const double dh[3] = {-Fx * iTn, -Fy * iTn, muf};
+        const double ddh[9] = {-(Fy * Fy + reg) * iT3, Fx * Fy * iT3, 0.0, Fx * Fy * iT3, -(Fx * Fx + reg) * iT3, 0.0, 0.0, 0.0, 0.0};
         for (int r = 0; r < 3; ++r) { S[LW_V_RV + 3 * kf + r] += p1 * dh[r]; for (int q = 0; q < 3; ++q) fr[3 * r + q] = p2 * dh[r] * dh[q] + p1 * ddh[3 * r + q]; }
         ds = p1 * (-shift);
       }
