@@ -30,7 +30,7 @@ __device__ __forceinline__ double ilqr_flow_lane(const double* mb, double xl, do
   double xb[12], Kb[KW_LEG];
 #pragma unroll
   for (int i = 0; i < 12; ++i) xb[i] = qm_bcast(xl, i);                 // momentum + base pose: wave-uniform
-  kin_base(mb, xb, Kb);
+  kin_base<true>(mb, xb, Kb);
   // the leg chain of this lane (lanes >= 4 repeat chain l & 3; their result is not read)
   const int c = l & 3, frame = chain_to_contact(c);
   double q3[3];
@@ -47,7 +47,7 @@ __device__ __forceinline__ double ilqr_flow_lane(const double* mb, double xl, do
     double t[3]; m3_mulv(Rp, mb + MB_JP + 3 * j, t);
     for (int i = 0; i < 3; ++i) pp[i] += t[i];
     m3_mul(Rp, mb + MB_JR + 9 * j, Rj);
-    rot_axis_angle(mb + MB_AXIS + 3 * j, q3[jj], Rq);
+    rot_axis_angle<true>(mb + MB_AXIS + 3 * j, q3[jj], Rq);
     m3_mul(Rj, Rq, Rn);
     for (int i = 0; i < 9; ++i) Rp[i] = Rn[i];
   }

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
   _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q];
   const double* ee = a.eeref + nb * 7;
   if (terminal) {
-    kin_base(mb, x, K); kin_arm(mb, x, K);
+    kin_base<true>(mb, x, K); kin_arm<true>(mb, x, K);
     _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
     double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq);
     _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q];
@@ -245,13 +245,13 @@ __global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
   }
   _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q];
   const double dt = a.node_dt[nb];
-  kin_base(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x, u, K); kin_arm(mb, x, K);
+  kin_base<true>(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg<true>(mb, c, x, u, K); kin_arm<true>(mb, x, K);
   _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
   { double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq); _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q]; }
   double x2[30]; double* f1 = qm_smem + 64 * 31 + (threadIdx.x & 63) * 31; double* f2 = f1;      // the flow values pass through the thread's second LDS row
   flow_from_kin(mb, x, u, K, f1);
   _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double fq = f1[q]; x2[q] = x[q] + dt * fq; rec[KR_F1 + q] = fq; rec[KR_X2 + q] = x2[q]; }
-  kin_base(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x2, u, K);
+  kin_base<true>(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg<true>(mb, c, x2, u, K);
   flow_from_kin(mb, x2, u, K, f2);
   _Pragma("unroll") for (int q = 0; q < KW_ARM; ++q) rec[KR_K2 + q] = K[q];
   _Pragma("unroll") for (int q = 0; q < 30; ++q) rec[KR_F2 + q] = f2[q];

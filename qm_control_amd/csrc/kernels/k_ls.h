@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   double* pf = a.perf + (size_t)nb * PF_SIZE;
   const int ev = a.node_ev[nb];
   if (i == n - 1) {
-    kin_base(mb, x, K); kin_arm(mb, x, K);
+    kin_base<true>(mb, x, K); kin_arm<true>(mb, x, K);
     pf[0] = node_cost_value(mb, st, x, nullptr, K, 0, nullptr, a.eeref + nb * 7, st[ST_MU_EEF_POS], st[ST_MU_EEF_ORI], false, u); pf[1] = 0.0; pf[2] = 0.0;
     return;
   }
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   if (a.ut) { _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.ut[nb * 30 + q]; }
   else { _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q] + al * a.du[nb * 30 + q]; }
   const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
-  kin_base(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x, u, K); kin_arm(mb, x, K);
+  kin_base<true>(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg<true>(mb, c, x, u, K); kin_arm<true>(mb, x, K);
   // a zero-length interval contributes neither cost nor constraint residual and needs no second Heun stage; besides skipping work, the guards
   // split this straight-line kernel into basic blocks, which bounds the live ranges the scheduler builds (measured: 20 % faster)
   double cost = 0.0, eq = 0.0;
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   flow_from_kin(mb, x, u, K, f1);
   _Pragma("unroll") for (int q = 0; q < 30; ++q) { x2[q] = x[q] + dt * f1[q]; f2[q] = f1[q]; }
   if (dt > 0.0) {
-    kin_base(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg(mb, c, x2, u, K);
+    kin_base<true>(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg<true>(mb, c, x2, u, K);
     flow_from_kin(mb, x2, u, K, f2);
   }
   double s = 0.0;

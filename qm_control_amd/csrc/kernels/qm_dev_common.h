@@ -49,21 +49,45 @@ __device__ __forceinline__ void m3_inv(const double* A, double* R) {   // cofact
   const double id = 1.0 / (A[0] * c00 + A[1] * c10 + A[2] * c20);
   R[0] = c00 * id; R[1] = c01 * id; R[2] = c02 * id; R[3] = c10 * id; R[4] = c11 * id; R[5] = c12 * id; R[6] = c20 * id; R[7] = c21 * id; R[8] = c22 * id;
 }
+// sin and cos of an angle together, ≈ 1 ulp for |x| < 1e5: Cody–Waite reduction x = k π/2 + r with the two-part constant of the classic medium-range path
+// (k π/2_hi is exact for |k| < 2^20), then the minimax kernels on |r| <= π/4 (the standard degree-13 / degree-14 coefficients).  ≈ 35 instructions for the pair;
+// the device library's sin() and cos() carry a full-range Payne–Hanek reduction in double-double arithmetic — ≈ 300 instructions EACH — and the thread-per-node
+// kinematics kernels evaluate 36 pairs per node: half of their instruction stream was trigonometry.  Joint and Euler angles never leave a few multiples of π;
+// anything beyond 1e5 takes the library path.
+__device__ __forceinline__ void qm_sincos(double x, double& sn, double& cs) {
+  if (!(fabs(x) < 1.0e5)) { sn = sin(x); cs = cos(x); return; }
+  const double k = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-k, 1.57079632673412561417e+00, x); r = fma(-k, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double sr = fma(r * z, ps, r), cr = fma(z, fma(z, pc, -0.5), 1.0);
+  const int q = (int)k & 3;                                   // k mod 4 (two's complement: also for negative k)
+  const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+  sn = (q & 2) ? -ss : ss; cs = ((q + 1) & 2) ? -cc : cc;
+}
+// FAST selects qm_sincos (the MPC's thread-per-node kinematics kernels); the default keeps the library's sin / cos: in the register-capped and the
+// one-wave-per-instance kernels the short inline pair lengthens live ranges enough to cost registers (WBC 441 -> 454: one allocation granule too many, k_grid.h)
+template <bool FAST = false>
 __device__ __forceinline__ void rot_axis_angle(const double* a, double q, double* R) {
-  const double s = sin(q), c = cos(q), oc = 1.0 - c;
+  double s, c; if (FAST) qm_sincos(q, s, c); else { s = sin(q); c = cos(q); } const double oc = 1.0 - c;
   R[0] = c + oc * (a[0] * a[0]);        R[1] = oc * (a[0] * a[1]) - s * a[2]; R[2] = oc * (a[0] * a[2]) + s * a[1];
   R[3] = oc * (a[1] * a[0]) + s * a[2]; R[4] = c + oc * (a[1] * a[1]);        R[5] = oc * (a[1] * a[2]) - s * a[0];
   R[6] = oc * (a[2] * a[0]) - s * a[1]; R[7] = oc * (a[2] * a[1]) + s * a[0]; R[8] = c + oc * (a[2] * a[2]);
 }
 // R = Rz(z) Ry(y) Rx(x); E maps zyx rates to world angular velocity
+template <bool FAST = false>
 __device__ __forceinline__ void rot_zyx(double z, double y, double x, double* R) {
-  const double sz = sin(z), cz = cos(z), sy = sin(y), cy = cos(y), sx = sin(x), cx = cos(x);
+  double sz, cz, sy, cy, sx, cx;
+  if (FAST) { qm_sincos(z, sz, cz); qm_sincos(y, sy, cy); qm_sincos(x, sx, cx); } else { sz = sin(z); cz = cos(z); sy = sin(y); cy = cos(y); sx = sin(x); cx = cos(x); }
   R[0] = cz * cy; R[1] = cz * sy * sx - sz * cx; R[2] = cz * sy * cx + sz * sx;
   R[3] = sz * cy; R[4] = sz * sy * sx + cz * cx; R[5] = sz * sy * cx - cz * sx;
   R[6] = -sy;     R[7] = cy * sx;                R[8] = cy * cx;
 }
+template <bool FAST = false>
 __device__ __forceinline__ void euler_E(double z, double y, double* E) {
-  const double sz = sin(z), cz = cos(z), sy = sin(y), cy = cos(y);
+  double sz, cz, sy, cy;
+  if (FAST) { qm_sincos(z, sz, cz); qm_sincos(y, sy, cy); } else { sz = sin(z); cz = cos(z); sy = sin(y); cy = cos(y); }
   E[0] = 0.0; E[1] = -sz; E[2] = cy * cz; E[3] = 0.0; E[4] = cz; E[5] = cy * sz; E[6] = 1.0; E[7] = 0.0; E[8] = -sy;
 }
 // natural logarithm for the barrier values: frexp + atanh series in s = (m − 1)/(m + 1), |s| <= 0.172, error < 1e-15 relative.

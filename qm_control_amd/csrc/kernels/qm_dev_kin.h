@@ -25,9 +25,10 @@
 #define KW_SIZE 196
 
 // base / centroidal part.  x = [h_lin, h_ang, p_b, zyx, q_j]
+template <bool FAST = false>
 __device__ __forceinline__ void kin_base(const double* mb, const double* x, double* K) {
-  rot_zyx(x[9], x[10], x[11], K + KW_RB);
-  euler_E(x[9], x[10], K + KW_E);
+  rot_zyx<FAST>(x[9], x[10], x[11], K + KW_RB);
+  euler_E<FAST>(x[9], x[10], K + KW_E);
   m3_inv(K + KW_E, K + KW_EINV);
   double Ii[9], T[9], Rt[9];
   m3_inv(mb + MB_INOM, Ii);
@@ -45,7 +46,7 @@ __device__ __forceinline__ void kin_base(const double* mb, const double* x, doub
 // s (optional, needs u): joint-induced tip velocity Σ qd_j a_j × (p − o_j)
 // HAS_S / HAS_REND are compile-time (not `if (s)` / `if (Rend)`): the outputs usually point into a thread-private workspace, and comparing such an address
 // with null keeps the whole workspace out of registers (address 0 is a valid private address on this target, the test cannot be folded)
-template <bool HAS_S, bool HAS_REND>
+template <bool HAS_S, bool HAS_REND, bool FAST = false>
 __device__ __forceinline__ void kin_chain(const double* mb, int j0, int nj, int frame, const double* x, const double* u, const double* K,
                                           double* a, double* o, double* p, double* s, double* Rend) {
   double Rp[9], pp[3], Rj[9], Rq[9], Rn[9];
@@ -57,7 +58,7 @@ __device__ __forceinline__ void kin_chain(const double* mb, int j0, int nj, int 
     for (int i = 0; i < 3; ++i) { pp[i] += t[i]; o[3 * jj + i] = pp[i]; }
     m3_mul(Rp, mb + MB_JR + 9 * j, Rj);
     m3_mulv(Rj, mb + MB_AXIS + 3 * j, a + 3 * jj);
-    rot_axis_angle(mb + MB_AXIS + 3 * j, x[12 + j], Rq);
+    rot_axis_angle<FAST>(mb + MB_AXIS + 3 * j, x[12 + j], Rq);
     m3_mul(Rj, Rq, Rn);
     for (int i = 0; i < 9; ++i) Rp[i] = Rn[i];
   }
@@ -74,15 +75,17 @@ __device__ __forceinline__ void kin_chain(const double* mb, int j0, int nj, int 
     }
   }
 }
+template <bool FAST = false>
 __device__ __forceinline__ void kin_leg(const double* mb, int chain, const double* x, const double* u, double* K) {
   double* L = K + KW_LEG + KW_LEGSZ * chain;
   // u must not be null (no `u ? … : nullptr` here: comparing the address of a thread-private array with null keeps the whole array out of registers,
   // address 0 being a valid private address on this target)
-  kin_chain<true, false>(mb, 3 * chain, 3, chain_to_contact(chain), x, u, K, L, L + 9, L + 18, L + 21, nullptr);
+  kin_chain<true, false, FAST>(mb, 3 * chain, 3, chain_to_contact(chain), x, u, K, L, L + 9, L + 18, L + 21, nullptr);
 }
+template <bool FAST = false>
 __device__ __forceinline__ void kin_arm(const double* mb, const double* x, double* K) {
   double* A = K + KW_ARM;
-  kin_chain<false, true>(mb, 12, 6, 4, x, nullptr, K, A, A + 18, A + 36, nullptr, A + 39);
+  kin_chain<false, true, FAST>(mb, 12, 6, 4, x, nullptr, K, A, A + 18, A + 36, nullptr, A + 39);
 }
 __device__ __forceinline__ const double* kin_foot(const double* K, int contact) { return K + KW_LEG + KW_LEGSZ * contact_to_chain(contact) + 18; }
 
