@@ -107,5 +107,9 @@ void emu_target_from_command(void* h, int B, const double* t0, const double* x0,
 void emu_target_download(void* h, int B, double* rt, double* rx, double* last) {
   EmuCtx* c = (EmuCtx*)h; memcpy(rt, c->mpc.d.ref_t, (size_t)B * c->mpc.d.nref * 8); memcpy(rx, c->mpc.d.ref_x, (size_t)B * c->mpc.d.nref * QM_NREF * 8); memcpy(last, c->front.f.last_ee, (size_t)B * 7 * 8);
 }
+// device math helpers on the host (tests/test_device_math.py)
+void emu_sincos(int n, const double* x, double* sn, double* cs) { for (int i = 0; i < n; ++i) qm_sincos(x[i], sn[i], cs[i]); }
+void emu_frcp(int n, const double* x, double* r) { for (int i = 0; i < n; ++i) r[i] = qm_frcp(x[i]); }
+void emu_log(int n, const double* x, double* r) { for (int i = 0; i < n; ++i) r[i] = qm_log(x[i]); }
 int emu_sizes(int which) { int v[] = {SR_SIZE, LQ_DBG_SIZE, PF_SIZE, LQ_LDS_BYTES, RW_LDS_BYTES, WBC_DBG_SIZE, LQ_KIN_LDS_BYTES, LS_EVAL_LDS_BYTES, WBC_LDS_BYTES, SIM_LDS_BYTES}; return v[which]; }
 }
