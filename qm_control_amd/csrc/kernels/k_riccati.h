@@ -215,13 +215,25 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
   qm_d4 SA[2][2], SB[2][MT];
   rw_zero<2, 2>(SA); rw_zero<2, MT>(SB);
   if (!(skip & 2)) {
-    rw_gemm_tn<2, 2, 2>(S, A, SA, 8, false);                         // [S A | S b]
+    // [S A | S b].  Rows 24..29 of A are unit rows (arm joints: x_j+ = x_j + dt u_j, no Px), rows 30, 31 padding: in the left column tile (columns < 16) the last two
+    // k-steps (rows 24..31 of A) multiply zeros and are skipped; the right one keeps them — column 30 carries b
+    { qm_d4 A0[2][1], A1[2][1], P0[2][1], P1[2][1];
+#pragma unroll
+      for (int K = 0; K < 2; ++K) { A0[K][0] = A[K][0]; A1[K][0] = A[K][1]; P0[K][0] = SA[K][0]; P1[K][0] = SA[K][1]; }
+      rw_gemm_tn<2, 2, 1>(S, A0, P0, 6, false);
+      rw_gemm_tn<2, 2, 1>(S, A1, P1, 8, false);
+#pragma unroll
+      for (int K = 0; K < 2; ++K) { SA[K][0] = P0[K][0]; SA[K][1] = P1[K][0]; } }
 #pragma unroll
     for (int I = 0; I < 2; ++I) SA[I][1] += sv[I];                    // column 30 += s
     rw_gemm_tn<2, 2, MT>(S, Bm, SB, 8, false);                       // S B
     rw_gemm_tn<2, MT, 2>(Bm, SA, Hux, 8, false);                     // [Hux | hu]
     rw_gemm_tn<2, MT, MT>(Bm, SB, Huu, 8, false);                    // Huu
-    rw_gemm_tn_upper<2>(A, SA, Sn, 8, false);                        // [Q + Aᵀ S A | q + Aᵀ (S b + s)], upper tiles  (row 30 is garbage, masked below)
+    // [Q + Aᵀ S A | q + Aᵀ (S b + s)], upper tiles (row 30 is garbage, masked below).  The unit rows 24..29 of A contribute row k of (S A) to row k of the result —
+    // the same fragment position: six k-steps on the matrix core and one lane-local addition instead of eight k-steps (the additions come last either way: same rounding)
+    rw_gemm_tn_upper<2>(A, SA, Sn, 6, false);
+    Sn[1][1][2] += SA[1][1][2];                                        // rows 24..27
+    Sn[1][1][3] += (g < 2) ? SA[1][1][3] : 0.0;                        // rows 28, 29
   }
   RWT(1)
   // ---- Cholesky of Huu and forward substitution of [Hux | hu] IN FRAGMENT LAYOUT (right-looking).
