@@ -4,8 +4,8 @@
 // own transcription: grid (K0), LQ model + projection (K1a / K1b) and Riccati factors (K3) are shared; what iLQR adds is
 //   mode 0  the NOMINAL rollout  x_{i+1} = RK2(x_i, u_i)  that makes the initial guess dynamically consistent (single shooting), and
 //   mode 1  the line search's NONLINEAR rollout with feedback at step length a:
-//             ũ_i = −L_i⁻ᵀ (W_i (x~_i − x_i) + a y_i),   u~_i = u_i + a Pe_i + Px_i (x~_i − x_i) + Pu_i ũ_i,   x~_{i+1} = RK2(x~_i, u~_i)
-//           (K_i = −L⁻ᵀ W, kff_i = −L⁻ᵀ y: the gains are applied through the factors K3 left in the stage record, never formed).
+//             ũ_i = K_i (x~_i − x_i) + a k_i,   u~_i = u_i + a Pe_i + Px_i (x~_i − x_i) + Pu_i ũ_i,   x~_{i+1} = RK2(x~_i, u~_i)
+//           (K_i = −L⁻ᵀ W, k_i = −L⁻ᵀ y: formed by K3's backward sweep on the matrix core and left in the stage record).
 // One WAVEFRONT per instance, nodes in sequence (a rollout is a serial chain of nonlinear steps): lane l < 30 carries component l of the state and of the input;
 // the four leg chains of the flow map run on lanes 0..3, the base block and the momentum sums are wave-uniform (v_readlane), the feedback products are one matrix row
 // per lane.  The arithmetic follows the scalar statement term by term (same summation orders), which the first version — one THREAD per instance, 2.4 KB of scratch,
@@ -105,23 +105,17 @@ __global__ void __launch_bounds__(64) qm_ilqr_rollout_kernel(QmRolloutArgs a) {
     const double* rec = a.stage + ((size_t)b * a.nmax + i) * SR_SIZE;
     const int m = (int)rec[SR_SCAL]; const int md = (int)rec[SR_MODEF];
     const double dxl = lx ? xc - a.x[nb * 30 + l] : 0.0;
-    // t = W dx + a y ;  v = L⁻ᵀ t (the record holds L⁻¹, lower triangle) ;  ũ = −v   (lane r: row r)
+    // ũ = K dx + a k  (lane r: row r; the record holds the gain K = −L⁻ᵀ W and the offset k = −L⁻ᵀ y the backward sweep formed)
     const int lr = (l < m) ? l : 0;
-    // every record entry this lane needs is requested BEFORE the first dependent use: 78 independent loads in flight instead of one L2 round trip per term
+    // every record entry this lane needs is requested BEFORE the first dependent use: 60 independent loads in flight instead of one L2 round trip per term
     const int r = lx ? l : 0; const bool hasPx = r >= 12 && r < 24; const int pr = hasPx ? r : 12;
-    double w[30], px[30], gq[QM_MMAX];
+    double w[30], px[30];
 #pragma unroll
     for (int q = 0; q < 30; ++q) { w[q] = rec[SR_PP + lr * 30 + q]; px[q] = rec[SR_PX + pr * 30 + q]; }
+    const double kl = rec[SR_KFF + lr], pel = rec[SR_PE + r];
+    double v = (l < m) ? al * kl : 0.0;
 #pragma unroll
-    for (int q = 0; q < QM_MMAX; ++q) gq[q] = rec[SR_RP + q * QM_MMAX + lr];
-    const double yl = rec[SR_KFF + lr], pel = rec[SR_PE + r];
-    double tv = (l < m) ? al * yl : 0.0;
-#pragma unroll
-    for (int q = 0; q < 30; ++q) tv += ((l < m) ? w[q] : 0.0) * qm_bcast(dxl, q);
-    double v = 0.0;
-#pragma unroll
-    for (int q = 0; q < QM_MMAX; ++q) if (q < m) v += ((l < m && q >= l) ? gq[q] : 0.0) * qm_bcast(tv, q);
-    v = (l < m) ? -v : 0.0;
+    for (int q = 0; q < 30; ++q) v += ((l < m) ? w[q] : 0.0) * qm_bcast(dxl, q);
     // du = a Pe + Px dx + Pu ũ : Px has the 12 leg-joint-velocity rows; Pu's columns are unit vectors (stance force components, arm joint velocities) and one
     // 3 x 2 null-space block per swing leg (SR_SWG), in the column order K1b's projector uses (k_riccati.h forward rollout)
     int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(md, k) ? 1 : 0;

@@ -21,8 +21,8 @@
 // The operands of the NEXT stage are copied global -> LDS asynchronously (global_load_lds_dwordx4, 1 KB per wave instruction, no
 // VGPRs) while the current stage computes; a stage starts by pulling its fragments out of that buffer.
 //
-// The backward sweep leaves L⁻¹ (in SR_RP; lower triangle), W (in SR_PP) and y (in SR_KFF) in the stage record; the forward rollout
-//   ut = −L⁻ᵀ (W dx + y),  dx+ = Ap dx + Bp ut + bp,  du = Px dx + Pu ut + Pe,  Armijo metric += qp·dx + rp·ut
+// The backward sweep leaves the gain K = −L⁻ᵀ W (in SR_PP) and the offset k = −L⁻ᵀ y (in SR_KFF) in the stage record; the forward rollout
+//   ut = K dx + k,  dx+ = Ap dx + Bp ut + bp,  du = Px dx + Pu ut + Pe,  Armijo metric += qp·dx + rp·ut
 // streams the records once more with one matrix row per lane.
 #pragma once
 #include "qm_dev_common.h"
@@ -53,10 +53,9 @@ struct QmRiccatiArgs {
 /* offsets inside one buffer */
 #define RFO_A   0                 /* [12][30] Ap rows 0..11 */
 #define RFO_B   360               /* [12][18] Bp rows 0..11 */
-#define RFO_W   576               /* [18][30] W  */
-#define RFO_L   1116              /* [18][18] L⁻¹ (lower triangle) */
-#define RFO_PX  1440              /* [12][30] Px rows 12..23 (the only non-zero ones: leg joint velocities) */
-#define RFO_V   1800              /* bp(30) qp(30) rp(18) Pe(30) | y(18) | swing blocks [4][6] (126..149) mode (150) dt (151) */
+#define RFO_W   576               /* [18][30] K = −L⁻ᵀ W */
+#define RFO_PX  1116              /* [12][30] Px rows 12..23 (the only non-zero ones: leg joint velocities) */
+#define RFO_V   1476              /* bp(30) qp(30) rp(18) Pe(30) | k(18) | swing blocks [4][6] (126..149) mode (150) dt (151) */
 /* backward prefetch buffer (global_load_lds): the fields of the NEXT regular stage's record the backward sweep reads, landing while the current stage computes;
    lives behind the 1200-double Cholesky / transposition buffer.  Six segments, each padded to whole 1 KB wave instructions so that an instruction's source
    offset is a compile-time constant.  The joint rows of the projected dynamics are NOT in the record: a joint row of the Heun-discretised flow map is exactly
@@ -75,7 +74,7 @@ struct QmRiccatiArgs {
 #define RW_MAXNODES 512
 #define RW_LDS_DOUBLES (RF_LIST + RW_MAXNODES / 2)
 #define RW_LDS_BYTES (RW_LDS_DOUBLES * 8)
-#define RF_NLOAD 16               /* ceil((360 + 216 + 864 + 360 + 108 + 18 + 24 + 2) / 128): sixteen-byte units, 64 per wave instruction */
+#define RF_NLOAD 13               /* ceil((360 + 216 + 540 + 360 + 108 + 18 + 24 + 2) / 128): sixteen-byte units, 64 per wave instruction */
 
 template <int KT, int IT, int JT>
 __device__ __forceinline__ void rw_gemm_tn(const qm_d4 (&Z)[KT][IT], const qm_d4 (&Y)[KT][JT], qm_d4 (&P)[IT][JT], int ksteps, bool neg) { qm_gemm_tn<KT, IT, JT>(Z, Y, P, 0, ksteps, neg); }
@@ -322,25 +321,33 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
         invr[I][r] = inv;
       }
     RWT(3)
-    // L⁻¹ (lower triangle), W and y go to the stage record for the forward rollout
+    // The forward rollout needs ũ = −L⁻ᵀ (W δx + y): its gain  K = −L⁻ᵀ W  and offset  k = −L⁻ᵀ y  (column 30) are formed HERE, on the matrix core, from the fragments
+    // at hand — G = L⁻¹ = Δ^(-1/2) L~⁻¹ is the scaled identity tile, (Gᵀ W) one more P = Zᵀ Y product — and go to the stage record in place of W and y: the rollout
+    // then has ONE matrix–vector product on its dependent chain instead of two and neither fetches nor multiplies a triangular factor
+    qm_d4 Gs[MT][MT];
 #pragma unroll
     for (int I = 0; I < MT; ++I)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + g + 4 * r; const double sc = invr[I][r];
+        const double sc = invr[I][r];
 #pragma unroll
-        for (int J = 0; J < 2; ++J) {
-          const int col = 16 * J + c; const double w = Hux[I][J][r] * sc; W[I][J][r] = w;
-          if (row < m) { if (col < 30) rec[SR_PP + row * 30 + col] = w; else if (col == 30) rec[SR_KFF + row] = w; }
-        }
-        // L⁻¹ = Δ^(-1/2) L~⁻¹ (its diagonal: 1 / L_jj), written as a FULL block over the tiles: exact zeros above the diagonal, unit rows for the padding rows
-        // (row >= m) — the forward rollout multiplies with the block as it is, without per-entry masks
+        for (int J = 0; J < 2; ++J) W[I][J][r] = Hux[I][J][r] * sc;
 #pragma unroll
-        for (int J = 0; J < MT; ++J) {
-          const int col = 16 * J + c;
-          if (row < QM_MMAX && col < QM_MMAX) rec[SR_RP + row * QM_MMAX + col] = (J <= I) ? E[I][J][r] * sc : 0.0;
-        }
+        for (int J = 0; J < MT; ++J) Gs[I][J][r] = (J <= I) ? E[I][J][r] * sc : 0.0;
       }
+    { qm_d4 Kf[MT][2]; rw_zero<MT, 2>(Kf);
+      rw_gemm_tn<MT, MT, 2>(Gs, W, Kf, (m + 3) >> 2, true);
+#pragma unroll
+      for (int I = 0; I < MT; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * I + g + 4 * r;
+#pragma unroll
+          for (int J = 0; J < 2; ++J) {
+            const int col = 16 * J + c;
+            if (row < m) { if (col < 30) rec[SR_PP + row * 30 + col] = Kf[I][J][r]; else if (col == 30) rec[SR_KFF + row] = Kf[I][J][r]; }
+          }
+        } }
   } else rw_zero<MT, 2>(W);
   RWT(4)
   if (!(skip & 2)) rw_gemm_tn_upper<MT>(W, W, Sn, (m + 3) >> 2, true);   // −[Wᵀ W | Wᵀ y], upper tiles
@@ -383,17 +390,17 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 }
 
 // flat fetch of everything the forward rollout needs from one stage record: element e of the concatenation
-// [Ap rows 0..11 | Bp rows 0..11 | W L | Px rows 12..23 | bp qp rp Pe | y | swing blocks | mode dt] lives at record offset rf_src(e).
+// [Ap rows 0..11 | Bp rows 0..11 | K | Px rows 12..23 | bp qp rp Pe | k | swing blocks | mode dt] lives at record offset rf_src(e).
 // Only the momentum / base-pose rows of the projected dynamics are read: a joint row of the Heun-discretised flow map is exactly
 // x_j+ = x_j + dt u_j (its rows of A_d, B_d are unit rows resp. dt times unit rows), so dx_j+ = dx_j + dt (du_j − Pe_j) + bp_j comes from the
 // input step du the same stage computes anyway — 31 % fewer bytes for a phase that runs at HBM speed.  (Px has no other non-zero rows:
 // contact forces and arm joint velocities are free or constant inputs, only the leg joint velocities depend on dx through the constraints.
 // Pu is not read at all: its columns are unit vectors — stance force components, arm joint velocities — and one 3x2 block per swing leg.)
 __device__ __forceinline__ int rf_src(int e) {
-  return (e < 360) ? e : ((e < 576) ? e + (SR_BP - 360) : ((e < 1440) ? e + (SR_PP - 576) : ((e < 1800) ? e + (SR_PX + 360 - 1440) : ((e < 1908) ? e + (SR_BPV - 1800) :
-         ((e < 1926) ? e + (SR_KFF - 1908) : ((e < 1950) ? e + (SR_SWG - 1926) : e + (SR_MODEF - 1950)))))));
+  return (e < 360) ? e : ((e < 576) ? e + (SR_BP - 360) : ((e < 1116) ? e + (SR_PP - 576) : ((e < 1476) ? e + (SR_PX + 360 - 1116) : ((e < 1584) ? e + (SR_BPV - 1476) :
+         ((e < 1602) ? e + (SR_KFF - 1584) : ((e < 1626) ? e + (SR_SWG - 1602) : e + (SR_MODEF - 1626)))))));
 }
-#define RF_TOTAL 1952
+#define RF_TOTAL 1628
 
 __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   extern __shared__ double qm_smem[];
@@ -544,19 +551,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
       }
       if (pu_kind == 2) { buf[RF_PUD + rr * QM_MMAX + pu_col] = c1; buf[RF_PUD + rr * QM_MMAX + pu_col + 1] = c2; }
       qm_wave_sync(); }
-    // v = L⁻ᵀ t (lane i keeps v_i = Σ_{q >= i} L⁻¹[q][i] t_q), ut = −v: a product with the inverse factor the backward sweep left in the record — 18 independent
-    // broadcast + FMA pairs in three partial sums instead of the 18-step dependent chain of a back substitution
-    double v;
-    { const int lc = (l < QM_MMAX) ? l : 0; double vp[3] = {0.0, 0.0, 0.0};
-      t = (l < m) ? t : 0.0;                                  // t_q = 0 for q >= m: the padding rows of the block contribute nothing
-#pragma unroll
-      for (int q = 0; q < 16; ++q) vp[q % 3] += F[RFO_L + q * QM_MMAX + lc] * qm_bcast(t, q);
-      if (m > 16) {                                           // rows 16, 17 of the block are only written by the two-tile stages
-#pragma unroll
-        for (int q = 16; q < QM_MMAX; ++q) vp[q % 3] += F[RFO_L + q * QM_MMAX + lc] * qm_bcast(t, q);
-      }
-      v = (vp[0] + vp[1]) + vp[2]; v = (l < m) ? v : 0.0; }
-    const double ut = -v;
+    const double ut = (l < m) ? t : 0.0;                       // ut = K dx + k: the gain and the offset come ready from the backward sweep
     RFT(4)
     armijo += qv * dxl + rp * ut;
     { double bp[3] = {0.0, 0.0, 0.0};

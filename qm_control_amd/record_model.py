@@ -8,8 +8,8 @@ LQ_WRITE_DOUBLES = 2669      # rows 0..11 of Ap 360 and Bp 216 (joint rows are e
 LQ_READ_DOUBLES = 620        # kin record (504) + x, u, references, node descriptors
 # ---- K3 qm_riccati_kernel ----
 RICCATI_BWD_READ_DOUBLES = 2804    # rows 0..11 of Ap 360 and Bp 216, Qp 900, Pp 540, Rp 324, rows 12..23 of Px 360, bp qp rp 78, swing blocks + mode + dt 26
-RICCATI_BWD_WRITE_DOUBLES = 882    # W 540, L 324, y 18
-RICCATI_FWD_READ_DOUBLES = 1952    # rows 0..11 of Ap (360) and Bp (216), W 540, L 324, rows 12..23 of Px 360, bp qp rp Pe 108, y 18, swing blocks + mode + dt 26
+RICCATI_BWD_WRITE_DOUBLES = 558    # the gain K = -L^-T W (540) and the offset k = -L^-T y (18), formed on the matrix core for the forward rollout
+RICCATI_FWD_READ_DOUBLES = 1628    # rows 0..11 of Ap (360) and Bp (216), K 540, rows 12..23 of Px 360, bp qp rp Pe 108, k 18, swing blocks + mode + dt 26
 RICCATI_FWD_IO_DOUBLES = 120       # x (2 nodes' worth of defect reads at events amortised), dx 30 + du 30 written, x0
 # ---- K6/K7 qm_wbc_kernel ----
 WBC_IO_DOUBLES = 900         # inputs 30 + 30 + 55, outputs 54, tip / Jacobian scratch ~ 730
