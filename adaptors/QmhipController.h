@@ -43,7 +43,7 @@ class QmhipController : public QMController {
   // QMController.cpp:272-276 (variant 0; a QMMpcController-style plugin passes 1, QMController.cpp:410-414)
   void setupWbc(ros::NodeHandle& controllerNh, const std::string& taskFile) override {
     wbc_ = std::make_shared<QmhipWbc>(qmInterface_->getPinocchioInterface(), qmInterface_->getCentroidalModelInfo(), *eeKinematicsPtr_, *armEeKinematicsPtr_, controllerNh,
-                                      hip_->hipContext(), /*variant*/ 0);
+                                      hip_->wbcContext(), /*variant*/ 0);      // its own context: a control tick never queues behind the MPC solve in flight
     wbc_->loadTasksSetting(taskFile, true);
   }
 

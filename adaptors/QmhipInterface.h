@@ -42,6 +42,11 @@ class QmhipInterface : public QMInterface {
     if (rc == QMHIP_ERR_FILE) throw std::invalid_argument(qmhip_last_error(nullptr));
     if (rc != QMHIP_OK) throw std::runtime_error(std::string("[QmhipInterface] qmhip_create failed: ") + qmhip_last_error(nullptr));
     ctx_.reset(raw);
+    // the control thread's own context (include/qmhip.h "Threads"): WbcBase::update runs on the ros_control thread while mpcThread_ is inside MPC_BASE::run
+    // (QMController.cpp:128-147 beside :315-333)
+    qmhip_ctx* rawWbc = nullptr;
+    if (qmhip_create_wbc_context(raw, opt.maxBatch, &rawWbc) != QMHIP_OK) throw std::runtime_error(std::string("[QmhipInterface] qmhip_create_wbc_context failed: ") + qmhip_last_error(nullptr));
+    wbcCtx_.reset(rawWbc);
     modelBlob_.resize(MB_SIZE); settingsBlob_.resize(ST_SIZE);
     qmhip_export_blobs(ctx_.get(), modelBlob_.data(), settingsBlob_.data());
   }
@@ -63,7 +68,8 @@ class QmhipInterface : public QMInterface {
       if (std::abs(x0(i) - settingsBlob_[ST_XINIT + i]) > 1e-12) throw std::runtime_error("[QmhipInterface] initialState of task.info parsed differently by the two ingestions");
   }
 
-  qmhip_ctx* hipContext() const { return ctx_.get(); }
+  qmhip_ctx* hipContext() const { return ctx_.get(); }        // MPC side: used by mpcThread_ (and by the thread that calls MPC_BASE::reset)
+  qmhip_ctx* wbcContext() const { return wbcCtx_.get(); }     // control-tick side: used by the ros_control thread only
   const DeviceOptions& deviceOptions() const { return opt_; }
   const std::vector<double>& modelBlob() const { return modelBlob_; }        // include/qmhip_layout.h: MB_*
   const std::vector<double>& settingsBlob() const { return settingsBlob_; }  // include/qmhip_layout.h: ST_*
@@ -71,7 +77,7 @@ class QmhipInterface : public QMInterface {
  private:
   struct CtxDeleter { void operator()(qmhip_ctx* c) const { qmhip_destroy(c); } };
   DeviceOptions opt_;
-  std::unique_ptr<qmhip_ctx, CtxDeleter> ctx_;
+  std::unique_ptr<qmhip_ctx, CtxDeleter> ctx_, wbcCtx_;
   std::vector<double> modelBlob_, settingsBlob_;
 };
 

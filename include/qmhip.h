@@ -7,7 +7,13 @@
  *
  * Conventions: plain pointers + sizes, no C++/torch types; f64 everywhere (ocs2::scalar_t); arrays are
  * instance-major and caller owned; pointers are HOST memory unless the name says `_dev`.
- * Return value 0 = ok, negative = error (qmhip_last_error gives the text).  A context is single-threaded.
+ * Return value 0 = ok, negative = error (qmhip_last_error gives the text).
+ *
+ * Threads.  Every entry point that takes a context locks it: calls on ONE context from several threads are safe and run one after another (a blocked
+ * caller waits for the other call's host work, e.g. the line search of an MPC solve).  The reference runs the MPC in `mpcThread_` (advanceMpc,
+ * qm_controllers/src/QMController.cpp:315-333) beside the ros_control thread's WbcBase::update (QMController.cpp:128-147); for that layout the control thread
+ * gets its OWN context from qmhip_create_wbc_context: own streams, own device copies of the model, own error string — a control tick then never waits for,
+ * and is never reordered by, an MPC solve in flight (tests/c_abi_threads.c).  Different contexts share nothing mutable; qmhip_last_error(NULL) is per thread.
  */
 #ifndef QMHIP_H
 #define QMHIP_H
@@ -30,6 +36,11 @@ int qmhip_create(const char* urdf_file, const char* task_file, const char* refer
 /* same, from the flat MODEL / SETTINGS blobs of qmhip_layout.h (no file I/O) */
 int qmhip_create_from_blobs(const double* model_blob, const double* settings_blob,
                             int device, int max_batch, int max_nodes, int max_ref_knots, int max_events, qmhip_ctx** out);
+/* WBC-only context for the control thread (see "Threads" above): the parent's model and settings VALUES (copied; later qmhip_set_setting calls go to whichever
+ * context they name — WBC gains to this one), the WBC buffers for max_batch instances, the WBC stream.  It serves qmhip_wbc_step / qmhip_wbc_reset / qmhip_wbc_download /
+ * qmhip_set_setting / the instrumentation calls; every MPC, front-end and plant entry point returns QMHIP_ERR_STATE on it.  Replaces nothing new in the reference:
+ * it is the `wbc_` object of QMController (QMController.h:80, constructed in setupWbc, QMController.cpp:272-276) as opposed to its `mpc_`. */
+int qmhip_create_wbc_context(const qmhip_ctx* parent, int max_batch, qmhip_ctx** out);
 void qmhip_destroy(qmhip_ctx* ctx);
 const char* qmhip_last_error(const qmhip_ctx* ctx);            /* ctx may be NULL: error of the last failed create */
 /* parse only (host): what getPinocchioInterface()/getCentroidalModelInfo()/settings getters expose
@@ -140,7 +151,7 @@ int qmhip_policy_eval(qmhip_ctx* ctx, int B, const double* t, double* x_des /*[B
  *      than the level's null space, -3 a hierarchy shape the shipped controllers never build (own inequality rows at a level below the first one: the general stacking
  *      of HoQp.cpp:92-124 with two slack blocks is not implemented; HierarchicalWbc / HierarchicalMpcWbc only put inequalities into level 0).
  *      The joint-acceleration state `inputLast_` (WbcBase.cpp:212-213) lives in the context per instance;
- *      qmhip_wbc_reset zeroes it. */
+ *      qmhip_wbc_reset zeroes it.  The call enqueues on the context's WBC stream only and waits for that stream only (pinned staging, asynchronous copies). */
 int qmhip_wbc_step(qmhip_ctx* ctx, int B, const double* x_des, const double* u_des, const double* rbd_meas /*[B][55]*/,
                    const int32_t* mode, double period, const double* time /*[B]*/, int variant,
                    double* out /*[B][54]*/, int32_t* qp_status /*[B][3]*/);

@@ -18,7 +18,7 @@ _ip = C.POINTER(C.c_int32)
 from . import layout as L
 MB_SIZE, ST_SIZE = L.MB_SIZE, L.ST_SIZE
 
-EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
+EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_create_wbc_context", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
            "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_update_references", "qmhip_mpc_solve_resident_warm",
            "qmhip_mpc_advance_resident", "qmhip_closed_loop_resident", "qmhip_mpc_download", "qmhip_policy_eval",
            "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
@@ -94,6 +94,18 @@ class QMInterface:
         self.max_batch, self.max_nodes, self.max_ref_knots, self.max_events = max_batch, max_nodes, max_ref_knots, max_events
         self.model_blob = np.zeros(MB_SIZE); self.settings_blob = np.zeros(ST_SIZE)
         self.lib.qmhip_export_blobs(self.h, _p(self.model_blob), _p(self.settings_blob))
+
+    def wbc_context(self, max_batch=None):
+        """WBC-only context for the control thread (include/qmhip.h "Threads"): an interface object whose handle serves HierarchicalWbc only"""
+        h = C.c_void_p()
+        mbatch = self.max_batch if max_batch is None else int(max_batch)
+        rc = self.lib.qmhip_create_wbc_context(self.h, mbatch, C.byref(h))
+        if rc != 0:
+            raise QmhipError("qmhip_create_wbc_context failed (%d): %s" % (rc, self.lib.qmhip_last_error(None).decode()))
+        o = object.__new__(QMInterface)
+        o.lib = self.lib; o.h = h; o.max_batch = mbatch; o.max_nodes, o.max_ref_knots, o.max_events = 3, 1, 1
+        o.model_blob = self.model_blob.copy(); o.settings_blob = self.settings_blob.copy()
+        return o
 
     def close(self):
         if getattr(self, "h", None):

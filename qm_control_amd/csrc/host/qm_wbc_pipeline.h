@@ -15,12 +15,18 @@ struct QmWbcPipeline {
   BK& bk; QmWbcBuffers w;
   explicit QmWbcPipeline(BK& b) : bk(b) {}
   template <class T> T* A(size_t n) { T* p = (T*)bk.alloc(n * sizeof(T)); bk.zero(p, n * sizeof(T)); return p; }
+  // The tick inputs [x_des | u_des | rbd | time | mode] and the outputs [out | qp_status] are carved from ONE allocation each, in this order, so that a
+  // batch of exactly Bmax instances (the ros_control plugin: 1) moves with one host copy per direction (qmhip_wbc_step)
+  static size_t in_bytes(int B) { return (size_t)B * ((30 + 30 + QM_NRBD + 1) * sizeof(double) + sizeof(int)); }
+  static size_t out_bytes(int B) { return (size_t)B * (QM_NWBC_OUT * sizeof(double) + 3 * sizeof(int)); }
   void allocate(int Bmax, bool debug = false) {
-    w.Bmax = Bmax; w.t = A<double>(Bmax); w.x_des = A<double>((size_t)Bmax * 30); w.u_des = A<double>((size_t)Bmax * 30); w.rbd = A<double>((size_t)Bmax * QM_NRBD);
-    w.mode = A<int>(Bmax); w.time = A<double>(Bmax); w.input_last = A<double>((size_t)Bmax * 30); w.out = A<double>((size_t)Bmax * QM_NWBC_OUT); w.qp_status = A<int>((size_t)Bmax * 3);
+    w.Bmax = Bmax; w.t = A<double>(Bmax);
+    w.x_des = (double*)bk.alloc(in_bytes(Bmax)); bk.zero(w.x_des, in_bytes(Bmax)); w.u_des = w.x_des + (size_t)Bmax * 30; w.rbd = w.u_des + (size_t)Bmax * 30; w.time = w.rbd + (size_t)Bmax * QM_NRBD; w.mode = (int*)(w.time + Bmax);
+    w.out = (double*)bk.alloc(out_bytes(Bmax)); bk.zero(w.out, out_bytes(Bmax)); w.qp_status = (int*)(w.out + (size_t)Bmax * QM_NWBC_OUT);
+    w.input_last = A<double>((size_t)Bmax * 30);
     w.scratch = A<double>((size_t)Bmax * WBC_SCRATCH); w.dbg = debug ? A<double>((size_t)Bmax * WBC_DBG_SIZE) : nullptr;
   }
-  void release() { void* ps[] = {w.t, w.x_des, w.u_des, w.rbd, w.mode, w.time, w.input_last, w.out, w.qp_status, w.scratch, w.dbg}; for (void* p : ps) if (p) bk.free(p); w = QmWbcBuffers(); }
+  void release() { void* ps[] = {w.t, w.x_des, w.input_last, w.out, w.scratch, w.dbg}; for (void* p : ps) if (p) bk.free(p); w = QmWbcBuffers(); }
   void reset() { bk.zero(w.input_last, (size_t)w.Bmax * 30 * 8); }
   const void* buffer(const char* name) const {
 #define F(n) if (!strcmp(name, "wbc_" #n)) return (const void*)w.n;

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../../include/qmhip.h"
@@ -14,8 +15,12 @@
 #include "qm_sim_pipeline.h"
 #include "qm_front_pipeline.h"
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;      // per calling thread: qmhip_last_error(NULL) is the error of THIS thread's last failed create
 
+// every entry point that takes a context serialises on it: calls from several threads are safe and run one after another (include/qmhip.h, "Threads")
+#define QM_GUARD(c) std::unique_lock<std::recursive_mutex> qm_lk_; if (c) qm_lk_ = std::unique_lock<std::recursive_mutex>(const_cast<qmhip_ctx*>(c)->mu)
+// entry points that touch horizon / front-end / plant buffers refuse a WBC-only context
+#define QM_NEED_MPC(c) do { if ((c) && (c)->wbc_only) { const_cast<qmhip_ctx*>(c)->fail(std::string(__func__) + ": not available on a WBC-only context (qmhip_create_wbc_context)"); return QMHIP_ERR_STATE; } } while (0)
 #define HIP_TRY(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->fail(std::string(#expr) + ": " + hipGetErrorString(e_)); return QMHIP_ERR_HIP; } } while (0)
 
 struct HipBackend {
@@ -85,6 +90,9 @@ struct qmhip_ctx {
   int device = 0, max_batch = 0, max_nodes = 0, max_ref = 0, max_ev = 0;
   double mb[MB_SIZE], st[ST_SIZE];
   HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc; QmFrontPipeline<HipBackend> front; QmSimPipeline<HipBackend> sim;
+  std::recursive_mutex mu;      // serialises the entry points of this context
+  bool wbc_only = false;        // created by qmhip_create_wbc_context: carries the model + the WBC buffers, no horizon buffers
+  char* tick_pin = nullptr;     // pinned host staging of the control-tick path (qmhip_wbc_step): [inputs of max_batch instances | outputs]
   std::string error; int lastB = 0; bool have_solution = false; int front_B = 0; long sim_ticks = 0;
   double* filler_out = nullptr; int filler_cap = 0;      // output of the profiling-only filler kernel (co-residency probe)
   bool filler_buffer(int waves) { if (filler_cap >= waves) return true; if (filler_out) hipFree(filler_out); filler_out = nullptr; filler_cap = 0;
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(64, 2) qm_filler_kernel(double* out, int iters
   out[blockIdx.x * 64 + l] = f + acc[1];
 }
 
-static int create_common(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out) {
+static int create_common(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out, bool wbc_only = false) {
   if (!out || max_batch <= 0 || max_nodes < 3 || max_nodes > RW_MAXNODES || max_ref < 1 || max_ev < 1) { g_create_error = "qmhip_create: bad argument (max_nodes must be in [3, 512])"; return QMHIP_ERR_ARG; }
   std::string err; if (!qmio::validateModelBlob(mb, err)) { g_create_error = err; return QMHIP_ERR_MODEL; }
   if (!setting_ok(ST_SQP_DT, st[ST_SQP_DT])) { g_create_error = "settings blob: sqp.dt must be a positive finite number"; return QMHIP_ERR_MODEL; }
@@ -144,11 +152,13 @@ static int create_common(const double* mb, const double* st, int device, int max
   memcpy(c->mb, mb, sizeof(c->mb)); memcpy(c->st, st, sizeof(c->st));
   if (hipStreamCreate(&c->bk.stream) != hipSuccess || hipStreamCreate(&c->bk.stream_b) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
   c->bk.cur = c->bk.stream; hipEventCreateWithFlags(&c->bk.ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->bk.ev_wbc, hipEventDisableTiming);
-  c->mpc.allocate(c->mb, c->st, max_batch, max_nodes, max_ref, max_ev, false); c->mpc.solver = (st[ST_SOLVER] == 1.0) ? 1 : ((st[ST_SOLVER] == 2.0) ? 2 : 0);
+  c->wbc_only = wbc_only;
+  c->mpc.allocate(c->mb, c->st, wbc_only ? 1 : max_batch, max_nodes, max_ref, max_ev, false); c->mpc.solver = (st[ST_SOLVER] == 1.0) ? 1 : ((st[ST_SOLVER] == 2.0) ? 2 : 0);
   c->wbc.allocate(max_batch);
-  c->front.allocate(max_batch);
+  if (!wbc_only) c->front.allocate(max_batch);
+  { void* h = nullptr; c->bk.check(hipHostMalloc(&h, QmWbcPipeline<HipBackend>::in_bytes(max_batch) + QmWbcPipeline<HipBackend>::out_bytes(max_batch), hipHostMallocDefault), "hipHostMalloc"); c->tick_pin = (char*)h; }
   c->bk.sync();
-  if (!c->bk.error.empty()) { g_create_error = c->bk.error; c->mpc.release(); c->wbc.release(); c->front.release(); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c; return QMHIP_ERR_HIP; }
+  if (!c->bk.error.empty()) { g_create_error = c->bk.error; c->mpc.release(); c->wbc.release(); c->front.release(); if (c->tick_pin) hipHostFree(c->tick_pin); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c; return QMHIP_ERR_HIP; }
   *out = c; return QMHIP_OK;
 }
 
@@ -173,34 +183,38 @@ int qmhip_create_from_blobs(const double* mb, const double* st, int device, int 
   if (!mb || !st) { g_create_error = "qmhip_create_from_blobs: null blob"; return QMHIP_ERR_ARG; }
   return create_common(mb, st, device, max_batch, max_nodes, max_ref, max_ev, out);
 }
+int qmhip_create_wbc_context(const qmhip_ctx* c, int max_batch, qmhip_ctx** out) { QM_GUARD(c);
+  if (!c || !out || max_batch <= 0) { g_create_error = "qmhip_create_wbc_context: bad argument"; return QMHIP_ERR_ARG; }
+  return create_common(c->mb, c->st, c->device, max_batch, 3, 1, 1, out, true);      // same model / settings values, own device copies, own streams: nothing mutable is shared
+}
 void qmhip_destroy(qmhip_ctx* c) {
-  if (!c) return; hipSetDevice(c->device); c->bk.sync(); if (c->filler_out) hipFree(c->filler_out); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release();
+  if (!c) return; hipSetDevice(c->device); c->bk.sync(); if (c->filler_out) hipFree(c->filler_out); if (c->tick_pin) hipHostFree(c->tick_pin); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release();
   for (auto e : c->bk.pool) hipEventDestroy(e); if (c->bk.ev_order) hipEventDestroy(c->bk.ev_order); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
 }
-const char* qmhip_last_error(const qmhip_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
-int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
-int qmhip_set_setting(qmhip_ctx* c, int idx, double v) {
+const char* qmhip_last_error(const qmhip_ctx* c) { QM_GUARD(c); return c ? c->error.c_str() : g_create_error.c_str(); }
+int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
+int qmhip_set_setting(qmhip_ctx* c, int idx, double v) { QM_GUARD(c);
   if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
   if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number"); return QMHIP_ERR_ARG; }
   if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR) or 2 (multiple-shooting IPM)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
   hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
 }
 
-int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) {
+int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c) return QMHIP_ERR_ARG;
   if (B <= 0 || B > c->max_batch || n_ref != c->max_ref || n_ev != c->max_ev || !t0 || !x0 || !ref_t || !ref_x || !ev || !modes) { c->fail("qmhip_mpc_upload: bad argument (B <= max_batch, n_ref == max_ref_knots, n_events == max_events required)"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); c->mpc.solved_B = 0; c->lastB = B; c->have_solution = false;
  return c->hipstate();
 }
-int qmhip_mpc_solve_resident(qmhip_ctx* c, int B, double horizon) {
+int qmhip_mpc_solve_resident(qmhip_ctx* c, int B, double horizon) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->mpc.grid(B, horizon); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true; return c->hipstate();
 }
-int qmhip_mpc_set_initial(qmhip_ctx* c, int B, const double* t0, const double* x0) {
+int qmhip_mpc_set_initial(qmhip_ctx* c, int B, const double* t0, const double* x0) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !t0 || !x0) { if (c) c->fail("qmhip_mpc_set_initial: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->bk.to_device(c->mpc.d.t0, t0, (size_t)B * 8); c->bk.to_device(c->mpc.d.x0, x0, (size_t)B * 30 * 8); return c->hipstate();
 }
-int qmhip_mpc_update_references(qmhip_ctx* c, int B, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) {
+int qmhip_mpc_update_references(qmhip_ctx* c, int B, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c) return QMHIP_ERR_ARG;
   if (B <= 0 || B != c->lastB || (!ref_t != !ref_x) || (!ev != !modes) || (ref_t && n_ref != c->max_ref) || (ev && n_ev != c->max_ev)) {
     c->fail("qmhip_mpc_update_references: bad argument (B == batch of the last upload, n_ref == max_ref_knots, n_events == max_events required; arrays come in pairs)"); return QMHIP_ERR_ARG; }
@@ -209,16 +223,16 @@ int qmhip_mpc_update_references(qmhip_ctx* c, int B, int n_ref, const double* re
   if (ev) { c->bk.to_device(c->mpc.d.ev, ev, (size_t)B * n_ev * 8); c->bk.to_device(c->mpc.d.modes, modes, (size_t)B * (n_ev + 1) * 4); }
   return c->hipstate();
 }
-int qmhip_mpc_solve_resident_warm(qmhip_ctx* c, int B, double horizon) {
+int qmhip_mpc_solve_resident_warm(qmhip_ctx* c, int B, double horizon) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_mpc_solve_resident_warm: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->mpc.grid(B, horizon, true); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true; return c->hipstate();
 }
-int qmhip_mpc_advance_resident(qmhip_ctx* c, int B, double dt) {
+int qmhip_mpc_advance_resident(qmhip_ctx* c, int B, double dt) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch) { if (c) c->fail("qmhip_mpc_advance_resident: bad argument"); return QMHIP_ERR_ARG; }
   if (!c->have_solution || c->mpc.solved_B != B) { c->fail("qmhip_mpc_advance_resident: no solution of this batch to advance along"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); c->mpc.advance(B, dt); return c->hipstate();
 }
-int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, double horizon, double period, double time0) {
+int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, double horizon, double period, double time0) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || n_steps <= 0 || !(horizon > 0) || !(period > 0)) { if (c) c->fail("qmhip_closed_loop_resident: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device);
   for (int k = 0; k < n_steps; ++k) {
@@ -231,46 +245,46 @@ int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, 
   return c->hipstate();
 }
 // ---- reference / gait front-end ----
-int qmhip_gait_set_templates(qmhip_ctx* c, int n_gaits, const int32_t* n_phases, const double* switching_times, const int32_t* mode_sequence) {
+int qmhip_gait_set_templates(qmhip_ctx* c, int n_gaits, const int32_t* n_phases, const double* switching_times, const int32_t* mode_sequence) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || n_gaits <= 0 || !n_phases || !switching_times || !mode_sequence) { if (c) c->fail("qmhip_gait_set_templates: bad argument"); return QMHIP_ERR_ARG; }
   for (int g = 0; g < n_gaits; ++g) if (n_phases[g] < 0 || n_phases[g] > QM_GAIT_MAX_PHASES) { c->fail("qmhip_gait_set_templates: a template has more than QMHIP_GAIT_MAX_PHASES phases"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->front.set_templates(n_gaits, n_phases, switching_times, mode_sequence); return c->hipstate();
 }
-int qmhip_gait_reset(qmhip_ctx* c, int B, int n_events, const double* event_times, const int32_t* mode_sequence, int default_template) {
+int qmhip_gait_reset(qmhip_ctx* c, int B, int n_events, const double* event_times, const int32_t* mode_sequence, int default_template) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || n_events < 1 || n_events > QM_GAIT_EVENT_SLOTS || !event_times || !mode_sequence || default_template < 0 || default_template >= c->front.f.n_gaits) {
     if (c) c->fail("qmhip_gait_reset: bad argument (templates must be set first; the initial schedule needs at least one event)"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->front.phase_transition_stance_time = c->st[ST_PHASE_TRANS_STANCE];
   c->front.gait_reset(B, n_events, event_times, mode_sequence, default_template); c->front_B = B; c->mpc.front_status = c->front.f.gs_status; c->mpc.front_B = B; return c->hipstate();
 }
-int qmhip_gait_insert_template(qmhip_ctx* c, int B, const int32_t* template_id, const double* start_time, const double* final_time) {
+int qmhip_gait_insert_template(qmhip_ctx* c, int B, const int32_t* template_id, const double* start_time, const double* final_time) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B != c->front_B || !template_id || !start_time || !final_time) { if (c) c->fail("qmhip_gait_insert_template: bad argument (B must be the batch of qmhip_gait_reset)"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->front.gait_insert(B, template_id, start_time, final_time); return c->hipstate();
 }
-int qmhip_gait_update_resident(qmhip_ctx* c, int B, double horizon) {
+int qmhip_gait_update_resident(qmhip_ctx* c, int B, double horizon) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B != c->front_B || !(horizon > 0)) { if (c) c->fail("qmhip_gait_update_resident: bad argument (B must be the batch of qmhip_gait_reset)"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->front.gait_schedule(c->mpc.d, B, horizon); return c->hipstate();
 }
-int qmhip_gait_download(qmhip_ctx* c, int B, int32_t* n_events, double* event_times, int32_t* mode_sequence, int32_t* template_id, int32_t* status) {
+int qmhip_gait_download(qmhip_ctx* c, int B, int32_t* n_events, double* event_times, int32_t* mode_sequence, int32_t* template_id, int32_t* status) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B != c->front_B || !n_events || !event_times || !mode_sequence || !template_id || !status) return QMHIP_ERR_ARG;
   hipSetDevice(c->device); c->front.gait_download(B, n_events, event_times, mode_sequence, template_id, status); return c->hipstate();
 }
-int qmhip_schedule_download(qmhip_ctx* c, int B, double* ev, int32_t* modes) {
+int qmhip_schedule_download(qmhip_ctx* c, int B, double* ev, int32_t* modes) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !ev || !modes) return QMHIP_ERR_ARG;
   if (B != c->lastB && B != c->front_B) { c->fail("qmhip_schedule_download: B differs from the batch size the schedule buffers were filled for"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); c->bk.to_host(ev, c->mpc.d.ev, (size_t)B * c->max_ev * 8); c->bk.to_host(modes, c->mpc.d.modes, (size_t)B * (c->max_ev + 1) * 4); return c->hipstate();
 }
-int qmhip_target_reset(qmhip_ctx* c, int B, const double* last_ee_target) {
+int qmhip_target_reset(qmhip_ctx* c, int B, const double* last_ee_target) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !last_ee_target) return QMHIP_ERR_ARG;
   hipSetDevice(c->device); c->front.target_reset(B, last_ee_target); return c->hipstate();
 }
-int qmhip_target_from_command(qmhip_ctx* c, int B, const int32_t* kind, const double* cmd, const double* ee_state, int ee_through_float, const qmhip_target_params* p) {
+int qmhip_target_from_command(qmhip_ctx* c, int B, const int32_t* kind, const double* cmd, const double* ee_state, int ee_through_float, const qmhip_target_params* p) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !kind || !cmd || !p || !(p->target_displacement_velocity > 0) || !(p->target_rotation_velocity > 0) || c->max_ref < 2) {
     if (c) c->fail("qmhip_target_from_command: bad argument (max_ref_knots >= 2 required)"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device);
   c->front.target_from_command(c->mpc.d, B, kind, cmd, ee_state, ee_through_float, p->time_to_target, p->target_displacement_velocity, p->target_rotation_velocity, p->com_height);
   return c->hipstate();
 }
-int qmhip_target_download(qmhip_ctx* c, int B, double* ref_t, double* ref_x, double* last_ee_target) {
+int qmhip_target_download(qmhip_ctx* c, int B, double* ref_t, double* ref_x, double* last_ee_target) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG;
   hipSetDevice(c->device);
   if (ref_t) c->bk.to_host(ref_t, c->mpc.d.ref_t, (size_t)B * c->max_ref * 8);
@@ -278,7 +292,7 @@ int qmhip_target_download(qmhip_ctx* c, int B, double* ref_t, double* ref_x, dou
   if (last_ee_target) c->bk.to_host(last_ee_target, c->front.f.last_ee, (size_t)B * 7 * 8);
   return c->hipstate();
 }
-int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) {
+int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG;
   if (!c->have_solution) { c->fail("qmhip_mpc_download: no solution available"); return QMHIP_ERR_STATE; }
   if (B != c->mpc.solved_B) { c->fail("qmhip_mpc_download: B differs from the batch size of the last solve (the solver buffers are strided by it)"); return QMHIP_ERR_STATE; }
@@ -299,13 +313,13 @@ int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oe
   return c->hipstate();
 }
 int qmhip_mpc_step(qmhip_ctx* c, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes, double horizon,
-                   int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) {
+                   int32_t* nn, double* ot, int32_t* oev, int32_t* omode, double* ox, double* ou, double* operf, int32_t* status) { QM_GUARD(c);
   int rc = qmhip_mpc_upload(c, B, t0, x0, n_ref, ref_t, ref_x, n_ev, ev, modes); if (rc) return rc;
   rc = qmhip_mpc_solve_resident(c, B, horizon); if (rc) return rc;
   return qmhip_mpc_download(c, B, nn, ot, oev, omode, ox, ou, operf, status);
 }
 
-int qmhip_policy_eval(qmhip_ctx* c, int B, const double* t, double* xd, double* ud, int32_t* mode) {
+int qmhip_policy_eval(qmhip_ctx* c, int B, const double* t, double* xd, double* ud, int32_t* mode) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !t) return QMHIP_ERR_ARG;
   if (!c->have_solution) { c->fail("qmhip_policy_eval: no policy received yet"); return QMHIP_ERR_STATE; }
   if (B != c->mpc.solved_B) { c->fail("qmhip_policy_eval: B differs from the batch size of the last solve"); return QMHIP_ERR_STATE; }
@@ -313,18 +327,40 @@ int qmhip_policy_eval(qmhip_ctx* c, int B, const double* t, double* xd, double* 
   if (xd) c->bk.to_host(xd, c->wbc.w.x_des, (size_t)B * 30 * 8); if (ud) c->bk.to_host(ud, c->wbc.w.u_des, (size_t)B * 30 * 8); if (mode) c->bk.to_host(mode, c->wbc.w.mode, (size_t)B * 4);
   return c->hipstate();
 }
-int qmhip_wbc_reset(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.cur = c->bk.stream_b; c->wbc.reset(); c->bk.cur = c->bk.stream; return c->hipstate(); }   // ordered with the WBC launches
-int qmhip_wbc_step(qmhip_ctx* c, int B, const double* xd, const double* ud, const double* rbd, const int32_t* mode, double period, const double* time, int variant, double* out, int32_t* qps) {
+int qmhip_wbc_reset(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.cur = c->bk.stream_b; c->wbc.reset(); c->bk.cur = c->bk.stream; return c->hipstate(); }   // ordered with the WBC launches
+// The control-tick path (WbcBase::update on the ros_control thread, QMController.cpp:145-147).  Everything it enqueues goes to the WBC stream and the host waits for
+// THAT stream only: inputs staged in pinned memory -> asynchronous copies -> qm_wbc_kernel -> asynchronous copy of [out | qp_status] -> one stream synchronisation.
+// On a context that also runs the MPC the WBC stream first waits (on the device, not the host) for what the MPC stream has enqueued so far, because the resident
+// step shares the WBC's input buffers; on a WBC-only context (qmhip_create_wbc_context) there is nothing to wait for and a tick never sees the MPC.
+int qmhip_wbc_step(qmhip_ctx* c, int B, const double* xd, const double* ud, const double* rbd, const int32_t* mode, double period, const double* time, int variant, double* out, int32_t* qps) { QM_GUARD(c);
   if (!c || B <= 0 || B > c->max_batch || !xd || !ud || !rbd || !mode || !time || !(period > 0)) { if (c) c->fail("qmhip_wbc_step: bad argument"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->wbc.upload(B, xd, ud, rbd, mode, time); c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, variant); c->bk.wbc_end();
-  return qmhip_wbc_download(c, B, out, qps);
+  hipSetDevice(c->device); HipBackend& bk = c->bk; QmWbcBuffers& w = c->wbc.w; typedef QmWbcPipeline<HipBackend> WP;
+  // host staging, sections in the device buffers' order: [x_des | u_des | rbd | time | mode]
+  char* hin = c->tick_pin; char* hout = c->tick_pin + WP::in_bytes(c->max_batch);
+  double* h_xd = (double*)hin; double* h_ud = h_xd + (size_t)B * 30; double* h_rbd = h_ud + (size_t)B * 30; double* h_time = h_rbd + (size_t)B * QM_NRBD; int* h_mode = (int*)(h_time + B);
+  memcpy(h_xd, xd, (size_t)B * 30 * 8); memcpy(h_ud, ud, (size_t)B * 30 * 8); memcpy(h_rbd, rbd, (size_t)B * QM_NRBD * 8); memcpy(h_time, time, (size_t)B * 8); memcpy(h_mode, mode, (size_t)B * 4);
+  hipStream_t sb = bk.stream_b;
+  if (!c->wbc_only) { bk.check(hipEventRecord(bk.ev_in, bk.stream), "hipEventRecord"); bk.check(hipStreamWaitEvent(sb, bk.ev_in, 0), "hipStreamWaitEvent"); }
+  if (B == w.Bmax) bk.check(hipMemcpyAsync(w.x_des, hin, WP::in_bytes(B), hipMemcpyHostToDevice, sb), "H2D");
+  else {
+    bk.check(hipMemcpyAsync(w.x_des, h_xd, (size_t)B * 30 * 8, hipMemcpyHostToDevice, sb), "H2D"); bk.check(hipMemcpyAsync(w.u_des, h_ud, (size_t)B * 30 * 8, hipMemcpyHostToDevice, sb), "H2D");
+    bk.check(hipMemcpyAsync(w.rbd, h_rbd, (size_t)B * QM_NRBD * 8, hipMemcpyHostToDevice, sb), "H2D"); bk.check(hipMemcpyAsync(w.time, h_time, (size_t)B * 8, hipMemcpyHostToDevice, sb), "H2D");
+    bk.check(hipMemcpyAsync(w.mode, h_mode, (size_t)B * 4, hipMemcpyHostToDevice, sb), "H2D");
+  }
+  bk.cur = sb; c->wbc.step(c->mpc.d, B, period, variant); bk.wbc_end();
+  double* h_out = (double*)hout; int* h_qps = (int*)(h_out + (size_t)B * QM_NWBC_OUT);
+  if (B == w.Bmax) bk.check(hipMemcpyAsync(hout, w.out, WP::out_bytes(B), hipMemcpyDeviceToHost, sb), "D2H");
+  else { bk.check(hipMemcpyAsync(h_out, w.out, (size_t)B * QM_NWBC_OUT * 8, hipMemcpyDeviceToHost, sb), "D2H"); bk.check(hipMemcpyAsync(h_qps, w.qp_status, (size_t)B * 3 * 4, hipMemcpyDeviceToHost, sb), "D2H"); }
+  bk.check(hipStreamSynchronize(sb), "sync");
+  if (out) memcpy(out, h_out, (size_t)B * QM_NWBC_OUT * 8); if (qps) memcpy(qps, h_qps, (size_t)B * 3 * 4);
+  return c->hipstate();
 }
-int qmhip_wbc_download(qmhip_ctx* c, int B, double* out, int32_t* qps) {
+int qmhip_wbc_download(qmhip_ctx* c, int B, double* out, int32_t* qps) { QM_GUARD(c);
   if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG; hipSetDevice(c->device);
   if (out) c->bk.to_host(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); if (qps) c->bk.to_host(qps, c->wbc.w.qp_status, (size_t)B * 3 * 4);
   return c->hipstate();
 }
-int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double period, double time) {
+int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double period, double time) { QM_GUARD(c); QM_NEED_MPC(c);
   int rc = qmhip_mpc_solve_resident(c, B, horizon); if (rc) return rc;
   // the WBC goes to its own stream: back-to-back steps overlap WBC(k) — one wave per SIMD whose run time is that of the instance with the most
   // active-set iterations — with the MPC kernels of step k + 1, which fill the SIMDs the finished WBC waves leave behind
@@ -334,38 +370,38 @@ int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double peri
 }
 
 // ---- batched rigid-body plant (QMHWSim.cpp:60-116) ----
-int qmhip_sim_set_params(qmhip_ctx* c, const double* p, int n) {
+int qmhip_sim_set_params(qmhip_ctx* c, const double* p, int n) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || !p || n < 1 || n > 7) { if (c) c->fail("qmhip_sim_set_params: bad argument"); return QMHIP_ERR_ARG; }
   QmSimParams& q = c->sim.p; double* f[6] = {&q.k_n, &q.d_n, &q.mu, &q.v_eps, &q.foot_radius, &q.delay};
   for (int i = 0; i < n && i < 6; ++i) *f[i] = p[i]; if (n == 7) q.saturate = p[6] != 0.0;
   if (!(q.k_n >= 0) || !(q.d_n >= 0) || !(q.mu >= 0) || !(q.v_eps > 0) || !(q.delay >= 0)) { c->fail("qmhip_sim_set_params: negative parameter"); return QMHIP_ERR_ARG; }
   return QMHIP_OK;
 }
-int qmhip_sim_set_controller(qmhip_ctx* c, int controller) {
+int qmhip_sim_set_controller(qmhip_ctx* c, int controller) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || (controller != 0 && controller != 1)) { if (c) c->fail("qmhip_sim_set_controller: 0 (QMController) or 1 (QMMpcController)"); return QMHIP_ERR_ARG; }
   c->sim.controller = controller; return QMHIP_OK;
 }
-int qmhip_sim_reset(qmhip_ctx* c, int B, const double* q, const double* v, const double* time) {
+int qmhip_sim_reset(qmhip_ctx* c, int B, const double* q, const double* v, const double* time) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !q || !v || !time) { if (c) c->fail("qmhip_sim_reset: bad argument"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->sim.allocate(c->max_batch); c->sim.reset(B, q, v, time); c->sim_ticks = 0;
   c->mpc.solved_B = 0; c->have_solution = false;      // a new episode starts cold, like the reference after "Simulation reset" (no warm start from the previous episode's trajectory)
   c->sim.step(c->mpc.d.mb, B, 0.0, 0); return c->hipstate();   // rbd / contact of the reset state
 }
-int qmhip_sim_set_command(qmhip_ctx* c, int B, const double* pos_des, const double* vel_des, const double* kp, const double* kd, const double* ff) {
+int qmhip_sim_set_command(qmhip_ctx* c, int B, const double* pos_des, const double* vel_des, const double* kp, const double* kd, const double* ff) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !pos_des || !vel_des || !kp || !kd || !ff) { if (c) c->fail("qmhip_sim_set_command: bad argument"); return QMHIP_ERR_ARG; }
   if (!c->sim.s.Bmax) { c->fail("qmhip_sim_set_command: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
   std::vector<double> cmd((size_t)B * (QM_SIM_CMD - 1)); const double* src[5] = {pos_des, vel_des, kp, kd, ff};
   for (int b = 0; b < B; ++b) for (int k = 0; k < 5; ++k) for (int j = 0; j < 18; ++j) cmd[(size_t)b * (QM_SIM_CMD - 1) + 18 * k + j] = src[k][(size_t)b * 18 + j];
   hipSetDevice(c->device); c->sim.set_command(B, cmd.data()); return c->hipstate();
 }
-int qmhip_sim_step(qmhip_ctx* c, int B, double period, int n_substeps, double* rbd, int32_t* contact) {
+int qmhip_sim_step(qmhip_ctx* c, int B, double period, int n_substeps, double* rbd, int32_t* contact) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !(period > 0) || n_substeps < 1) { if (c) c->fail("qmhip_sim_step: bad argument"); return QMHIP_ERR_ARG; }
   if (!c->sim.s.Bmax) { c->fail("qmhip_sim_step: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); c->sim.step(c->mpc.d.mb, B, period, n_substeps);
   if (rbd) c->bk.to_host(rbd, c->sim.s.rbd, (size_t)B * QM_NRBD * 8); if (contact) c->bk.to_host(contact, c->sim.s.contact, (size_t)B * 4 * 4);
   return c->hipstate();
 }
-int qmhip_sim_get_state(qmhip_ctx* c, int B, double* q, double* v, double* time, double* force, int32_t* status) {
+int qmhip_sim_get_state(qmhip_ctx* c, int B, double* q, double* v, double* time, double* force, int32_t* status) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch) { if (c) c->fail("qmhip_sim_get_state: bad argument"); return QMHIP_ERR_ARG; }
   if (!c->sim.s.Bmax) { c->fail("qmhip_sim_get_state: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device);
@@ -377,7 +413,7 @@ int qmhip_sim_get_state(qmhip_ctx* c, int B, double* q, double* v, double* time,
 // device-resident control loop around the plant: per tick [state estimate (ground truth) -> MPC call every mpc_every ticks (warm-started SQP on the observation)
 // -> policy at the plant time -> WBC on the measured state -> hybrid joint command -> one simulation step]; QMController::update + mpcThread_
 // (qm_controllers/src/QMController.cpp:128-175, 315-332), the MPC synchronous with the tick it is triggered on
-int qmhip_closed_loop_sim(qmhip_ctx* c, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd) {
+int qmhip_closed_loop_sim(qmhip_ctx* c, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || n_ticks <= 0 || !(period > 0) || n_substeps < 1 || mpc_every < 1 || !(horizon > 0)) { if (c) c->fail("qmhip_closed_loop_sim: bad argument"); return QMHIP_ERR_ARG; }
   if (!c->sim.s.Bmax) { c->fail("qmhip_closed_loop_sim: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); c->bk.sync();
@@ -387,7 +423,7 @@ int qmhip_closed_loop_sim(qmhip_ctx* c, int B, int n_ticks, double period, int n
   return c->hipstate();
 }
 
-int qmhip_closed_loop_sim_pipelined(qmhip_ctx* c, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd) {
+int qmhip_closed_loop_sim_pipelined(qmhip_ctx* c, int B, int n_ticks, double period, int n_substeps, int mpc_every, double horizon, double arm_kp, double arm_kd) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || n_ticks <= 0 || !(period > 0) || n_substeps < 1 || mpc_every < 1 || !(horizon > 0)) { if (c) c->fail("qmhip_closed_loop_sim_pipelined: bad argument"); return QMHIP_ERR_ARG; }
   if (!c->sim.s.Bmax) { c->fail("qmhip_closed_loop_sim_pipelined: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
   if (n_ticks % mpc_every || c->sim_ticks % mpc_every) { c->fail("qmhip_closed_loop_sim_pipelined: n_ticks and the tick counter must be multiples of mpc_every"); return QMHIP_ERR_ARG; }
@@ -398,19 +434,19 @@ int qmhip_closed_loop_sim_pipelined(qmhip_ctx* c, int B, int n_ticks, double per
   return c->hipstate();
 }
 
-int qmhip_set_profiling(qmhip_ctx* c, int en) { if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.profiling = (en == 2) ? 2 : (en != 0); return QMHIP_OK; }
-int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launches) {
+int qmhip_set_profiling(qmhip_ctx* c, int en) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.profiling = (en == 2) ? 2 : (en != 0); return QMHIP_OK; }
+int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launches) { QM_GUARD(c);
   if (!c || !name) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.resolve(); auto it = c->bk.acc.find(name);
   if (ms) *ms = it == c->bk.acc.end() ? 0.0 : it->second.first; if (launches) *launches = it == c->bk.acc.end() ? 0 : it->second.second; return QMHIP_OK;
 }
-int qmhip_reset_kernel_ms(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.acc.clear(); return QMHIP_OK; }
-int qmhip_synchronize(qmhip_ctx* c) { if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
-int qmhip_last_ls_trials(const qmhip_ctx* c) { return c ? c->mpc.ls_trials_run : -1; }
-int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; } return QMHIP_ERR_ARG; }
+int qmhip_reset_kernel_ms(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.acc.clear(); return QMHIP_OK; }
+int qmhip_synchronize(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
+int qmhip_last_ls_trials(const qmhip_ctx* c) { QM_GUARD(c); return c ? c->mpc.ls_trials_run : -1; }
+int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { QM_GUARD(c); if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; } return QMHIP_ERR_ARG; }
 // profiling only: `waves` filler waves of `iters` steps on the second stream (see qm_filler_kernel); *ms (may be null) = its duration when waited for
 // profiling only: one MPC iteration of the resident batch with the filler started on the second stream right when the LQ kernel starts; ms[0] = LQ kernel,
 // ms[1] = filler, ms[2] = both (first start to last end), all from HIP events
-int qmhip_debug_lq_with_filler(qmhip_ctx* c, int B, double horizon, int waves, int iters, double* ms) {
+int qmhip_debug_lq_with_filler(qmhip_ctx* c, int B, double horizon, int waves, int iters, double* ms) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !ms) return QMHIP_ERR_ARG; hipSetDevice(c->device);
   if (waves > 0 && !c->filler_buffer(waves)) { c->fail("hipMalloc of the filler buffer failed"); return QMHIP_ERR_HIP; }
   double* out = c->filler_out;
@@ -435,7 +471,7 @@ int qmhip_debug_lq_with_filler(qmhip_ctx* c, int B, double horizon, int waves, i
   hipEventDestroy(a0); hipEventDestroy(a1); hipEventDestroy(b0); hipEventDestroy(b1); (void)lq_done;
   return c->hipstate();
 }
-int qmhip_debug_filler(qmhip_ctx* c, int waves, int iters, int wait, double* ms) {
+int qmhip_debug_filler(qmhip_ctx* c, int waves, int iters, int wait, double* ms) { QM_GUARD(c);
   if (!c || waves <= 0 || iters <= 0) return QMHIP_ERR_ARG; hipSetDevice(c->device);
   if (!c->filler_buffer(waves)) { c->fail("hipMalloc of the filler buffer failed"); return QMHIP_ERR_HIP; }
   double* out = c->filler_out;
@@ -447,14 +483,15 @@ int qmhip_debug_filler(qmhip_ctx* c, int waves, int iters, int wait, double* ms)
   hipEventDestroy(e0); hipEventDestroy(e1);
   return c->hipstate();
 }
-int qmhip_debug_get(const qmhip_ctx* c, const char* key, int* value) {
+int qmhip_debug_get(const qmhip_ctx* c, const char* key, int* value) { QM_GUARD(c);
   if (!c || !key || !value) return QMHIP_ERR_ARG;
   if (!strcmp(key, "riccati_skip")) { *value = c->mpc.riccati_skip; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { *value = c->wbc.wbc_stop; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { *value = c->mpc.lq_prof; return QMHIP_OK; }
   return QMHIP_ERR_ARG;
 }
-int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) {
+int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) { QM_GUARD(c);
   if (!c || !name || !dst) return QMHIP_ERR_ARG; hipSetDevice(c->device); const QmMpcBuffers& d = c->mpc.d; const void* p = nullptr;
 #define F(n) if (!strcmp(name, #n)) p = d.n;
+  if (c->wbc_only) { p = c->wbc.buffer(name); if (!p) { c->fail("qmhip_debug_read: a WBC-only context only has the wbc_* buffers"); return QMHIP_ERR_ARG; } c->bk.to_host(dst, p, bytes); return c->hipstate(); }
   if (!strcmp(name, "sim_rbd")) p = c->sim.s.rbd; if (!strcmp(name, "sim_cmd")) p = c->sim.s.cmd;
   F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
 #undef F
@@ -462,7 +499,7 @@ int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) {
   if (!p) { c->fail(std::string("qmhip_debug_read: unknown buffer ") + name); return QMHIP_ERR_ARG; }
   c->bk.to_host(dst, p, bytes); return c->hipstate();
 }
-int qmhip_microbench_fp64(qmhip_ctx* c, int use_mfma, double* tflops) {
+int qmhip_microbench_fp64(qmhip_ctx* c, int use_mfma, double* tflops) { QM_GUARD(c);
   if (!c || !tflops) return QMHIP_ERR_ARG; hipSetDevice(c->device);
   const int blocks = 256 * 8, threads = 256, iters = 20000; double* out = (double*)c->bk.alloc((size_t)blocks * threads * 8);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
