@@ -254,7 +254,7 @@ def secondary_figures(args, eng, cfg, dist, device, world, rank):
     # (3) SURVEY.md §8(f) rank 3: the whole controller around the batched rigid-body plant, device resident — per 1 ms tick
     #     [state estimate -> MPC every 10 ticks (warm) -> policy -> WBC -> updateControlLaw -> plant step with the 9 ms command delay]
     if not args.no_plant_loop and world == 1:
-        sim = api.QMHWSim(itf); t_shift = 20.0                                  # the reference switches the legs on at time > 10 (QMController.cpp:179)
+        sim = api.QMHWSim(itf, robust_grid=True); t_shift = 20.0                                  # the reference switches the legs on at time > 10 (QMController.cpp:179)
         mpc.set_problem(cfg["t0"] + t_shift, cfg["x0"], cfg["ref_t"] + t_shift, cfg["ref_x"], cfg["ev"] + t_shift, cfg["modes"]); wbc.reset()
         q0 = np.array(cfg["x0"][:, 6:30]); q0[:, 0:2] = 0.0; q0[:, 2] = 0.385; q0[:, 3:6] = 0.0
         sim.reset(q0, np.zeros((B, 24)), cfg["t0"] + t_shift)

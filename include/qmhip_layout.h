@@ -109,7 +109,14 @@
 #define ST_IPM_G_MAX     1037 /* ipm.g_max                                                                */
 #define ST_IPM_G_MIN     1038 /* ipm.g_min                                                                */
 #define ST_IPM_MU        1039 /* ipm.initialBarrierParameter (carried; no inequality rows to apply it to) */
-#define ST_SIZE       1040
+/* minimum step of the SQP time grid (`dt_min` of [upstream ocs2_oc timeDiscretizationWithEvents], default 10 * numeric_traits::limitEpsilon): a node closer than this to its
+   predecessor overwrites it.  The ingestion writes the upstream default.  With it, a node that falls within weakEpsilon (1e-6) BEFORE a gait event opens an interval whose adapted
+   duration (interval end − start, ∓ weakEpsilon at events) is negative and the solve reports status -4, as upstream would fail; fixed-rate loops whose observation times share a
+   raster with the gait events opt into the robust variant QM_GRID_DT_MIN_ROBUST through qmhip_set_setting */
+#define ST_GRID_DT_MIN 1040
+#define QM_GRID_DT_MIN_UPSTREAM 2.220446049250313e-15
+#define QM_GRID_DT_MIN_ROBUST   1.0e-5
+#define ST_SIZE       1048  /* 1041..1047 reserved */
 
 /* contact-mode ids: 8*LF + 4*RF + 2*LH + 1*RH (ocs2_legged_robot MotionPhaseDefinition) */
 #define QM_MODE_STANCE 15

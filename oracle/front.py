@@ -34,7 +34,7 @@ ST = dict(Q=0, R=30, XINIT=930, MU_EE_POS=960, MU_EE_ORI=961, MU_EEF_POS=962, MU
           KD_BASE_H=1001, KP_BASE_LIN=1002, KD_BASE_LIN=1003, KP_BASE_ANG=1004, KD_BASE_ANG=1005,
           KP_ARM_J=1006, KD_ARM_J=1012, KP_EE_LIN=1018, KD_EE_LIN=1021, KP_EE_ANG=1024,
           KD_EE_ANG=1027, SOLVER=1030, DDP_MIN_STEP=1031, DDP_MAX_STEP=1032, DDP_PENALTY=1033,
-          IPM_DT=1034, IPM_ITER=1035, IPM_DELTA_TOL=1036, IPM_G_MAX=1037, IPM_G_MIN=1038, IPM_MU=1039, SIZE=1040)
+          IPM_DT=1034, IPM_ITER=1035, IPM_DELTA_TOL=1036, IPM_G_MAX=1037, IPM_G_MIN=1038, IPM_MU=1039, GRID_DT_MIN=1040, SIZE=1048)
 
 FOOT_FRAMES = ["LF_FOOT", "RF_FOOT", "LH_FOOT", "RH_FOOT"]   # ModelSettings.h:38 (contact order)
 MODE_NAMES = {"FLY": 0, "RH": 1, "LH": 2, "LH_RH": 3, "RF": 4, "RF_RH": 5, "RF_LH": 6,
@@ -357,6 +357,13 @@ def build_settings(task_info_path, model_blob):
     R[12:24, 12:24] = J.T @ Rt[12:24, 12:24] @ J
     s[ST['R']: ST['R'] + NU * NU] = R.ravel()
     g = lambda k: float(info_get(t, k))
+
+    def gopt(k, default):
+        try:
+            v = info_get(t, k)
+        except (KeyError, TypeError):
+            return float(default)
+        return float(v) if v != '' else float(default)
     s[ST['MU_EE_POS']] = g('endEffector.muPosition')
     s[ST['MU_EE_ORI']] = g('endEffector.muOrientation')
     s[ST['MU_EEF_POS']] = g('finalEndEffector.muPosition')
@@ -398,12 +405,15 @@ def build_settings(task_info_path, model_blob):
     s[ST['KD_EE_ANG']: ST['KD_EE_ANG'] + 3] = w['kd_ee_angular']
     # discrete iLQR: the controller instantiates SqpMpc whatever `ddp.algorithm` says (QMController.cpp:287-288) -> solver 0
     s[ST['SOLVER']] = 0.0
-    s[ST['DDP_MIN_STEP']] = g('ddp.lineSearch.minStepLength')
-    s[ST['DDP_MAX_STEP']] = g('ddp.lineSearch.maxStepLength')
-    s[ST['DDP_PENALTY']] = g('ddp.constraintPenaltyInitialValue')
+    # the `ddp` / `ipm` blocks are optional ([upstream, recalled] loadSettings keeps the struct defaults for missing keys); the default solver reads neither
+    s[ST['DDP_MIN_STEP']] = gopt('ddp.lineSearch.minStepLength', 0.05)
+    s[ST['DDP_MAX_STEP']] = gopt('ddp.lineSearch.maxStepLength', 1.0)
+    s[ST['DDP_PENALTY']] = gopt('ddp.constraintPenaltyInitialValue', 2.0)
+    s[ST['GRID_DT_MIN']] = 10.0 * 2.220446049250313e-16      # [upstream] timeDiscretizationWithEvents' default dt_min
     # `ipm` block (task.info:94-125, loaded at QMInterface.cpp:72, never instantiated): the multiple-shooting parameter set of solver 2
-    for k, key in (('IPM_DT', 'ipm.dt'), ('IPM_ITER', 'ipm.ipmIteration'), ('IPM_DELTA_TOL', 'ipm.deltaTol'), ('IPM_G_MAX', 'ipm.g_max'), ('IPM_G_MIN', 'ipm.g_min'), ('IPM_MU', 'ipm.initialBarrierParameter')):
-        s[ST[k]] = g(key)
+    for k, key, dflt in (('IPM_DT', 'ipm.dt', 0.01), ('IPM_ITER', 'ipm.ipmIteration', 10.0), ('IPM_DELTA_TOL', 'ipm.deltaTol', 1e-6), ('IPM_G_MAX', 'ipm.g_max', 1e6), ('IPM_G_MIN', 'ipm.g_min', 1e-6),
+                         ('IPM_MU', 'ipm.initialBarrierParameter', 1e-2)):
+        s[ST[k]] = gopt(key, dflt)
     return s
 
 

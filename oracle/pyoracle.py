@@ -95,10 +95,11 @@ class Oracle:
         self.lib.qmo_frame_pose(self.h, _p(q), C.c_int(f), _p(p), _p(R))
         return p, R
 
-    def time_grid(self, t0, tf, dt, ev):
+    def time_grid(self, t0, tf, dt, ev, dt_min=10.0 * 2.220446049250313e-16):
+        """[upstream timeDiscretizationWithEvents]; dt_min defaults to upstream's 10 * limitEpsilon"""
         ev = np.ascontiguousarray(ev, float)
         t = np.zeros(self.MAXN); e = np.zeros(self.MAXN, np.int32)
-        n = self.lib.qmo_time_grid(C.c_double(t0), C.c_double(tf), C.c_double(dt), C.c_int(len(ev)), _p(ev), C.c_int(self.MAXN), _p(t), _pi(e))
+        n = self.lib.qmo_time_grid(C.c_double(t0), C.c_double(tf), C.c_double(dt), C.c_int(len(ev)), _p(ev), C.c_int(self.MAXN), _p(t), _pi(e), C.c_double(dt_min))
         assert n > 0
         return t[:n].copy(), e[:n].copy()
 

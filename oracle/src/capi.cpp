@@ -40,8 +40,8 @@ void qmo_frame_pose(void* h, const double* q, int f, double* pos, double* Rm) {
 }
 void qmo_mat_to_quat(const double* Rm, double* q) { M3<double> R; for (int i = 0; i < 9; ++i) R.m[i] = Rm[i]; matToQuat<double>(R, q); }
 
-int qmo_time_grid(double t0, double tf, double dt, int nev, const double* ev, int maxn, double* out_t, int* out_ev) {
-  Vec e(ev, ev + nev); auto g = timeDiscretizationWithEvents(t0, tf, dt, e);
+int qmo_time_grid(double t0, double tf, double dt, int nev, const double* ev, int maxn, double* out_t, int* out_ev, double dt_min) {
+  Vec e(ev, ev + nev); auto g = timeDiscretizationWithEvents(t0, tf, dt, e, dt_min);
   if ((int)g.size() > maxn) return -(int)g.size();
   for (size_t i = 0; i < g.size(); ++i) { out_t[i] = g[i].t; out_ev[i] = g[i].ev; }
   return (int)g.size();

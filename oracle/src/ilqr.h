@@ -20,7 +20,7 @@ inline double ilqrMerit(const Problem& P, const Performance& p) { return p.cost 
 
 inline void ilqrIteration(const Problem& P, double t0, double tf, const Vec& x0, SqpResult& R, const SqpResult* prev = nullptr) {
   const Model& M = *P.M; const double* st = M.st;
-  R.grid = timeDiscretizationWithEvents(t0, tf, st[ST_SQP_DT], P.ms.ev);
+  R.grid = timeDiscretizationWithEvents(t0, tf, st[ST_SQP_DT], P.ms.ev, st[ST_GRID_DT_MIN]);
   const int N = (int)R.grid.size() - 1;
   R.mode.resize(N + 1); for (int i = 0; i <= N; ++i) R.mode[i] = P.ms.modeAt(intervalStart(R.grid[i]));
   // ---- 1. inputs as the SQP's initial guess, states by rollout ----

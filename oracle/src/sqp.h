@@ -66,11 +66,10 @@ inline double intervalStart(const Node& n) { return n.ev == QM_EV_POST ? n.t + k
 inline double intervalEnd(const Node& n) { return n.ev == QM_EV_PRE ? n.t - kWeakEps : n.t; }
 
 // [upstream timeDiscretizationWithEvents]
-inline std::vector<Node> timeDiscretizationWithEvents(double t0, double tf, double dt, const Vec& ev) {
-  // minimum step: [upstream]'s default is a few machine epsilons; a grid node that falls within weakEpsilon BEFORE an event would then open an interval whose
-  // adapted duration (intervalEnd − intervalStart, ±weakEpsilon at events) is NEGATIVE — a fixed-rate loop (t0 = k · 1 ms, events on the same raster)
-  // hits that exactly.  Steps shorter than 10 weakEpsilon are merged instead (robustness deviation, identical grids otherwise).
-  const double dtMin = 10.0 * kWeakEps;
+// dtMin: [upstream]'s `dt_min` argument, default 10 * limitEpsilon (settings slot ST_GRID_DT_MIN).  With that default a grid node that falls within weakEpsilon BEFORE an
+// event opens an interval whose adapted duration (intervalEnd − intervalStart, ∓ weakEpsilon at events) is NEGATIVE — a fixed-rate loop (t0 = k · 1 ms, events on the
+// same raster) hits that exactly and the Riccati recursion then fails (status -4), as upstream's would.  QM_GRID_DT_MIN_ROBUST (10 weakEpsilon) is the opt-in variant.
+inline std::vector<Node> timeDiscretizationWithEvents(double t0, double tf, double dt, const Vec& ev, double dtMin = 10.0 * kLimitEps) {
   std::vector<Node> g; g.push_back({t0, QM_EV_NONE});
   int k = findIndexInTimeArray(ev, t0);
   Node next = g.back();
@@ -244,7 +243,7 @@ inline void evaluatePolicy(const SqpResult& R, const ModeSchedule& ms, double t,
 inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, const std::vector<Vec>* xInit, const std::vector<Vec>* uInit, SqpResult& R, const SqpResult* prev = nullptr);
 inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, const std::vector<Vec>* xInit, const std::vector<Vec>* uInit, SqpResult& R, const SqpResult* prev) {
   const Model& M = *P.M; const double* st = M.st;
-  R.grid = timeDiscretizationWithEvents(t0, tf, msParam(st, MsParam::Dt), P.ms.ev);
+  R.grid = timeDiscretizationWithEvents(t0, tf, msParam(st, MsParam::Dt), P.ms.ev, st[ST_GRID_DT_MIN]);
   const int N = (int)R.grid.size() - 1;
   R.mode.resize(N + 1); for (int i = 0; i <= N; ++i) R.mode[i] = P.ms.modeAt(intervalStart(R.grid[i]));
   // initializeStateInputTrajectories, cold start: QMInitializer::compute (QMInitializer.cpp:33-41)

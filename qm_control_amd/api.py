@@ -277,10 +277,14 @@ class QMHWSim:
     readSim (rbd state in the estimator's layout, contact flags)."""
     PARAMS = ("contact_stiffness", "contact_damping", "friction", "friction_speed_eps", "foot_radius", "delay", "saturate_effort")
 
-    def __init__(self, interface, **params):
+    def __init__(self, interface, robust_grid=False, **params):
+        """robust_grid: opt into the SQP time grid's robust minimum step (ST_GRID_DT_MIN = QM_GRID_DT_MIN_ROBUST, include/qmhip_layout.h) — for long fixed-rate loops whose
+        1 ms observation raster can land within weakEpsilon of a gait event; the default keeps [upstream]'s 10 * limitEpsilon"""
         self.itf = interface
         self.lib = interface.lib
         self.B = 0
+        if robust_grid:
+            interface.set_setting(L.ST_GRID_DT_MIN, L.QM_GRID_DT_MIN_ROBUST)
         if params:
             self.set_params(**params)
 

@@ -273,12 +273,18 @@ bool buildSettingsBlob(const std::string& taskInfo, const double* mb, double* st
                    {"model_settings.positionErrorGain", ST_POS_ERR_GAIN}, {"model_settings.phaseTransitionStanceTime", ST_PHASE_TRANS_STANCE},
                    {"swing_trajectory_config.liftOffVelocity", ST_LIFTOFF_VEL}, {"swing_trajectory_config.touchDownVelocity", ST_TOUCHDOWN_VEL}, {"swing_trajectory_config.swingHeight", ST_SWING_HEIGHT},
                    {"swing_trajectory_config.swingTimeScale", ST_SWING_TIME_SCALE}, {"sqp.dt", ST_SQP_DT}, {"sqp.sqpIteration", ST_SQP_ITER}, {"sqp.deltaTol", ST_DELTA_TOL}, {"sqp.g_max", ST_G_MAX}, {"sqp.g_min", ST_G_MIN},
-                   {"mpc.timeHorizon", ST_TIME_HORIZON}, {"frictionConeTask.frictionCoefficient", ST_WBC_FRIC},
-                   {"ddp.lineSearch.minStepLength", ST_DDP_MIN_STEP}, {"ddp.lineSearch.maxStepLength", ST_DDP_MAX_STEP}, {"ddp.constraintPenaltyInitialValue", ST_DDP_PENALTY},
-                   {"ipm.dt", ST_IPM_DT}, {"ipm.ipmIteration", ST_IPM_ITER}, {"ipm.deltaTol", ST_IPM_DELTA_TOL}, {"ipm.g_max", ST_IPM_G_MAX}, {"ipm.g_min", ST_IPM_G_MIN}, {"ipm.initialBarrierParameter", ST_IPM_MU}};
+                   {"mpc.timeHorizon", ST_TIME_HORIZON}, {"frictionConeTask.frictionCoefficient", ST_WBC_FRIC}};
   for (const KV& e : kv) if (!infoScalar(t, e.key, st[e.idx], err)) return false;
+  // The `ddp` and `ipm` blocks are read by solver slots 1 / 2 only, which the reference never instantiates (QMController.cpp:287-288): a task.info without them is
+  // accepted and gets the solver structs' defaults ([upstream, recalled] ddp::Settings / ipm::Settings: loadSettings leaves the default where a key is missing).
+  struct KVD { const char* key; int idx; double dflt; };
+  const KVD opt[] = {{"ddp.lineSearch.minStepLength", ST_DDP_MIN_STEP, 0.05}, {"ddp.lineSearch.maxStepLength", ST_DDP_MAX_STEP, 1.0}, {"ddp.constraintPenaltyInitialValue", ST_DDP_PENALTY, 2.0},
+                     {"ipm.dt", ST_IPM_DT, 0.01}, {"ipm.ipmIteration", ST_IPM_ITER, 10.0}, {"ipm.deltaTol", ST_IPM_DELTA_TOL, 1e-6}, {"ipm.g_max", ST_IPM_G_MAX, 1e6}, {"ipm.g_min", ST_IPM_G_MIN, 1e-6},
+                     {"ipm.initialBarrierParameter", ST_IPM_MU, 1e-2}};
+  for (const KVD& e : opt) { std::string ignored; if (!infoScalar(t, e.key, st[e.idx], ignored)) st[e.idx] = e.dflt; }
   if (!(st[ST_SQP_DT] > 0.0) || !(st[ST_SQP_DT] < 1.0e300)) { err = "INFO: sqp.dt must be a positive finite number"; return false; }   // K0 walks t0 + k dt up to the horizon
-  if (!(st[ST_IPM_DT] > 0.0) || !(st[ST_IPM_DT] < 1.0e300)) { err = "INFO: ipm.dt must be a positive finite number"; return false; }
+  // ipm.dt is validated where it is used: qmhip_set_setting(ST_SOLVER, 2) / (ST_IPM_DT, .) and K0's `sane` guard
+  st[ST_GRID_DT_MIN] = QM_GRID_DT_MIN_UPSTREAM;         // [upstream] timeDiscretizationWithEvents' default dt_min = 10 * limitEpsilon
   st[ST_FRIC_REG] = 25.0; st[ST_FRIC_SHIFT] = 1e-6;     // [upstream] FrictionConeConstraint::Config defaults
   st[ST_SOLVER] = 0.0;                                  // the controller instantiates SqpMpc whatever `ddp.algorithm` says (QMController.cpp:287-288)
   if (!infoMatrix(t, "jointVelocityLimits.lowerBound.arm", 6, 1, lo, err) || !infoMatrix(t, "jointVelocityLimits.upperBound.arm", 6, 1, hi, err)) return false;

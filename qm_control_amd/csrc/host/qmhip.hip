@@ -121,7 +121,7 @@ __global__ void qm_bench_mfma_kernel(double* out, int iters) {
 }
 
 // settings whose value the kernels' loop bounds depend on (K0 walks t0 + k dt up to the horizon)
-static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT || idx == ST_IPM_DT) return v > 0.0 && std::isfinite(v); return true; }
+static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT || idx == ST_IPM_DT) return v > 0.0 && std::isfinite(v); if (idx == ST_GRID_DT_MIN) return v >= 0.0 && std::isfinite(v); return true; }
 
 // ---- co-residency probe (profiling only): a latency-bound stand-in for a narrow (<= 256 VGPR, <= 20 KB LDS) one-wave-per-instance solver wave — chains of
 // dependent f64 MFMAs and FMAs with an LDS round trip per step, ≈ 40 % issue utilisation like qm_riccati_kernel — launched on the second stream beside the
@@ -195,7 +195,8 @@ const char* qmhip_last_error(const qmhip_ctx* c) { QM_GUARD(c); return c ? c->er
 int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
 int qmhip_set_setting(qmhip_ctx* c, int idx, double v) { QM_GUARD(c);
   if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
-  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number"); return QMHIP_ERR_ARG; }
+  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number, the grid's minimum step a non-negative one"); return QMHIP_ERR_ARG; }
+  if (idx == ST_SOLVER && v == 2.0 && !setting_ok(ST_IPM_DT, c->st[ST_IPM_DT])) { c->fail("qmhip_set_setting: solver 2 needs a positive finite ipm.dt"); return QMHIP_ERR_ARG; }
   if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR) or 2 (multiple-shooting IPM)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
   hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
 }

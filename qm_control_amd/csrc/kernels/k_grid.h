@@ -72,8 +72,7 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
   if (b < a.B) {
   const double* ev = a.ev + (size_t)b * a.nev; const int* modes = a.modes + (size_t)b * (a.nev + 1);
   const double t0 = a.t0[b], tf = t0 + a.horizon, dt = qm_ms_param(a.st, ST_SQP_DT);
-  const double dtMin = 10.0 * QM_WEAK_EPS;   // steps shorter than this are merged: with [upstream]'s few-epsilon default a node within weakEpsilon before an event opens an
-                                             // interval of negative adapted duration (a fixed-rate loop with events on the same raster hits that exactly)
+  const double dtMin = a.st[ST_GRID_DT_MIN];  // [upstream] dt_min (default 10 limitEpsilon): a closer node overwrites its predecessor; QM_GRID_DT_MIN_ROBUST is the opt-in for fixed-rate loops
   int status = a.front_status ? a.front_status[b] : 0;
   // ---- time discretisation with events ----
   a.node_t[0 * a.B + b] = t0; a.node_ev[0 * a.B + b] = QM_EV_NONE; n = 1;

@@ -20,3 +20,25 @@ def summary():
     ric = RICCATI_BWD_READ_DOUBLES + RICCATI_BWD_WRITE_DOUBLES + RICCATI_FWD_READ_DOUBLES + RICCATI_FWD_IO_DOUBLES
     return {"lq_doubles_per_interval": lq, "riccati_doubles_per_interval": ric, "wbc_doubles_per_instance": WBC_IO_DOUBLES,
             "lq_bytes_per_interval": 8 * lq, "riccati_bytes_per_interval": 8 * ric}
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the device + launch sources a counter profile depends on (csrc/kernels/*.h, csrc/host/*, include/*.h, file names included, sorted).
+    tools/gpu_round_profile.sh records it next to the PMC passes, the digests stamp it into profiles/flops_pmc.json / hbm_traffic.json, and bench.py labels a roofline
+    priced on counters of OTHER sources `stale`."""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for d in ("qm_control_amd/csrc/kernels", "qm_control_amd/csrc/host", "include"):
+        full = os.path.join(root, d)
+        for f in sorted(os.listdir(full)):
+            if f.endswith((".h", ".hip", ".cpp")):
+                h.update((d + "/" + f + "\n").encode())
+                with open(os.path.join(full, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+if __name__ == "__main__":
+    print(kernel_source_hash())

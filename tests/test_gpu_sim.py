@@ -162,7 +162,7 @@ def test_every_gait_template_walks_on_the_plant(blobs):
         c["ev"], c["modes"] = scenarios._pad_schedules([e] * B, [m] * B); c["ref_x"][:, 1, 6] += 0.3
         q = np.tile(c["xbar"][6:30], (B, 1)); q[:, 2] = 0.385; q[:, 6:18] += 0.02 * rng.normal(size=(B, 12))
         itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=160, max_ref_knots=2, max_events=c["ev"].shape[1])
-        mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+        mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)      # 1.2 s on a 1 ms raster: the robust minimum step of the time grid
         sim.reset(q, np.zeros((B, 24)), 20.0); rbd0, _ = sim.step(1e-9, 1)
         for b in range(B):
             c["ref_x"][b, :, 30:37] = rbd0[b, 48:55]

@@ -6,7 +6,13 @@ taken from SQ_WAVES (waves per SE) against the launch's grid.  flops = 512 x MFM
 — wave-level instruction counts priced at a full exec mask, i.e. an UPPER bound of the vector part (masked lanes count) and the matrix part includes
 tile padding / rank-1 updates: this is the "issued" view that sits next to the algorithmic model of bench.py.
 usage: python tools/flops_pmc_digest.py <flops_a.csv> <flops_b.csv> <round tag> [n_se=32] [out.json]"""
-import csv, json, re, sys
+import csv, json, os, re, sys
+
+
+def _stamp():
+    """hash of the kernel sources the profiled run was built from: written on the GPU box by tools/gpu_round_profile.sh (gpurun_out/kernel_source_hash.txt)"""
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "kernel_source_hash.txt")
+    return open(p).read().strip() if os.path.exists(p) else None
 
 
 def main(a_csv, b_csv, tag, n_se="32", out="profiles/flops_pmc.json"):
@@ -15,7 +21,7 @@ def main(a_csv, b_csv, tag, n_se="32", out="profiles/flops_pmc.json"):
         for r in csv.DictReader(open(f)):
             rows.setdefault(r["Kernel"], {})[r["Counter"]] = float(r["AvgPerDispatch"])
     short = lambda k: (re.match(r"_Z\d+(qm_\w+_kernel)", k) or [None, k])[1]
-    res = {"round": tag, "_comment": __doc__.split("usage")[0].strip(), "n_shader_engines": n_se, "kernels": {}}
+    res = {"round": tag, "kernel_source_hash": _stamp(), "_comment": __doc__.split("usage")[0].strip(), "n_shader_engines": n_se, "kernels": {}}
     for k, c in rows.items():
         if not k.startswith("_Z"):
             continue

@@ -5,6 +5,7 @@ set -x
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+python qm_control_amd/record_model.py > gpurun_out/kernel_source_hash.txt      # the sources these counters belong to (bench.py: roofline `stale` on mismatch)
 if [ "$1" != "noprof" ]; then
 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -5 gpurun_out/pytest_gpu.log
 fi

@@ -16,7 +16,7 @@ def make(Bk, seed):
     c = setup("trot", Bk, horizon)
     q = np.tile(c["xbar"][6:30], (Bk, 1)); q[:, 2] = 0.385; q[:, 6:18] += 0.03 * rng.normal(size=(Bk, 12)); q[:, 18:] += 0.1 * rng.normal(size=(Bk, 6)); q[:, 5] += 0.1 * rng.normal(size=Bk)
     itf = api.QMInterface(blobs=(c["mb"], c["st"]), max_batch=Bk, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)
     sim.reset(q, np.zeros((Bk, 24)), 20.0); rbd0, _ = sim.step(1e-9, 1)
     for b in range(Bk):
         c["ref_x"][b, :, 30:37] = rbd0[b, 48:55]; c["ref_x"][b, :, 11] = q[b, 5]; c["ref_x"][b, :, 9] = 0.0

@@ -32,7 +32,7 @@ if __name__ == "__main__":
         q0 = c["xbar"][6:30].copy(); q0[2] = z0; s0.reset(q0[None], np.zeros((1, 24)), 20.0); rbd0, _ = s0.step(1e-9, 1); itf0.close()
         c = setup(gait, B, horizon, ee_pose=rbd0[0, 48:55])
     itf = api.QMInterface(blobs=(c["mb"], c["st"]), max_batch=B, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)
     extra = {k.lower()[4:]: float(v) for k, v in os.environ.items() if k.startswith("SIM_")}     # e.g. SIM_DELAY=0 SIM_CONTACT_DAMPING=400
     if extra: sim.set_params(**extra)
     mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset()

@@ -15,7 +15,7 @@ for name, g in gaits.items():
     c["ref_x"][:, 1, 6] += 0.3
     q = np.tile(c["xbar"][6:30], (B, 1)); q[:, 2] = 0.385; q[:, 6:18] += 0.02 * rng.normal(size=(B, 12))
     itf = api.QMInterface(blobs=(c["mb"], c["st"]), max_batch=B, max_nodes=160, max_ref_knots=2, max_events=c["ev"].shape[1])
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)
     sim.reset(q, np.zeros((B, 24)), 20.0); rbd0, _ = sim.step(1e-9, 1)
     for b in range(B): c["ref_x"][b, :, 30:37] = rbd0[b, 48:55]
     mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset(); sim.reset(q, np.zeros((B, 24)), 20.0)

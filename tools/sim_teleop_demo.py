@@ -11,7 +11,7 @@ def run(blobs, gait="trot", B=8, vx=0.3, walk_s=3.0, verbose=True, seed=2):
     mb, st = blobs; gaits = scenarios.load_gaits(); horizon = 1.0; t_start = 20.0; rng = np.random.default_rng(seed)
     xbar = st[scenarios.ST_XINIT:scenarios.ST_XINIT + 30].copy(); qnom = mb[scenarios.MB_QNOM:scenarios.MB_QNOM + 18].copy()
     itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=160, max_ref_knots=2, max_events=48)
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)
     q = np.tile(xbar[6:30], (B, 1)); q[:, 2] = 0.385; q[:, 6:18] += 0.02 * rng.normal(size=(B, 12))
     sim.reset(q, np.zeros((B, 24)), t_start); rbd0, _ = sim.step(1e-9, 1)
     base = xbar[6:12].copy(); base[2] = scenarios.COM_HEIGHT
