@@ -48,7 +48,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="instances per GPU (weak scaling: the global batch grows with --gpus)")
+    ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling (SURVEY.md §8(d) C4 / BASELINE.json config 4): a fixed global batch, e.g. 8192, cut into "
+                    "contiguous shards of global/G instances for G GPUs; overrides --batch")
     ap.add_argument("--n-intervals", type=int, default=100, help="horizon N (the metric is quoted at 100; other values are for tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary figures (closed loops, latency, C5)")
@@ -76,7 +78,7 @@ class HipEngine:
         self.itf = api.QMInterface(blobs=scenarios.load_blobs(), device=local_rank, max_batch=self.B, max_nodes=nm, max_ref_knots=2, max_events=cfg["ev"].shape[1])
         self.mpc = api.SqpMpc(self.itf); self.wbc = api.HierarchicalWbc(self.itf)
         self.upload(cfg)
-        for key in ("riccati_skip", "wbc_stop", "lq_prof"):      # profiling-only switches make results meaningless: they must all be off
+        for key in ("riccati_skip", "wbc_stop", "lq_prof", "lq_debug", "lds_pad"):      # profiling-only switches make results meaningless: they must all be off
             assert self.itf.debug_get(key) == 0, key
 
     def upload(self, cfg):
@@ -119,7 +121,10 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = sharding.init_distributed(backend, local) if (world > 1 or os.environ.get("QM_BENCH_FORCE_DIST")) else None     # (the env switch exercises the RCCL path on one GPU)
-    B = args.batch
+    strong = getattr(args, "global_batch", 0) > 0
+    if strong and args.global_batch % world:
+        raise SystemExit("--global-batch %d is not divisible by %d ranks" % (args.global_batch, world))
+    B = args.global_batch // world if strong else args.batch
     # C4: seed 1235, contiguous shard of the global batch for this rank
     cfg = sharding.shard_config(scenarios.make_config("C4", batch=B * world, n_intervals=args.n_intervals), rank, world)
     eng = make_engine(cfg, local)
@@ -169,7 +174,9 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
             tf = mdl["flop"] * units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0; tb = mdl["bytes"] * units / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"kernel": "qm_%s_kernel" % name, "avg_launch_ms": ms, "units_per_launch": units, "unit": mdl["unit"], "flop_per_launch": mdl["flop"] * units, "bytes_per_launch": mdl["bytes"] * units,
                     "tflops": tf, "frac_fp64": tf / FP64_PEAK_TFLOPS, "tbs": tb, "frac_hbm": tb / HBM_PEAK_TBS}
-        roofline = None; roofs = {}
+        roofline = None; roofs = {}; flops_stale = traffic_stale = None
+        from qm_control_amd import record_model as _rm
+        src_hash = _rm.kernel_source_hash()
         if hip:
             roofs = {k: roof(k) for k in KM}
             # flops the kernels ISSUE, from the SQ instruction counters of this same command (tools/gpu_round_profile.sh -> profiles/flops_pmc.json: a STATIC file of the
@@ -179,12 +186,14 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
             try:
                 with open(os.path.join(ROOT, "profiles", "flops_pmc.json")) as fh:
                     fp = json.load(fh)
+                flops_stale = fp.get("kernel_source_hash") != src_hash
                 for k, v in roofs.items():
                     f = fp["kernels"].get(v["kernel"], {}).get("flops_per_launch")
                     if f and v["avg_launch_ms"] > 0 and B == 1024 and args.n_intervals == 100:      # the counters were collected on the default workload
                         v["survey_dense_flop_per_launch"] = v["flop_per_launch"]; v["survey_dense_frac_fp64"] = v["frac_fp64"]
                         v["flop_per_launch"] = f; v["tflops"] = f / (v["avg_launch_ms"] * 1e-3) / 1e12; v["frac_fp64"] = v["tflops"] / FP64_PEAK_TFLOPS
-                if B == 1024 and args.n_intervals == 100: flop_src = "instrumented: SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 + SQ_INSTS_VALU_MFMA_MOPS_F64 per launch, profiles/flops_pmc.json round %s (same command, B=1024; not measured in this run)" % fp.get("round", "?")
+                if B == 1024 and args.n_intervals == 100: flop_src = "instrumented: SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 + SQ_INSTS_VALU_MFMA_MOPS_F64 per launch, profiles/flops_pmc.json round %s (same command, B=1024; not measured in this run)%s" % (
+                    fp.get("round", "?"), " — STALE: collected on kernel sources %s, this tree is %s" % (fp.get("kernel_source_hash"), src_hash) if flops_stale else "")
             except (OSError, KeyError, ValueError):
                 pass
             dom = max(roofs, key=lambda k: roofs[k]["avg_launch_ms"]); rd = roofs[dom]      # the dominant kernel = the longest average launch among the modelled ones
@@ -204,18 +213,25 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
                 with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as fh:
                     ht = json.load(fh)
                 roofline["traffic"] = ht["kernels"][rd["kernel"]]["traffic_bytes"]
+                traffic_stale = ht.get("kernel_source_hash") != src_hash
                 roofline["traffic_source"] = "profiles/hbm_traffic.json, round %s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, B=1024; not measured in this run)" % ht.get("round", "r01 v18")
             except (OSError, KeyError, ValueError):
                 pass
+            # the counter files are static: say so when they were collected on other kernel sources than the ones that just ran
+            roofline["kernel_source_hash"] = src_hash
+            roofline["counters"] = {"flops_pmc": None if flops_stale is None else ("stale" if flops_stale else "current"),
+                                    "hbm_traffic": None if traffic_stale is None else ("stale" if traffic_stale else "current")}
+            if flops_stale or traffic_stale:
+                roofline["stale"] = True
         total_steps = B * world * args.steps
         line = {
             "metric": "MPC+WBC control steps/sec (24-DoF quadruped-manipulator, SQP horizon N=100)", "value": total_steps / elapsed, "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C3/C4: trot gait, horizon N=%d (dt 0.015), %d random initial states per GPU (seed 1235), cold start, 1 SQP iteration + policy eval + 3-level WBC; "
                                    "back-to-back steps, the WBC of a step on its own stream beside the next step's MPC kernels (pipelined THROUGHPUT: the per-kernel times add up to more "
                                    "than ms_per_step; the unpipelined step latency is latency_ms)" % (args.n_intervals, B),
-                       "instances_per_gpu": B, "parallelism": "shard%d" % world, "all_status_ok": bool(per_rank[:, 4].all()), "ls_trials": res["ls_trials"], "engine": getattr(eng, "name", "?")},
+                       "instances_per_gpu": B, "global_batch": B * world, "parallelism": "shard%d" % world, "all_status_ok": bool(per_rank[:, 4].all()), "ls_trials": res["ls_trials"], "engine": getattr(eng, "name", "?")},
             "per_rank": {"seconds": [float(v) for v in per_rank[:, 0]], "lq_ms": [float(v) for v in per_rank[:, 1]], "riccati_ms": [float(v) for v in per_rank[:, 2]],
                          "wbc_ms": [float(v) for v in per_rank[:, 3]], "intervals_per_launch": [int(v) for v in per_rank[:, 5]]},
         }
@@ -273,6 +289,17 @@ def secondary_figures(args, eng, cfg, dist, device, world, rank):
     el5, _ = timed_region(e5, steps5, dist, device); r5 = e5.results(); e5.close()
     out["config_C5"] = {"workload": "C5: EE-tracking target, trot -> stance -> trot, N = 150, arm near joint limits, %d instances per GPU (seed 1236)" % B5, "value": B5 * world * steps5 / el5,
                         "unit": "steps/s", "n_gpus": world, "steps": steps5, "ms_per_step": el5 / steps5 * 1e3, "all_status_ok": r5["ok"], "ls_trials": r5["ls_trials"]}
+    # (4b) BASELINE.json config 4 as SURVEY.md §8(d) defines it — STRONG scaling: global batch 8192 cut into 8192 / G contiguous shards for G GPUs (the headline `value`
+    #      keeps 1024 instances per GPU, i.e. weak scaling; the two coincide at G = 8).  `python bench.py --global-batch 8192` makes this the headline instead.
+    if not getattr(args, "global_batch", 0) and 8192 % world == 0:
+        Bs = 8192 // world; steps_s = max(2, args.steps // 10)
+        cfgs = sharding.shard_config(scenarios.make_config("C4", batch=8192, n_intervals=args.n_intervals), rank, world)
+        es = HipEngine(cfgs, int(os.environ.get("LOCAL_RANK", "0")))
+        es.step(); es.sync()
+        els, _ = timed_region(es, steps_s, dist, device); rs = es.results(); es.close()
+        out["strong_scaling_C4"] = {"workload": "C4: trot, N = %d, global batch 8192 (seed 1235) in contiguous shards of %d instances per GPU" % (args.n_intervals, Bs), "value": 8192 * steps_s / els,
+                                    "unit": "steps/s", "n_gpus": world, "global_batch": 8192, "instances_per_gpu": Bs, "steps": steps_s, "ms_per_step": els / steps_s * 1e3, "scaling": "strong",
+                                    "all_status_ok": rs["ok"]}
     # (5) BASELINE.json config 2: a single instance (B = 1): the dependency-chain latency of one control step
     if rank == 0:
         cfg2 = scenarios.make_config("C2"); e2 = HipEngine(cfg2, int(os.environ.get("LOCAL_RANK", "0")), max_nodes=128)
@@ -281,7 +308,32 @@ def secondary_figures(args, eng, cfg, dist, device, world, rank):
         e2.sync(); t = time.perf_counter()
         for _ in range(20):
             e2.step(); e2.sync()
-        lat1 = (time.perf_counter() - t) / 20 * 1e3; r2 = e2.results(); e2.close()
+        lat1 = (time.perf_counter() - t) / 20 * 1e3; r2 = e2.results()
+        # the two timers the reference prints (ocs2 benchmark::RepeatedTimer: mpcTimer_ around MPC_BASE::run, QMController.cpp:321-323; wbcTimer_ around WbcBase::update,
+        # QMController.cpp:145-147), on the GPU for ONE robot: a cold MPC iteration alone (solve + device synchronisation), and one WBC update through the control-tick
+        # entry point qmhip_wbc_step on a WBC-only context (host inputs in, torques out: what the ros_control thread sees)
+        e2.sync(); t = time.perf_counter()
+        for _ in range(20):
+            e2.mpc.solve_resident(cfg2["horizon"]); e2.sync()
+        mpc1 = (time.perf_counter() - t) / 20 * 1e3
+        e2.mpc.solve_resident(cfg2["horizon"], warm=True); e2.sync(); t = time.perf_counter()
+        for _ in range(20):
+            e2.mpc.solve_resident(cfg2["horizon"], warm=True); e2.sync()
+        mpc1w = (time.perf_counter() - t) / 20 * 1e3
+        xd2, ud2, md2 = e2.mpc.evaluatePolicy(cfg2["t0"])
+        rbd2 = np.zeros((1, 55)); rbd2[0, 0:3] = cfg2["x0"][0, 9:12]; rbd2[0, 3:6] = cfg2["x0"][0, 6:9]; rbd2[0, 6:24] = cfg2["x0"][0, 12:30]
+        witf = e2.itf.wbc_context(); w2 = api.HierarchicalWbc(witf); w2.reset()
+        for _ in range(3):
+            w2.update(xd2, ud2, rbd2, md2, cfg2["period"], np.full(1, cfg2["time"]))
+        t = time.perf_counter()
+        for _ in range(50):
+            w2.update(xd2, ud2, rbd2, md2, cfg2["period"], np.full(1, cfg2["time"]))
+        wbc1 = (time.perf_counter() - t) / 50 * 1e3
+        witf.close(); e2.close()
+        out["single_instance_ms_gpu"] = {"mpc_ms_B1": mpc1, "mpc_ms_B1_warm": mpc1w, "wbc_ms_B1": wbc1, "workload": "BASELINE.json config 2 (trot, N = 100, one robot)",
+                                         "note": "mpc: one SQP iteration + device synchronisation (cold / warm-started), no host copies; wbc: qmhip_wbc_step on its own context incl. the host "
+                                                 "copies of its 116 input and 54 output doubles and the ctypes call (the C client of tests/c_abi_threads.c sees ~0.3 ms); counterparts of "
+                                                 "cpu_baseline.single_instance_ms"}
         out["latency_ms"] = {"B1_C2": lat1, "B%d_unpipelined" % B: lat_b, "note": "one control step with a device synchronisation after every step (no stream overlap between steps); "
                              "B1_C2 = BASELINE.json config 2 (single instance, trot, N = 100): %.0f Hz" % (1e3 / lat1), "C2_status_ok": r2["ok"]}
     return out
@@ -300,7 +352,10 @@ def cpu_baseline(cfg, gpu_out, B):
     tb = time.perf_counter()
     bad, _, _, w = pyoracle.batch_step(*ob, cores, cfg["t0"][:S], cfg["horizon"], cfg["x0"][:S], cfg["ref_t"][:S], cfg["ref_x"][:S], cfg["ev"][:S], cfg["modes"][:S], cfg["period"], cfg["time"])
     tcpu = time.perf_counter() - tb
-    err = float(np.abs(gpu_out[:S] - w).max() / np.abs(w).max())
+    # per-block relative errors (accelerations / contact forces / torques each on its own scale: one figure over the 54-vector would let 134 N of contact
+    # force hide a joint acceleration)
+    blocks = {"vdot": (slice(0, 24), 1e-2), "contact_forces": (slice(24, 36), 1.0), "torques": (slice(36, 54), 1e-1)}
+    errs = {k: float(np.abs(gpu_out[:S][:, sl] - w[:, sl]).max() / max(float(np.abs(w[:, sl]).max()), fl)) for k, (sl, fl) in blocks.items()}
     # single instance = BASELINE.json config 2 (trot, N = 100)
     o = pyoracle.Oracle(*ob); c2 = scenarios.make_config("C2")
     o.set_schedule(c2["ev"][0], c2["modes"][0]); o.set_target(c2["ref_t"][0], c2["ref_x"][0])
@@ -319,7 +374,8 @@ def cpu_baseline(cfg, gpu_out, B):
         t = time.perf_counter(); o.wbc(xd, ud, rbd, mode, 0.002, 20.0); best = min(best, (time.perf_counter() - t) * 1e3)
     single["wbc_ms_1thread"] = best
     return {"value": S / tcpu, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "first %d instances of the same batch, %d threads over instances (thread count = min(os.cpu_count(), 64)); max rel diff of GPU torques on the sample %.1e" % (S, cores, err),
+            "sample": "first %d instances of the same batch, %d threads over instances (thread count = min(os.cpu_count(), 64)); max rel diff GPU vs oracle on the sample per block: %s" % (S, cores, ", ".join("%s %.1e" % kv for kv in errs.items())),
+            "parity_on_sample": errs,
             "single_instance_ms": single,
             "note": "the oracle is a RESTATEMENT with forward-mode AD Jacobians (Dual<60>) and an O(n^4) Lagrangian mass matrix — much slower than the OCS2 / Pinocchio / HPIPM binary the "
                     "reference runs (SURVEY.md a11: ~5-10 ms per MPC iteration on 3 cores); it is a reported baseline, never a speed-up claim"}

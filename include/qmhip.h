@@ -171,7 +171,8 @@ int qmhip_wbc_download(qmhip_ctx* ctx, int B, double* out /*[B][54]*/, int32_t* 
  *        feet, then QMHWSim::readSim (QMHWSim.cpp:60-75): rbd[b] is the state in the estimator's layout (qm_estimation/src/StateEstimateBase.cpp:41-103),
  *        contact[b] the four contact flags (LF RF LH RH).  rbd / contact may be null (results stay resident).
  *      sim_reset: generalized coordinates q = [pos(3), zyx(3), joints(18)], v = [world linear velocity, zyx rates, joint rates], time per instance;
- *        clears the delay buffer ("Simulation reset", QMHWSim.cpp:101-103).
+ *        clears the delay buffer ("Simulation reset", QMHWSim.cpp:101-103).  A new episode starts cold: the MPC's previous primal solution is dropped, so until the next
+ *        solve qmhip_policy_eval / qmhip_mpc_download / qmhip_mpc_advance_resident return QMHIP_ERR_STATE and the next warm solve is a cold one.
  *      sim_set_params: {contact stiffness [N/m], contact damping [N s/m], friction coefficient, friction regularisation speed [m/s], foot radius [m],
  *        command delay [s], saturate efforts (0/1)}; Gazebo's ODE contact solver is not part of the reference's sources, the contact model is this library's own.
  *      sim_get_state: q, v, time, contact forces [B][12] (world frame) of the last sub-step, status [B] (0 ok, 1 mass matrix not positive definite); any may be null. */
@@ -179,7 +180,8 @@ int qmhip_sim_set_params(qmhip_ctx* ctx, const double* params, int n);
 /*      sim_set_controller: which controller plugin the closed loops below run — 0 qm::QMController (HierarchicalWbc; updateControlLaw QMController.cpp:177-190),
  *        1 qm::QMMpcController (HierarchicalMpcWbc, QMController.cpp:410-414; updateControlLaw QMController.cpp:431-445: legs commanded on every tick, the arm as
  *        position commands q_meas + velDes / 100 re-published when more than 1/100 s have passed — arm_kp / arm_kd of the loop calls are then the gains of the arm's
- *        position controllers and no arm torque is fed forward).  Takes effect at the next qmhip_sim_reset. */
+ *        position controllers and no arm torque is fed forward).  The control law switches with the next tick; the arm's held position command / publication
+ *        times (QMController::starting, QMController.cpp:127) are only re-initialised by qmhip_sim_reset, so switch before a reset. */
 int qmhip_sim_set_controller(qmhip_ctx* ctx, int controller);
 int qmhip_sim_reset(qmhip_ctx* ctx, int B, const double* q /*[B][24]*/, const double* v /*[B][24]*/, const double* time /*[B]*/);
 int qmhip_sim_set_command(qmhip_ctx* ctx, int B, const double* pos_des /*[B][18]*/, const double* vel_des, const double* kp, const double* kd, const double* ff);
@@ -210,7 +212,9 @@ int qmhip_synchronize(qmhip_ctx* ctx);
 int qmhip_last_ls_trials(const qmhip_ctx* ctx);
 /* debug/parity access to a device buffer by name (see QmMpcBuffers); copies `bytes` to host */
 int qmhip_debug_read(qmhip_ctx* ctx, const char* buffer, void* dst, size_t bytes);
-/* profiling-only switches (e.g. "riccati_skip" bit mask of kernel phases to skip; results are then meaningless) */
+/* profiling / parity switches: "riccati_skip" bit mask of kernel phases to skip (results are then meaningless; 20 = no backward stage and no rollout, i.e. the stage
+ * records stay as the LQ kernel wrote them), "wbc_stop", "lq_prof", "lq_debug" (1: the LQ kernel also writes the unprojected LQ model of every interval into the
+ * buffer "lqdbg" and the null-space basis into the stage record — tests/test_gpu_lq_records.py) */
 int qmhip_debug_set(qmhip_ctx* ctx, const char* key, int value);
 /* read such a switch back (bench.py asserts they are all 0 before it times anything) */
 int qmhip_debug_get(const qmhip_ctx* ctx, const char* key, int* value);

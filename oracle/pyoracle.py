@@ -245,8 +245,9 @@ def _wbc_tasks(self):
 Oracle.wbc_tasks = _wbc_tasks
 
 
-def batch_step(model_blob, settings_blob, nthreads, t0, horizon, x0, ref_t, ref_x, ev, modes, period, time):
-    """cpu_baseline driver: B instances of (MPC step + policy eval at t0 + WBC) over nthreads."""
+def batch_step(model_blob, settings_blob, nthreads, t0, horizon, x0, ref_t, ref_x, ev, modes, period, time, traj_nodes=0):
+    """cpu_baseline driver: B instances of (MPC step + policy eval at t0 + WBC) over nthreads.
+    traj_nodes > 0: a fifth return value dict(num_nodes[B], t, event, mode [B][traj_nodes], x, u [B][traj_nodes][30]) with every instance's whole primal solution."""
     build()
     lib = C.CDLL(_LIB)
     mb = np.ascontiguousarray(model_blob, float); st = np.ascontiguousarray(settings_blob, float)
@@ -256,5 +257,20 @@ def batch_step(model_blob, settings_blob, nthreads, t0, horizon, x0, ref_t, ref_
     B = x0.shape[0]; K = ref_t.shape[1]; nev = ev.shape[1]
     xf = np.zeros((B, 30)); uf = np.zeros((B, 30)); w = np.zeros((B, 54))
     bad = lib.qmo_batch_step(_p(mb), _p(st), C.c_int(B), C.c_int(nthreads), _p(t0), C.c_double(horizon), _p(x0), C.c_int(K), _p(ref_t), _p(ref_x),
-                             C.c_int(nev), _p(ev), _pi(modes), C.c_double(period), C.c_double(time), _p(xf), _p(uf), _p(w))
+                             C.c_int(nev), _p(ev), _pi(modes), C.c_double(period), C.c_double(time), _p(xf), _p(uf), _p(w), *_traj_args(B, traj_nodes))
+    if traj_nodes:
+        return bad, xf, uf, w, _traj_last
     return bad, xf, uf, w
+
+
+_traj_last = None
+
+
+def _traj_args(B, maxn):
+    global _traj_last
+    if not maxn:
+        _traj_last = None
+        return [C.c_int(0)] + [None] * 6
+    tr = dict(num_nodes=np.zeros(B, np.int32), t=np.zeros((B, maxn)), event=np.zeros((B, maxn), np.int32), mode=np.zeros((B, maxn), np.int32), x=np.zeros((B, maxn, 30)), u=np.zeros((B, maxn, 30)))
+    _traj_last = tr
+    return [C.c_int(maxn), _pi(tr["num_nodes"]), _p(tr["t"]), _pi(tr["event"]), _pi(tr["mode"]), _p(tr["x"]), _p(tr["u"])]

@@ -206,7 +206,9 @@ void qmo_rbd_from_q(void* h, const double* q, const double* v /*24 pinocchio, ma
 // inst arrays are per instance; schedule & target given per instance with fixed strides.
 int qmo_batch_step(const double* mb, const double* st, int B, int nthreads, const double* t0, double horizon, const double* x0 /*[B][30]*/,
                    int K, const double* ref_t /*[B][K]*/, const double* ref_x /*[B][K][37]*/, int nev, const double* ev /*[B][nev]*/, const int* modes /*[B][nev+1]*/,
-                   double period, double time, double* x_first /*[B][30]*/, double* u_first /*[B][30]*/, double* wbc_out /*[B][54]*/) {
+                   double period, double time, double* x_first /*[B][30]*/, double* u_first /*[B][30]*/, double* wbc_out /*[B][54]*/,
+                   int maxn, int* n_nodes /*[B]*/, double* node_t /*[B][maxn]*/, int* node_ev, int* node_mode, double* xs /*[B][maxn][30]*/, double* us /*[B][maxn][30]*/) {
+  // the trailing arrays (any may be null, maxn 0) receive each instance's whole primal solution: the full-size parity test compares trajectories, not only the policy at t0
   std::atomic<int> next(0), bad(0);
   auto work = [&]() {
     Oracle o; std::memcpy(o.M.mb, mb, sizeof(double) * MB_SIZE); std::memcpy(o.M.st, st, sizeof(double) * ST_SIZE);
@@ -218,6 +220,15 @@ int qmo_batch_step(const double* mb, const double* st, int B, int nthreads, cons
       Vec x0v(x0 + (size_t)b * QM_NX, x0 + (size_t)(b + 1) * QM_NX);
       o.R = SqpResult(); sqpIteration(o.P, t0[b], t0[b] + horizon, x0v, nullptr, nullptr, o.R);
       if (o.R.status != 0) { ++bad; continue; }
+      { const int n = (int)o.R.grid.size(); if (n_nodes) n_nodes[b] = n;
+        for (int i = 0; i < n && i < maxn; ++i) {
+          const size_t k = (size_t)b * maxn + i;
+          if (node_t) node_t[k] = o.R.grid[i].t;
+          if (node_ev) node_ev[k] = o.R.grid[i].ev;
+          if (node_mode) node_mode[k] = o.R.mode[i];
+          if (xs) std::memcpy(xs + k * QM_NX, o.R.x[i].data(), QM_NX * 8);
+          if (us) std::memcpy(us + k * QM_NU, o.R.u[i].data(), QM_NU * 8);
+        } }
       Vec xd, ud; int mode; evaluatePolicy(o.R, o.P.ms, t0[b], xd, ud, mode);
       double rbd[QM_NRBD]; qmo_rbd_from_q(&o, x0v.data() + 6, nullptr, rbd);
       o.W = WbcState(); Vec rb(rbd, rbd + QM_NRBD);

@@ -34,6 +34,7 @@ struct HipBackend {
   std::vector<Span> spans; std::vector<hipEvent_t> pool;
   std::map<std::string, std::pair<double, int>> acc;
   std::map<const void*, int> lds_set;
+  std::map<std::string, int> lds_pad;      // profiling only (occupancy sweep, tools/occupancy_sweep.py): extra dynamic LDS per workgroup of a kernel group -> fewer resident workgroups per CU
   hipEvent_t ev() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e = nullptr; check(hipEventCreate(&e), "hipEventCreate"); return e; }
   void check(hipError_t e, const char* what) { if (e != hipSuccess && error.empty()) error = std::string(what) + ": " + hipGetErrorString(e); }
   template <class K> const char* name_of(K k) {
@@ -44,6 +45,7 @@ struct HipBackend {
   }
   template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {
     if (grid <= 0) return;
+    if (!lds_pad.empty()) { auto it = lds_pad.find(name_of(kernel)); if (it != lds_pad.end()) lds += (size_t)it->second; }
     if (lds > 48 * 1024) {
       const void* p = (const void*)kernel; auto it = lds_set.find(p);
       if (it == lds_set.end() || it->second < (int)lds) { check(hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); lds_set[p] = (int)lds; }
@@ -99,6 +101,8 @@ struct qmhip_ctx {
                                   if (hipMalloc(&filler_out, (size_t)waves * 64 * 8) != hipSuccess) return false; filler_cap = waves; return true; }
   qmhip_ctx() : mpc(bk), wbc(bk), front(bk), sim(bk) {}
   void fail(const std::string& m) { error = m; }
+  // getModeSchedule on the device GaitSchedule -> the solver's schedule buffers; from here on its sticky status speaks for the schedule of this batch (until the host supplies one)
+  void gait_schedule(int B, double horizon) { front.gait_schedule(mpc.d, B, horizon); mpc.front_status = front.f.gs_status; mpc.front_B = B; }
   // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
   // them (an instance whose line search finds no step just keeps its iterate)
   int sqp_iterations() const { const int n = (int)qm_ms_param(st, ST_SQP_ITER); return n < 1 ? 1 : (n > 50 ? 50 : n); }      // ipm.ipmIteration with solver 2
@@ -205,6 +209,7 @@ int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, in
   if (!c) return QMHIP_ERR_ARG;
   if (B <= 0 || B > c->max_batch || n_ref != c->max_ref || n_ev != c->max_ev || !t0 || !x0 || !ref_t || !ref_x || !ev || !modes) { c->fail("qmhip_mpc_upload: bad argument (B <= max_batch, n_ref == max_ref_knots, n_events == max_events required)"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes); c->mpc.solved_B = 0; c->lastB = B; c->have_solution = false;
+  c->mpc.front_status = nullptr; c->mpc.front_B = 0;      // the schedule now comes from the host: a failed device GaitSchedule update no longer speaks for it (re-attached by the next qmhip_gait_update_resident)
  return c->hipstate();
 }
 int qmhip_mpc_solve_resident(qmhip_ctx* c, int B, double horizon) { QM_GUARD(c); QM_NEED_MPC(c);
@@ -221,7 +226,7 @@ int qmhip_mpc_update_references(qmhip_ctx* c, int B, int n_ref, const double* re
     c->fail("qmhip_mpc_update_references: bad argument (B == batch of the last upload, n_ref == max_ref_knots, n_events == max_events required; arrays come in pairs)"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device);
   if (ref_t) { c->bk.to_device(c->mpc.d.ref_t, ref_t, (size_t)B * n_ref * 8); c->bk.to_device(c->mpc.d.ref_x, ref_x, (size_t)B * n_ref * QM_NREF * 8); }
-  if (ev) { c->bk.to_device(c->mpc.d.ev, ev, (size_t)B * n_ev * 8); c->bk.to_device(c->mpc.d.modes, modes, (size_t)B * (n_ev + 1) * 4); }
+  if (ev) { c->bk.to_device(c->mpc.d.ev, ev, (size_t)B * n_ev * 8); c->bk.to_device(c->mpc.d.modes, modes, (size_t)B * (n_ev + 1) * 4); c->mpc.front_status = nullptr; c->mpc.front_B = 0; }
   return c->hipstate();
 }
 int qmhip_mpc_solve_resident_warm(qmhip_ctx* c, int B, double horizon) { QM_GUARD(c); QM_NEED_MPC(c);
@@ -238,7 +243,7 @@ int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, 
   hipSetDevice(c->device);
   for (int k = 0; k < n_steps; ++k) {
     if (k > 0) c->mpc.advance(B, mpc_dt);
-    if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon);     // device-resident GaitSchedule active: modifyReferences before every MPC call
+    if (c->front_B == B) c->gait_schedule(B, horizon);     // device-resident GaitSchedule active: modifyReferences before every MPC call
     c->mpc.grid(B, horizon, true); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true;
     c->bk.wbc_inputs_next(); c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time0 + k * mpc_dt);
     c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
@@ -263,7 +268,7 @@ int qmhip_gait_insert_template(qmhip_ctx* c, int B, const int32_t* template_id, 
 }
 int qmhip_gait_update_resident(qmhip_ctx* c, int B, double horizon) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B != c->front_B || !(horizon > 0)) { if (c) c->fail("qmhip_gait_update_resident: bad argument (B must be the batch of qmhip_gait_reset)"); return QMHIP_ERR_ARG; }
-  hipSetDevice(c->device); c->front.gait_schedule(c->mpc.d, B, horizon); return c->hipstate();
+  hipSetDevice(c->device); c->gait_schedule(B, horizon); return c->hipstate();
 }
 int qmhip_gait_download(qmhip_ctx* c, int B, int32_t* n_events, double* event_times, int32_t* mode_sequence, int32_t* template_id, int32_t* status) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B != c->front_B || !n_events || !event_times || !mode_sequence || !template_id || !status) return QMHIP_ERR_ARG;
@@ -419,7 +424,7 @@ int qmhip_closed_loop_sim(qmhip_ctx* c, int B, int n_ticks, double period, int n
   if (!c->sim.s.Bmax) { c->fail("qmhip_closed_loop_sim: qmhip_sim_reset has not been called"); return QMHIP_ERR_STATE; }
   hipSetDevice(c->device); c->bk.sync();
   qm_closed_loop_sim_ticks(c->bk, c->mpc, c->wbc, c->sim, c->sim_ticks, B, n_ticks, period, n_substeps, mpc_every, horizon, arm_kp, arm_kd, c->sqp_iterations(),
-                           [&]() { if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon); });
+                           [&]() { if (c->front_B == B) c->gait_schedule(B, horizon); });
   c->lastB = B; c->have_solution = true;
   return c->hipstate();
 }
@@ -430,7 +435,7 @@ int qmhip_closed_loop_sim_pipelined(qmhip_ctx* c, int B, int n_ticks, double per
   if (n_ticks % mpc_every || c->sim_ticks % mpc_every) { c->fail("qmhip_closed_loop_sim_pipelined: n_ticks and the tick counter must be multiples of mpc_every"); return QMHIP_ERR_ARG; }
   hipSetDevice(c->device); c->bk.sync();
   qm_closed_loop_sim_pipelined(c->bk, c->mpc, c->wbc, c->sim, c->sim_ticks, B, n_ticks, period, n_substeps, mpc_every, horizon, arm_kp, arm_kd, c->sqp_iterations(),
-                               [&]() { if (c->front_B == B) c->front.gait_schedule(c->mpc.d, B, horizon); });
+                               [&]() { if (c->front_B == B) c->gait_schedule(B, horizon); });
   c->lastB = B; c->have_solution = true; c->bk.sync();
   return c->hipstate();
 }
@@ -443,35 +448,44 @@ int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launche
 int qmhip_reset_kernel_ms(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.acc.clear(); return QMHIP_OK; }
 int qmhip_synchronize(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
 int qmhip_last_ls_trials(const qmhip_ctx* c) { QM_GUARD(c); return c ? c->mpc.ls_trials_run : -1; }
-int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { QM_GUARD(c); if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; } return QMHIP_ERR_ARG; }
-// profiling only: `waves` filler waves of `iters` steps on the second stream (see qm_filler_kernel); *ms (may be null) = its duration when waited for
+int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { QM_GUARD(c); if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; }
+  if (!strncmp(key, "lds_pad:", 8)) {   // profiling only: "lds_pad:<kernel group>" (lq, lq_kin, riccati, ls_eval, wbc, ...) = extra dynamic LDS bytes per workgroup; 0 removes it
+    if (value < 0 || value > 160 * 1024) return QMHIP_ERR_ARG; if (value) c->bk.lds_pad[key + 8] = value; else c->bk.lds_pad.erase(key + 8); return QMHIP_OK; }
+  if (!strcmp(key, "lq_debug")) {      // parity tests: K1b additionally writes the UNPROJECTED LQ model of every interval (buffer "lqdbg", [B][max_nodes][LQ_DBG_SIZE]) and Pu / the zero rows of Px into the stage record
+    QM_NEED_MPC(c); hipSetDevice(c->device); c->bk.sync();
+    if (value && !c->mpc.d.lqdbg) c->mpc.d.lqdbg = c->mpc.A<double>((size_t)c->max_nodes * c->max_batch * LQ_DBG_SIZE);
+    if (!value && c->mpc.d.lqdbg) { c->bk.free(c->mpc.d.lqdbg); c->mpc.d.lqdbg = nullptr; }
+    c->bk.sync(); return c->hipstate();
+  }
+  return QMHIP_ERR_ARG; }
 // profiling only: one MPC iteration of the resident batch with the filler started on the second stream right when the LQ kernel starts; ms[0] = LQ kernel,
-// ms[1] = filler, ms[2] = both (first start to last end), all from HIP events
+// ms[1] = filler, ms[2] = Riccati kernel, all from HIP events
 int qmhip_debug_lq_with_filler(qmhip_ctx* c, int B, double horizon, int waves, int iters, double* ms) { QM_GUARD(c); QM_NEED_MPC(c);
   if (!c || B <= 0 || B > c->max_batch || !ms) return QMHIP_ERR_ARG; hipSetDevice(c->device);
   if (waves > 0 && !c->filler_buffer(waves)) { c->fail("hipMalloc of the filler buffer failed"); return QMHIP_ERR_HIP; }
   double* out = c->filler_out;
-  hipEvent_t a0, a1, b0, b1; hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
+  hipEvent_t a0 = nullptr, b0 = nullptr, b1 = nullptr;
+  if (hipEventCreate(&a0) != hipSuccess || hipEventCreate(&b0) != hipSuccess || hipEventCreate(&b1) != hipSuccess) { c->fail("hipEventCreate failed"); return QMHIP_ERR_HIP; }
   c->bk.sync();
+  bool fired = false;      // the hook runs once per sqp iteration; the filler is started by the first call only
   c->mpc.before_lq = [&]() {
+    if (fired) return; fired = true;
     hipEventRecord(a0, c->bk.stream); hipStreamWaitEvent(c->bk.stream_b, a0, 0);      // the filler starts when everything before the LQ kernel is done
     hipEventRecord(b0, c->bk.stream_b);
     if (waves > 0) hipLaunchKernelGGL(qm_filler_kernel, dim3(waves), dim3(64), 20 * 1024, c->bk.stream_b, out, iters);
     hipEventRecord(b1, c->bk.stream_b);
-    c->mpc.before_lq = [&]() {};                                                       // (re-armed below: the hook fires once per sqp iteration)
   };
-  auto lq_done = [&]() {};
   c->mpc.grid(B, horizon);
-  // one iteration; a1 is recorded by wrapping: the Riccati launch follows the LQ launch on the same stream, so record right after sqp_iteration's LQ launch is not
-  // reachable from here — use kernel spans instead
+  // one iteration with a span around every launch: the LQ and Riccati kernel times come from those spans
   const int prof = c->bk.profiling; c->bk.resolve(); c->bk.acc.clear(); c->bk.profiling = 1;
   c->mpc.sqp_iteration(B, 14, true);
   c->bk.sync(); c->bk.resolve(); c->bk.profiling = prof; c->mpc.before_lq = nullptr;
   float fb = 0; hipEventElapsedTime(&fb, b0, b1);
   ms[0] = c->bk.acc["lq"].first; ms[1] = fb; ms[2] = c->bk.acc["riccati"].first;
-  hipEventDestroy(a0); hipEventDestroy(a1); hipEventDestroy(b0); hipEventDestroy(b1); (void)lq_done;
+  hipEventDestroy(a0); hipEventDestroy(b0); hipEventDestroy(b1);
   return c->hipstate();
 }
+// profiling only: `waves` filler waves of `iters` steps on the second stream (see qm_filler_kernel); *ms (may be null) = its duration when waited for
 int qmhip_debug_filler(qmhip_ctx* c, int waves, int iters, int wait, double* ms) { QM_GUARD(c);
   if (!c || waves <= 0 || iters <= 0) return QMHIP_ERR_ARG; hipSetDevice(c->device);
   if (!c->filler_buffer(waves)) { c->fail("hipMalloc of the filler buffer failed"); return QMHIP_ERR_HIP; }
@@ -487,6 +501,8 @@ int qmhip_debug_filler(qmhip_ctx* c, int waves, int iters, int wait, double* ms)
 int qmhip_debug_get(const qmhip_ctx* c, const char* key, int* value) { QM_GUARD(c);
   if (!c || !key || !value) return QMHIP_ERR_ARG;
   if (!strcmp(key, "riccati_skip")) { *value = c->mpc.riccati_skip; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { *value = c->wbc.wbc_stop; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { *value = c->mpc.lq_prof; return QMHIP_OK; }
+  if (!strcmp(key, "lq_debug")) { *value = c->mpc.d.lqdbg ? 1 : 0; return QMHIP_OK; }
+  if (!strcmp(key, "lds_pad")) { *value = (int)c->bk.lds_pad.size(); return QMHIP_OK; }      // number of kernel groups running with padded LDS
   return QMHIP_ERR_ARG;
 }
 int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) { QM_GUARD(c);
@@ -494,7 +510,7 @@ int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) { 
 #define F(n) if (!strcmp(name, #n)) p = d.n;
   if (c->wbc_only) { p = c->wbc.buffer(name); if (!p) { c->fail("qmhip_debug_read: a WBC-only context only has the wbc_* buffers"); return QMHIP_ERR_ARG; } c->bk.to_host(dst, p, bytes); return c->hipstate(); }
   if (!strcmp(name, "sim_rbd")) p = c->sim.s.rbd; if (!strcmp(name, "sim_cmd")) p = c->sim.s.cmd;
-  F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
+  F(lqdbg) F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
 #undef F
   if (!p) p = c->wbc.buffer(name);
   if (!p) { c->fail(std::string("qmhip_debug_read: unknown buffer ") + name); return QMHIP_ERR_ARG; }

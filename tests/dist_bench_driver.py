@@ -56,7 +56,7 @@ def main():
     orig_close = EmuEngine.close
 
     def close_and_gather(self):
-        pad = np.zeros((args.batch, 54)); pad[:self.B] = self.out
+        pad = np.zeros((self.B, 54)); pad[:self.B] = self.out      # equal shards in both modes (--batch per rank / --global-batch over the ranks)
         holder["all_out"] = sharding.gather_rows(pad, dist if dist.is_initialized() else None, "cpu")
         orig_close(self)
     EmuEngine.close = close_and_gather

@@ -30,6 +30,7 @@ void* emu_create(const double* mb, const double* st, int Bmax, int nmax, int nre
   EmuCtx* c = new EmuCtx(); c->mpc.allocate(mb, st, Bmax, nmax, nref, nev, true); c->wbc.allocate(Bmax, true); c->front.allocate(Bmax); c->front.phase_transition_stance_time = st[ST_PHASE_TRANS_STANCE]; return c;
 }
 void emu_set_solver(void* h, int solver) { ((EmuCtx*)h)->mpc.solver = solver; }      // 0 SQP, 1 discrete iLQR (qmhip_set_setting(ST_SOLVER, .))
+void emu_set_riccati_skip(void* h, int mask) { ((EmuCtx*)h)->mpc.riccati_skip = mask; }      // qmhip_debug_set("riccati_skip", .): 20 leaves K1b's stage records untouched
 void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); delete c; }
 int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes, double horizon, int max_trials) {
   EmuCtx* c = (EmuCtx*)h;

@@ -54,6 +54,10 @@ class Emu:
     def set_solver(self, solver):
         self.lib.emu_set_solver(self.h, C.c_int(solver))
 
+    def set_riccati_skip(self, mask):
+        """profiling / parity switch of the product (qmhip_debug_set "riccati_skip"): 16 | 4 = no backward stage, no rollout -> the stage records stay as K1b wrote them"""
+        self.lib.emu_set_riccati_skip(self.h, C.c_int(mask))
+
     def grid_only(self, cfg, batch=None):
         """upload + K0 (time discretisation, modes, references, initial guess) without the SQP iteration"""
         B = cfg["B"] if batch is None else batch

@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 from conftest import ROOT, assert_blocks
 
 
@@ -21,18 +22,20 @@ def test_shard_bounds():
     assert [sharding.shard_bounds(r, 8, 8192) for r in (0, 7)] == [(0, 1024), (7168, 8192)]
 
 
-def test_bench_code_path_two_ranks_over_gloo(oracle):
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_code_path_two_ranks_over_gloo(oracle, mode):
+    """weak: --batch B per rank (the default headline); strong: --global-batch 2 B cut into two contiguous shards — the same instances either way"""
     import emu_harness
     emu_harness.build()                                                    # once, before two ranks race for the build
     B, N, K, W = 2, 8, 2, 1
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "tests", "dist_bench_driver.py"), "--gpus", "2", "--steps", str(K), "--warmup", str(W), "--batch", str(B), "--n-intervals", str(N), "--no-cpu-baseline", "--no-secondary"]
+           os.path.join(ROOT, "tests", "dist_bench_driver.py"), "--gpus", "2", "--steps", str(K), "--warmup", str(W)] + (["--batch", str(B)] if mode == "weak" else ["--global-batch", str(2 * B)]) + ["--n-intervals", str(N), "--no-cpu-baseline", "--no-secondary"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     payload = [l for l in p.stdout.splitlines() if l.startswith("BENCH_LINE ")]
     assert len(payload) == 1, p.stdout[-2000:]                             # ONE line, from rank 0
     d = json.loads(payload[0][len("BENCH_LINE "):]); line = d["line"]; allw = np.array(d["all_out"])
-    assert line["n_gpus"] == 2 and line["steps"] == K and line["warmup"] == W and line["scaling"] == "weak" and line["config"]["engine"] == "emu"
+    assert line["n_gpus"] == 2 and line["steps"] == K and line["warmup"] == W and line["scaling"] == mode and line["config"]["engine"] == "emu" and line["config"]["global_batch"] == 2 * B
     assert line["config"]["all_status_ok"] and line["config"]["instances_per_gpu"] == B and line["config"]["parallelism"] == "shard2"
     secs = line["per_rank"]["seconds"]
     assert len(secs) == 2 and len(line["per_rank"]["intervals_per_launch"]) == 2

@@ -161,3 +161,24 @@ def test_ipm_slot_runs_the_multiple_shooting_step_on_the_ipm_block(blobs, oblobs
         out[(solver, dt)] = (n, r["alpha"], r["ls_trials"])
     assert blobs[1][L.ST_IPM_G_MAX] == 10.0 and blobs[1][L.ST_G_MAX] == 1e-2 and blobs[1][L.ST_IPM_DT] == blobs[1][L.ST_SQP_DT]
     assert out[(2, 0.02)][0] < out[(2, None)][0] == out[(0, None)][0]                 # a coarser ipm.dt gives a shorter grid; equal dt, equal grid
+
+
+@pytest.mark.parametrize("name,N", [("C2", 26), ("C5", 60)])
+@pytest.mark.parametrize("skip", [20, 0])
+def test_lq_records_entrywise(blobs, oracle, name, N, skip):
+    """what K1a / K1b leave in HBM, entry by entry — unprojected A_d, B_d, b, Q, R, q, r, C, D, e and the projected stage record
+    (Ap, Bp, bp, Qp, Pp, Rp, qp, rp, Px, Pe, range of Pu) — and, after K3 (skip = 0), the gains K, k it writes into the record; <= 1e-10 per block"""
+    import emu_harness, lq_record_check as LC
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config(name, batch=1, n_intervals=N)
+    r = _oracle(oracle, cfg); n = len(r["t"])
+    e = emu_harness.Emu(blobs[0], blobs[1], 1, n + 3, 2, cfg["ev"].shape[1]); e.set_riccati_skip(skip)
+    e.mpc_step(cfg)
+    worst = {}
+    for i in range(n - 1):
+        if r["ev"][i] == 1:
+            continue
+        for k, v in LC.check_interval(e.stage(0, i), e.lqdbg(0, i), oracle.node_lq(i), oracle.node_proj(i), after_riccati=(skip == 0)).items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    bad = {k: v for k, v in worst.items() if not v <= 1e-10}
+    assert not bad, (bad, worst)

@@ -78,12 +78,20 @@ def test_instances_are_independent(full_run, blobs):
 
 
 def test_sample_matches_oracle(full_run, blobs):
+    """64 seeded instances of the full batch against the oracle (64 threads over instances): the WHOLE optimal state / input trajectories (N = 100), node times and
+    integer schedules, the policy at t0 and the WBC output — per block, 1e-6"""
+    import os
     import pyoracle
-    r = full_run; cfg = r["cfg"]
-    idx = np.array([0, 17, 255, 256, 511, 640, 901, 1023])
-    bad, xf, uf, w = pyoracle.batch_step(*pyoracle.load_blobs(), 8, cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx],
-                                         cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"])
+    r = full_run; cfg = r["cfg"]; res = r["res"]
+    idx = np.sort(np.random.default_rng(20260926).choice(1024, 64, replace=False)); idx[0] = 0; idx[-1] = 1023
+    nm = res["x"].shape[1]
+    bad, xf, uf, w, tr = pyoracle.batch_step(*pyoracle.load_blobs(), min(64, os.cpu_count() or 1), cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx],
+                                             cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"], traj_nodes=nm)
     assert bad == 0
     assert_blocks(r["xd"][idx], xf, "x", TOL, "policy x"); assert_blocks(r["ud"][idx], uf, "u", TOL, "policy u")
     for j, b in enumerate(idx):
+        n = int(tr["num_nodes"][j])
+        assert n == int(res["num_nodes"][b]), b
+        assert np.array_equal(res["t"][b, :n], tr["t"][j, :n]) and np.array_equal(res["event"][b, :n], tr["event"][j, :n]) and np.array_equal(res["mode"][b, :n], tr["mode"][j, :n]), b
+        assert_blocks(res["x"][b, :n], tr["x"][j, :n], "x", TOL, "x* of instance %d" % b); assert_blocks(res["u"][b, :n], tr["u"][j, :n], "u", TOL, "u* of instance %d" % b)
         assert_blocks(r["out"][b], w[j], "wbc", TOL, b)
