@@ -65,7 +65,11 @@ class Oracle:
         ms = np.zeros(3); self.lib.qmo_phase_ms(self.h, _p(ms)); return ms
 
     def set_setting(self, idx, v):
+        """one settings slot of this oracle (the device side's qmhip_set_setting), e.g. ST_GRID_DT_MIN for the fixed-rate loops; returns the previous value"""
+        self.lib.qmo_get_setting.restype = C.c_double
+        old = self.lib.qmo_get_setting(self.h, C.c_int(idx))
         self.lib.qmo_set_setting(self.h, C.c_int(idx), C.c_double(v))
+        return old
 
     # ---- probes ----
     def flow_map(self, x, u, jac=False):

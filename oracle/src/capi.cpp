@@ -40,6 +40,7 @@ void qmo_frame_pose(void* h, const double* q, int f, double* pos, double* Rm) {
 }
 void qmo_mat_to_quat(const double* Rm, double* q) { M3<double> R; for (int i = 0; i < 9; ++i) R.m[i] = Rm[i]; matToQuat<double>(R, q); }
 
+double qmo_get_setting(void* h, int idx) { return (idx < 0 || idx >= ST_SIZE) ? 0.0 : ((Oracle*)h)->M.st[idx]; }
 int qmo_time_grid(double t0, double tf, double dt, int nev, const double* ev, int maxn, double* out_t, int* out_ev, double dt_min) {
   Vec e(ev, ev + nev); auto g = timeDiscretizationWithEvents(t0, tf, dt, e, dt_min);
   if ((int)g.size() > maxn) return -(int)g.size();
@@ -127,6 +128,7 @@ int qmo_mpc_step_warm(void* h, double t0, double tf, const double* x0, int maxn,
   Oracle* o = (Oracle*)h; Vec x0v(x0, x0 + QM_NX);
   SqpResult prev = o->R; o->R = SqpResult();
   try { sqpIteration(o->P, t0, tf, x0v, nullptr, nullptr, o->R, &prev); } catch (const std::exception&) { return -2; }
+  if (o->R.status != 0) return o->R.status;      // e.g. -4: Riccati recursion not positive definite (a failed solve has no trajectories to copy)
   const SqpResult& R = o->R; const int n = (int)R.grid.size(); if (n > maxn) return -1;
   *n_nodes = n;
   for (int i = 0; i < n; ++i) { node_t[i] = R.grid[i].t; node_ev[i] = R.grid[i].ev; node_mode[i] = R.mode[i]; std::memcpy(xs + QM_NX * i, R.x[i].data(), QM_NX * 8); std::memcpy(us + QM_NU * i, R.u[i].data(), QM_NU * 8); }

@@ -22,7 +22,7 @@ static double in_x[NIN][QM_NX], in_u[NIN][QM_NU], in_rbd[NIN][QM_NRBD]; static i
 static double x0[QM_NX], horizon, t_first;
 static volatile int stop_mpc = 0;
 
-typedef struct { qmhip_ctx* ctx; int n_ticks; double* out; int32_t* qps; double lat_max, lat_sum; int err, late; } tick_job;
+typedef struct { qmhip_ctx* ctx; int n_ticks; double* out; int32_t* qps; double* lat; double lat_max, lat_sum; int err, late, max_at; } tick_job;
 typedef struct { qmhip_ctx* ctx; int solves, bad_status, err; double ms_sum, ms_max; } mpc_job;
 
 /* the control thread: n_ticks WBC updates on a 2 ms raster */
@@ -35,7 +35,7 @@ static void* tick_thread(void* p) {
     const int rc = qmhip_wbc_step(j->ctx, 1, in_x[k], in_u[k], in_rbd[k], &in_mode[k], 0.002, &time, 0, j->out + (size_t)i * QM_NWBC_OUT, j->qps + 3 * (size_t)i);
     const double ms = 1e3 * (now_s() - a);
     if (rc != QMHIP_OK) { if (!j->err) fprintf(stderr, "qmhip_wbc_step failed (%d): %s\n", rc, qmhip_last_error(j->ctx)); j->err++; }
-    j->lat_sum += ms; if (ms > j->lat_max) j->lat_max = ms;
+    j->lat[i] = ms; j->lat_sum += ms; if (ms > j->lat_max) { j->lat_max = ms; j->max_at = i; }
   }
   return NULL;
 }
@@ -58,9 +58,11 @@ static void* mpc_thread(void* p) {
   return NULL;
 }
 
+static int cmp_double(const void* a, const void* b) { const double x = *(const double*)a, y = *(const double*)b; return (x > y) - (x < y); }
+
 static int run_phase(const char* name, qmhip_ctx* mpc_ctx, qmhip_ctx* tick_ctx, int n_ticks, const double* ref_out, double* out, int32_t* qps) {
   pthread_t ta, tb; tick_job tj; mpc_job mj; memset(&tj, 0, sizeof(tj)); memset(&mj, 0, sizeof(mj));
-  tj.ctx = tick_ctx; tj.n_ticks = n_ticks; tj.out = out; tj.qps = qps; mj.ctx = mpc_ctx;
+  tj.ctx = tick_ctx; tj.n_ticks = n_ticks; tj.out = out; tj.qps = qps; mj.ctx = mpc_ctx; tj.lat = (double*)calloc((size_t)n_ticks, sizeof(double));
   if (qmhip_wbc_reset(tick_ctx) != QMHIP_OK) { fprintf(stderr, "qmhip_wbc_reset: %s\n", qmhip_last_error(tick_ctx)); return 1; }
   stop_mpc = 0;
   if (mpc_ctx) pthread_create(&ta, NULL, mpc_thread, &mj);
@@ -69,8 +71,10 @@ static int run_phase(const char* name, qmhip_ctx* mpc_ctx, qmhip_ctx* tick_ctx, 
   int mismatches = 0, bad_qp = 0;
   if (ref_out) for (int i = 0; i < n_ticks; ++i) if (memcmp(ref_out + (size_t)i * QM_NWBC_OUT, out + (size_t)i * QM_NWBC_OUT, QM_NWBC_OUT * sizeof(double))) mismatches++;
   for (int i = 0; i < 3 * n_ticks; ++i) if (qps[i] != 0) bad_qp++;
-  printf("%s: ticks %d mismatches %d bad_qp %d late_ticks %d wbc_ms_mean %.4f wbc_ms_max %.4f tick_errors %d mpc_solves %d mpc_ms_mean %.4f mpc_ms_max %.4f mpc_bad_status %d mpc_errors %d\n",
-         name, n_ticks, mismatches, bad_qp, tj.late, tj.lat_sum / n_ticks, tj.lat_max, tj.err, mj.solves, mj.solves ? mj.ms_sum / mj.solves : 0.0, mj.ms_max, mj.bad_status, mj.err);
+  int over_half = 0, over_one = 0; for (int i = 0; i < n_ticks; ++i) { over_half += tj.lat[i] > 0.5; over_one += tj.lat[i] > 1.0; }
+  qsort(tj.lat, (size_t)n_ticks, sizeof(double), cmp_double); const double p99 = tj.lat[(int)(0.99 * (n_ticks - 1))], p999 = tj.lat[(int)(0.999 * (n_ticks - 1))]; free(tj.lat);
+  printf("%s: ticks %d mismatches %d bad_qp %d late_ticks %d wbc_ms_mean %.4f wbc_ms_p99 %.4f wbc_ms_p999 %.4f wbc_ms_max %.4f max_at_tick %d ticks_over_0.5ms %d ticks_over_1ms %d tick_errors %d mpc_solves %d mpc_ms_mean %.4f mpc_ms_max %.4f mpc_bad_status %d mpc_errors %d\n",
+         name, n_ticks, mismatches, bad_qp, tj.late, tj.lat_sum / n_ticks, p99, p999, tj.lat_max, tj.max_at, over_half, over_one, tj.err, mj.solves, mj.solves ? mj.ms_sum / mj.solves : 0.0, mj.ms_max, mj.bad_status, mj.err);
   return (mismatches || tj.err || mj.err || mj.bad_status || (mpc_ctx && mj.solves < 10)) ? 1 : 0;
 }
 

@@ -72,7 +72,7 @@ def test_closed_loop_around_the_plant_vs_oracle(blobs, oracle, gait):
     B = 2; horizon = 0.6; c = setup(gait, B, horizon, t_start=20.0 if gait == "stance" else 20.3)   # trot: the first gait event falls inside the horizon
     q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
     itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)
     mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset()
     t_start = float(c["t0"][0]); sim.reset(np.tile(q0, (B, 1)), np.zeros((B, 24)), t_start)
     n_ticks = 24; dev = []
@@ -102,7 +102,7 @@ def test_mpc_controller_loop_vs_oracle(blobs, oracle):
     B = 2; horizon = 0.6; t_start = 5.3; c = setup("trot", B, horizon, t_start=t_start)
     q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
     itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)
     sim.set_controller(1)
     mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset()
     sim.reset(np.tile(q0, (B, 1)), np.zeros((B, 24)), t_start)
@@ -138,7 +138,7 @@ def test_plant_and_closed_loop_match_the_goldens(blobs):
     g = np.load(os.path.join(ROOT, "tests", "golden", "sim_closed_loop_trot_T20.npz")); horizon = float(g["horizon"]); t_start = float(g["t_start"])
     c = setup("trot", 1, horizon, t_start=t_start)
     itf = api.QMInterface(blobs=blobs, max_batch=1, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)
     mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset(); sim.reset(g["q0"][None], np.zeros((1, 24)), t_start)
     for k in range(20):
         sim.closed_loop(1, 0.001, horizon, n_substeps=2, mpc_every=int(g["mpc_every"])); s = sim.state(); out, st3 = wbc.download(1)
@@ -199,7 +199,7 @@ def test_pipelined_loop_vs_oracle(blobs, oracle):
     mb, st = blobs
     B = 2; horizon = 0.6; c = setup("trot", B, horizon, t_start=20.3); q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
     itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=c["ev"].shape[1])
-    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf)
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf); sim = api.QMHWSim(itf, robust_grid=True)
     mpc.set_problem(c["t0"], c["x0"], c["ref_t"], c["ref_x"], c["ev"], c["modes"]); wbc.reset(); sim.reset(np.tile(q0, (B, 1)), np.zeros((B, 24)), 20.3)
     dev = []
     for p in range(4):

@@ -108,7 +108,25 @@ def centroidal_from_rbd(mb, rbd):
     return x
 
 
-def oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0, pipelined=False, controller=0):
+def robust_grid_settings(st):
+    """settings blob of a fixed-rate loop: the time grid's robust minimum step (what api.QMHWSim(robust_grid=True) sets on a device context)"""
+    from qm_control_amd import layout as L
+    st = np.array(st, float); st[L.ST_GRID_DT_MIN] = L.QM_GRID_DT_MIN_ROBUST
+    return st
+
+
+def oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0, pipelined=False, controller=0, robust_grid=True):
+    """robust_grid: the loop's observation times (time0 + k ms) share a raster with the gait events, so a grid node can land within weakEpsilon of an event; like the
+    device loops (api.QMHWSim(robust_grid=True)) the oracle then runs with ST_GRID_DT_MIN = QM_GRID_DT_MIN_ROBUST for the duration of the loop"""
+    from qm_control_amd import layout as L
+    old = oracle.set_setting(L.ST_GRID_DT_MIN, L.QM_GRID_DT_MIN_ROBUST if robust_grid else L.QM_GRID_DT_MIN_UPSTREAM)
+    try:
+        return _oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0, pipelined, controller)
+    finally:
+        oracle.set_setting(L.ST_GRID_DT_MIN, old)
+
+
+def _oracle_closed_loop(oracle, mb, cfg, q0, n_ticks, period, nsub, mpc_every, horizon, arm_kp, arm_kd, time0, pipelined=False, controller=0):
     """QMController::update around the oracle's plant, same order of operations as qmhip_closed_loop_sim; pipelined: as qmhip_closed_loop_sim_pipelined — the MPC
     triggered at a tick observes the plant there, its solution is used from the next MPC period on (the first one is synchronous)"""
     oracle.set_schedule(cfg["ev"][0], cfg["modes"][0]); oracle.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
@@ -165,7 +183,7 @@ def test_emulated_closed_loop_around_the_plant_vs_oracle(blobs, oracle):
     mb, st = blobs
     horizon = 0.45; c = setup("trot", 1, horizon, t_start=20.2)
     q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
-    e = emu_harness.Emu(mb, st, 1, 64, 2, c["ev"].shape[1])
+    e = emu_harness.Emu(mb, robust_grid_settings(st), 1, 64, 2, c["ev"].shape[1])
     c["horizon"] = horizon; c["B"] = 1; e.grid_only(c, batch=1)   # uploads reference and schedule
     e.lib.emu_wbc_reset(e.h); e.sim_params(); e.sim_reset(q0[None], np.zeros((1, 24)), 20.2); e.sim_command(0, 0, 0, 0, 0)
     n_ticks = 10; dev = []
@@ -188,7 +206,7 @@ def test_emulated_mpc_controller_loop_vs_oracle(blobs, oracle):
     mb, st = blobs
     horizon = 0.45; t_start = 5.2; c = setup("trot", 1, horizon, t_start=t_start)
     q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
-    e = emu_harness.Emu(mb, st, 1, 64, 2, c["ev"].shape[1])
+    e = emu_harness.Emu(mb, robust_grid_settings(st), 1, 64, 2, c["ev"].shape[1])
     c["horizon"] = horizon; c["B"] = 1; e.grid_only(c, batch=1)
     e.sim_set_controller(1)
     e.lib.emu_wbc_reset(e.h); e.sim_params(); e.sim_reset(q0[None], np.zeros((1, 24)), t_start); e.sim_command(0, 0, 0, 0, 0)
@@ -235,7 +253,7 @@ def test_emulated_pipelined_loop_vs_oracle(blobs, oracle):
     mb, st = blobs
     horizon = 0.45; c = setup("trot", 1, horizon, t_start=20.2); c["horizon"] = horizon; c["B"] = 1
     q0 = c["xbar"][6:30].copy(); q0[2] = 0.385
-    e = emu_harness.Emu(mb, st, 1, 64, 2, c["ev"].shape[1]); e.grid_only(c, batch=1)
+    e = emu_harness.Emu(mb, robust_grid_settings(st), 1, 64, 2, c["ev"].shape[1]); e.grid_only(c, batch=1)
     e.lib.emu_wbc_reset(e.h); e.sim_params(); e.sim_reset(q0[None], np.zeros((1, 24)), 20.2); e.sim_command(0, 0, 0, 0, 0)
     dev = []
     for p in range(3):
