@@ -135,11 +135,13 @@ struct QmMpcPipeline {
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof; q.ncap = ncap;
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, LQ_KIN_LDS_BYTES, q);
     if (before_lq) before_lq();
-    bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node; an empty workgroup costs the dispatcher as much as a full one
+    if (d.lqdbg || lq_prof) bk.launch(qm_lq_dbg_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // the instance with debug records / phase cycle stamps (parity tests, profiling)
+    else bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node; an empty workgroup costs the dispatcher as much as a full one
     QmLsArgs l = ls_args(B); if (ilqr) { l.xt = d.xt; l.ut = d.ut; l.ilqr = 1; }
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
     r.perf = d.perf; r.base_sum = d.base_sum; r.alpha = d.alpha; r.done = d.done; r.out_perf = d.out_perf; r.open_cnt = d.open_cnt; r.tickets = d.tickets;   // baseline merit + arming of the line search
-    bk.launch(qm_riccati_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // one wavefront per instance
+    if (riccati_skip) bk.launch(qm_riccati_prof_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // instrumented instance: phase skip bits, in-kernel cycle counters (profiling / parity tests only)
+    else bk.launch(qm_riccati_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // one wavefront per instance
     ls_trials_run = 0;
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;

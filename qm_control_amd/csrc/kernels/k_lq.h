@@ -258,7 +258,10 @@ __global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
 }
 
 // ---- K1b: one wavefront per node ----
-__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
+// DBG: the instance that also writes the debug records (a.dbg) and the phase cycle stamps (a.prof) — parity tests and profiling; the product instance has neither branch
+template <bool DBG>
+__device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
+  if (!DBG) { a.dbg = nullptr; a.prof = 0; }
   extern __shared__ double qm_smem[];
   double* S = qm_smem;
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
@@ -266,7 +269,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   const int nb = i * a.B + b;                       // node-major index
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   double* rec = a.stage + ((size_t)b * a.nmax + i) * SR_SIZE;
-  double* dbg = a.dbg ? a.dbg + ((size_t)b * a.nmax + i) * LQ_DBG_SIZE : nullptr;
+  double* dbg = (DBG && a.dbg) ? a.dbg + ((size_t)b * a.nmax + i) * LQ_DBG_SIZE : nullptr;
   const double* kr = a.kin + (size_t)nb * KR_SIZE;
   // every input address depends on (b, i) only: issue all loads before looking at the node's status (one memory round trip)
   const int nn = a.n_nodes[b]; const int ev = a.node_ev[nb];
@@ -287,7 +290,9 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
     return;
   }
   long long tp_[10]; int np_ = 0;
-#define LQT() { if (a.prof) tp_[np_] = (long long)__builtin_readcyclecounter(); ++np_; }
+// phase boundary: a scheduling barrier in every instance (without one the scheduler merges the phases of the product instance into one region, lengthens the
+// fragments' live ranges and spills 100 bytes per lane), a cycle stamp in the instrumented one
+#define LQT() { __builtin_amdgcn_sched_barrier(0); if (DBG && a.prof) tp_[np_] = (long long)__builtin_readcyclecounter(); ++np_; }
   LQT()
   // ---- P0: inputs and the kin record -> LDS ----
   double* T = S + LW_T; double* X = S + LW_V_X; double* U = S + LW_V_U; double* K1 = S + LW_K1; double* K2 = S + LW_K2; double* EE = S + LW_V_EE;
@@ -363,7 +368,13 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   const double bl = (l < 30) ? X[l] + 0.5 * dt * f1 + 0.5 * dt * f2 - xn : 0.0;
   if (l < 32) S[LW_V_B + l] = bl;
   qm_wave_sync();
-  if (dbg) {
+  // Pin the results of phase I: the discrete-time Jacobians are complete HERE.  Without a use at this point the compiler sinks their arithmetic towards the
+  // products of phase II, keeps the six stage Jacobian fragments alive next to them and spills 100 bytes per lane (the debug stores below used to be that use).
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 2; ++J) { QM_PIN4(Ad[I][J]); QM_PIN4(Bdt[I][J]); }
+  if (DBG && dbg) {
     qm_frag_store<2, 2>(Ad, dbg + LQ_DBG_A, 30, 30, 30);
 #pragma unroll
     for (int I = 0; I < 2; ++I)
@@ -418,7 +429,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   }
   qm_wave_sync();
   const double* Ct = T; const double* Dt = T + 16 * LW_TLD;
-  if (dbg) { for (int idx = l; idx < 480; idx += 64) { const int r = idx / 30, cc = idx - r * 30; dbg[LQ_DBG_C + idx] = Ct[r * LW_TLD + cc]; dbg[LQ_DBG_D + idx] = Dt[r * LW_TLD + cc]; } if (l < 16) dbg[LQ_DBG_e + l] = S[LW_V_E + l]; if (l == 0) dbg[LQ_DBG_nc] = nc; }
+  if (DBG && dbg) { for (int idx = l; idx < 480; idx += 64) { const int r = idx / 30, cc = idx - r * 30; dbg[LQ_DBG_C + idx] = Ct[r * LW_TLD + cc]; dbg[LQ_DBG_D + idx] = Dt[r * LW_TLD + cc]; } if (l < 16) dbg[LQ_DBG_e + l] = S[LW_V_E + l]; if (l == 0) dbg[LQ_DBG_nc] = nc; }
   LQT()
   // per contact: stance -> Ginv (3x3) of the joint-velocity block; swing -> g/(g.g) and a 3x2 orthonormal complement of g
   double* G = S + LW_V_G;
@@ -543,7 +554,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double p = Rm[I][0][r] * d0 + Rm[I][1][r] * d1;
-        p += qm_dpp<0x111, 0xf>(0.0, p); p += qm_dpp<0x112, 0xf>(0.0, p); p += qm_dpp<0x114, 0xf>(0.0, p); p += qm_dpp<0x118, 0xf>(0.0, p);   // row_shr 1, 2, 4, 8: lane 15 of each row holds the sum
+        p += qm_dpp0<0x111>(p); p += qm_dpp0<0x112>(p); p += qm_dpp0<0x114>(p); p += qm_dpp0<0x118>(p);   // row_shr 1, 2, 4, 8: lane 15 of each row holds the sum
         const int row = 16 * I + g + 4 * r;
         if (c == 15 && row < 30) S[LW_V_RV + row] = p;
       }
@@ -627,7 +638,7 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
 #pragma unroll
       for (int J = 0; J < 2; ++J) Qa[I][J] *= dt;
   }
-  if (dbg) {
+  if (DBG && dbg) {
     qm_frag_store<2, 2>(Qa, dbg + LQ_DBG_Q, 30, 30, 30); qm_frag_store<2, 2>(Rm, dbg + LQ_DBG_R, 30, 30, 30);
 #pragma unroll
     for (int I = 0; I < 2; ++I)
@@ -642,10 +653,10 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   for (int J = 0; J < 2; ++J) {
     const int col = 16 * J + c;
     if (col < 30) { rec[SR_PX + (12 + g) * 30 + col] = PxA[0][J][3]; rec[SR_PX + (16 + g) * 30 + col] = PxA[1][J][0]; rec[SR_PX + (20 + g) * 30 + col] = PxA[1][J][1]; }
-    if (dbg && col < 30) { for (int r = 0; r < 3; ++r) rec[SR_PX + (g + 4 * r) * 30 + col] = 0.0; rec[SR_PX + (24 + g) * 30 + col] = 0.0; if (g < 2) rec[SR_PX + (28 + g) * 30 + col] = 0.0; }
+    if (DBG && dbg && col < 30) { for (int r = 0; r < 3; ++r) rec[SR_PX + (g + 4 * r) * 30 + col] = 0.0; rec[SR_PX + (24 + g) * 30 + col] = 0.0; if (g < 2) rec[SR_PX + (28 + g) * 30 + col] = 0.0; }
   }
   double rpe = 0.0;
-  if (m <= 16) lw_project<1>(S, rec, dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe); else lw_project<2>(S, rec, dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe);
+  if (m <= 16) lw_project<1>(S, rec, DBG && dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe); else lw_project<2>(S, rec, DBG && dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe);
   // what K3's forward rollout needs to apply Pu without reading it: the swing legs' null-space blocks and the contact mode
   if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
   if (l == 24) rec[SR_MODEF] = (double)mode;
@@ -653,6 +664,8 @@ __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) {
   if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
   if (l == 0) { rec[SR_SCAL] = (double)m; rec[SR_SCAL + 1] = ctot + rpe; }
   LQT()
-  if (a.prof && l == 0) for (int k = 0; k + 1 < np_ && k < 9; ++k) rec[SR_K + k] = (double)(tp_[k + 1] - tp_[k]);
+  if (DBG && a.prof && l == 0) for (int k = 0; k + 1 < np_ && k < 9; ++k) rec[SR_K + k] = (double)(tp_[k + 1] - tp_[k]);
 #undef LQT
 }
+__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) { qm_lq_body<false>(a); }
+__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_dbg_kernel(QmLqArgs a) { qm_lq_body<true>(a); }      // with debug records (parity tests) / phase cycle stamps (profiling)

@@ -190,11 +190,14 @@ __device__ __forceinline__ void rw_load_B(qm_d4 (&Bm)[2][MT], const double* PB, 
       }
 }
 // one regular stage of the backward sweep; MT = number of 16-row tiles covering the m reduced inputs
-template <int MT>
-__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip, int& chol_fail, long long (&tacc)[8], RwPuCodes& pc, int md) {
+// PROF: the instrumented instance (qm_riccati_prof_kernel) — phase skip bits and in-kernel cycle counters; the product instance carries neither (the eight 64-bit
+// accumulators and the skip tests cost scalar registers — spilled to vector-register lanes around every phase boundary — and branches on the hot path)
+template <int MT, bool PROF>
+__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip_arg, int& chol_fail, long long (&tacc)[8], RwPuCodes& pc, int md) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
-  const bool prof = (skip & 32) != 0; long long tq_ = prof ? (long long)__builtin_readcyclecounter() : 0;
-#define RWT(i) { if (prof) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[i] += t_ - tq_; tq_ = t_; } }
+  const int skip = PROF ? skip_arg : 0;
+  const bool prof = PROF && (skip & 32) != 0; long long tq_ = prof ? (long long)__builtin_readcyclecounter() : 0;
+#define RWT(i) { if (PROF && prof) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[i] += t_ - tq_; tq_ = t_; } }
   qm_d4 A[2][2], Bm[2][MT], Hux[MT][2], Huu[MT][MT], Sn[2][2];
   {
     // this stage's operands were copied into LDS (asynchronously, global_load_lds) while the previous stage computed
@@ -402,7 +405,9 @@ __device__ __forceinline__ int rf_src(int e) {
 }
 #define RF_TOTAL 1628
 
-__global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
+template <bool PROF>
+__device__ __forceinline__ void qm_riccati_body(QmRiccatiArgs a) {
+  if (!PROF) a.skip = 0;
   extern __shared__ double qm_smem[];
   double* buf = qm_smem;
   int* nlist = (int*)(qm_smem + RF_LIST);
@@ -430,7 +435,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   int chol_fail = 0;
   RwPuCodes pc; pc.mode = -1; pc.pk[0] = pc.pk[1] = 0;
   if (l == 0) { buf[RP_REC + RPO_SWG + 26] = 1.0; buf[RP_REC + RPO_SWG + 27] = 0.0; }      // constants behind the swing blocks (the copies never touch them)
-  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long tstart = (long long)__builtin_readcyclecounter();
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long tstart = PROF ? (long long)__builtin_readcyclecounter() : 0;
   qm_d4 S[2][2], sv[2];
   {   // terminal value function
     const double* rec = a.stage + ((size_t)b * a.nmax + (n - 1)) * SR_SIZE;
@@ -462,10 +467,10 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
     int kn = k - 1; while (kn >= 0 && evlist(kn) == QM_EV_PRE) --kn;      // next regular stage: its operands are prefetched into LDS
     const double* nrec = (kn >= 0) ? a.stage + ((size_t)b * a.nmax + kn) * SR_SIZE : nullptr;
     const int m = mlist(k);
-    if (m <= 16) rw_stage<1>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
-    else rw_stage<2>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
+    if (m <= 16) rw_stage<1, PROF>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
+    else rw_stage<2, PROF>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
   }
-  const long long tback = (long long)__builtin_readcyclecounter();
+  const long long tback = PROF ? (long long)__builtin_readcyclecounter() : 0;
   // L, W, y were stored by other lanes than the ones that read them back below
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // same wave, same CU: ordering only, no L2 write-back
   // ---- forward rollout.  The fields of a stage record the rollout reads are copied global -> LDS by the DMA path (global_load_lds, 16 B per lane, no VGPRs) one
@@ -489,8 +494,8 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   };
   int cur = 0;
   { int k0 = 0; while (k0 < n - 1 && evlist(k0) == QM_EV_PRE) ++k0; if (k0 < n - 1 && !(a.skip & 4)) fetch(k0, 0); }
-  long long tfw[6] = {0, 0, 0, 0, 0, 0}; long long tfl = (long long)__builtin_readcyclecounter();
-#define RFT(i) { if (a.skip & 32) { const long long now_ = (long long)__builtin_readcyclecounter(); tfw[i] += now_ - tfl; tfl = now_; } }
+  long long tfw[6] = {0, 0, 0, 0, 0, 0}; long long tfl = PROF ? (long long)__builtin_readcyclecounter() : 0;
+#define RFT(i) { if (PROF && (a.skip & 32)) { const long long now_ = (long long)__builtin_readcyclecounter(); tfw[i] += now_ - tfl; tfl = now_; } }
   double du_pend = 0.0; int nb_pend = -1;                   // du of the last regular stage, not yet stored
   for (int k = 0; k < n - 1; ++k) {
     if (a.skip & 4) break;
@@ -572,7 +577,7 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   }
   double arm = armijo, sx = dx2, su = du2;
   for (int off = 32; off > 0; off >>= 1) { arm += __shfl_xor(arm, off, 64); sx += __shfl_xor(sx, off, 64); su += __shfl_xor(su, off, 64); }
-  if ((a.skip & 32) && l == 0) {                      // profiling: cycles per backward phase, whole sweeps
+  if (PROF && (a.skip & 32) && l == 0) {              // profiling: cycles per backward phase, whole sweeps
     double* r0 = a.stage + (size_t)b * a.nmax * SR_SIZE + SR_K;
     for (int i = 0; i < 7; ++i) r0[i] = (double)tacc[i];
     r0[7] = (double)(tback - tstart); r0[8] = (double)((long long)__builtin_readcyclecounter() - tback);
@@ -580,6 +585,8 @@ __global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) {
   }
   if (l == 0) { a.step_info[b * 4] = arm; a.step_info[b * 4 + 1] = sx; a.step_info[b * 4 + 2] = su; a.step_info[b * 4 + 3] = (double)chol_fail; }
 }
+__global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) { qm_riccati_body<false>(a); }
+__global__ void __launch_bounds__(RW_BLOCK) qm_riccati_prof_kernel(QmRiccatiArgs a) { qm_riccati_body<true>(a); }      // profiling / parity switches only (a.skip != 0)
 #undef mlist
 #undef evlist
 #undef modelist

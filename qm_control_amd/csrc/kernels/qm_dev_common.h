@@ -22,6 +22,12 @@
 
 typedef double qm_d4 __attribute__((ext_vector_type(4)));
 
+// "this fragment register is complete here": an empty asm that uses the four values keeps the compiler from sinking their arithmetic past this point
+// (the host emulator defines it away)
+#ifndef QM_PIN4
+#define QM_PIN4(q) asm volatile("" :: "v"((q)[0]), "v"((q)[1]), "v"((q)[2]), "v"((q)[3]))
+#endif
+
 // Read-only parameter tables (model blob `mb`, settings `st`) are read through the CONSTANT address space: their loads become
 // scalar (s_load into SGPRs, one copy per wave) instead of 64-lane vector loads into VGPR pairs.  No kernel writes these tables.
 typedef const double __attribute__((address_space(4)))* qm_ctab;
@@ -165,10 +171,18 @@ __device__ __forceinline__ double qm_dpp(double old, double src) {
   v.i[1] = __builtin_amdgcn_update_dpp(o.i[1], v.i[1], CTRL, ROW_MASK, 0xf, false);
   return v.d;
 }
+// row_shr step that shifts ZEROS in (bound_ctrl): no `old` operand, hence no zero initialisation of the destination pair in front of every step
+template <int CTRL>
+__device__ __forceinline__ double qm_dpp0(double src) {
+  union { double d; int i[2]; } v; v.d = src;
+  v.i[0] = __builtin_amdgcn_mov_dpp(v.i[0], CTRL, 0xf, 0xf, true);
+  v.i[1] = __builtin_amdgcn_mov_dpp(v.i[1], CTRL, 0xf, 0xf, true);
+  return v.d;
+}
 // wave-wide sum / max, result in every lane: four row_shr steps inside the 16-lane rows, two row broadcasts, one v_readlane
 // (no LDS crossbar traffic: ds_bpermute-based butterflies cost several times more on a lone wave)
 __device__ __forceinline__ double qm_wave_sum(double v) {
-  v += qm_dpp<0x111, 0xf>(0.0, v); v += qm_dpp<0x112, 0xf>(0.0, v); v += qm_dpp<0x114, 0xf>(0.0, v); v += qm_dpp<0x118, 0xf>(0.0, v);
+  v += qm_dpp0<0x111>(v); v += qm_dpp0<0x112>(v); v += qm_dpp0<0x114>(v); v += qm_dpp0<0x118>(v);
   v += qm_dpp<0x142, 0xa>(0.0, v); v += qm_dpp<0x143, 0xc>(0.0, v);
   return qm_bcast(v, 63);
 }

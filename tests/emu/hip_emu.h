@@ -27,6 +27,7 @@
 #define QM_MAX_VGPRS(n)            /* register caps mean nothing on the host */
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)   /* instruction-scheduling fence: no meaning on the host */
 #define QM_TABLE_OPAQUE(p)            /* device-only register constraint */
+#define QM_PIN4(q) ((void)0)             /* device-only scheduling pin */
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 
@@ -124,6 +125,8 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
   }
   emu::wavesync(); return r;
 }
+// v_mov_b32_dpp without an `old` operand: the kernels use it with bound_ctrl and a full row mask only (zeros shifted in)
+inline int __builtin_amdgcn_mov_dpp(int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) { return __builtin_amdgcn_update_dpp(0, src, ctrl, row_mask, bank_mask, bound_ctrl); }
 inline unsigned long long __ballot(int pred) {
   emu::Block* blk = emu::B; const int w = emu::cur().wave, l = emu::cur().lane;
   blk->xa[w * 64 + l] = pred ? 1.0 : 0.0; emu::wavesync();

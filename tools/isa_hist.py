@@ -1,0 +1,45 @@
+"""tools/isa_hist.py — static instruction mix of the gfx950 kernels of libqmhip from the compiler's assembly (no GPU needed): per kernel the counts by class
+(FP64 VALU, other VALU, MFMA, SALU, LDS, vector memory) and, with --lines, the source lines that own the most instructions (hipcc -gline-tables-only).
+The dynamic mix (SQ PMC counters, profiles/flops_pmc.json) says how often; this says WHERE.
+usage: python tools/isa_hist.py [--lines N] [kernel ...]      (default kernels: qm_lq_kernel qm_riccati_kernel qm_wbc_kernel)"""
+import collections, os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def classify(op):
+    if op.startswith('v_mfma'): return 'mfma'
+    if op.startswith('v_') and 'f64' in op: return 'valu_f64'
+    if op.startswith('v_'): return 'valu_other'
+    if op.startswith('s_'): return 'salu'
+    if op.startswith('ds_'): return 'lds'
+    if op.startswith(('global_', 'buffer_', 'flat_', 'scratch_')): return 'vmem'
+    return 'other'
+
+
+def main(argv):
+    nlines = 0
+    if argv and argv[0] == '--lines': nlines = int(argv[1]); argv = argv[2:]
+    kernels = argv or ['qm_lq_kernel', 'qm_riccati_kernel', 'qm_wbc_kernel']
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-Wno-unused-value', '-Wno-unused-result'] + (['-gline-tables-only'] if nlines else []) +
+                              ['-I' + os.path.join(ROOT, 'include'), '--save-temps', '-c', os.path.join(ROOT, 'qm_control_amd', 'csrc', 'host', 'qmhip.hip'), '-o', os.path.join(d, 'q.o')], cwd=d, stderr=subprocess.DEVNULL)
+        s = open(os.path.join(d, 'qmhip-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
+    files = {int(m.group(1)): (m.group(3) or m.group(2)).split('/')[-1] for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', s)}
+    for name in kernels:
+        m = re.search(r'^(_Z\d+%s\w*):[^\n]*\n(.*?)\n\.Lfunc_end' % name, s, re.S | re.M)
+        if not m: print(name, 'not found'); continue
+        cls = collections.Counter(); ops = collections.Counter(); per = collections.Counter(); perop = collections.defaultdict(collections.Counter); cur = None
+        for line in m.group(2).split('\n'):
+            t = line.strip()
+            if t.startswith('.loc'): p = t.split(); cur = (files.get(int(p[1]), p[1]), int(p[2])); continue
+            if not t or t.startswith(('.', ';', '//')) or t.endswith(':'): continue
+            op = t.split()[0]; cls[classify(op)] += 1; ops[op] += 1; per[cur] += 1; perop[cur][op] += 1
+        tot = sum(cls.values()); valu = cls['valu_f64'] + cls['valu_other'] + cls['mfma']
+        print('%s: %d instructions %s; non-FP64 share of VALU %.2f' % (name, tot, dict(cls), cls['valu_other'] / max(1, valu)))
+        print('   top opcodes: ' + ' '.join('%s:%d' % x for x in ops.most_common(14)))
+        for k, n in per.most_common(nlines):
+            print('   %5d %s:%d  %s' % (n, k[0] if k else None, k[1] if k else 0, ' '.join('%s:%d' % x for x in perop[k].most_common(4))))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:])
