@@ -93,7 +93,7 @@ struct QmLqArgs {
 #define LW_PD    (LW_K2 + KW_SIZE)      /* Pu column descriptors: first source row i0 as double [32], weights [32][3] */
 #define LW_LDS_DOUBLES (LW_PD + 128)
 #define LQ_LDS_BYTES (LW_LDS_DOUBLES * 8)
-#define LQ_KIN_LDS_BYTES (2 * 64 * 31 * 8)  /* K1a: two 31-double rows per thread (the input u, a flow-map value) */
+#define LQ_KIN_LDS_BYTES (64 * 31 * 8)      /* K1a: one 31-double row per thread (the input u): 15.5 KB per wave, eight waves per CU */
 
 // value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column
 __device__ __forceinline__ void lw_set_col30(qm_d4 (&F)[2][2], const double* v) {
@@ -221,7 +221,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
 }
 
 // ---- K1a: scalar kinematics, one thread per (node, instance) ----
-__global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
+__global__ void __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = g / a.B, b = g - i * a.B;
   if (i >= a.nmax) return;
@@ -245,16 +245,23 @@ __global__ void __launch_bounds__(64) qm_lq_kin_kernel(QmLqArgs a) {
   }
   _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q];
   const double dt = a.node_dt[nb];
-  kin_base<true>(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg<true>(mb, c, x, u, K); kin_arm<true>(mb, x, K);
-  _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
+  // Every block of the workspace goes to the record as soon as it is complete and only what the flow map needs (the feet, the base block) stays live: the
+  // kernel then fits 256 registers and one 31-double LDS row per thread, i.e. TWO waves per SIMD — all 1664 wavefronts of the benchmark launch are resident at
+  // once and a wave's dependent chains (≈ 20 cycles per instruction on a lone wave) overlap with its neighbour's
+  kin_base<true>(mb, x, K);
+  _Pragma("unroll") for (int q = 0; q < KW_LEG; ++q) rec[KR_K1 + q] = K[q];
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) { kin_leg<true>(mb, c, x, u, K); _Pragma("unroll") for (int q = 0; q < KW_LEGSZ; ++q) rec[KR_K1 + KW_LEG + KW_LEGSZ * c + q] = K[KW_LEG + KW_LEGSZ * c + q]; __builtin_amdgcn_sched_barrier(0); }
+  kin_arm<true>(mb, x, K);
+  _Pragma("unroll") for (int q = KW_ARM; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
   { double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq); _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q]; }
-  double x2[30]; double* f1 = qm_smem + 64 * 31 + (threadIdx.x & 63) * 31; double* f2 = f1;      // the flow values pass through the thread's second LDS row
-  flow_from_kin(mb, x, u, K, f1);
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double fq = f1[q]; x2[q] = x[q] + dt * fq; rec[KR_F1 + q] = fq; rec[KR_X2 + q] = x2[q]; }
-  kin_base<true>(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg<true>(mb, c, x2, u, K);
-  flow_from_kin(mb, x2, u, K, f2);
-  _Pragma("unroll") for (int q = 0; q < KW_ARM; ++q) rec[KR_K2 + q] = K[q];
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) rec[KR_F2 + q] = f2[q];
+  double x2[30], f[12];                                 // the joint part of the flow value is the input's joint velocities (u, in LDS)
+  flow_head_from_kin(mb, x, u, K, f);
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double fq = (q < 12) ? f[q < 12 ? q : 0] : u[q]; x2[q] = x[q] + dt * fq; rec[KR_F1 + q] = fq; rec[KR_X2 + q] = x2[q]; }
+  kin_base<true>(mb, x2, K);
+  _Pragma("unroll") for (int q = 0; q < KW_LEG; ++q) rec[KR_K2 + q] = K[q];
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) { kin_leg<true>(mb, c, x2, u, K); _Pragma("unroll") for (int q = 0; q < KW_LEGSZ; ++q) rec[KR_K2 + KW_LEG + KW_LEGSZ * c + q] = K[KW_LEG + KW_LEGSZ * c + q]; __builtin_amdgcn_sched_barrier(0); }
+  flow_head_from_kin(mb, x2, u, K, f);
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) rec[KR_F2 + q] = (q < 12) ? f[q < 12 ? q : 0] : u[q];
 }
 
 // ---- K1b: one wavefront per node ----
@@ -661,6 +668,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
   if (l == 24) rec[SR_MODEF] = (double)mode;
   if (l == 25) rec[SR_MODEF + 1] = dt;                 // the joint rows of the projected dynamics are not read back by the rollout: x_j+ = x_j + dt u_j
+  if (l == 26 || l == 27) rec[SR_MODEF + l - 24] = (l == 26) ? 1.0 : 0.0;      // the constants K3's Bp = dt Pu rebuild reads behind (swing blocks, mode, dt): copied into LDS with them
   if (l < 30) rec[SR_PE + l] = S[LW_V_PE + l];
   if (l == 0) { rec[SR_SCAL] = (double)m; rec[SR_SCAL + 1] = ctot + rpe; }
   LQT()

@@ -35,7 +35,8 @@ struct QmLsArgs {
   const double* xt; const double* ut; int ilqr;
 };
 #define QM_LS_MAX_TRIALS 16
-#define LS_EVAL_LDS_BYTES (2 * 64 * 31 * 8)   /* qm_ls_eval_kernel: two 31-double rows per thread = 31 KB per wave: FOUR waves fit a CU's 160 KB (three rows were 46.5 KB: three waves per CU, a SIMD idle) */
+#define LS_EVAL_LDS_BYTES (64 * 31 * 8)      /* one 31-double row per thread (the trial input): 15.5 KB per wave, eight waves per CU; was */
+#define LS_EVAL_LDS_BYTES_V27 (2 * 64 * 31 * 8)   /* qm_ls_eval_kernel: two 31-double rows per thread = 31 KB per wave: FOUR waves fit a CU's 160 KB (three rows were 46.5 KB: three waves per CU, a SIMD idle) */
 
 // cost value of one intermediate node (a2 + a6 + a7 + a5), not yet × dt; K must hold base, legs and arm
 __device__ __forceinline__ double node_cost_value(const double* mb, const double* st, const double* x, const double* u, const double* K, int mode,
@@ -62,6 +63,30 @@ __device__ __forceinline__ double node_cost_value(const double* mb, const double
   for (int r = 0; r < 6; ++r) c += 0.5 * (r < 3 ? muPos : muOri) * g[r] * g[r];
   return c;
 }
+// the terms of an intermediate node's cost that need no kinematics (a2 tracking + input weight, a6 boxes, a7 friction cone), not yet × dt; the same arithmetic,
+// in the same order, as the `intermediate` part of node_cost_value; u − u_nominal lives in registers
+__device__ __forceinline__ double node_cost_value_xu(const double* mb, const double* st, const double* x, const double* u, int mode, const double* xref) {
+  double c = 0.0, du[30];
+  int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
+  _Pragma("unroll") for (int i = 0; i < 30; ++i) { const double d = x[i] - xref[i]; c += 0.5 * st[ST_Q + i] * d * d; du[i] = u[i]; }
+  if (nst > 0) { _Pragma("unroll") for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) du[3 * k + 2] -= mb[MB_ROBOTMASS] * 9.81 / nst; }
+  _Pragma("unroll") for (int i = 0; i < 30; ++i) { double s = 0.0; _Pragma("unroll") for (int j = 0; j < 30; ++j) s += st[ST_R + 30 * i + j] * du[j]; c += 0.5 * du[i] * s; }
+  __builtin_amdgcn_sched_barrier(0);
+  _Pragma("unroll") for (int i = 0; i < 6; ++i) {
+    const double lo = mb[MB_QLO + 12 + i], hi = mb[MB_QHI + 12 + i], z = x[24 + i], mu = st[ST_JPOS_MU], de = st[ST_JPOS_DELTA];
+    c += barrier_val(mu, de, z - lo) + barrier_val(mu, de, hi - z) - (barrier_val(mu, de, -lo) + barrier_val(mu, de, hi));
+    const double vlo = st[ST_JVEL_LO + i], vhi = st[ST_JVEL_HI + i], w = u[24 + i], mv = st[ST_JVEL_MU], dv = st[ST_JVEL_DELTA];
+    c += barrier_val(mv, dv, w - vlo) + barrier_val(mv, dv, vhi - w) - (barrier_val(mv, dv, -vlo) + barrier_val(mv, dv, vhi));
+    __builtin_amdgcn_sched_barrier(0);      // one joint's eight barrier values at a time: scheduled together, the 52 independent logarithms of a node spill
+  }
+  for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) {
+    const double Fx = u[3 * k], Fy = u[3 * k + 1], Fz = u[3 * k + 2];
+    const double h = st[ST_FRIC_COEF] * Fz - sqrt(Fx * Fx + Fy * Fy + st[ST_FRIC_REG]);
+    c += barrier_val(st[ST_FRIC_MU], st[ST_FRIC_DELTA], h);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return c;
+}
 // squared norm of the equality residual of one intermediate node (a8)
 __device__ __forceinline__ double node_eq_sse(const double* st, const double* x, const double* u, const double* K, int mode, const double* zvel, const double* zpos) {
   const double gain = st[ST_POS_ERR_GAIN]; double s = 0.0;
@@ -77,7 +102,7 @@ __device__ __forceinline__ double node_eq_sse(const double* st, const double* x,
   return s;
 }
 
-__global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
+__global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel(QmLsArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = g / a.B, b = g - i * a.B;
   if (i >= a.nmax) return;
@@ -104,21 +129,55 @@ __global__ void __launch_bounds__(64) qm_ls_eval_kernel(QmLsArgs a) {
   if (a.ut) { _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.ut[nb * 30 + q]; }
   else { _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q] + al * a.du[nb * 30 + q]; }
   const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
-  kin_base<true>(mb, x, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg<true>(mb, c, x, u, K); kin_arm<true>(mb, x, K);
-  // a zero-length interval contributes neither cost nor constraint residual and needs no second Heun stage; besides skipping work, the guards
-  // split this straight-line kernel into basic blocks, which bounds the live ranges the scheduler builds (measured: 20 % faster)
+  // Ordered for a SMALL live set (256 registers, one LDS row per thread -> two waves per SIMD, every wavefront of the launch resident at once): first the cost terms
+  // that need no kinematics (tracking, input weight, boxes, friction cone), then base -> arm (end-effector term), then the legs ONE AT A TIME, each consumed at once
+  // by the equality residual and the flow map's momentum sums — the full workspace K[196] never exists.  A zero-length interval contributes neither cost nor
+  // constraint residual and needs no second Heun stage; the guards also split this straight-line kernel into basic blocks, which bounds the scheduler's live ranges.
   double cost = 0.0, eq = 0.0;
-  if (dt > 0.0) cost = node_cost_value(mb, st, x, u, K, mode, a.xref + nb * 30, a.eeref + nb * 7, st[ST_MU_EE_POS], st[ST_MU_EE_ORI], true, qm_ls_u + 64 * 31 + (threadIdx.x & 63) * 31);
-  if (dt > 0.0) eq = node_eq_sse(st, x, u, K, mode, a.zvel + nb * 4, a.zpos + nb * 4);
-  double x2[30], f2[30]; double* f1 = qm_ls_u + 64 * 31 + (threadIdx.x & 63) * 31;      // first Heun stage's flow value: the thread's second LDS row again (the input cost's u − u_nominal is dead by now)
-  flow_from_kin(mb, x, u, K, f1);
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) { x2[q] = x[q] + dt * f1[q]; f2[q] = f1[q]; }
+  if (dt > 0.0) cost = node_cost_value_xu(mb, st, x, u, mode, a.xref + nb * 30);
+  kin_base<true>(mb, x, K);
+  if (dt > 0.0) { kin_arm<true>(mb, x, K); double g[6], qee[4]; ee_error(K, a.eeref + nb * 7, a.eeref + nb * 7 + 3, qee, g); const double mp = st[ST_MU_EE_POS], mo = st[ST_MU_EE_ORI];
+                  for (int r = 0; r < 6; ++r) cost += 0.5 * (r < 3 ? mp : mo) * g[r] * g[r]; }
+  const double mass = mb[MB_ROBOTMASS], im = 1.0 / mass, gain = st[ST_POS_ERR_GAIN];
+  double f1[12], f2[12];
+  { double lin[3] = {0.0, 0.0, -9.81 * mass}, ang[3] = {0.0, 0.0, 0.0};
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {
+      kin_leg<true>(mb, c, x, u, K); const int k = chain_to_contact(c); const double* L = K + KW_LEG + KW_LEGSZ * c;
+      const double d[3] = {L[18] - K[KW_COM], L[19] - K[KW_COM + 1], L[20] - K[KW_COM + 2]};
+      double t[3]; v3_cross(d, u + 3 * k, t);
+      for (int q = 0; q < 3; ++q) { lin[q] += u[3 * k + q]; ang[q] += t[q]; }
+      if (dt > 0.0) {                                       // equality residual of this leg's contact (a8): same terms as node_eq_sse
+        double w[3]; v3_cross(K + KW_OM, d, w); const double v[3] = {x[0] + w[0] + L[21], x[1] + w[1] + L[22], x[2] + w[2] + L[23]}; const double pz = L[20];
+        if (mode_flag(mode, k)) { for (int r = 0; r < 3; ++r) { const double e = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); eq += e * e; } }
+        else {
+          for (int r = 0; r < 3; ++r) eq += u[3 * k + r] * u[3 * k + r];
+          double bb = -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * a.zpos[nb * 4 + k];
+          const double e = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0); eq += e * e;
+        }
+      }
+    }
+    double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
+    for (int q = 0; q < 3; ++q) { f1[q] = lin[q] * im; f1[3 + q] = ang[q] * im; f1[6 + q] = x[q] + wr[q]; f1[9 + q] = K[KW_THD + q]; } }
+  _Pragma("unroll") for (int q = 0; q < 12; ++q) f2[q] = f1[q];
   if (dt > 0.0) {
-    kin_base<true>(mb, x2, K); _Pragma("unroll") for (int c = 0; c < 4; ++c) kin_leg<true>(mb, c, x2, u, K);
-    flow_from_kin(mb, x2, u, K, f2);
+    double x2[30];
+    _Pragma("unroll") for (int q = 0; q < 30; ++q) x2[q] = x[q] + dt * ((q < 12) ? f1[q < 12 ? q : 0] : u[q]);
+    kin_base<true>(mb, x2, K);
+    double lin[3] = {0.0, 0.0, -9.81 * mass}, ang[3] = {0.0, 0.0, 0.0};
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {
+      kin_leg<true>(mb, c, x2, u, K); const int k = chain_to_contact(c); const double* L = K + KW_LEG + KW_LEGSZ * c;
+      const double d[3] = {L[18] - K[KW_COM], L[19] - K[KW_COM + 1], L[20] - K[KW_COM + 2]};
+      double t[3]; v3_cross(d, u + 3 * k, t);
+      for (int q = 0; q < 3; ++q) { lin[q] += u[3 * k + q]; ang[q] += t[q]; }
+    }
+    double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
+    for (int q = 0; q < 3; ++q) { f2[q] = lin[q] * im; f2[3 + q] = ang[q] * im; f2[6 + q] = x2[q] + wr[q]; f2[9 + q] = K[KW_THD + q]; }
   }
   double s = 0.0;
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double xnq = a.xt ? a.xt[nbn * 30 + q] : a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]; const double d = x[q] + 0.5 * dt * f1[q] + 0.5 * dt * f2[q] - xnq; s += d * d; }
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) {
+    const double xnq = a.xt ? a.xt[nbn * 30 + q] : a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q];
+    const double fa = (q < 12) ? f1[q < 12 ? q : 0] : u[q], fb = (q < 12) ? f2[q < 12 ? q : 0] : u[q];      // joint rows of the flow map: the input's joint velocities in both stages
+    const double d = x[q] + 0.5 * dt * fa + 0.5 * dt * fb - xnq; s += d * d; }
   pf[0] = cost * dt; pf[1] = dt * s; pf[2] = dt * eq;
 }
 

@@ -109,21 +109,26 @@ __device__ __forceinline__ void rw_load(qm_d4 (&T)[IT][JT], const double* src, i
       }
 }
 
-// asynchronous copy of the backward operands of one stage record into the LDS prefetch buffer: 24 wave instructions of (up to) 1 KB
+// asynchronous copy of the backward operands of one stage record into the LDS prefetch buffer: 24 wave instructions of 1 KB.  Every instruction copies a FULL
+// 1 KB chunk: a segment's last chunk runs past the segment's end into the fields that follow it in the record (all sources end inside the record) and lands in
+// the segment's padding in LDS — no per-chunk lane mask.  The lane's byte offset 16 l is one 32-bit register for all of them, the chunk's address a wave-uniform
+// base (scalar registers): global_load_lds with scalar base + vector offset instead of a 64-bit vector address per instruction.
 template <int SRC, int DST, int LEN>
-__device__ __forceinline__ void rw_prefetch_seg(const double* rec, double* lds, int l) {
+__device__ __forceinline__ void rw_prefetch_seg(const double* rec, double* lds, unsigned lane_bytes) {
 #pragma unroll
-  for (int t = 0; t * 128 < LEN; ++t) if (128 * t + 2 * l < LEN) qm_dma16(rec + SRC + 128 * t + 2 * l, lds + RP_REC + DST + 128 * t);
+  for (int t = 0; t * 128 < LEN; ++t) qm_dma16((const double*)((const char*)(rec + SRC + 128 * t) + lane_bytes), lds + RP_REC + DST + 128 * t);
 }
 __device__ __forceinline__ void rw_prefetch(const double* rec, double* lds) {
-  const int l = threadIdx.x & 63;
-  rw_prefetch_seg<SR_AP, RPO_A, 360>(rec, lds, l);
-  rw_prefetch_seg<SR_BP, RPO_B, 216>(rec, lds, l);
-  rw_prefetch_seg<SR_QP, RPO_Q, 1764>(rec, lds, l);
-  rw_prefetch_seg<SR_PX + 360, RPO_PX, 360>(rec, lds, l);
-  rw_prefetch_seg<SR_BPV, RPO_VEC, 78>(rec, lds, l);
-  rw_prefetch_seg<SR_SWG, RPO_SWG, 26>(rec, lds, l);
+  const unsigned lane_bytes = 16u * (threadIdx.x & 63);
+  rw_prefetch_seg<SR_AP, RPO_A, 360>(rec, lds, lane_bytes);
+  rw_prefetch_seg<SR_BP, RPO_B, 216>(rec, lds, lane_bytes);
+  rw_prefetch_seg<SR_QP, RPO_Q, 1764>(rec, lds, lane_bytes);
+  rw_prefetch_seg<SR_PX + 360, RPO_PX, 360>(rec, lds, lane_bytes);
+  rw_prefetch_seg<SR_BPV, RPO_VEC, 78>(rec, lds, lane_bytes);
+  rw_prefetch_seg<SR_SWG, RPO_SWG, 26>(rec, lds, lane_bytes);      // brings SR_MODEF (mode, dt) and the constants 1.0, 0.0 K1b keeps behind them
 }
+static_assert(SR_AP + 384 <= SR_SIZE && SR_BP + 256 <= SR_SIZE && SR_QP + 1792 <= SR_SIZE && SR_PX + 360 + 384 <= SR_SIZE && SR_BPV + 128 <= SR_SIZE && SR_SWG + 128 <= SR_SIZE, "a full 1 KB chunk must end inside the record");
+static_assert(RPO_A + 384 <= RPO_B && RPO_B + 256 <= RPO_Q && RPO_Q + 1792 <= RPO_PX && RPO_PX + 384 <= RPO_VEC && RPO_VEC + 128 <= RPO_SWG && RP_REC + RPO_SWG + 128 <= RP_END, "segments are padded to whole chunks");
 // [Ap | bp] as D-layout fragments: rows 0..11 from the record, rows 12..23 = e_j + dt Px[j], rows 24..29 = e_j (arm joints), column 30 = bp.
 // Unconditional loads + selects: a read at column 30 / 31 of a 30-wide row lands in the next row (inside the buffer) and is replaced afterwards — the exec-mask
 // bookkeeping of conditional loads (save / branch / restore per element) costs more here than the selects
@@ -434,7 +439,7 @@ __device__ __forceinline__ void qm_riccati_body(QmRiccatiArgs a) {
   qm_wave_sync();
   int chol_fail = 0;
   RwPuCodes pc; pc.mode = -1; pc.pk[0] = pc.pk[1] = 0;
-  if (l == 0) { buf[RP_REC + RPO_SWG + 26] = 1.0; buf[RP_REC + RPO_SWG + 27] = 0.0; }      // constants behind the swing blocks (the copies never touch them)
+  // (the constants 1.0, 0.0 behind the swing blocks — indices 26, 27 of the swing segment — arrive with every stage's copy: K1b writes them into the record)
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const long long tstart = PROF ? (long long)__builtin_readcyclecounter() : 0;
   qm_d4 S[2][2], sv[2];
   {   // terminal value function

@@ -89,7 +89,20 @@ __device__ __forceinline__ void kin_arm(const double* mb, const double* x, doubl
 }
 __device__ __forceinline__ const double* kin_foot(const double* K, int contact) { return K + KW_LEG + KW_LEGSZ * contact_to_chain(contact) + 18; }
 
-// a3: flow map value from a filled workspace (legs + base)
+// a3: flow map value from a filled workspace (legs + base).  flow_head_from_kin: the twelve non-trivial rows only (momentum rates, base pose rates); rows 12..29 are
+// the input's joint velocities u[12..29]
+__device__ __forceinline__ void flow_head_from_kin(const double* mb, const double* x, const double* u, const double* K, double* f) {
+  const double m = mb[MB_ROBOTMASS], im = 1.0 / m;
+  double lin[3] = {0.0, 0.0, -9.81 * m}, ang[3] = {0.0, 0.0, 0.0};
+  for (int i = 0; i < 4; ++i) {
+    const double* p = kin_foot(K, i);
+    const double d[3] = {p[0] - K[KW_COM], p[1] - K[KW_COM + 1], p[2] - K[KW_COM + 2]};
+    double c[3]; v3_cross(d, u + 3 * i, c);
+    for (int k = 0; k < 3; ++k) { lin[k] += u[3 * i + k]; ang[k] += c[k]; }
+  }
+  double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
+  for (int k = 0; k < 3; ++k) { f[k] = lin[k] * im; f[3 + k] = ang[k] * im; f[6 + k] = x[k] + wr[k]; f[9 + k] = K[KW_THD + k]; }
+}
 __device__ __forceinline__ void flow_from_kin(const double* mb, const double* x, const double* u, const double* K, double* f) {
   const double m = mb[MB_ROBOTMASS], im = 1.0 / m;
   double lin[3] = {0.0, 0.0, -9.81 * m}, ang[3] = {0.0, 0.0, 0.0};

@@ -36,7 +36,10 @@ def test_register_and_scratch_budgets():
     assert alloc("qm_wbc_kernel") + alloc("qm_grid_nodes_kernel") <= 512 and alloc("qm_wbc_kernel") + alloc("qm_grid_kernel") <= 512, (k["qm_wbc_kernel"], k["qm_grid_nodes_kernel"])
     assert alloc("qm_wbc_kernel") + alloc("qm_policy_kernel") <= 512
     assert 2 * alloc("qm_lq_kernel") <= 512, k["qm_lq_kernel"]
-    assert k["qm_lq_kin_kernel"]["scratch"] <= 64 and k["qm_ls_eval_kernel"]["scratch"] <= 192       # what is left of the thread-per-node kernels' spills
+    # the thread-per-node kernels are capped at 256 registers (two waves per SIMD: every wavefront of the benchmark launch resident at once); what does not fit is a
+    # handful of spill stores / reloads among ~ 30 k instructions (round 3: 108 B and 352 B per lane; at one wave per SIMD they had 0 / 108 B and were 17 % / 9 % slower)
+    assert alloc("qm_lq_kin_kernel") <= 256 and alloc("qm_ls_eval_kernel") <= 256
+    assert k["qm_lq_kin_kernel"]["scratch"] <= 128 and k["qm_ls_eval_kernel"]["scratch"] <= 384
 
 
 def test_lds_budgets_fit_the_intended_waves_per_cu():
@@ -44,4 +47,4 @@ def test_lds_budgets_fit_the_intended_waves_per_cu():
     lib = C.CDLL(emu_harness.build())
     cu = 160 * 1024
     lq, ric, kin, ev, wbc, sim = (lib.emu_sizes(i) for i in (3, 4, 6, 7, 8, 9))
-    assert 8 * lq <= cu and 4 * ric <= cu and 4 * kin <= cu and 4 * ev <= cu and 4 * wbc <= cu and 4 * sim <= cu, (lq, ric, kin, ev, wbc, sim)
+    assert 8 * lq <= cu and 4 * ric <= cu and 8 * kin <= cu and 8 * ev <= cu and 4 * wbc <= cu and 4 * sim <= cu, (lq, ric, kin, ev, wbc, sim)
