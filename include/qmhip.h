@@ -148,8 +148,11 @@ int qmhip_policy_eval(qmhip_ctx* ctx, int B, const double* t, double* x_des /*[B
 /* ---- WBC: replaces qm::WbcBase::update / HierarchicalWbc::update (qm_wbc/include/qm_wbc/WbcBase.h:31-32,
  *      qm_wbc/src/HierarchicalWbc.cpp:18-44; variant 1 = HierarchicalMpcWbc.cpp:18-34).
  *      out[b] = [vdot(24), F(12), tau(18)]; qp_status[b][3] per priority level: 0 ok, 1 iteration limit (qpOASES' nWSR = 100, HoQp.cpp:141), 2 working set larger
- *      than the level's null space, -3 a hierarchy shape the shipped controllers never build (own inequality rows at a level below the first one: the general stacking
- *      of HoQp.cpp:92-124 with two slack blocks is not implemented; HierarchicalWbc / HierarchicalMpcWbc only put inequalities into level 0).
+ *      than the level's null space (a degenerate vertex).  `variant` selects one of the two hierarchies the reference ships; both put inequality rows into their first
+ *      level only, and the cascade kernel is specialised to that shape (slack eliminated analytically at level 0, hard rows below).  The GENERAL stacking of
+ *      HoQp.cpp:92-124 — own inequality rows at a lower level, with the reference's current-first / previous-first pairing of stacked rows and slack solutions — cannot
+ *      be requested through this ABI (there is no third variant); it is restated in the oracle (oracle/src/wbc.h: solveHoLevel) and pinned against the literal cascade
+ *      (tests/test_hoqp_literal.py::test_general_stacking_equals_literal_hoqp).  A WbcBase subclass with another hierarchy is another kernel, not a runtime option.
  *      The joint-acceleration state `inputLast_` (WbcBase.cpp:212-213) lives in the context per instance;
  *      qmhip_wbc_reset zeroes it.  The call enqueues on the context's WBC stream only and waits for that stream only (pinned staging, asynchronous copies). */
 int qmhip_wbc_step(qmhip_ctx* ctx, int B, const double* x_des, const double* u_des, const double* rbd_meas /*[B][55]*/,

@@ -267,6 +267,20 @@ def batch_step(model_blob, settings_blob, nthreads, t0, horizon, x0, ref_t, ref_
     return bad, xf, uf, w
 
 
+def hoqp(tasks):
+    """qm::HoQp cascade on arbitrary tasks [dict(A, b, D, f), ...] from the highest priority down (oracle/src/wbc.h: solveHoLevel, general stacking included).
+    Returns (x of the last level, status per level, active-set iterations per level)."""
+    build()
+    lib = C.CDLL(_LIB)
+    n = int(np.asarray(tasks[0]["A"]).shape[1]) if np.asarray(tasks[0]["A"]).size else int(np.asarray(tasks[0]["D"]).shape[1])
+    ma = np.array([np.asarray(t["A"]).reshape(-1, n).shape[0] for t in tasks], np.int32); md = np.array([np.asarray(t["D"]).reshape(-1, n).shape[0] for t in tasks], np.int32)
+    cat = lambda k: np.ascontiguousarray(np.concatenate([np.asarray(t[k], float).ravel() for t in tasks] + [np.zeros(1)]))
+    A, b, D, f = cat("A"), cat("b"), cat("D"), cat("f")
+    x = np.zeros(n); st = np.zeros(len(tasks), np.int32); it = np.zeros(len(tasks), np.int32)
+    lib.qmo_hoqp(C.c_int(len(tasks)), C.c_int(n), _pi(ma), _pi(md), _p(A), _p(b), _p(D), _p(f), _p(x), _pi(st), _pi(it))
+    return x, st, it
+
+
 _traj_last = None
 
 

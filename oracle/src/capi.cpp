@@ -194,6 +194,24 @@ int qmo_sim_step(void* h, double period, int nsub, double* q, double* v, double*
   for (int i = 0; i < QM_NQ; ++i) { q[i] = o->sim.q[i]; v[i] = o->sim.v[i]; } *time = o->sim.time; for (int i = 0; i < 12; ++i) force[i] = o->sim.force[i]; for (int i = 0; i < 4; ++i) contact[i] = o->sim.contact[i];
   return o->sim.status;
 }
+// qm::HoQp on an ARBITRARY cascade (HoQp.h:17-36: HoQp(task, higherProblem) level by level, getSolutions() of the last one): n decision variables, per level
+// ma[k] equality rows (A row-major [ma][n], b) and md[k] inequality rows (D, f), concatenated over the levels from the highest priority down.  status[k] per level.
+int qmo_hoqp(int n_levels, int n, const int* ma, const int* md, const double* A, const double* b, const double* D, const double* f, double* x_out, int* status, int* iters) {
+  std::vector<HoLevel> lv; lv.reserve(n_levels);
+  size_t oa = 0, ob = 0, od = 0, of = 0;
+  for (int k = 0; k < n_levels; ++k) {
+    Task t; t.A = Mat(ma[k], n); t.b.assign(b + ob, b + ob + ma[k]); t.D = Mat(md[k], n); t.f.assign(f + of, f + of + md[k]);
+    for (int i = 0; i < ma[k]; ++i) for (int j = 0; j < n; ++j) t.A(i, j) = A[oa + (size_t)i * n + j];
+    for (int i = 0; i < md[k]; ++i) for (int j = 0; j < n; ++j) t.D(i, j) = D[od + (size_t)i * n + j];
+    oa += (size_t)ma[k] * n; ob += ma[k]; od += (size_t)md[k] * n; of += md[k];
+    lv.push_back(solveHoLevel(t, k ? &lv[k - 1] : nullptr, n));
+    if (status) status[k] = lv[k].status;
+    if (iters) iters[k] = lv[k].iters;
+  }
+  for (int j = 0; j < n; ++j) x_out[j] = lv.back().x[j];
+  return lv.back().status;
+}
+
 // rbd state (55) from generalized coordinates: zero velocities, EE pose by FK (StateEstimateBase.cpp:41-103 layout)
 void qmo_rbd_from_q(void* h, const double* q, const double* v /*24 pinocchio, may be null*/, double* rbd) {
   Oracle* o = (Oracle*)h; std::fill(rbd, rbd + QM_NRBD, 0.0);

@@ -124,6 +124,46 @@ inline void eqConstrainedLS(const Mat& G, const Vec& g, const Mat& E, const Vec&
   for (int i = me - 1; i >= 0; --i) { double s = -ytg[i]; for (int j = i + 1; j < me; ++j) s -= Re(i, j) * lam[j]; lam[i] = s / Re(i, i); }
 }
 
+// min |G y − g|² s.t. C y <= c, from a feasible y: primal active set (Nocedal & Wright alg. 16.3) on the QR-based equality-constrained solves above.
+// status: 0 converged, 1 iteration limit (qpOASES' nWSR = 100, HoQp.cpp:141), 2 working set larger than the problem's dimension
+inline void primalActiveSetLSI(const Mat& G0, const Vec& g0, const Mat& DZ, const Vec& fb, Vec& z, int& status, int& iters) {
+  const int n = G0.c, mh = DZ.r;
+  std::vector<int> W; bool degenerate = false; double pscale = 0.0;
+  for (iters = 0; iters < 100; ++iters) {
+    Mat E((int)W.size(), n); Vec e(W.size());
+    for (size_t a = 0; a < W.size(); ++a) { for (int j = 0; j < n; ++j) E((int)a, j) = DZ(W[a], j); e[a] = fb[W[a]]; }
+    Vec zn, lam; eqConstrainedLS(G0, g0, E, e, zn, lam);
+    Vec p = vsub(zn, z); double pn = 0; for (double v : p) pn = std::max(pn, std::fabs(v));
+    double zs = 1.0; for (double v : z) zs = std::max(zs, std::fabs(v));
+    pscale = std::max(pscale, pn);
+    if (pn <= 1e-9 * std::max(zs, pscale)) {      // relative to the largest step seen: the problem's own length scale
+      // stationary on the working set: drop a row with a negative multiplier (most negative; lowest index after a degenerate step — Bland)
+      int worst = -1; double lw = 0.0; double lscale = 1.0; for (double v : lam) lscale = std::max(lscale, std::fabs(v));
+      for (size_t a = 0; a < W.size(); ++a) if (lam[a] < -1e-9 * lscale) { if (degenerate) { if (worst < 0 || W[a] < W[worst]) worst = (int)a; } else if (lam[a] < lw) { lw = lam[a]; worst = (int)a; } }
+      if (worst < 0) break;
+      W.erase(W.begin() + worst);
+    } else {
+      double alpha = 1.0; int block = -1; Vec Dz = matvec(DZ, z), Dp = matvec(DZ, p);
+      for (int i = 0; i < mh; ++i) {
+        if (std::find(W.begin(), W.end(), i) != W.end()) continue;
+        if (Dp[i] > 1e-10 * std::max(1.0, pn)) { const double a = std::max(0.0, (fb[i] - Dz[i]) / Dp[i]); if (a < alpha) { alpha = a; block = i; } }   // relative threshold: E p = 0 only to round-off; ties: lowest index
+      }
+      for (int j = 0; j < n; ++j) z[j] += alpha * p[j];
+      degenerate = (alpha <= 1e-12);
+      if (block >= 0) {
+        if ((int)W.size() < n) W.push_back(block);
+        else { status = 2; break; }                   // more than n independent rows cannot be active
+      }
+    }
+  }
+  if (iters >= 100 && status == 0) status = 1;
+}
+
+// The higher levels' rows, relaxed by their slack solutions, hold at the previous solution by construction — unless SURVEY.md a17's quirk has paired rows and slacks
+// of two higher levels wrongly (inequality rows on two higher levels, a non-zero slack among them): the reference then hands qpOASES a problem whose intended
+// feasible point is infeasible and ignores the return code.  Status 3; the level keeps the previous solution.
+inline bool hardRowsHoldAtPrevious(const Vec& fb) { double sc = 1.0; for (double v : fb) sc = std::max(sc, std::fabs(v)); for (double v : fb) if (v < -1e-9 * sc) return false; return true; }
+
 inline HoLevel solveHoLevel(const Task& task, const HoLevel* prev, int nx) {
   const double rho = 1e-12;                              // HoQp.cpp:66
   HoLevel L;
@@ -131,7 +171,6 @@ inline HoLevel solveHoLevel(const Task& task, const HoLevel* prev, int nx) {
   const int n = Zp.c;
   const bool hasEq = task.A.r > 0, hasIneq = task.D.r > 0;
   const bool hasPrevIneq = prev && prev->Dstack.r > 0;
-  if (hasIneq && hasPrevIneq) { L.status = -3; return L; }   // shape not produced by the shipped hierarchies
   // stacked LS rows: [A Zp; sqrt(rho) I] z ≈ [b − A xp; 0]
   Mat AZ = hasEq ? matmul(task.A, Zp) : Mat(0, n);
   Vec rb = hasEq ? vsub(task.b, matvec(task.A, xp)) : Vec();
@@ -139,7 +178,30 @@ inline HoLevel solveHoLevel(const Task& task, const HoLevel* prev, int nx) {
   for (int i = 0; i < AZ.r; ++i) { for (int j = 0; j < n; ++j) G0(i, j) = AZ(i, j); g0[i] = rb[i]; }
   for (int j = 0; j < n; ++j) G0(AZ.r + j, j) = std::sqrt(rho);
   Vec z(n, 0.0);
-  if (hasIneq) {
+  // General stacking (HoQp.cpp:92-124): OWN inequality rows at a level below the first one.  The shipped hierarchies never build it (their levels 1, 2 carry
+  // equalities only); a WbcBase subclass with, say, torque limits one level below the friction cones does.  The slack stays a VARIABLE here: y = [z; w],
+  //   minimise ½|G0 z − g0|² + ½|w|²   s.t.  −w <= 0,   Dp Zp z <= fp − Dp xp + wp*  (rows of the higher levels),   D Zp z − w <= f − D xp
+  // — the rows in HoQp::buildDMatrix's order — solved by the same primal active set from the feasible point z = 0, w = max(0, −(f − D xp)).
+  // SURVEY.md a17's quirk is reproduced by construction: prev->Dstack / fstack hold the higher levels' rows CURRENT-FIRST (stackedTasks_ = task_ + stackedTasksPrev_,
+  // HoQp.cpp:46) while prev->wstack holds their slack solutions PREVIOUS-FIRST (HoQp.cpp:152-158): with inequality rows on two higher levels of different
+  // sizes the slacks are added to the wrong rows, exactly as the reference does.
+  if (hasIneq && hasPrevIneq) {
+    Mat DZ = matmul(task.D, Zp); Vec fbo = vsub(task.f, matvec(task.D, xp)); const int ms = DZ.r;
+    Mat HZ = matmul(prev->Dstack, Zp); Vec fbh = vadd(vsub(prev->fstack, matvec(prev->Dstack, xp)), prev->wstack); const int mh = HZ.r;
+    const int ny = n + ms;
+    Mat G(G0.r + ms, ny); Vec g(G0.r + ms, 0.0);
+    for (int i = 0; i < G0.r; ++i) { for (int j = 0; j < n; ++j) G(i, j) = G0(i, j); g[i] = g0[i]; }
+    for (int i = 0; i < ms; ++i) G(G0.r + i, n + i) = 1.0;
+    Mat C(2 * ms + mh, ny); Vec c(2 * ms + mh, 0.0);
+    for (int i = 0; i < ms; ++i) C(i, n + i) = -1.0;
+    for (int i = 0; i < mh; ++i) { for (int j = 0; j < n; ++j) C(ms + i, j) = HZ(i, j); c[ms + i] = fbh[i]; }
+    for (int i = 0; i < ms; ++i) { for (int j = 0; j < n; ++j) C(ms + mh + i, j) = DZ(i, j); C(ms + mh + i, n + i) = -1.0; c[ms + mh + i] = fbo[i]; }
+    Vec y(ny, 0.0); for (int i = 0; i < ms; ++i) y[n + i] = std::max(0.0, -fbo[i]);
+    if (!hardRowsHoldAtPrevious(fbh)) L.status = 3; else
+    primalActiveSetLSI(G, g, C, c, y, L.status, L.iters);
+    for (int j = 0; j < n; ++j) z[j] = y[j];
+    L.w.assign(ms, 0.0); for (int i = 0; i < ms; ++i) L.w[i] = std::max(0.0, y[n + i]);
+  } else if (hasIneq) {
     // soft rows: phi(z) = ½|G0 z − g0|² + ½ sum (d_i z − f_i)_+²  — Newton on the active set with exact line search
     Mat DZ = matmul(task.D, Zp); Vec fb = vsub(task.f, matvec(task.D, xp)); const int ms = DZ.r;
     std::vector<char> act(ms, 0);
@@ -168,37 +230,10 @@ inline HoLevel solveHoLevel(const Task& task, const HoLevel* prev, int nx) {
     if (L.iters >= 100) L.status = 1;                      // nWSR exhausted
     Vec Dzn = matvec(DZ, z); L.w.assign(ms, 0.0); for (int i = 0; i < ms; ++i) L.w[i] = std::max(0.0, Dzn[i] - fb[i]);
   } else if (hasPrevIneq) {
-    // hard rows of the higher levels: primal active-set (Nocedal & Wright alg. 16.3) from the feasible z = 0
-    Mat DZ = matmul(prev->Dstack, Zp); Vec fb = vadd(vsub(prev->fstack, matvec(prev->Dstack, xp)), prev->wstack); const int mh = DZ.r;
-    std::vector<int> W; bool degenerate = false; double pscale = 0.0;
-    for (L.iters = 0; L.iters < 100; ++L.iters) {
-      Mat E((int)W.size(), n); Vec e(W.size());
-      for (size_t a = 0; a < W.size(); ++a) { for (int j = 0; j < n; ++j) E((int)a, j) = DZ(W[a], j); e[a] = fb[W[a]]; }
-      Vec zn, lam; eqConstrainedLS(G0, g0, E, e, zn, lam);
-      Vec p = vsub(zn, z); double pn = 0; for (double v : p) pn = std::max(pn, std::fabs(v));
-      double zs = 1.0; for (double v : z) zs = std::max(zs, std::fabs(v));
-      pscale = std::max(pscale, pn);
-      if (pn <= 1e-9 * std::max(zs, pscale)) {      // relative to the largest step seen: the problem's own length scale
-        // stationary on the working set: drop a row with a negative multiplier (most negative; lowest index after a degenerate step — Bland)
-        int worst = -1; double lw = 0.0; double lscale = 1.0; for (double v : lam) lscale = std::max(lscale, std::fabs(v));
-        for (size_t a = 0; a < W.size(); ++a) if (lam[a] < -1e-9 * lscale) { if (degenerate) { if (worst < 0 || W[a] < W[worst]) worst = (int)a; } else if (lam[a] < lw) { lw = lam[a]; worst = (int)a; } }
-        if (worst < 0) break;
-        W.erase(W.begin() + worst);
-      } else {
-        double alpha = 1.0; int block = -1; Vec Dz = matvec(DZ, z), Dp = matvec(DZ, p);
-        for (int i = 0; i < mh; ++i) {
-          if (std::find(W.begin(), W.end(), i) != W.end()) continue;
-          if (Dp[i] > 1e-10 * std::max(1.0, pn)) { const double a = std::max(0.0, (fb[i] - Dz[i]) / Dp[i]); if (a < alpha) { alpha = a; block = i; } }   // relative threshold: E p = 0 only to round-off; ties: lowest index
-        }
-        for (int j = 0; j < n; ++j) z[j] += alpha * p[j];
-        degenerate = (alpha <= 1e-12);
-        if (block >= 0) {
-          if ((int)W.size() < n) W.push_back(block);
-          else { L.status = 2; break; }                   // more than n independent rows cannot be active
-        }
-      }
-    }
-    if (L.iters >= 100 && L.status == 0) L.status = 1;
+    // hard rows of the higher levels: primal active-set from the feasible z = 0
+    Mat DZ = matmul(prev->Dstack, Zp); Vec fb = vadd(vsub(prev->fstack, matvec(prev->Dstack, xp)), prev->wstack);
+    if (!hardRowsHoldAtPrevious(fb)) L.status = 3; else
+    primalActiveSetLSI(G0, g0, DZ, fb, z, L.status, L.iters);
   } else {
     Vec lam; eqConstrainedLS(G0, g0, Mat(0, n), Vec(), z, lam);
   }

@@ -129,8 +129,11 @@ def solve_qp_certified(H, c, D, f):
     raise AssertionError("active-set polish did not converge")
 
 
-def hoqp_literal(tasks):
-    """tasks: list of dict(A, b, D, f) from the highest priority down.  Returns x of the last level and per-level records."""
+def hoqp_literal(tasks, tau=None, eps_reg=0.0):
+    """tasks: list of dict(A, b, D, f) from the highest priority down.  Returns x of the last level and per-level records.
+    tau / eps_reg (tools/qpoases_termination_study.py): a model of how qpOASES' stopping rule and Hessian regularisation can move a level's solution — the level QP is
+    solved for the homotopy data of parameter tau < 1 (gradient tau c; bounds that are violated at the cold start y = 0 only a fraction tau of the way in) and with
+    eps_reg I added to the Hessian; None / 0: the exact problem."""
     nx = tasks[0]["A"].shape[1]
     Zp = np.eye(nx, dtype=LD); xp = np.zeros(nx, LD); Dst = np.zeros((0, nx), LD); fst = np.zeros(0, LD); wst = np.zeros(0, LD)
     levels = []
@@ -152,6 +155,10 @@ def hoqp_literal(tasks):
                        [Dst @ Zp, np.zeros((nps, ns), LD)],
                        [Dc @ Zp if ns else np.zeros((0, nz), LD), -np.eye(ns, dtype=LD)]])
         fv = np.concatenate([np.zeros(ns, LD), fst - Dst @ xp + wst, fc - Dc @ xp if ns else np.zeros(0, LD)])
+        if eps_reg:
+            H = H + LD(eps_reg) * np.eye(H.shape[0], dtype=LD)
+        if tau is not None:
+            c = LD(tau) * c; fv = np.where(fv < 0, LD(tau) * fv, fv)
         y, lam = solve_qp_certified(H, c, Dm, fv)
         z, w = y[:nz], y[nz:]
         x = xp + Zp @ z                                             # HoQp::getSolutions (HoQp.h:30-33)

@@ -94,3 +94,52 @@ def test_product_cascade_equals_literal_hoqp(blobs, oblobs, oracle, variant):
         assert list(st[k]) == [0, 0, 0], (k, st[k])
         assert_blocks(out[k], lit, "wbc", STRESS_TOL, "weak case %d mode %d" % (k, c["mode"]))
     itf.close()
+
+
+def _random_cascade(rng, n, shapes, active_frac=0.5):
+    """levels with `shapes` = [(equality rows, inequality rows), ...]; every inequality set has a strict interior around a common point x_c, and about half of each
+    level's soft rows are in conflict with the level's equality target (so slacks come out non-zero and lower levels meet them as hard rows)"""
+    xc = rng.normal(size=n)
+    tasks = []
+    for ma, md in shapes:
+        A = rng.normal(size=(ma, n)); b = A @ (xc + rng.normal(size=n))
+        D = rng.normal(size=(md, n)); margin = np.where(rng.uniform(size=md) < active_frac, -rng.uniform(0.1, 1.0, md), rng.uniform(0.1, 2.0, md))
+        f = D @ xc + margin            # negative margin: x_c itself violates the row -> the soft row is active / in conflict somewhere
+        tasks.append(dict(A=A, b=b, D=D, f=f))
+    return tasks
+
+
+# (the LAST level always has as many equality rows as dimensions are left: x is then unique without the 1e-12 regulariser — directions only it sees are noise / 1e-12)
+@pytest.mark.parametrize("shapes", [[(3, 5), (9, 4)],                        # inequality rows on levels 0 AND 1: the general level solve, always well posed
+                                     [(1, 6), (11, 5)],                       # a top level that is almost all inequalities
+                                     [(3, 5), (2, 4), (7, 0)],                # a third level below two levels with inequality rows: SURVEY a17's quirk (see below)
+                                     [(2, 4), (2, 6), (2, 3), (6, 0)]])
+def test_general_stacking_equals_literal_hoqp(shapes):
+    """HoQp.cpp:92-124 with OWN inequality rows below the first level — never produced by the shipped hierarchies, reachable by any WbcBase subclass: the oracle's
+    general level solve (slack kept as a variable, rows in buildDMatrix's order, current-first / previous-first stacking of rows and slack solutions) against the
+    cascade built literally and solved in 80-bit arithmetic with a KKT certificate (tests/hoqp_literal.py).
+    Below TWO levels with inequality rows the reference pairs the stacked rows (current level first, HoQp.cpp:46) with the stacked slack solutions (previous level
+    first, HoQp.cpp:152-158) wrongly; with a non-zero slack among them the level's problem can lose its feasible point — the literal solve then finds no KKT point
+    and the oracle reports status 3 (or 2 at the degenerate vertex).  Those cascades are counted, not compared; every cascade the literal solve certifies must agree."""
+    import pyoracle
+    from hoqp_literal import hoqp_literal
+    rng = np.random.default_rng(77 + len(shapes) + shapes[0][0])
+    worst = 0.0; compared = 0; ill_posed = 0; slack_below_top = 0
+    for rep in range(16):
+        tasks = _random_cascade(rng, 12, shapes)
+        x, st, it = pyoracle.hoqp(tasks)
+        try:
+            xl, levels = hoqp_literal(tasks)
+        except AssertionError:
+            ill_posed += 1
+            assert len(shapes) > 2 and (st != 0).any(), (rep, st)          # only the quirk makes a cascade ill posed, and the oracle says so
+            continue
+        if (st != 0).any():
+            ill_posed += 1; assert len(shapes) > 2, (rep, st); continue
+        compared += 1
+        worst = max(worst, float(np.abs(x - xl).max() / max(1.0, np.abs(xl).max())))
+        slack_below_top += sum(1 for k, lv in enumerate(levels) if k > 0 and lv["ns"] and float(np.abs(np.asarray(lv["w"], float)).max()) > 1e-6)
+    assert worst <= 1e-8, worst
+    assert compared >= (16 if len(shapes) == 2 else 3), (compared, ill_posed)
+    if len(shapes) == 2:
+        assert slack_below_top > 0                           # the general branch ran with active soft rows below level 0
