@@ -23,17 +23,18 @@ def summary():
 
 
 def kernel_source_hash():
-    """sha256 (first 16 hex digits) over the device + launch sources a counter profile depends on (csrc/kernels/*.h, csrc/host/*, include/*.h, file names included, sorted).
+    """sha256 (first 16 hex digits) over the device + launch sources a counter profile depends on: csrc/kernels/*.h, the launch sequences csrc/host/*_pipeline.h and
+    include/qmhip_layout.h (file names included, sorted) — not the C ABI glue or header comments, which cannot move a kernel's counters.
     tools/gpu_round_profile.sh records it next to the PMC passes, the digests stamp it into profiles/flops_pmc.json / hbm_traffic.json, and bench.py labels a roofline
     priced on counters of OTHER sources `stale`."""
     import hashlib
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for d in ("qm_control_amd/csrc/kernels", "qm_control_amd/csrc/host", "include"):
+    for d, keep in (("qm_control_amd/csrc/kernels", lambda f: f.endswith(".h")), ("qm_control_amd/csrc/host", lambda f: f.endswith("pipeline.h")), ("include", lambda f: f == "qmhip_layout.h")):
         full = os.path.join(root, d)
         for f in sorted(os.listdir(full)):
-            if f.endswith((".h", ".hip", ".cpp")):
+            if keep(f):
                 h.update((d + "/" + f + "\n").encode())
                 with open(os.path.join(full, f), "rb") as fh:
                     h.update(fh.read())
