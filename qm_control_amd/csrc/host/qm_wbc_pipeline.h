@@ -53,7 +53,7 @@ struct QmWbcPipeline {
   void step(const QmMpcBuffers& d, int B, double period, int variant, const double* rbd_dev = nullptr, const double* time_dev = nullptr) {
     QmWbcArgs a; a.mb = d.mb; a.st = d.st; a.B = B; a.x_des = w.x_des; a.u_des = w.u_des; a.rbd = w.rbd; a.mode = w.mode; a.time = w.time; a.period = period; a.variant = variant;
     a.input_last = w.input_last; a.out = w.out; a.qp_status = w.qp_status; a.scratch = w.scratch; a.dbg = w.dbg; a.stop = wbc_stop; if (rbd_dev) a.rbd = rbd_dev; if (time_dev) a.time = time_dev;
-    if (wbc_stop < 0) bk.launch(qm_wbc_prof_kernel, B, WBC_BLOCK, WBC_LDS_BYTES, a);   // instrumented instance: in-kernel cycle counters (profiling only)
+    if (wbc_stop != 0 || w.dbg) bk.launch(qm_wbc_prof_kernel, B, WBC_BLOCK, WBC_LDS_BYTES, a);   // instrumented instance: in-kernel cycle counters, early-return switches, debug records (profiling / parity tests)
     else bk.launch(qm_wbc_kernel, B, WBC_BLOCK, WBC_LDS_BYTES, a);   // one wavefront per instance
   }
 };

@@ -117,9 +117,9 @@ __device__ __forceinline__ void grid_policy_segment(const double* node_t, const 
 }
 
 // K0b: per (node, instance): interval start/duration, mode, swing-z references, reference interpolation, cold start
-// 64 registers: the WBC of the previous step runs beside this kernel on its own stream with 448 of a SIMD's 512 registers allocated (441 rounded up to the
-// allocation granule of 8) — a wave of this kernel must fit into what is left or the whole launch waits for WBC wavefronts to retire
-__global__ void QM_MAX_VGPRS(64) qm_grid_nodes_kernel(QmGridArgs a) {
+// 72 registers: the WBC of the previous step runs beside this kernel on its own stream with 440 of a SIMD's 512 registers allocated (437 rounded up to the
+// allocation granule of 8) — a wave of this kernel must fit into what is left or the whole launch waits for WBC wavefronts to retire (tests/test_kernel_budgets.py)
+__global__ void QM_MAX_VGPRS(72) qm_grid_nodes_kernel(QmGridArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = g / a.B, b = g - i * a.B;
   if (i >= a.nmax) return;

@@ -645,7 +645,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
     for (int i = 0; i < 3; ++i) { baseAcc[i] = rate[i] / m - t[i]; baseAcc[3 + i] = thdd[i]; }
   }
   qm_wave_sync();
-  if (a.stop == 1) return;
+  if (PROF && a.stop == 1) return;
   WT(0)
   // ---- cascade ----
   double* A = S + WL_AZ; double* bb = S + WL_BB; double* AZ = S + WL_AZ; double* Zp = S + WL_ZP; double* x = S + WL_X; double* z = S + WL_Z; double* zn = S + WL_ZN; double* p = S + WL_P;
@@ -905,9 +905,9 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
       if (PROF && a.stop == -4 && l == 0) gs[WS_TIME + 12 + level] = (double)it;      // profiling: active-set iterations of this level
     }
     wv_Z_times(Zp, n, z, Zz);
-    if (l < WNV) { x[l] += Zz[l]; if (a.dbg) a.dbg[(size_t)b * WBC_DBG_SIZE + 126 + level * WNV + l] = x[l]; }
+    if (l < WNV) { x[l] += Zz[l]; if (PROF && a.dbg) a.dbg[(size_t)b * WBC_DBG_SIZE + 126 + level * WNV + l] = x[l]; }
     qm_wave_sync();
-    if (a.stop == 2 + level) return;
+    if (PROF && a.stop == 2 + level) return;
     WT(10)
     if (level < 2) nz = (level == 0) ? wv_null_space<WNV, PROF>(S, ra, n, tnull) : wv_null_space<WVLD, PROF>(S, ra, n, tnull + 5);
     WT(7)
@@ -924,7 +924,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
   if (PROF && a.stop == -2 && l == 0) for (int k = 0; k < 9; ++k) gs[WS_TIME + k] = (double)tfine[k];
   if (PROF && a.stop == -3 && l == 0) for (int k = 0; k < 10; ++k) gs[WS_TIME + k] = (double)tnull[k];
 #undef WT
-  if (a.dbg) {
+  if (PROF && a.dbg) {
     double* d = a.dbg + (size_t)b * WBC_DBG_SIZE;
     if (l < 24) { d[l] = q[l]; d[24 + l] = v[l]; d[48 + l] = qd[l]; d[72 + l] = vd[l]; d[102 + l] = nle[l]; }
     if (l < 6) d[96 + l] = baseAcc[l];
