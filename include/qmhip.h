@@ -151,14 +151,26 @@ int qmhip_policy_eval(qmhip_ctx* ctx, int B, const double* t, double* x_des /*[B
  *      than the level's null space (a degenerate vertex).  `variant` selects one of the two hierarchies the reference ships; both put inequality rows into their first
  *      level only, and the cascade kernel is specialised to that shape (slack eliminated analytically at level 0, hard rows below).  The GENERAL stacking of
  *      HoQp.cpp:92-124 — own inequality rows at a lower level, with the reference's current-first / previous-first pairing of stacked rows and slack solutions — cannot
- *      be requested through this ABI (there is no third variant); it is restated in the oracle (oracle/src/wbc.h: solveHoLevel) and pinned against the literal cascade
- *      (tests/test_hoqp_literal.py::test_general_stacking_equals_literal_hoqp).  A WbcBase subclass with another hierarchy is another kernel, not a runtime option.
+ *      is what qmhip_hoqp_solve below offers on explicit task matrices (a generic kernel); restated in the oracle (oracle/src/wbc.h: solveHoLevel) and pinned against
+ *      the literal cascade (tests/test_hoqp_literal.py).
  *      The joint-acceleration state `inputLast_` (WbcBase.cpp:212-213) lives in the context per instance;
  *      qmhip_wbc_reset zeroes it.  The call enqueues on the context's WBC stream only and waits for that stream only (pinned staging, asynchronous copies). */
 int qmhip_wbc_step(qmhip_ctx* ctx, int B, const double* x_des, const double* u_des, const double* rbd_meas /*[B][55]*/,
                    const int32_t* mode, double period, const double* time /*[B]*/, int variant,
                    double* out /*[B][54]*/, int32_t* qp_status /*[B][3]*/);
 int qmhip_wbc_reset(qmhip_ctx* ctx);
+
+/* ---- qm::HoQp on ARBITRARY task hierarchies: replaces the cascade HoQp(task_k, HoQp(task_k-1, ...)) + getSolutions() of qm_wbc/include/qm_wbc/HoQp.h:17-36 /
+ *      qm_wbc/src/HoQp.cpp:12-158 for a WbcBase subclass that stacks its tasks differently from the two shipped hierarchies — the general stacking, own inequality
+ *      rows below the first level included, with the reference's pairing of stacked rows (current level first, HoQp.cpp:46) and stacked slack solutions (previous
+ *      levels first, HoQp.cpp:152-158).  B independent cascades of ONE shape: n decision variables (<= 36), n_levels (<= 8) tasks from the highest priority down with
+ *      ma[k] equality rows A x = b (<= 36) and md[k] inequality rows D x <= f (<= 64; <= 128 over all levels); arrays instance-major, the levels concatenated:
+ *      A [B][sum ma][n], b [B][sum ma], D [B][sum md][n], f [B][sum md].  x [B][n] = getSolutions() of the last level; status [B][n_levels]: 0 ok, 1 iteration limit
+ *      (qpOASES' nWSR = 100), 2 working set larger than the problem (degenerate vertex), 3 the higher levels' rows do not hold at the previous solution (the
+ *      row / slack pairing quirk with inequality rows on two higher levels and a non-zero slack: the reference would hand qpOASES that problem and ignore the return
+ *      code).  A generic kernel (dense factorisations on a per-problem workspace, one wavefront per problem): not on the benchmark's path. */
+int qmhip_hoqp_solve(qmhip_ctx* ctx, int B, int n_levels, int n, const int32_t* ma, const int32_t* md,
+                     const double* A, const double* b, const double* D, const double* f, double* x /*[B][n]*/, int32_t* status /*[B][n_levels]*/);
 
 /* ---- whole control step on resident data (benchmark "step"): SQP iteration + policy evaluation at t0 + WBC with
  *      the measured state built from x0 (zero velocities, EE pose by FK) */

@@ -21,7 +21,7 @@ MB_SIZE, ST_SIZE = L.MB_SIZE, L.ST_SIZE
 EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_create_wbc_context", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
            "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_update_references", "qmhip_mpc_solve_resident_warm",
            "qmhip_mpc_advance_resident", "qmhip_closed_loop_resident", "qmhip_mpc_download", "qmhip_policy_eval",
-           "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
+           "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_hoqp_solve", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
            "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_debug_get", "qmhip_debug_filler", "qmhip_debug_lq_with_filler", "qmhip_microbench_fp64",
            "qmhip_gait_set_templates", "qmhip_gait_reset", "qmhip_gait_insert_template", "qmhip_gait_update_resident", "qmhip_gait_download", "qmhip_schedule_download",
            "qmhip_target_reset", "qmhip_target_from_command", "qmhip_target_download",
@@ -269,6 +269,28 @@ class HierarchicalWbc:
         out = np.zeros((B, 54)); st = np.zeros((B, 3), np.int32)
         self.itf._check(self.lib.qmhip_wbc_download(self.itf.h, B, _p(out), _pi(st)), "qmhip_wbc_download")
         return out, st
+
+
+class HoQp:
+    """qm::HoQp-shaped front of the general cascade (qm_wbc/include/qm_wbc/HoQp.h:17-36): tasks from the highest priority down, every task dict(A, b, D, f) with
+    arrays [B][rows][n] / [B][rows] (or without the batch axis for one problem); getSolutions() of the last level and the per-level status"""
+
+    def __init__(self, interface):
+        self.itf = interface; self.lib = interface.lib
+
+    def solve(self, tasks):
+        first = np.asarray(tasks[0]["A"] if np.asarray(tasks[0]["A"]).size else tasks[0]["D"], float)
+        single = first.ndim == 2
+        n = first.shape[-1]
+        arr = lambda t, k, w: np.asarray(t[k], float).reshape((1, -1, n) if w else (1, -1)) if single else np.asarray(t[k], float).reshape((len(np.asarray(t[k])), -1, n) if w else (len(np.asarray(t[k])), -1))
+        As = [arr(t, "A", True) for t in tasks]; bs = [arr(t, "b", False) for t in tasks]; Ds = [arr(t, "D", True) for t in tasks]; fs = [arr(t, "f", False) for t in tasks]
+        B = max(a.shape[0] for a in As + Ds)
+        ma = np.array([a.shape[1] for a in As], np.int32); md = np.array([d.shape[1] for d in Ds], np.int32)
+        A = _f(np.concatenate(As, axis=1)) if ma.sum() else np.zeros(1); b = _f(np.concatenate(bs, axis=1)) if ma.sum() else np.zeros(1)
+        D = _f(np.concatenate(Ds, axis=1)) if md.sum() else np.zeros(1); f = _f(np.concatenate(fs, axis=1)) if md.sum() else np.zeros(1)
+        x = np.zeros((B, n)); st = np.zeros((B, len(tasks)), np.int32)
+        self.itf._check(self.lib.qmhip_hoqp_solve(self.itf.h, B, len(tasks), n, _pi(ma), _pi(md), _p(A), _p(b), _p(D), _p(f), _p(x), _pi(st)), "qmhip_hoqp_solve")
+        return (x[0], st[0]) if single else (x, st)
 
 
 class QMHWSim:

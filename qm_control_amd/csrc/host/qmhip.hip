@@ -14,6 +14,7 @@
 #include "qm_wbc_pipeline.h"
 #include "qm_sim_pipeline.h"
 #include "qm_front_pipeline.h"
+#include "qm_hoqp_pipeline.h"
 
 static thread_local std::string g_create_error;      // per calling thread: qmhip_last_error(NULL) is the error of THIS thread's last failed create
 
@@ -40,7 +41,7 @@ struct HipBackend {
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
     if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel || p == (const void*)qm_lq_dbg_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel || p == (const void*)qm_riccati_prof_kernel) return "riccati";
-    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_ilqr_rollout_kernel) return "rollout"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy";
+    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_ilqr_rollout_kernel) return "rollout"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy"; if (p == (const void*)qm_hoqp_kernel) return "hoqp";
     return "ls_misc";
   }
   template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {
@@ -91,7 +92,7 @@ struct HipBackend {
 struct qmhip_ctx {
   int device = 0, max_batch = 0, max_nodes = 0, max_ref = 0, max_ev = 0;
   double mb[MB_SIZE], st[ST_SIZE];
-  HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc; QmFrontPipeline<HipBackend> front; QmSimPipeline<HipBackend> sim;
+  HipBackend bk; QmMpcPipeline<HipBackend> mpc; QmWbcPipeline<HipBackend> wbc; QmFrontPipeline<HipBackend> front; QmSimPipeline<HipBackend> sim; QmHoqpPipeline<HipBackend> hoqp;
   std::recursive_mutex mu;      // serialises the entry points of this context
   bool wbc_only = false;        // created by qmhip_create_wbc_context: carries the model + the WBC buffers, no horizon buffers
   char* tick_pin = nullptr;     // pinned host staging of the control-tick path (qmhip_wbc_step): [inputs of max_batch instances | outputs]
@@ -99,7 +100,7 @@ struct qmhip_ctx {
   double* filler_out = nullptr; int filler_cap = 0;      // output of the profiling-only filler kernel (co-residency probe)
   bool filler_buffer(int waves) { if (filler_cap >= waves) return true; if (filler_out) hipFree(filler_out); filler_out = nullptr; filler_cap = 0;
                                   if (hipMalloc(&filler_out, (size_t)waves * 64 * 8) != hipSuccess) return false; filler_cap = waves; return true; }
-  qmhip_ctx() : mpc(bk), wbc(bk), front(bk), sim(bk) {}
+  qmhip_ctx() : mpc(bk), wbc(bk), front(bk), sim(bk), hoqp(bk) {}
   void fail(const std::string& m) { error = m; }
   // getModeSchedule on the device GaitSchedule -> the solver's schedule buffers; from here on its sticky status speaks for the schedule of this batch (until the host supplies one)
   void gait_schedule(int B, double horizon) { front.gait_schedule(mpc.d, B, horizon); mpc.front_status = front.f.gs_status; mpc.front_B = B; }
@@ -192,7 +193,7 @@ int qmhip_create_wbc_context(const qmhip_ctx* c, int max_batch, qmhip_ctx** out)
   return create_common(c->mb, c->st, c->device, max_batch, 3, 1, 1, out, true);      // same model / settings values, own device copies, own streams: nothing mutable is shared
 }
 void qmhip_destroy(qmhip_ctx* c) {
-  if (!c) return; hipSetDevice(c->device); c->bk.sync(); if (c->filler_out) hipFree(c->filler_out); if (c->tick_pin) hipHostFree(c->tick_pin); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release();
+  if (!c) return; hipSetDevice(c->device); c->bk.sync(); if (c->filler_out) hipFree(c->filler_out); if (c->tick_pin) hipHostFree(c->tick_pin); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); c->hoqp.release();
   for (auto e : c->bk.pool) hipEventDestroy(e); if (c->bk.ev_order) hipEventDestroy(c->bk.ev_order); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
 }
 const char* qmhip_last_error(const qmhip_ctx* c) { QM_GUARD(c); return c ? c->error.c_str() : g_create_error.c_str(); }
@@ -360,6 +361,14 @@ int qmhip_wbc_step(qmhip_ctx* c, int B, const double* xd, const double* ud, cons
   bk.check(hipStreamSynchronize(sb), "sync");
   if (out) memcpy(out, h_out, (size_t)B * QM_NWBC_OUT * 8); if (qps) memcpy(qps, h_qps, (size_t)B * 3 * 4);
   return c->hipstate();
+}
+// qm::HoQp on arbitrary task hierarchies (HoQp.h:17-36): B independent cascades of the same shape, solved by the general kernel (k_hoqp.h)
+int qmhip_hoqp_solve(qmhip_ctx* c, int B, int n_levels, int n, const int32_t* ma, const int32_t* md, const double* A, const double* b, const double* D, const double* f, double* x, int32_t* status) { QM_GUARD(c);
+  if (!c || B <= 0 || !ma || !md || !x || !status || !QmHoqpPipeline<HipBackend>::shapes_ok(n_levels, n, ma, md)) {
+    if (c) c->fail("qmhip_hoqp_solve: bad argument (1 <= n <= 36 variables, <= 8 levels, <= 36 equality and <= 64 inequality rows per level, <= 128 inequality rows in total)"); return QMHIP_ERR_ARG; }
+  int sa = 0, sd = 0; for (int k = 0; k < n_levels; ++k) { sa += ma[k]; sd += md[k]; }
+  if ((sa && (!A || !b)) || (sd && (!D || !f))) { c->fail("qmhip_hoqp_solve: null task array"); return QMHIP_ERR_ARG; }
+  hipSetDevice(c->device); c->hoqp.solve(B, n_levels, n, ma, md, A, b, D, f, x, status); return c->hipstate();
 }
 int qmhip_wbc_download(qmhip_ctx* c, int B, double* out, int32_t* qps) { QM_GUARD(c);
   if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG; hipSetDevice(c->device);

@@ -5,6 +5,7 @@
 #include "../../qm_control_amd/csrc/host/qm_wbc_pipeline.h"
 #include "../../qm_control_amd/csrc/host/qm_sim_pipeline.h"
 #include "../../qm_control_amd/csrc/host/qm_front_pipeline.h"
+#include "../../qm_control_amd/csrc/host/qm_hoqp_pipeline.h"
 
 struct EmuBackend {
   template <class K, class A> void launch(K kernel, int grid, int block, size_t, const A& args) { emu::launch(dim3(grid), dim3(block), [&]() { kernel(args); }); }
@@ -109,6 +110,11 @@ void emu_target_download(void* h, int B, double* rt, double* rx, double* last) {
   EmuCtx* c = (EmuCtx*)h; memcpy(rt, c->mpc.d.ref_t, (size_t)B * c->mpc.d.nref * 8); memcpy(rx, c->mpc.d.ref_x, (size_t)B * c->mpc.d.nref * QM_NREF * 8); memcpy(last, c->front.f.last_ee, (size_t)B * 7 * 8);
 }
 // device math helpers on the host (tests/test_device_math.py)
+// qmhip_hoqp_solve on the host emulator: the general HoQp kernel (k_hoqp.h)
+int emu_hoqp(int B, int n_levels, int n, const int* ma, const int* md, const double* A, const double* b, const double* D, const double* f, double* x, int* status) {
+  if (!QmHoqpPipeline<EmuBackend>::shapes_ok(n_levels, n, ma, md)) return -1;
+  EmuBackend bk; QmHoqpPipeline<EmuBackend> h(bk); h.solve(B, n_levels, n, ma, md, A, b, D, f, x, status); h.release(); return 0;
+}
 void emu_sincos(int n, const double* x, double* sn, double* cs) { for (int i = 0; i < n; ++i) qm_sincos(x[i], sn[i], cs[i]); }
 void emu_frcp(int n, const double* x, double* r) { for (int i = 0; i < n; ++i) r[i] = qm_frcp(x[i]); }
 void emu_log(int n, const double* x, double* r) { for (int i = 0; i < n; ++i) r[i] = qm_log(x[i]); }

@@ -204,3 +204,16 @@ class Emu:
         out = np.zeros((B, 54)); st = np.zeros((B, 3), np.int32); rbd = np.zeros((B, 55))
         self.lib.emu_control_step(self.h, C.c_int(B), C.c_double(cfg["horizon"]), C.c_double(cfg["period"]), C.c_double(cfg["time"]), _p(out), _pi(st), _p(rbd))
         return out, st, rbd
+
+
+def hoqp(tasks):
+    """the product's general HoQp kernel (csrc/kernels/k_hoqp.h, behind qmhip_hoqp_solve) on the host emulator: one cascade, tasks = [dict(A, b, D, f), ...]"""
+    build(); lib = C.CDLL(_LIB)
+    n = int(np.asarray(tasks[0]["A"]).shape[1]) if np.asarray(tasks[0]["A"]).size else int(np.asarray(tasks[0]["D"]).shape[1])
+    ma = np.array([np.asarray(t["A"]).reshape(-1, n).shape[0] for t in tasks], np.int32); md = np.array([np.asarray(t["D"]).reshape(-1, n).shape[0] for t in tasks], np.int32)
+    cat = lambda k: np.ascontiguousarray(np.concatenate([np.asarray(t[k], float).ravel() for t in tasks] + [np.zeros(1)]))
+    A, b, D, f = cat("A"), cat("b"), cat("D"), cat("f")
+    x = np.zeros(n); st = np.zeros(len(tasks), np.int32)
+    rc = lib.emu_hoqp(C.c_int(1), C.c_int(len(tasks)), C.c_int(n), _pi(ma), _pi(md), _p(A), _p(b), _p(D), _p(f), _p(x), _pi(st))
+    assert rc == 0
+    return x, st
