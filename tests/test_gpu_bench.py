@@ -16,9 +16,10 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _check_line(line, world, B, K, W):
+def _check_line(line, world, B, K, W, scaling="weak"):
     assert line["metric"].startswith("MPC+WBC control steps/sec") and line["unit"] == "steps/s" and line["dtype"] == "f64" and line["data"] == "synthetic"
-    assert line["n_gpus"] == world and line["steps"] == K and line["warmup"] == W and line["scaling"] == "weak" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["n_gpus"] == world and line["steps"] == K and line["warmup"] == W and line["scaling"] == scaling and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["config"]["global_batch"] == world * B and line["roofline"]["counters"]["flops_pmc"] in ("current", "stale", None)
     assert line["config"]["all_status_ok"] and line["config"]["instances_per_gpu"] == B and line["config"]["engine"] == "hip"
     assert abs(line["value"] - world * B * K / (line["ms_per_step"] * K / 1e3)) <= 1e-6 * line["value"]
     r = line["roofline"]
@@ -26,16 +27,17 @@ def _check_line(line, world, B, K, W):
     assert len(line["per_rank"]["seconds"]) == world
 
 
-def test_bench_rccl_branch_world_1():
+@pytest.mark.parametrize("mode", ["weak", "strong"])
+def test_bench_rccl_branch_world_1(mode):
     B, K, W = 64, 2, 1
     env = dict(os.environ, QM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(K), "--warmup", str(W), "--batch", str(B), "--no-cpu-baseline", "--no-secondary"]
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(K), "--warmup", str(W)] + (["--batch", str(B)] if mode == "weak" else ["--global-batch", str(B)]) + ["--no-cpu-baseline", "--no-secondary"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    _check_line(json.loads(lines[0]), 1, B, K, W)
+    _check_line(json.loads(lines[0]), 1, B, K, W, mode)
 
 
 def test_bench_default_line_with_secondaries_and_cpu_baseline():
@@ -52,3 +54,8 @@ def test_bench_default_line_with_secondaries_and_cpu_baseline():
     assert line["latency_ms"]["B1_C2"] > 0 and line["latency_ms"]["C2_status_ok"]
     c5 = line["config_C5"]; assert c5["all_status_ok"] and c5["value"] > 0
     assert line["closed_loop_warm_start"]["all_status_ok"] and line["closed_loop_plant"]["all_status_ok"]
+    # round 3: per-block parity figure, GPU counterparts of the reference's two timers, the strong-scaling point of SURVEY.md §8(d) C4
+    assert set(cb["parity_on_sample"]) == {"vdot", "contact_forces", "torques"} and max(cb["parity_on_sample"].values()) < 1e-6
+    sg = line["single_instance_ms_gpu"]; assert 0 < sg["wbc_ms_B1"] < sg["mpc_ms_B1"] < 50
+    ss = line["strong_scaling_C4"]; assert ss["scaling"] == "strong" and ss["global_batch"] == 8192 and ss["instances_per_gpu"] == 8192 and ss["value"] > 0
+    assert ss["instances_with_nonzero_mpc_status"] <= 8 and ss["instances_with_nonzero_wbc_status"] <= 8
