@@ -24,15 +24,17 @@ struct EmuBackend {
   void copy_dd(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 };
 
-struct EmuCtx { EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; QmSimPipeline<EmuBackend> sim; EmuCtx() : mpc(bk), wbc(bk), front(bk), sim(bk) {} };
+struct EmuCtx { double* lqdbg_stash = nullptr; EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; QmSimPipeline<EmuBackend> sim; EmuCtx() : mpc(bk), wbc(bk), front(bk), sim(bk) {} };
 
 extern "C" {
 void* emu_create(const double* mb, const double* st, int Bmax, int nmax, int nref, int nev) {
   EmuCtx* c = new EmuCtx(); c->mpc.allocate(mb, st, Bmax, nmax, nref, nev, true); c->wbc.allocate(Bmax, true); c->front.allocate(Bmax); c->front.phase_transition_stance_time = st[ST_PHASE_TRANS_STANCE]; return c;
 }
 void emu_set_solver(void* h, int solver) { ((EmuCtx*)h)->mpc.solver = solver; }      // 0 SQP, 1 discrete iLQR (qmhip_set_setting(ST_SOLVER, .))
+// 0: run the PRODUCT instance of the LQ kernel (qm_lq_kernel: no debug records, no cycle stamps); 1 (default): qm_lq_dbg_kernel.  qmhip_debug_set("lq_debug", .)
+void emu_set_lq_debug(void* h, int on) { EmuCtx* c = (EmuCtx*)h; if (!c->lqdbg_stash) c->lqdbg_stash = c->mpc.d.lqdbg; c->mpc.d.lqdbg = on ? c->lqdbg_stash : nullptr; }
 void emu_set_riccati_skip(void* h, int mask) { ((EmuCtx*)h)->mpc.riccati_skip = mask; }      // qmhip_debug_set("riccati_skip", .): 20 leaves K1b's stage records untouched
-void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); delete c; }
+void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; if (c->lqdbg_stash) c->mpc.d.lqdbg = c->lqdbg_stash; c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); delete c; }
 int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes, double horizon, int max_trials) {
   EmuCtx* c = (EmuCtx*)h;
   c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes);

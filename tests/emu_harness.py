@@ -54,6 +54,10 @@ class Emu:
     def set_solver(self, solver):
         self.lib.emu_set_solver(self.h, C.c_int(solver))
 
+    def set_lq_debug(self, on):
+        """False: the PRODUCT instance of the LQ kernel runs (qm_lq_kernel: no debug records); True (default): qm_lq_dbg_kernel"""
+        self.lib.emu_set_lq_debug(self.h, C.c_int(int(bool(on))))
+
     def set_riccati_skip(self, mask):
         """profiling / parity switch of the product (qmhip_debug_set "riccati_skip"): 16 | 4 = no backward stage, no rollout -> the stage records stay as K1b wrote them"""
         self.lib.emu_set_riccati_skip(self.h, C.c_int(mask))

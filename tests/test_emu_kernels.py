@@ -182,3 +182,27 @@ def test_lq_records_entrywise(blobs, oracle, name, N, skip):
             worst[k] = max(worst.get(k, 0.0), v)
     bad = {k: v for k, v in worst.items() if not v <= 1e-10}
     assert not bad, (bad, worst)
+
+
+@pytest.mark.parametrize("name,N", [("C2", 26), ("C5", 40), ("C1", 12)])
+def test_product_instances_match_the_instrumented_ones(blobs, oracle, name, N):
+    """the LQ and Riccati kernels exist in two instances of one body each — the product's (qm_lq_kernel, qm_riccati_kernel) and the instrumented one the entrywise tests
+    read (qm_lq_dbg_kernel with debug records; qm_riccati_prof_kernel, here with skip = 32: counters on, results intact).  Same stage records (bit for bit, apart from the
+    fields only the debug instance writes) and the same solution."""
+    import emu_harness, lq_record_check as LC
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config(name, batch=1, n_intervals=N)
+    r = _oracle(oracle, cfg); n = len(r["t"])
+    outs = []
+    for dbg, skip in ((True, 32), (False, 0)):
+        e = emu_harness.Emu(blobs[0], blobs[1], 1, n + 3, 2, cfg["ev"].shape[1]); e.set_lq_debug(dbg); e.set_riccati_skip(skip)
+        e.mpc_step(cfg)
+        outs.append((np.stack([e.stage(0, i) for i in range(n)]), e.node_arr("xs", 30)[:n, 0].copy(), e.node_arr("us", 30)[:n, 0].copy(), e.buf("out_perf", (10,)).copy()))
+    keep = np.ones(LC.SR["SR_SIZE"], bool); keep[LC.SR["SR_PU"]:LC.SR["SR_BPV"]] = False; keep[LC.SR["SR_K"]:LC.SR["SR_K"] + 32] = False      # Pu: debug instance only; SR_K head: cycle stamps
+    px = np.zeros((30, 30), bool); px[12:24] = True; keep[LC.SR["SR_PX"]:LC.SR["SR_PX"] + 900] = px.ravel()                                   # the zero rows of Px likewise
+    for i in range(n - 1):
+        if r["ev"][i] == 1:
+            continue
+        assert np.array_equal(outs[1][0][i][keep], outs[0][0][i][keep]), (i, np.nonzero(outs[1][0][i][keep] != outs[0][0][i][keep])[0][:10])
+    assert np.array_equal(outs[1][1], outs[0][1]) and np.array_equal(outs[1][2], outs[0][2]) and np.array_equal(outs[1][3], outs[0][3])
+    assert_blocks(outs[1][1], r["x"], "x", TOL); assert_blocks(outs[1][2], r["u"], "u", TOL)

@@ -39,4 +39,9 @@ def test_lq_and_stage_records_entrywise(blobs, oracle, name):
     res_dbg = mpc.download()
     mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"]); mpc.solve_resident(cfg["horizon"]); res = mpc.download()
     assert np.array_equal(res["x"], res_dbg["x"]) and np.array_equal(res["u"], res_dbg["u"])
+    # ... and the instrumented Riccati instance (skip = 32: cycle counters on, results intact) returns what the product instance returns
+    itf.debug_set("riccati_skip", 32)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"]); mpc.solve_resident(cfg["horizon"]); res_prof = mpc.download()
+    itf.debug_set("riccati_skip", 0)
+    assert np.array_equal(res["x"], res_prof["x"]) and np.array_equal(res["u"], res_prof["u"])
     itf.close()
