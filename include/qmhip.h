@@ -59,10 +59,11 @@ int qmhip_set_setting(qmhip_ctx* ctx, int settings_index, double value);   /* e.
  *      input trajectories (primal solution: input of event nodes copied from the previous node, last input repeated),
  *      perf[10] = baseline{merit,cost,dynSSE,eqSSE}, after-step{...}, step size alpha, armijo metric.
  *      status[b]: 0 ok, -1 node buffer too small, -2 swing phase not enclosed by stance in the schedule, -4 Riccati not PD.
- *      Solver slot (qmhip_set_setting(ST_SOLVER, .)): 0 the SQP above; 1 a discrete iLQR on the `ddp` block (task.info:33-71); 2 the multiple-shooting IPM on the `ipm`
- *      block (task.info:94-125) — this OCP has no hard inequality constraints (QMInterface.cpp:79-142: friction cones and joint limits are soft costs), so there are no
- *      slack / dual variables and the iteration is the multiple-shooting step run with ipm.dt / ipmIteration / deltaTol / g_max / g_min (ST_IPM_*).  The reference loads both
- *      blocks (QMInterface.cpp:70-72) and instantiates neither solver. */
+ *      Solver slot (qmhip_set_setting(ST_SOLVER, .)): 0 the SQP above; 1 a discrete iLQR on the `ddp` block (task.info:33-71); 2 the SAME multiple-shooting step as
+ *      slot 0, run with the `ipm` block's parameters (task.info:94-125: ipm.dt / ipmIteration / deltaTol / g_max / g_min, ST_IPM_*).  Slot 2 is NOT an interior-point
+ *      method: this OCP has no hard inequality constraints (QMInterface.cpp:79-142 registers friction cones and joint limits as soft costs), so an IpmMpc in the MPC_BASE
+ *      slot would carry no slack / dual variables; a hard-friction-cone IPM is out of scope.  The reference loads both blocks (QMInterface.cpp:70-72) and
+ *      instantiates neither solver. */
 int qmhip_mpc_step(qmhip_ctx* ctx, int B, const double* t0, const double* x0 /*[B][30]*/,
                    int n_ref, const double* ref_t /*[B][n_ref]*/, const double* ref_x /*[B][n_ref][37]*/,
                    int n_events, const double* event_times /*[B][n_events]*/, const int32_t* modes /*[B][n_events+1]*/,

@@ -96,7 +96,7 @@
 #define ST_KP_EE_ANG  1024  /* [3] */
 #define ST_KD_EE_ANG  1027  /* [3] */
 /* discrete iLQR behind the same MPC entry points (settings block `ddp`, task.info:33-71, loaded at QMInterface.cpp:70) */
-#define ST_SOLVER     1030  /* 0: multiple-shooting SQP (what QMController instantiates, QMController.cpp:287-288), 1: discrete iLQR, 2: multiple-shooting IPM (the `ipm` block); set through qmhip_set_setting */
+#define ST_SOLVER     1030  /* 0: multiple-shooting SQP (what QMController instantiates, QMController.cpp:287-288), 1: discrete iLQR, 2: the same multiple-shooting step on the `ipm` block's parameters (NOT an interior-point method, see below); set through qmhip_set_setting */
 #define ST_DDP_MIN_STEP 1031 /* ddp.lineSearch.minStepLength (task.info:66)                              */
 #define ST_DDP_MAX_STEP 1032 /* ddp.lineSearch.maxStepLength (task.info:67)                              */
 #define ST_DDP_PENALTY  1033 /* ddp.constraintPenaltyInitialValue (task.info:56)                         */

@@ -48,7 +48,7 @@ struct QmMpcPipeline {
   int ls_trials_run = 0;
   int riccati_skip = 0;   // profiling only
   int lq_prof = 0;        // profiling only
-  int solver = 0;         // 0: multiple-shooting SQP (the reference's SqpMpc), 1: discrete iLQR, 2: multiple-shooting IPM = the SQP path on the `ipm` block's parameters
+  int solver = 0;         // 0: multiple-shooting SQP (the reference's SqpMpc), 1: discrete iLQR, 2: the SQP path run on the `ipm` block's parameters (not an interior-point method)
                           // (no hard inequality rows in this OCP: include/qmhip_layout.h, ST_IPM_*); settings slot ST_SOLVER
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)

@@ -274,6 +274,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
   const int b = blockIdx.x / a.ncap, i = blockIdx.x - b * a.ncap;
   const int nb = i * a.B + b;                       // node-major index
+  // instrumented instance, profiling on: wave entry in shader-clock cycles and in ticks of the constant 100 MHz reference clock (tools/lq_residency_probe.py)
+  const long long c0_ = (DBG && a.prof) ? (long long)__builtin_readcyclecounter() : 0; const long long r0_ = (DBG && a.prof) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   double* rec = a.stage + ((size_t)b * a.nmax + i) * SR_SIZE;
   double* dbg = (DBG && a.dbg) ? a.dbg + ((size_t)b * a.nmax + i) * LQ_DBG_SIZE : nullptr;
@@ -673,6 +675,11 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   if (l == 0) { rec[SR_SCAL] = (double)m; rec[SR_SCAL + 1] = ctot + rpe; }
   LQT()
   if (DBG && a.prof && l == 0) for (int k = 0; k + 1 < np_ && k < 9; ++k) rec[SR_K + k] = (double)(tp_[k + 1] - tp_[k]);
+  // [9] wave lifetime in cycles (entry -> all stores acknowledged), [10] the same in 10 ns ticks, [11], [12] entry / exit tick, [13], [14] HW_ID / XCC_ID of the slot,
+  // [15] entry -> first stamp, [16] last stamp -> vmcnt 0: clock under load, resident waves per SIMD, slot gaps, prologue and store-drain shares
+  if (DBG && a.prof && l == 0) { __builtin_amdgcn_s_waitcnt(0); const long long c1_ = (long long)__builtin_readcyclecounter(); const long long r1_ = (long long)__builtin_amdgcn_s_memrealtime();
+    rec[SR_K + 9] = (double)(c1_ - c0_); rec[SR_K + 10] = (double)(r1_ - r0_); rec[SR_K + 11] = (double)r0_; rec[SR_K + 12] = (double)r1_;
+    rec[SR_K + 13] = (double)__builtin_amdgcn_s_getreg(63492); rec[SR_K + 14] = (double)__builtin_amdgcn_s_getreg(63508); rec[SR_K + 15] = (double)(tp_[0] - c0_); rec[SR_K + 16] = (double)(c1_ - tp_[np_ - 1]); }
 #undef LQT
 }
 __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) { qm_lq_body<false>(a); }

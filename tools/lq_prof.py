@@ -12,5 +12,5 @@ mpc.solve_resident(cfg["horizon"]); itf.synchronize()
 nm = 128; SR = 5312
 stage = itf.debug_read("stage", (B * nm, SR))
 rows = stage[np.arange(B)[:, None] * nm + np.arange(5, 95)[None, :]].reshape(-1, SR)[:, 4752:4761]
-ln = ["P0 stage inputs", "I jacobian columns", "I RK2 composition", "II constraint rows", "II projector", "II projected dynamics", "III cost model", "III projected cost + stores"]
-print(json.dumps({n: float(rows[:, i].mean()) for i, n in enumerate(ln)}, indent=1)); print("LQ total cycles/node", rows[:, :8].sum(1).mean())
+ln = ["P0 stage inputs", "I jacobian columns", "I RK2 composition", "II constraint rows", "II projector", "II projected dynamics", "III cost model (input / state terms, barriers)", "III EE term, [Q | q], R assembly", "III projected cost + stores"]
+print(json.dumps({n: float(rows[:, i].mean()) for i, n in enumerate(ln)}, indent=1)); print("LQ cycles/node between the first and the last stamp", rows[:, :9].sum(1).mean())
