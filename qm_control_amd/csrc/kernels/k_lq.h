@@ -151,7 +151,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
       for (int J = 0; J < MT; ++J)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; const double* src = T + ci0[J] * LW_TLD + row; Bp[I][J][r] = cw[J][0] * src[0] + cw[J][1] * src[LW_TLD] + cw[J][2] * src[2 * LW_TLD]; }
-    qm_frag_store<2, MT>(Bp, rec + SR_BP, QM_MMAX, 12, m); }        // rows 0..11 only: a joint row is dt Pu[j], K3 rebuilds it (k_riccati.h)
+    qm_frag_store<2, MT, true>(Bp, rec + SR_BP, QM_MMAX, 12, m); }        // rows 0..11 only: a joint row is dt Pu[j], K3 rebuilds it (k_riccati.h)
   // [R Px | R Pe + r]: Px rows 12..23 (k-steps 3..5); Pe also has rows 0..11 (column 30 only -> tile column 1, k-steps 0..2)
   qm_d4 RPx[2][2]; qm_frag_zero<2, 2>(RPx);
   qm_gemm_tn<2, 2, 2>(Rm, PxA, RPx, 3, 6, false);
@@ -172,14 +172,15 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
   rpe = qm_wave_sum((l < 30) ? (S[LW_V_RV + l] + 0.5 * (S[LW_V_RR + l] - S[LW_V_RV + l])) * S[LW_V_PE + l] : 0.0);
   // [Qp | qp] = [Q | q] + Pxᵀ [R Px | rr]
   qm_gemm_tn<2, 2, 2>(PxA, RPx, Qa, 3, 6, false);
-  { // Qp is symmetric and K3 forms only the upper tiles of the value function: the lower-left tile (rows 16.., columns < 16) is not stored
-    const int g = l >> 4, c = l & 15;
+  double* const frag = rec + SR_FRAG + l;                              // fragment-order operands of K3's backward sweep: register r of a tile = one contiguous 512-byte row
+  { // [Qp | qp] as it stands in the registers (column 30 carries qp; rows 30, 31 and column 31 are padding K3 never looks at).  Qp is symmetric and K3 forms only the
+    // upper tiles of the value function: the lower-left tile (rows 16.., columns < 16) is not stored
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
       for (int J = I; J < 2; ++J)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < 30 && col < 30) rec[SR_QP + row * 30 + col] = Qa[I][J][r]; } }
+        for (int r = 0; r < 4; ++r) QM_STREAM_ST(frag + SR_F_QP + (4 * (I + J) + r) * 64, Qa[I][J][r]); }
   qm_wave_sync();
   lw_get_col30<2>(Qa, S + LW_V_QV, 30);
   // [Pp | rp] = Puᵀ [R Px | rr]: Pp[j][col] = Σ_k w_k(j) [R Px | rr][i0(j) + k][col]
@@ -191,7 +192,14 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
       for (int J = 0; J < 2; ++J)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int j = 16 * I + g + 4 * r; const double* src = T + (int)PD[j] * LW_TLD + 16 * J + c; Pp[I][J][r] = PD[32 + 3 * j] * src[0] + PD[33 + 3 * j] * src[LW_TLD] + PD[34 + 3 * j] * src[2 * LW_TLD]; }
-    qm_frag_store<MT, 2>(Pp, rec + SR_PP, 30, m, 30); lw_get_col30<MT>(Pp, S + LW_V_RV, m); }
+    // [Pp | rp]: rows >= m are zero in the record (K3's Wᵀ W runs over whole k-steps); of the second tile row only rows 16..19 (register 0) can be live (m <= 18)
+#pragma unroll
+    for (int J = 0; J < 2; ++J) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) QM_STREAM_ST(frag + SR_F_PP + (4 * J + r) * 64, (g + 4 * r < m) ? Pp[0][J][r] : 0.0);
+      if (MT == 2) QM_STREAM_ST(frag + SR_F_PP1 + J * 64, (16 + g < m) ? Pp[MT - 1][J][0] : 0.0);
+    }
+    lw_get_col30<MT>(Pp, S + LW_V_RV, m); }
   // Rp = Puᵀ (R Pu): first R Pu[i][j] = Σ_k w_k(j) R[i][i0(j) + k], then the rows of that by the same descriptors
   qm_wave_sync(); tile_put(Rm); qm_wave_sync();
   load_col_desc();
@@ -214,7 +222,14 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
       for (int J = 0; J < MT; ++J)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int j = 16 * I + g + 4 * r; const double* src = T + (int)PD[j] * LW_TLD + 16 * J + c; Rp[I][J][r] = PD[32 + 3 * j] * src[0] + PD[33 + 3 * j] * src[LW_TLD] + PD[34 + 3 * j] * src[2 * LW_TLD]; }
-    qm_frag_store<MT, MT>(Rp, rec + SR_RP, QM_MMAX, m, m); }
+    // Rp: zero outside [0, m) x [0, m) (K3 puts the unit diagonal of the padding rows itself); the lower-left tile is never read (symmetric)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) QM_STREAM_ST(frag + SR_F_RP + r * 64, (g + 4 * r < m && c < m) ? Rp[0][0][r] : 0.0);
+    if (MT == 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) QM_STREAM_ST(frag + SR_F_RP01 + r * 64, (g + 4 * r < m && 16 + c < m) ? Rp[0][MT - 1][r] : 0.0);
+      QM_STREAM_ST(frag + SR_F_RP11, (16 + g < m && 16 + c < m) ? Rp[MT - 1][MT - 1][0] : 0.0);
+    } }
   qm_wave_sync();
   if (l < 30) rec[SR_QPV + l] = S[LW_V_QV + l];
   if (l < m) rec[SR_RPV + l] = S[LW_V_RV + l];
@@ -535,7 +550,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
       qm_gemm_tn<2, 2, 1>(Bdt, Y1, P1, 0, 3, false);
 #pragma unroll
       for (int I = 0; I < 2; ++I) ApA[I][1] = P1[I][0]; }
-    qm_frag_store<2, 2>(ApA, rec + SR_AP, 30, 12, 30);               // rows 0..11 only: a joint row is e_j + dt Px[j], K3 rebuilds it (k_riccati.h)
+    qm_frag_store<2, 2, true>(ApA, rec + SR_AP, 30, 12, 30);               // rows 0..11 only: a joint row is e_j + dt Px[j], K3 rebuilds it (k_riccati.h)
     const int gg2 = l >> 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const int row = gg2 + 4 * r; if (c == 14) rec[SR_BPV + row] = ApA[0][1][r]; }
@@ -661,7 +676,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
 #pragma unroll
   for (int J = 0; J < 2; ++J) {
     const int col = 16 * J + c;
-    if (col < 30) { rec[SR_PX + (12 + g) * 30 + col] = PxA[0][J][3]; rec[SR_PX + (16 + g) * 30 + col] = PxA[1][J][0]; rec[SR_PX + (20 + g) * 30 + col] = PxA[1][J][1]; }
+    if (col < 30) { QM_STREAM_ST(rec + SR_PX + (12 + g) * 30 + col, PxA[0][J][3]); QM_STREAM_ST(rec + SR_PX + (16 + g) * 30 + col, PxA[1][J][0]); QM_STREAM_ST(rec + SR_PX + (20 + g) * 30 + col, PxA[1][J][1]); }
     if (DBG && dbg && col < 30) { for (int r = 0; r < 3; ++r) rec[SR_PX + (g + 4 * r) * 30 + col] = 0.0; rec[SR_PX + (24 + g) * 30 + col] = 0.0; if (g < 2) rec[SR_PX + (28 + g) * 30 + col] = 0.0; }
   }
   double rpe = 0.0;

@@ -63,14 +63,12 @@ struct QmRiccatiArgs {
 #define RP_REC   1200
 #define RPO_A    0                 /* [12][30] Ap rows 0..11                     <- SR_AP            360 */
 #define RPO_B    384               /* [12][18] Bp rows 0..11                     <- SR_BP            216 */
-#define RPO_Q    640               /* Qp [30][30], Pp [18][30], Rp [18][18]      <- SR_QP           1764 */
-#define RPO_PP   (RPO_Q + 900)
-#define RPO_RP   (RPO_Q + 1440)
-#define RPO_PX   2432              /* [12][30] Px rows 12..23                    <- SR_PX + 360      360 */
-#define RPO_VEC  2816              /* bp(30) qp(30) rp(18)                       <- SR_BPV            78 */
-#define RPO_SWG  2944              /* swing blocks [4][6], mode, dt              <- SR_SWG            26 */
-#define RP_END   (RP_REC + 3072)
-#define RF_LIST  4496             /* int list[RW_MAXNODES]: m | event tag << 8 per node (behind both the prefetch buffer and the forward staging) */
+#define RPO_Q    640               /* [Qp | qp], [Pp | rp], Rp in fragment order <- SR_FRAG          1536 (+ 448 when m > 16) */
+#define RPO_PX   2688              /* [12][30] Px rows 12..23                    <- SR_PX + 360      360 */
+#define RPO_VEC  3072              /* bp(30) qp(30) rp(18)                       <- SR_BPV            78 */
+#define RPO_SWG  3200              /* swing blocks [4][6], mode, dt              <- SR_SWG            26 */
+#define RP_END   (RP_REC + 3328)
+#define RF_LIST  4528             /* int list[RW_MAXNODES]: m | event tag << 8 per node (behind both the prefetch buffer and the forward staging) */
 #define RW_MAXNODES 512
 #define RW_LDS_DOUBLES (RF_LIST + RW_MAXNODES / 2)
 #define RW_LDS_BYTES (RW_LDS_DOUBLES * 8)
@@ -118,17 +116,18 @@ __device__ __forceinline__ void rw_prefetch_seg(const double* rec, double* lds, 
 #pragma unroll
   for (int t = 0; t * 128 < LEN; ++t) qm_dma16((const double*)((const char*)(rec + SRC + 128 * t) + lane_bytes), lds + RP_REC + DST + 128 * t);
 }
-__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds) {
+__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds, int m) {
   const unsigned lane_bytes = 16u * (threadIdx.x & 63);
   rw_prefetch_seg<SR_AP, RPO_A, 360>(rec, lds, lane_bytes);
   rw_prefetch_seg<SR_BP, RPO_B, 216>(rec, lds, lane_bytes);
-  rw_prefetch_seg<SR_QP, RPO_Q, 1764>(rec, lds, lane_bytes);
+  rw_prefetch_seg<SR_FRAG, RPO_Q, SR_F_PP1>(rec, lds, lane_bytes);
+  if (m > 16) rw_prefetch_seg<SR_FRAG + SR_F_PP1, RPO_Q + SR_F_PP1, SR_F_SIZE - SR_F_PP1>(rec, lds, lane_bytes);      // wave-uniform: the second tile row of the reduced inputs
   rw_prefetch_seg<SR_PX + 360, RPO_PX, 360>(rec, lds, lane_bytes);
   rw_prefetch_seg<SR_BPV, RPO_VEC, 78>(rec, lds, lane_bytes);
   rw_prefetch_seg<SR_SWG, RPO_SWG, 26>(rec, lds, lane_bytes);      // brings SR_MODEF (mode, dt) and the constants 1.0, 0.0 K1b keeps behind them
 }
-static_assert(SR_AP + 384 <= SR_SIZE && SR_BP + 256 <= SR_SIZE && SR_QP + 1792 <= SR_SIZE && SR_PX + 360 + 384 <= SR_SIZE && SR_BPV + 128 <= SR_SIZE && SR_SWG + 128 <= SR_SIZE, "a full 1 KB chunk must end inside the record");
-static_assert(RPO_A + 384 <= RPO_B && RPO_B + 256 <= RPO_Q && RPO_Q + 1792 <= RPO_PX && RPO_PX + 384 <= RPO_VEC && RPO_VEC + 128 <= RPO_SWG && RP_REC + RPO_SWG + 128 <= RP_END, "segments are padded to whole chunks");
+static_assert(SR_AP + 384 <= SR_SIZE && SR_BP + 256 <= SR_SIZE && SR_FRAG + SR_F_SIZE <= SR_SIZE && SR_F_PP1 % 128 == 0 && SR_F_SIZE % 128 == 0 && SR_PX + 360 + 384 <= SR_SIZE && SR_BPV + 128 <= SR_SIZE && SR_SWG + 128 <= SR_SIZE, "a full 1 KB chunk must end inside the record");
+static_assert(RPO_A + 384 <= RPO_B && RPO_B + 256 <= RPO_Q && RPO_Q + SR_F_SIZE <= RPO_PX && RPO_PX + 384 <= RPO_VEC && RPO_VEC + 128 <= RPO_SWG && RP_REC + RPO_SWG + 128 <= RP_END, "segments are padded to whole chunks");
 // [Ap | bp] as D-layout fragments: rows 0..11 from the record, rows 12..23 = e_j + dt Px[j], rows 24..29 = e_j (arm joints), column 30 = bp.
 // Unconditional loads + selects: a read at column 30 / 31 of a 30-wide row lands in the next row (inside the buffer) and is replaced afterwards — the exec-mask
 // bookkeeping of conditional loads (save / branch / restore per element) costs more here than the selects
@@ -198,7 +197,7 @@ __device__ __forceinline__ void rw_load_B(qm_d4 (&Bm)[2][MT], const double* PB, 
 // PROF: the instrumented instance (qm_riccati_prof_kernel) — phase skip bits and in-kernel cycle counters; the product instance carries neither (the eight 64-bit
 // accumulators and the skip tests cost scalar registers — spilled to vector-register lanes around every phase boundary — and branches on the hot path)
 template <int MT, bool PROF>
-__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip_arg, int& chol_fail, long long (&tacc)[8], RwPuCodes& pc, int md) {
+__device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec, int mnext, double* buf, qm_d4 (&S)[2][2], qm_d4 (&sv)[2], int skip_arg, int& chol_fail, long long (&tacc)[8], RwPuCodes& pc, int md) {
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
   const int skip = PROF ? skip_arg : 0;
   const bool prof = PROF && (skip & 32) != 0; long long tq_ = prof ? (long long)__builtin_readcyclecounter() : 0;
@@ -212,11 +211,24 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
     const double dt = P[RPO_SWG + 25];
     rw_load_A(A, P + RPO_A, P + RPO_PX, PV, dt);                    // [Ap | bp]
     rw_load_B<MT>(Bm, P + RPO_B, P + RPO_SWG, pc, dt, m);
-    rw_load<MT, 2>(Hux, P + RPO_PP, 30, m, 30, PV + 60);            // [Pp | rp]
-    rw_load<MT, MT>(Huu, P + RPO_RP, QM_MMAX, m, m, nullptr);
-    rw_load<2, 2>(Sn, P + RPO_Q, 30, 30, 30, PV + 30);              // [Qp | qp]
+    // [Pp | rp], Rp, [Qp | qp]: K1b left them in fragment order (SR_FRAG) — one LDS load per register, no masks, no per-element addresses
+    { const double* F = P + RPO_Q + l;
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Hux[0][J][r] = F[SR_F_PP + (4 * J + r) * 64];
+          if (MT == 2) Hux[MT - 1][J][r] = (r == 0) ? F[SR_F_PP1 + J * 64] : 0.0;
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Huu[0][0][r] = F[SR_F_RP + r * 64];
+        if (MT == 2) { Huu[0][MT - 1][r] = F[SR_F_RP01 + r * 64]; Huu[MT - 1][0][r] = 0.0; Huu[MT - 1][MT - 1][r] = (r == 0) ? F[SR_F_RP11] : 0.0; }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { Sn[0][0][r] = F[SR_F_QP + r * 64]; Sn[0][1][r] = F[SR_F_QP + (4 + r) * 64]; Sn[1][1][r] = F[SR_F_QP + (8 + r) * 64]; Sn[1][0][r] = 0.0; } }
     qm_lds_drain();
-    if (nrec) rw_prefetch(nrec, buf);                               // next regular stage: flies during this stage's products and Cholesky
+    if (nrec) rw_prefetch(nrec, buf, mnext);                        // next regular stage: flies during this stage's products and Cholesky
   }
   RWT(0)
   qm_d4 SA[2][2], SB[2][MT];
@@ -451,7 +463,7 @@ __device__ __forceinline__ void qm_riccati_body(QmRiccatiArgs a) {
       for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; sv[I][r] = (c == 14 && row < 30) ? rec[SR_QPV + row] : 0.0; }
   }
   { int k0 = n - 2; while (k0 >= 0 && evlist(k0) == QM_EV_PRE) --k0;
-    if (k0 >= 0 && !(a.skip & 16)) rw_prefetch(a.stage + ((size_t)b * a.nmax + k0) * SR_SIZE, buf); }
+    if (k0 >= 0 && !(a.skip & 16)) rw_prefetch(a.stage + ((size_t)b * a.nmax + k0) * SR_SIZE, buf, mlist(k0)); }
   for (int k = n - 2; k >= 0; --k) {
     double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE;
     if (evlist(k) == QM_EV_PRE) {
@@ -471,9 +483,9 @@ __device__ __forceinline__ void qm_riccati_body(QmRiccatiArgs a) {
     if (a.skip & 16) continue;
     int kn = k - 1; while (kn >= 0 && evlist(kn) == QM_EV_PRE) --kn;      // next regular stage: its operands are prefetched into LDS
     const double* nrec = (kn >= 0) ? a.stage + ((size_t)b * a.nmax + kn) * SR_SIZE : nullptr;
-    const int m = mlist(k);
-    if (m <= 16) rw_stage<1, PROF>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
-    else rw_stage<2, PROF>(rec, m, nrec, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
+    const int m = mlist(k), mnext = (kn >= 0) ? mlist(kn) : 0;
+    if (m <= 16) rw_stage<1, PROF>(rec, m, nrec, mnext, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
+    else rw_stage<2, PROF>(rec, m, nrec, mnext, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
   }
   const long long tback = PROF ? (long long)__builtin_readcyclecounter() : 0;
   // L, W, y were stored by other lanes than the ones that read them back below

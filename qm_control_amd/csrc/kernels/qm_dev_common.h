@@ -194,7 +194,9 @@ __device__ __forceinline__ double qm_wave_max(double v) {
 
 // asynchronous global -> LDS copy of 16 bytes per lane (global_load_lds_dwordx4): lane l's 16 bytes land at lds_chunk + 16 l, no VGPR
 // is touched; completion is tracked by vmcnt (qm_dma_wait), the data becomes visible to ds_read after that
-__device__ __forceinline__ void qm_dma16(const double* g, double* lds_chunk) { __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 0); }
+// (cache policy 2 = nt, non-temporal: the copies stream stage records that are read once per sweep — measured K3 1.12 -> 1.05 ms against the default policy;
+// the scope bits sc0 / sc1 on top of it change nothing)
+__device__ __forceinline__ void qm_dma16(const double* g, double* lds_chunk) { __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 2); }
 __device__ __forceinline__ void qm_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }      // vmcnt(0)
 __device__ __forceinline__ void qm_lds_drain() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }     // lgkmcnt(0): every ds_read has returned
 
@@ -289,7 +291,10 @@ __device__ __forceinline__ void qm_frag_load_tile(qm_d4 (&T)[IT][JT], const doub
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; T[I][J][r] = TR ? src[col * ld + row] : src[row * ld + col]; }
 }
-template <int IT, int JT>
+// STREAMING data — written once by one kernel, read once by a later one, with gigabytes of other traffic in between (stage records K1b -> K3: 2.8 GB per launch) —
+// is stored with the non-temporal hint (global_store ... nt): the lines do not stay in L2 / MALL at the expense of what IS re-read (measured: K3 − 7 %, step − 3 %)
+#define QM_STREAM_ST(p, v) __builtin_nontemporal_store((double)(v), (p))
+template <int IT, int JT, bool STREAM = false>
 __device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* dst, int ld, int rows, int cols) {
   const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
 #pragma unroll
@@ -297,7 +302,7 @@ __device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* 
 #pragma unroll
     for (int J = 0; J < JT; ++J)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < rows && col < cols) dst[row * ld + col] = T[I][J][r]; }
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < rows && col < cols) { if (STREAM) QM_STREAM_ST(dst + row * ld + col, T[I][J][r]); else dst[row * ld + col] = T[I][J][r]; } }
 }
 
 // parameter of the multiple-shooting transcription / filter line search for the selected solver: the `ipm` block's value with ST_SOLVER == 2, the `sqp` block's otherwise
@@ -311,9 +316,9 @@ __host__ __device__ __forceinline__ double qm_ms_param(const double* st, int sqp
 #define QM_MMAX 18
 #define SR_AP   0                      /* [30][30]  A + B Px : rows 0..11 written (joint rows: e_j + dt Px[j]) */
 #define SR_BP   900                    /* [30][18]  B Pu     : rows 0..11 written (joint rows: dt Pu[j])       */
-#define SR_QP   1440                   /* [30][30]                      */
-#define SR_PP   2340                   /* [18][30]  Puᵀ(P + R Px)       */
-#define SR_RP   2880                   /* [18][18]  Puᵀ R Pu            */
+#define SR_QP   1440                   /* [30][30]  terminal record only (intermediate nodes: SR_FRAG) */
+#define SR_PP   2340                   /* [18][30]  the gain K = −L⁻ᵀ W, written by K3 (Pp itself travels in SR_FRAG) */
+#define SR_RP   2880                   /* [18][18]  unused (Rp travels in SR_FRAG) */
 #define SR_PX   3204                   /* [30][30]  du = Pe + Px dx + Pu ut */
 #define SR_PU   4104                   /* [30][18]  (written only with the debug records: K3 rebuilds Pu ut from SR_SWG / SR_MODEF) */
 #define SR_BPV  4644                   /* [30]      b + B Pe            */
@@ -325,7 +330,19 @@ __host__ __device__ __forceinline__ double qm_ms_param(const double* st, int sqp
 #define SR_MODEF (SR_K + 56)            /* contact mode of the interval (as double): Pu = {identity columns, SR_SWG blocks} is rebuilt from it */
 #define SR_KFF  5292                   /* [18]  y = L⁻¹ hu (written by K3) */
 #define SR_SCAL 5310                   /* [0]=m (as double) [1]=cp      */
-#define SR_SIZE 5312
+/* K3's backward operands [Qp | qp], [Pp | rp], Rp in FRAGMENT order: register r of tile t is one contiguous 512-byte row, element (t, r, lane l) at (4 t + r) 64 + l, i.e.
+   matrix entry (16 I + (l >> 4) + 4 r, 16 J + (l & 15)) of tile (I, J).  K1b stores its fragments as they are (one unconditional 512-byte store per register, padding
+   rows / columns of Pp, Rp zeroed by a select) and K3 reads them back with one LDS load per register: no masks, no per-element addresses on either side.
+   The vectors ride in column 30.  m <= 16 (one tile row of reduced inputs) reads the first 1536 doubles only. */
+#define SR_FRAG   5312
+#define SR_F_QP    0                    /* tiles (0,0), (0,1), (1,1) of [Qp | qp]: 3 x 256 (the lower-left tile is the mirror image, never formed) */
+#define SR_F_PP    768                  /* tile row 0 of [Pp | rp]: tiles (0,0), (0,1)                                                              */
+#define SR_F_RP    1280                 /* tile (0,0) of Rp                                                                                           */
+#define SR_F_PP1   1536                 /* m > 16: register 0 (rows 16..19) of tiles (1,0), (1,1) of [Pp | rp]                                        */
+#define SR_F_RP01  1664                 /* m > 16: tile (0,1) of Rp                                                                                   */
+#define SR_F_RP11  1920                 /* m > 16: register 0 of tile (1,1) of Rp                                                                     */
+#define SR_F_SIZE  2048
+#define SR_SIZE (SR_FRAG + SR_F_SIZE)
 
 // per-node performance terms: cost, dynamics defect SSE (dt weighted), equality SSE (dt weighted)
 #define PF_SIZE 4

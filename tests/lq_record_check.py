@@ -33,6 +33,27 @@ def _err(a, b, floor=1e-3):
     return float(np.abs(a - b).max() / max(float(np.abs(b).max()), floor))
 
 
+def frag_tile(rec, off, regs=4):
+    """16 x 16 tile stored in fragment order at rec[off:]: register r, lane l = 16 g + c holds entry (g + 4 r, c); `regs` < 4: only the first registers exist (rest zero)"""
+    T = np.zeros((16, 16))
+    for r in range(regs):
+        T[np.arange(4)[:, None] + 4 * r, np.arange(16)[None, :]] = np.asarray(rec[off + 64 * r:off + 64 * r + 64]).reshape(4, 16)
+    return T
+
+
+def frag_operands(rec, m):
+    """the fragment-order region of a stage record (SR_FRAG): [Qp | qp] (32 x 32, lower-left tile mirrored), [Pp | rp] (m x 32), Rp (m x m, lower-left mirrored)"""
+    F = SR["SR_FRAG"]
+    Q = np.zeros((32, 32)); Q[:16, :16] = frag_tile(rec, F + SR["SR_F_QP"]); Q[:16, 16:] = frag_tile(rec, F + SR["SR_F_QP"] + 256); Q[16:, 16:] = frag_tile(rec, F + SR["SR_F_QP"] + 512)
+    Q[16:, :16] = Q[:16, 16:].T
+    P = np.zeros((32, 32)); P[:16, :16] = frag_tile(rec, F + SR["SR_F_PP"]); P[:16, 16:] = frag_tile(rec, F + SR["SR_F_PP"] + 256)
+    R = np.zeros((32, 32)); R[:16, :16] = frag_tile(rec, F + SR["SR_F_RP"])
+    if m > 16:
+        P[16:, :16] = frag_tile(rec, F + SR["SR_F_PP1"], 1); P[16:, 16:] = frag_tile(rec, F + SR["SR_F_PP1"] + 64, 1)
+        R[:16, 16:] = frag_tile(rec, F + SR["SR_F_RP01"]); R[16:, 16:] = frag_tile(rec, F + SR["SR_F_RP11"], 1); R[16:, :16] = R[:16, 16:].T
+    return Q, P, R
+
+
 def check_interval(rec, dbg, lq, pr, after_riccati=False):
     """rec: stage record as K1b wrote it (SR_SIZE doubles, debug mode: SR_PU and the zero rows of Px present); dbg: debug record; lq / pr: oracle.node_lq(i) / node_proj(i).
     after_riccati: the record has been through K3, which replaced Pp by the feedback gain K and left the feed-forward k in SR_KFF (ut = K dx + k): those are then
@@ -60,19 +81,16 @@ def check_interval(rec, dbg, lq, pr, after_riccati=False):
     Ap = s(SR["SR_AP"], 30, 30).copy(); Bp = s(SR["SR_BP"], 30, 18)[:, :m].copy()
     Ap[12:] = np.eye(30)[12:] + dt * Px[12:]; Bp[12:] = dt * Pu[12:]
     e["Ap"] = _err(Ap, pr["Ap"]); e["Bp"] = _err(Bp, pr["Bp"][:, :m] @ T); e["bp"] = _err(s(SR["SR_BPV"], 30), pr["bp"])
-    # symmetric blocks: the upper 16 x 16 tiles are stored
-    def sym(M):
-        M = M.copy(); n = M.shape[0]
-        for i in range(16, n):
-            M[i, :16] = M[:16, i]
-        return M
-    e["Qp"] = _err(sym(s(SR["SR_QP"], 30, 30)), pr["Qp"]); e["qp"] = _err(s(SR["SR_QPV"], 30), pr["qp"])
-    Rp = s(SR["SR_RP"], 18, 18)[:m, :m]
-    e["Rp"] = _err(sym(Rp) if m > 16 else np.triu(Rp) + np.triu(Rp, 1).T, T.T @ pr["Rp"][:m, :m] @ T)
-    e["rp"] = _err(s(SR["SR_RPV"], 18)[:m], T.T @ pr["rp"][:m])
+    # [Qp | qp], [Pp | rp], Rp: the fragment-order region K3's backward sweep reads (upper tiles of the symmetric blocks; vectors in column 30), which K3 leaves untouched
+    Qf, Pf, Rf = frag_operands(rec, m)
+    e["Qp"] = _err(Qf[:30, :30], pr["Qp"]); e["qp"] = _err(Qf[:30, 30], pr["qp"]); e["qp (vector copy)"] = _err(s(SR["SR_QPV"], 30), pr["qp"])
+    Rp = Rf[:m, :m]
+    e["Rp"] = _err(Rp if m > 16 else np.triu(Rp) + np.triu(Rp, 1).T, T.T @ pr["Rp"][:m, :m] @ T)
+    e["rp"] = _err(Pf[:m, 30], T.T @ pr["rp"][:m]); e["rp (vector copy)"] = _err(s(SR["SR_RPV"], 18)[:m], T.T @ pr["rp"][:m])
+    e["Pp"] = _err(Pf[:m, :30], T.T @ pr["Pp"][:m])
+    # what K3 relies on in the padding: rows >= m of [Pp | rp] and everything outside [0, m) x [0, m) of Rp are exactly zero
+    e["padding"] = float(max(np.abs(Pf[m:]).max(initial=0.0), np.abs(Rf[m:]).max(initial=0.0), np.abs(Rf[:, m:]).max(initial=0.0)))
     if after_riccati:
         Ti = np.linalg.inv(T)
         e["K"] = _err(s(SR["SR_PP"], 18, 30)[:m], Ti @ pr["K"][:m]); e["k"] = _err(s(SR["SR_KFF"], 18)[:m], Ti @ pr["kff"][:m])
-    else:
-        e["Pp"] = _err(s(SR["SR_PP"], 18, 30)[:m], T.T @ pr["Pp"][:m])
     return e

@@ -163,7 +163,7 @@ def test_ipm_slot_runs_the_multiple_shooting_step_on_the_ipm_block(blobs, oblobs
     assert out[(2, 0.02)][0] < out[(2, None)][0] == out[(0, None)][0]                 # a coarser ipm.dt gives a shorter grid; equal dt, equal grid
 
 
-@pytest.mark.parametrize("name,N", [("C2", 26), ("C5", 60)])
+@pytest.mark.parametrize("name,N", [("C2", 26), ("C5", 60), ("C1", 10)])
 @pytest.mark.parametrize("skip", [20, 0])
 def test_lq_records_entrywise(blobs, oracle, name, N, skip):
     """what K1a / K1b leave in HBM, entry by entry — unprojected A_d, B_d, b, Q, R, q, r, C, D, e and the projected stage record

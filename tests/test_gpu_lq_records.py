@@ -1,6 +1,6 @@
 """GPU parity of the INTERMEDIATES of the MPC iteration, read back through qmhip_debug_read: the unprojected LQ model of every shooting
 interval (A_d, B_d, b, Q, R, q, r, C, D, e), the projected stage record K1b hands to K3 (Ap, Bp, bp, Qp, Pp, Rp, qp, rp, Px, Pe, range of Pu) and the gains K, k
-K3 leaves in it — entry by entry against the oracle on BASELINE.json config 2 (trot, N = 100) and on a C5 instance.  End-to-end agreement of x*, u* makes a
+K3 leaves in it — entry by entry against the oracle on BASELINE.json config 2 (trot, N = 100), on a C5 instance and on C1 (stance: m = 18, two tile rows).  End-to-end agreement of x*, u* makes a
 compensating error unlikely; this makes it impossible at the level of the blocks."""
 import numpy as np
 import pytest
@@ -9,7 +9,7 @@ import lq_record_check as LC
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["C2", "C5"])
+@pytest.mark.parametrize("name", ["C2", "C5", "C1"])
 def test_lq_and_stage_records_entrywise(blobs, oracle, name):
     from qm_control_amd import api, scenarios
     cfg = scenarios.make_config(name, batch=1)

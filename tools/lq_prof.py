@@ -9,7 +9,7 @@ mpc = api.SqpMpc(itf); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["
 mpc.solve_resident(cfg["horizon"]); itf.synchronize()
 itf.debug_set("lq_prof", 1)
 mpc.solve_resident(cfg["horizon"]); itf.synchronize()
-nm = 128; SR = 5312
+nm = 128; SR = 7360
 stage = itf.debug_read("stage", (B * nm, SR))
 rows = stage[np.arange(B)[:, None] * nm + np.arange(5, 95)[None, :]].reshape(-1, SR)[:, 4752:4761]
 ln = ["P0 stage inputs", "I jacobian columns", "I RK2 composition", "II constraint rows", "II projector", "II projected dynamics", "III cost model (input / state terms, barriers)", "III EE term, [Q | q], R assembly", "III projected cost + stores"]

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np
 from qm_control_amd import api, scenarios
 if os.environ.get("QM_AB_LIB"): api.LIB_PATH = os.path.join(ROOT, os.environ["QM_AB_LIB"])
-B = 1024; nm = 128; SR = 5312; SRK = 4752
+B = 1024; nm = 128; SR = 7360; SRK = 4752
 cfg = scenarios.make_config("C4", batch=B)
 itf = api.QMInterface(blobs=scenarios.load_blobs(), max_batch=B, max_nodes=nm, max_ref_knots=2, max_events=cfg["ev"].shape[1])
 mpc = api.SqpMpc(itf); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])

@@ -12,7 +12,7 @@ mpc.solve_resident(cfg["horizon"]); itf.synchronize()
 import sys as _s
 itf.debug_set("riccati_skip", 32 | int(os.environ.get("RSKIP", "0")))
 mpc.solve_resident(cfg["horizon"]); itf.synchronize()
-nm = 128; SR = 5312
+nm = 128; SR = 7360
 stage = itf.debug_read("stage", (B * nm, SR))
 rows = stage[np.arange(B) * nm][:, 4752:4767]
 names = ["operands LDS->frag (+dma wait)", "5 products", "stage to LDS + columns", "Cholesky loop", "scale, stores, W reload", "WtW", "symmetrise", "BACKWARD total", "FORWARD total", "fwd: loop head + dx store", "fwd: record regs -> LDS", "fwd: next-record fetch issue", "fwd: A dx, W dx", "fwd: triangular solve", "fwd: Pu ut, B ut, du store"]
