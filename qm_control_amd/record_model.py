@@ -1,13 +1,14 @@
 """Byte model of the three big kernels, in f64 counts per unit — the ONE set of figures bench.py, DESIGN.md §4 and
 tools/hbm_traffic_digest.py use (unit: one non-event shooting interval for K1b / K3, one instance for the WBC).
 
-Stage record written by K1b and read by K3 (csrc/kernels/qm_dev_common.h, SR_*): only what is structurally non-zero is moved.
+Stage record written by K1b and read by K3 (csrc/kernels/qm_dev_common.h, SR_*): only what is structurally non-zero is moved; K3's backward operands travel in
+fragment order (SR_FRAG: whole 16 x 16 tiles, the padding of a 30-wide block included).
 """
 # ---- K1b qm_lq_kernel ----
-LQ_WRITE_DOUBLES = 2669      # rows 0..11 of Ap 360 and Bp 216 (joint rows are e_j + dt Px[j] resp. dt Pu[j]: rebuilt by K3), the upper 16x16 tiles of Qp 676+..., Pp 540, Rp 324, the 12 non-zero rows of Px 360, vectors 108+30, swing blocks 24+2 (Pu is implied by the contact mode)
+LQ_WRITE_DOUBLES = 2665      # rows 0..11 of Ap 360 and Bp 216 (joint rows are e_j + dt Px[j] resp. dt Pu[j]: rebuilt by K3), [Qp | qp] [Pp | rp] Rp in fragment order 768 + 512 + 256 (SR_FRAG; m <= 16), the 12 non-zero rows of Px 360, vectors 108+30, swing blocks 24+2 (Pu is implied by the contact mode)
 LQ_READ_DOUBLES = 620        # kin record (504) + x, u, references, node descriptors
 # ---- K3 qm_riccati_kernel ----
-RICCATI_BWD_READ_DOUBLES = 2804    # rows 0..11 of Ap 360 and Bp 216, Qp 900, Pp 540, Rp 324, rows 12..23 of Px 360, bp qp rp 78, swing blocks + mode + dt 26
+RICCATI_BWD_READ_DOUBLES = 2576    # rows 0..11 of Ap 360 and Bp 216, the fragment-order operands 1536 (three upper tiles of [Qp | qp], tile row 0 of [Pp | rp], tile (0,0) of Rp; + 448 when m > 16), rows 12..23 of Px 360, bp qp rp 78, swing blocks + mode + dt 26
 RICCATI_BWD_WRITE_DOUBLES = 558    # the gain K = -L^-T W (540) and the offset k = -L^-T y (18), formed on the matrix core for the forward rollout
 RICCATI_FWD_READ_DOUBLES = 1628    # rows 0..11 of Ap (360) and Bp (216), K 540, rows 12..23 of Px 360, bp qp rp Pe 108, k 18, swing blocks + mode + dt 26
 RICCATI_FWD_IO_DOUBLES = 120       # x (2 nodes' worth of defect reads at events amortised), dx 30 + du 30 written, x0
