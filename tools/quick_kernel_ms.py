@@ -6,7 +6,7 @@ from qm_control_amd import api, scenarios
 if os.environ.get("QM_AB_LIB"): api.LIB_PATH = os.path.join(ROOT, os.environ["QM_AB_LIB"])       # A/B runs of two builds on one box (tools/ab_kernel_ms.sh)
 B = int(os.environ.get("QM_B", "1024"))
 cfg = scenarios.make_config("C4", batch=B)
-itf = api.QMInterface(blobs=scenarios.load_blobs(), max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+itf = api.QMInterface(blobs=scenarios.load_blobs(), max_batch=B, max_nodes=int(os.environ.get("QM_NMAX", "128")), max_ref_knots=2, max_events=cfg["ev"].shape[1])
 mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
 mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
 MPC_ONLY = bool(os.environ.get("QM_MPC_ONLY"))
