@@ -70,8 +70,8 @@ struct QmLqArgs {
 
 // LDS carve (doubles) of one wave
 #define LW_BLOCK 64
-#define LW_TLD 34
-#define LW_T     0                    /* [32][34] hand-over tile (columns from lanes -> fragments) */
+#define LW_TLD 33                   /* odd: the transposed fragment reads (lanes run down a column, stride LW_TLD doubles) then hit 16 different bank pairs; 34 made them 2-way conflicts (K1b − 0.5 %) */
+#define LW_T     0                    /* [32][LW_TLD] hand-over tile (columns from lanes -> fragments) */
 #define LW_V     1088
 #define LW_V_X   (LW_V + 0)
 #define LW_V_U   (LW_V + 32)

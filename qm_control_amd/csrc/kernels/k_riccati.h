@@ -43,7 +43,7 @@ struct QmRiccatiArgs {
 };
 
 #define RW_BLOCK 64
-#define RW_TLD 34                 /* transposition buffer [32][34] */
+#define RW_TLD 34                 /* transposition buffer [32][34] (33 measured: no difference here) */
 /* forward staging (aliases the backward buffers): two flat copies (double buffer) of the fields of a stage record the rollout reads, in the order of the fetch
    list below, written by global_load_lds (no VGPR staging, 1 KB per wave instruction) one stage ahead of their use */
 #define RF_F0   0                 /* buffer of the even regular stages */
