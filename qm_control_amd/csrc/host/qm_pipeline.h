@@ -147,9 +147,10 @@ struct QmMpcPipeline {
       l.trial = t;
       if (ilqr) { ro.mode = 1; ro.trial = t; bk.launch(qm_ilqr_rollout_kernel, B, 64, 0, ro); }      // nonlinear rollout with feedback at the instance's step length
       bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
+      d.host_open[t] = -1;                                 // armed: the launch's last block overwrites it with the count of the instances still searching
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching
       ++ls_trials_run;
-      bk.wait_launched();                                  // the last block of the launch has published the count in host-visible memory
+      bk.wait_flag(d.host_open + t, -1);                   // spin on the host-visible word (a stream synchronisation costs 10-30 us of wake-up latency per step)
       if (d.host_open[t] == 0) break;
     }
     bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
