@@ -57,7 +57,7 @@ class QmhipSolver final : public ocs2::SolverBase {
       : ctx_(ctx), sz_(sizes), problem_(problemForGetters), t_(sizes.maxNodes), x_((size_t)sizes.maxNodes * QM_NX), u_((size_t)sizes.maxNodes * QM_NU),
         event_(sizes.maxNodes), mode_(sizes.maxNodes) {}
 
-  void reset() override { havePrevious_ = false; primal_.clear(); iterations_ = 0; log_.clear(); }
+  void reset() override { havePrevious_ = false; primal_.clear(); iterations_ = 0; log_.clear(); warnings_ = 0; }
   ocs2::scalar_t getFinalTime() const override { return primal_.timeTrajectory_.empty() ? 0.0 : primal_.timeTrajectory_.back(); }
   void getPrimalSolution(ocs2::scalar_t /*finalTime*/, ocs2::PrimalSolution* out) const override { *out = primal_; }
   size_t getNumIterations() const override { return iterations_; }
@@ -72,7 +72,8 @@ class QmhipSolver final : public ocs2::SolverBase {
   ocs2::ScalarFunctionQuadraticApproximation getHamiltonian(ocs2::scalar_t, const ocs2::vector_t&, const ocs2::vector_t&) override { throw std::runtime_error("[QmhipSolver] getHamiltonian() not available"); }
   ocs2::vector_t getStateInputEqualityConstraintLagrangian(ocs2::scalar_t, const ocs2::vector_t&) const override { throw std::runtime_error("[QmhipSolver] getStateInputEqualityConstraintLagrangian() not available"); }
 
-  int lastStatus() const { return status_; }                          // 0 ok; see include/qmhip.h (qmhip_mpc_step) for the codes
+  int lastStatus() const { return status_; }                          // 0 ok, > 0 warning bits on a valid solution (QM_MPC_WARN_PIVOT), < 0 failure; include/qmhip.h (qmhip_mpc_step)
+  size_t warningCount() const { return warnings_; }                   // solves that completed with a warning since construction / reset
   const double* lastPerformance() const { return perf_; }             // baseline{merit,cost,dynSSE,eqSSE}, after{...}, alpha, armijo
 
  private:
@@ -104,7 +105,11 @@ class QmhipSolver final : public ocs2::SolverBase {
     int32_t n = 0;
     rc = qmhip_mpc_download(ctx_, 1, &n, t_.data(), event_.data(), mode_.data(), x_.data(), u_.data(), perf_, &status_);
     check(rc, "qmhip_mpc_download");
-    if (status_ != 0) throw std::runtime_error("[QmhipSolver] MPC iteration failed with status " + std::to_string(status_));   // caught by mpcThread_, QMController.cpp:327-330
+    // Only FAILURES (< 0) throw — mpcThread_ answers an exception by stopping the controller (QMController.cpp:327-330).  A positive status is a warning on a valid solution:
+    // QM_MPC_WARN_PIVOT = the observation time put a shooting node within weakEpsilon in front of a gait event (about once in 3700 calls at 100 Hz on ROS time) and the
+    // zero-duration stage there was solved with zeroed pivots, like [upstream, recalled] HPIPM does — the reference's solver does not report that to its thread either.
+    if (status_ < 0) throw std::runtime_error("[QmhipSolver] MPC iteration failed with status " + std::to_string(status_));
+    if (status_ > 0) ++warnings_;
     toPrimalSolution(n, t_.data(), event_.data(), x_.data(), u_.data(), ms, primal_);
     performance_.merit = perf_[4]; performance_.cost = perf_[5]; performance_.dynamicsViolationSSE = perf_[6]; performance_.equalityConstraintsSSE = perf_[7];
     log_.assign(1, performance_); iterations_ = 1; havePrevious_ = true;
@@ -140,7 +145,7 @@ class QmhipSolver final : public ocs2::SolverBase {
 
   qmhip_ctx* ctx_; Sizes sz_; const ocs2::OptimalControlProblem* problem_;
   std::vector<double> t_, x_, u_, ev_, refT_, refX_; std::vector<int32_t> event_, mode_, modes_;
-  double perf_[10] = {0}; int32_t status_ = 0; bool havePrevious_ = false;
+  double perf_[10] = {0}; int32_t status_ = 0; bool havePrevious_ = false; size_t warnings_ = 0;
   ocs2::PrimalSolution primal_; ocs2::PerformanceIndex performance_; std::vector<ocs2::PerformanceIndex> log_; size_t iterations_ = 0;
 };
 

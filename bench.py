@@ -95,8 +95,9 @@ class HipEngine:
     def results(self):
         res = self.mpc.download(); out, qps = self.wbc.download(self.cfg["B"])
         n_intervals = int(sum(int(res["num_nodes"][b]) - 1 - int((res["event"][b, :res["num_nodes"][b]] == 1).sum()) for b in range(self.cfg["B"])))
-        return dict(ok=bool((res["status"] == 0).all() and (qps == 0).all()), out=out, n_intervals=n_intervals, ls_trials=int(res["ls_trials"]),
-                    n_bad_mpc=int((res["status"] != 0).sum()), n_bad_wbc=int((qps != 0).any(axis=1).sum()))
+        # status >= 0 is success (include/qmhip.h): > 0 are warning bits on a valid solution (QM_MPC_WARN_PIVOT: zeroed Riccati pivots on the stage in front of a gait event)
+        return dict(ok=bool((res["status"] >= 0).all() and (qps == 0).all()), out=out, n_intervals=n_intervals, ls_trials=int(res["ls_trials"]),
+                    n_bad_mpc=int((res["status"] < 0).sum()), n_warn_mpc=int((res["status"] > 0).sum()), n_bad_wbc=int((qps != 0).any(axis=1).sum()))
 
     def close(self):
         self.itf.close()
@@ -267,7 +268,7 @@ def secondary_figures(args, eng, cfg, dist, device, world, rank):
     tcl = time.perf_counter(); mpc.closed_loop_resident(cl_steps, cl_dt, cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize(); tcl = time.perf_counter() - tcl
     res_cl = mpc.download(); _, qps_cl = wbc.download(B)
     out["closed_loop_warm_start"] = {"value": B * cl_steps / tcl, "unit": "steps/s per GPU", "steps": cl_steps, "mpc_dt": cl_dt, "ms_per_step": tcl / cl_steps * 1e3,
-                                     "all_status_ok": bool((res_cl["status"] == 0).all() and (qps_cl == 0).all()), "ls_trials_last": int(res_cl["ls_trials"])}
+                                     "all_status_ok": bool((res_cl["status"] >= 0).all() and (qps_cl == 0).all()), "ls_trials_last": int(res_cl["ls_trials"])}
     # (3) SURVEY.md §8(f) rank 3: the whole controller around the batched rigid-body plant, device resident — per 1 ms tick
     #     [state estimate -> MPC every 10 ticks (warm) -> policy -> WBC -> updateControlLaw -> plant step with the 9 ms command delay]
     if not args.no_plant_loop and world == 1:
@@ -279,7 +280,7 @@ def secondary_figures(args, eng, cfg, dist, device, world, rank):
         n_ticks = 30; tp = time.perf_counter(); sim.closed_loop(n_ticks, 0.001, cfg["horizon"], n_substeps=2, mpc_every=10); itf.synchronize(); tp = time.perf_counter() - tp
         sp = sim.state(); res_p = mpc.download(); _, qps_p = wbc.download(B)
         out["closed_loop_plant"] = {"value": B * n_ticks / tp, "unit": "plant + controller ticks/s per GPU (1 ms ticks, MPC every 10th)", "ticks": n_ticks, "ms_per_tick": tp / n_ticks * 1e3,
-                                    "realtime_factor_per_instance": n_ticks * 0.001 / tp, "all_status_ok": bool((res_p["status"] == 0).all() and (qps_p == 0).all() and (sp["status"] == 0).all()),
+                                    "realtime_factor_per_instance": n_ticks * 0.001 / tp, "all_status_ok": bool((res_p["status"] >= 0).all() and (qps_p == 0).all() and (sp["status"] == 0).all()),
                                     "all_finite": bool(np.isfinite(sp["q"]).all()), "base_height_range": [float(sp["q"][:, 2].min()), float(sp["q"][:, 2].max())]}
     # (4) BASELINE.json config 5: EE-tracking task, trot -> stance -> trot, N = 150, arm near its joint limits, 512 instances per GPU (4096 over 8), seed 1236
     B5 = min(512, B); steps5 = max(2, args.steps // 5)
@@ -300,9 +301,10 @@ def secondary_figures(args, eng, cfg, dist, device, world, rank):
         els, _ = timed_region(es, steps_s, dist, device); rs = es.results(); es.close()
         out["strong_scaling_C4"] = {"workload": "C4: trot, N = %d, global batch 8192 (seed 1235) in contiguous shards of %d instances per GPU" % (args.n_intervals, Bs), "value": 8192 * steps_s / els,
                                     "unit": "steps/s", "n_gpus": world, "global_batch": 8192, "instances_per_gpu": Bs, "steps": steps_s, "ms_per_step": els / steps_s * 1e3, "scaling": "strong",
-                                    "all_status_ok": rs["ok"], "instances_with_nonzero_mpc_status": rs["n_bad_mpc"], "instances_with_nonzero_wbc_status": rs["n_bad_wbc"],
-                                    "note": "a few of the 8192 random initial states make the Riccati recursion indefinite (status -4) in product AND oracle (tools/status_sweep.py); "
-                                            "they are solved and timed like every other instance"}
+                                    "all_status_ok": rs["ok"], "instances_with_failed_mpc_status": rs["n_bad_mpc"], "instances_with_mpc_warning": rs["n_warn_mpc"], "instances_with_nonzero_wbc_status": rs["n_bad_wbc"],
+                                    "note": "a warning (status 1 = QM_MPC_WARN_PIVOT) marks an instance whose observation time puts a shooting node within 1e-6 s in front of a gait event "
+                                            "(instance 2453 of this batch): the negative-duration stage there is solved with zeroed pivots in product and oracle alike "
+                                            "(tests/test_grid_fuzz.py, tests/test_gpu_fullsize.py); the solution is valid"}
     # (5) BASELINE.json config 2: a single instance (B = 1): the dependency-chain latency of one control step
     if rank == 0:
         cfg2 = scenarios.make_config("C2"); e2 = HipEngine(cfg2, int(os.environ.get("LOCAL_RANK", "0")), max_nodes=128)

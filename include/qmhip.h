@@ -60,7 +60,10 @@ int qmhip_set_setting(qmhip_ctx* ctx, int settings_index, double value);   /* e.
  *      Outputs (any may be NULL): node count, node times / event tags / modes (int, bit-exact), optimal state and
  *      input trajectories (primal solution: input of event nodes copied from the previous node, last input repeated),
  *      perf[10] = baseline{merit,cost,dynSSE,eqSSE}, after-step{...}, step size alpha, armijo metric.
- *      status[b]: 0 ok, -1 node buffer too small, -2 swing phase not enclosed by stance in the schedule, -4 Riccati not PD.
+ *      status[b]: 0 ok; < 0 failure: -1 node buffer too small, -2 swing phase not enclosed by stance in the schedule, -3 device gait schedule over capacity,
+ *      -4 Riccati not PD (only with ST_RICCATI_STRICT); > 0 WARNING bits on a valid solution: QM_MPC_WARN_PIVOT (1) = a stage's Huu had non-positive pivots, which were
+ *      zeroed ([upstream, recalled] BLASFEO / HPIPM behaviour; qmhip_layout.h) — the stage in front of a gait event when a shooting node falls within weakEpsilon
+ *      before it, i.e. about one call in 3700 for an MPC thread on continuous time (QMController.cpp:315-330).  Callers treat status >= 0 as success.
  *      Solver slot (qmhip_set_setting(ST_SOLVER, .)): 0 the SQP above; 1 a discrete iLQR on the `ddp` block (task.info:33-71); 2 the SAME multiple-shooting step as
  *      slot 0, run with the `ipm` block's parameters (task.info:94-125: ipm.dt / ipmIteration / deltaTol / g_max / g_min, ST_IPM_*).  Slot 2 is NOT an interior-point
  *      method: this OCP has no hard inequality constraints (QMInterface.cpp:79-142 registers friction cones and joint limits as soft costs), so an IpmMpc in the MPC_BASE

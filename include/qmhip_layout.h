@@ -110,13 +110,21 @@
 #define ST_IPM_G_MIN     1038 /* ipm.g_min                                                                */
 #define ST_IPM_MU        1039 /* ipm.initialBarrierParameter (carried; no inequality rows to apply it to) */
 /* minimum step of the SQP time grid (`dt_min` of [upstream ocs2_oc timeDiscretizationWithEvents], default 10 * numeric_traits::limitEpsilon): a node closer than this to its
-   predecessor overwrites it.  The ingestion writes the upstream default.  With it, a node that falls within weakEpsilon (1e-6) BEFORE a gait event opens an interval whose adapted
-   duration (interval end − start, ∓ weakEpsilon at events) is negative and the solve reports status -4, as upstream would fail; fixed-rate loops whose observation times share a
-   raster with the gait events opt into the robust variant QM_GRID_DT_MIN_ROBUST through qmhip_set_setting */
+   predecessor overwrites it.  The ingestion writes the upstream default, so node schedules are upstream's bit for bit.  With it, a node that falls within weakEpsilon (1e-6)
+   BEFORE a gait event opens an interval whose adapted duration (interval end − start, ∓ weakEpsilon at events) is NEGATIVE: that stage's cost blocks (× duration) are negative
+   definite and Huu of the Riccati recursion is not positive definite.  The solve SURVIVES that stage (ST_RICCATI_STRICT below) and reports the warning bit
+   QM_MPC_WARN_PIVOT; QM_GRID_DT_MIN_ROBUST (the node is merged into the event node instead) stays available through qmhip_set_setting */
 #define ST_GRID_DT_MIN 1040
 #define QM_GRID_DT_MIN_UPSTREAM 2.220446049250313e-15
 #define QM_GRID_DT_MIN_ROBUST   1.0e-5
-#define ST_SIZE       1048  /* 1041..1047 reserved */
+/* non-positive pivot in the Cholesky factorisation of a stage's Huu.  0 (default): the pivot's reciprocal and column are zeroed — what [upstream, recalled] BLASFEO's
+   dpotrf kernels under HPIPM's Riccati factorisation do — so the reduced input of that pivot gets no update on that stage, everything else is solved as if it were not
+   there, and the instance's status carries QM_MPC_WARN_PIVOT (a warning: status > 0).  1: strict — the same arithmetic, but the instance reports the hard failure
+   status -4 (the behaviour of rounds 1-3) */
+#define ST_RICCATI_STRICT 1041
+/* MPC status words: 0 ok, < 0 failure (qmhip.h), > 0 warning bits — the solution is valid */
+#define QM_MPC_WARN_PIVOT 1
+#define ST_SIZE       1048  /* 1042..1047 reserved */
 
 /* contact-mode ids: 8*LF + 4*RF + 2*LH + 1*RH (ocs2_legged_robot MotionPhaseDefinition) */
 #define QM_MODE_STANCE 15

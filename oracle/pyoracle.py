@@ -142,7 +142,7 @@ class Oracle:
             raise RuntimeError("oracle mpc_step failed rc=%d" % rc)
         k = n.value
         return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf,
-                    alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h))
+                    alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h), warn=self.lib.qmo_last_warn(self.h))
 
     def ilqr_step(self, t0, tf, x0, warm=False):
         """one discrete iLQR iteration (oracle/src/ilqr.h): same result dict as mpc_step"""
@@ -153,7 +153,7 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("oracle ilqr_step failed rc=%d" % rc)
         k = n.value
-        return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf, alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h))
+        return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf, alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h), warn=self.lib.qmo_last_warn(self.h))
 
     def node_lq(self, i):
         z = lambda *s: np.zeros(s)

@@ -106,6 +106,7 @@ int qmo_get_step(void* h, double* dx, double* du) {
   return n;
 }
 int qmo_ls_trials(void* h) { return ((Oracle*)h)->R.lsTrials; }
+int qmo_last_warn(void* h) { return ((Oracle*)h)->R.warn; }      // warning bits of the last (valid) solve: QM_MPC_WARN_PIVOT
 void qmo_phase_ms(void* h, double* ms3) { for (int i = 0; i < 3; ++i) ms3[i] = ((Oracle*)h)->R.phaseMs[i]; }
 // one more SQP iteration on the iterate the last call left (sqp.sqpIteration > 1, [upstream SqpSolver::runImpl loop]); same outputs as qmo_mpc_step
 int qmo_mpc_iterate(void* h, double t0, double tf, const double* x0, int maxn, int* n_nodes, double* node_t, int* node_ev, int* node_mode, double* xs, double* us, double* perf) {

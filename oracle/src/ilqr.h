@@ -53,7 +53,7 @@ inline void ilqrIteration(const Problem& P, double t0, double tf, const Vec& x0,
   const Performance base = computePerformance(P, R.grid, x0, x, u);
   R.baseline = base; R.baseline.merit = ilqrMerit(P, base);
   // ---- 3. Riccati ----
-  if (!riccatiSolve(R, x0, x)) return;
+  if (!riccatiSolve(R, x0, x, st[ST_RICCATI_STRICT] != 0.0)) return;
   // ---- 4. line search on nonlinear rollouts with feedback ----
   const double armijoCoefficient = 1e-4, contraction = 0.5;
   std::vector<Vec> xt(N + 1), ut(N); Performance pt; bool accepted = false; double alpha = st[ST_DDP_MAX_STEP]; R.lsTrials = 0;

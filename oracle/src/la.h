@@ -58,10 +58,24 @@ inline bool cholesky(const Mat& A, Mat& L) {
   }
   return true;
 }
-inline void cholSolveInPlace(const Mat& L, double* b) {   // solves L Lᵀ x = b
+// Cholesky that survives an indefinite matrix the way [upstream, recalled] BLASFEO's dpotrf kernels do (what HPIPM's Riccati factorisation runs on): a pivot that is
+// not positive gets a ZERO diagonal entry and a zero reciprocal, i.e. its whole column of L is zero — the variable drops out of the factorisation and of every later
+// pivot's update.  Together with cholSolveInPlace below (a zero diagonal yields a zero component) the solve returns x_j = 0 for such a j and, for the others, the solution of
+// the system with row and column j deleted.  Returns the number of pivots treated that way (0: A is positive definite and L is the ordinary factor).
+inline int choleskyZeroPivots(const Mat& A, Mat& L) {
+  const int n = A.r; L = Mat(n, n); int nz = 0;
+  for (int j = 0; j < n; ++j) {
+    double d = A(j, j); for (int k = 0; k < j; ++k) d -= L(j, k) * L(j, k);
+    if (!(d > 0.0)) { ++nz; continue; }                      // L(j, j) = 0 and L(i, j) = 0 for i > j
+    L(j, j) = std::sqrt(d);
+    for (int i = j + 1; i < n; ++i) { double s = A(i, j); for (int k = 0; k < j; ++k) s -= L(i, k) * L(j, k); L(i, j) = s / L(j, j); }
+  }
+  return nz;
+}
+inline void cholSolveInPlace(const Mat& L, double* b) {   // solves L Lᵀ x = b; a zero diagonal entry (choleskyZeroPivots) stands for a zero reciprocal: that component is 0
   const int n = L.r;
-  for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L(i, k) * b[k]; b[i] = s / L(i, i); }
-  for (int i = n - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < n; ++k) s -= L(k, i) * b[k]; b[i] = s / L(i, i); }
+  for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L(i, k) * b[k]; b[i] = (L(i, i) != 0.0) ? s / L(i, i) : 0.0; }
+  for (int i = n - 1; i >= 0; --i) { double s = b[i]; for (int k = i + 1; k < n; ++k) s -= L(k, i) * b[k]; b[i] = (L(i, i) != 0.0) ? s / L(i, i) : 0.0; }
 }
 inline Mat cholSolve(const Mat& L, const Mat& B) {
   Mat X(B.r, B.c); Vec col(B.r);

@@ -67,8 +67,9 @@ inline double intervalEnd(const Node& n) { return n.ev == QM_EV_PRE ? n.t - kWea
 
 // [upstream timeDiscretizationWithEvents]
 // dtMin: [upstream]'s `dt_min` argument, default 10 * limitEpsilon (settings slot ST_GRID_DT_MIN).  With that default a grid node that falls within weakEpsilon BEFORE an
-// event opens an interval whose adapted duration (intervalEnd − intervalStart, ∓ weakEpsilon at events) is NEGATIVE — a fixed-rate loop (t0 = k · 1 ms, events on the
-// same raster) hits that exactly and the Riccati recursion then fails (status -4), as upstream's would.  QM_GRID_DT_MIN_ROBUST (10 weakEpsilon) is the opt-in variant.
+// event opens an interval whose adapted duration (intervalEnd − intervalStart, ∓ weakEpsilon at events) is NEGATIVE — any observation time in a 1 µs window per event and grid
+// phase, about one MPC call in 3700 at 100 Hz.  That stage's cost blocks (× duration) are negative definite; riccatiSolve below survives it the way [upstream, recalled]
+// HPIPM / BLASFEO does (zeroed pivots) and flags SqpResult::warn.  QM_GRID_DT_MIN_ROBUST (10 weakEpsilon: the node merges into the event node) is the opt-in variant.
 inline std::vector<Node> timeDiscretizationWithEvents(double t0, double tf, double dt, const Vec& ev, double dtMin = 10.0 * kLimitEps) {
   std::vector<Node> g; g.push_back({t0, QM_EV_NONE});
   int k = findIndexInTimeArray(ev, t0);
@@ -100,6 +101,7 @@ struct SqpResult {
   std::vector<Node> grid; std::vector<int> mode; std::vector<Vec> x, u;   // u has grid.size() entries (primal solution)
   std::vector<Vec> dx, du; std::vector<NodeLQ> lq; NodeLQ terminal;
   Performance baseline, after; double alpha = 0; int lsTrials = 0; double armijo = 0; int status = 0;
+  int warn = 0;                    // warning bits of a VALID solution: QM_MPC_WARN_PIVOT = some stage's Huu had non-positive pivots, zeroed (riccatiSolve)
   double phaseMs[3] = {0, 0, 0};   // wall time of the last iteration: LQ approximation + projection, Riccati solve, line search (the timers ocs2's benchmark prints)
 };
 
@@ -194,7 +196,13 @@ inline double trajectoryNorm(const std::vector<Vec>& v) { double s = 0; for (aut
 
 // QP sub-problem of the projected LQ model: Riccati backward sweep (feedback gains K, feed-forward kff per node) and the LINEAR forward rollout
 // (dx, du, Armijo descent metric).  Shared by the SQP iteration and the discrete iLQR iteration.  
-inline bool riccatiSolve(SqpResult& R, const Vec& x0, const std::vector<Vec>& x) {
+// A stage whose Huu is NOT positive definite (the negative-duration interval in front of a gait event, see timeDiscretizationWithEvents) does not abort the solve:
+// [upstream, recalled — HPIPM's d_ocp_qp_fact_solve_kkt_unconstr factorises with BLASFEO dpotrf kernels, which store a zero diagonal entry and a zero reciprocal for a pivot
+// that is not positive instead of failing] the pivot's column of L is zero, so that reduced input gets K_j = 0, kff_j = 0 (no update on this stage) and drops out of the
+// Schur complement S' = Q + AᵀSA + Huxᵀ K; the other inputs are solved as if it were not there.  The pivot ORDER is the order of the reduced inputs ũ, i.e. of this restatement's
+// null-space basis (OCS2's differs), so WHICH directions are dropped is not pinned to upstream — on the stage this is there for (duration ≈ −5e-7 s, Huu ≈ duration · R)
+// every pivot is negative and every order drops them all.  strict (settings slot ST_RICCATI_STRICT): report the hard failure of rounds 1-3 instead (status -2 here, -4 on the device).
+inline bool riccatiSolve(SqpResult& R, const Vec& x0, const std::vector<Vec>& x, bool strict = false) {
   const int N = (int)R.grid.size() - 1;
   // ---- QP solve: Riccati ----
   Mat S = R.terminal.Qp; Vec s = R.terminal.qp;
@@ -209,7 +217,7 @@ inline bool riccatiSolve(SqpResult& R, const Vec& x0, const std::vector<Vec>& x)
       Mat Hux = add(n.Pp, matmul(BtS, n.Ap));
       Vec hu = vadd(n.rp, matvecT(n.Bp, spSb));
       for (int i = 0; i < Huu.r; ++i) for (int j = i + 1; j < Huu.c; ++j) { const double a = 0.5 * (Huu(i, j) + Huu(j, i)); Huu(i, j) = Huu(j, i) = a; }
-      Mat L; if (!cholesky(Huu, L)) { R.status = -2; return false; }
+      Mat L; if (choleskyZeroPivots(Huu, L) > 0) { if (strict) { R.status = -2; return false; } R.warn |= QM_MPC_WARN_PIVOT; }
       n.K = scaled(cholSolve(L, Hux), -1.0); n.kff = vscaled(cholSolve(L, hu), -1.0);
       Mat Snew = add(add(n.Qp, matmulTN(n.Ap, SA)), matmulTN(Hux, n.K));
       for (int i = 0; i < QM_NX; ++i) for (int j = i + 1; j < QM_NX; ++j) { const double a = 0.5 * (Snew(i, j) + Snew(j, i)); Snew(i, j) = Snew(j, i) = a; }
@@ -291,7 +299,7 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
   { double s = 0; for (int k = 0; k < QM_NX; ++k) { const double d = x0[k] - x[0][k]; s += d * d; } base.dynSSE += s; }
   base.merit = base.cost; R.baseline = base;
   const auto tq1 = std::chrono::steady_clock::now();
-  if (!riccatiSolve(R, x0, x)) return;
+  if (!riccatiSolve(R, x0, x, st[ST_RICCATI_STRICT] != 0.0)) return;
   const double armijo = R.armijo;
   const auto tq2 = std::chrono::steady_clock::now();
   // ---- takeStep: filter line-search ----

@@ -1,6 +1,7 @@
 // qmhip.hip — libqmhip.so: HIP backend of the launch sequence (qm_pipeline.h) + the C ABI of include/qmhip.h.
 // gfx950 only.  One context = one device, one HIP stream, all buffers resident in HBM for max_batch instances.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -79,9 +80,19 @@ struct HipBackend {
   void* alloc_mapped(size_t n, void** host_view) { void* h = nullptr; void* dv = nullptr; check(hipHostMalloc(&h, n ? n : 8, hipHostMallocMapped), "hipHostMalloc"); check(hipHostGetDevicePointer(&dv, h, 0), "hipHostGetDevicePointer"); *host_view = h; return dv; }
   void free_mapped(void* host_view) { hipHostFree(host_view); }
   void wait_launched() { check(hipStreamSynchronize(cur), "sync"); }     // everything launched so far on the current stream has completed
-  // spin on a host-visible word a kernel already launched on `stream` overwrites (anything but `pending`); falls back to a stream synchronisation
+  // wait for a host-visible word a kernel already launched on `cur` overwrites (anything but `pending`): a BOUNDED spin — a stream synchronisation costs 10-30 us of
+  // wake-up latency, which matters for a line-search trial of a few tens of microseconds, but a solve must not hold a host core beside the ros_control thread for its
+  // whole length — of at most spin_us microseconds (the trial kernels of a 1024-batch take ≈ 0.25 ms), then the stream synchronisation
+  int spin_us = 400;
   void wait_flag(volatile int* word, int pending) {
-    for (long spin = 0; *word == pending; ++spin) if (spin > 50000000L) { check(hipStreamSynchronize(stream), "sync"); check(hipStreamSynchronize(cur), "sync"); if (*word == pending && error.empty()) error = "a kernel did not publish its host-visible word"; return; }
+    if (*word != pending) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      for (int k = 0; k < 256; ++k) if (*word != pending) return;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+    }
+    check(hipStreamSynchronize(stream), "sync"); if (cur != stream) check(hipStreamSynchronize(cur), "sync");
+    if (*word == pending && error.empty()) error = "a kernel did not publish its host-visible word";
   }
   // WBC of the current step on stream_b: its inputs were produced on `stream` (ev_in); the next producers on `stream` wait for ev_wbc
   void wbc_inputs_next() { if (wbc_pending) { check(hipStreamWaitEvent(stream, ev_wbc, 0), "hipStreamWaitEvent"); wbc_pending = false; } }
@@ -126,7 +137,7 @@ __global__ void qm_bench_mfma_kernel(double* out, int iters) {
 }
 
 // settings whose value the kernels' loop bounds depend on (K0 walks t0 + k dt up to the horizon)
-static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT || idx == ST_IPM_DT) return v > 0.0 && std::isfinite(v); if (idx == ST_GRID_DT_MIN) return v >= 0.0 && std::isfinite(v); return true; }
+static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT || idx == ST_IPM_DT) return v > 0.0 && std::isfinite(v); if (idx == ST_GRID_DT_MIN) return v >= 0.0 && std::isfinite(v); if (idx == ST_RICCATI_STRICT) return v == 0.0 || v == 1.0; return true; }
 
 // ---- co-residency probe (profiling only): a latency-bound stand-in for a narrow (<= 256 VGPR, <= 20 KB LDS) one-wave-per-instance solver wave — chains of
 // dependent f64 MFMAs and FMAs with an LDS round trip per step, ≈ 40 % issue utilisation like qm_riccati_kernel — launched on the second stream beside the
@@ -150,6 +161,10 @@ static int create_common(const double* mb, const double* st, int device, int max
   if (!out || max_batch <= 0 || max_nodes < 3 || max_nodes > RW_MAXNODES || max_ref < 1 || max_ev < 1) { g_create_error = "qmhip_create: bad argument (max_nodes must be in [3, 512])"; return QMHIP_ERR_ARG; }
   std::string err; if (!qmio::validateModelBlob(mb, err)) { g_create_error = err; return QMHIP_ERR_MODEL; }
   if (!setting_ok(ST_SQP_DT, st[ST_SQP_DT])) { g_create_error = "settings blob: sqp.dt must be a positive finite number"; return QMHIP_ERR_MODEL; }
+  // a blob of an older layout (no size / version stamp travels with it) would put garbage into the slots added since: check the ones a kernel's control flow depends on
+  if (!setting_ok(ST_GRID_DT_MIN, st[ST_GRID_DT_MIN])) { g_create_error = "settings blob: the time grid's minimum step (ST_GRID_DT_MIN) must be a non-negative finite number - is the blob of an older layout (ST_SIZE)?"; return QMHIP_ERR_MODEL; }
+  if (st[ST_RICCATI_STRICT] != 0.0 && st[ST_RICCATI_STRICT] != 1.0) { g_create_error = "settings blob: ST_RICCATI_STRICT must be 0 or 1 - is the blob of an older layout (ST_SIZE)?"; return QMHIP_ERR_MODEL; }
+  if (st[ST_SOLVER] != 0.0 && st[ST_SOLVER] != 1.0 && st[ST_SOLVER] != 2.0) { g_create_error = "settings blob: ST_SOLVER must be 0, 1 or 2"; return QMHIP_ERR_MODEL; }
   int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (libqmhip has no CPU fallback)"; return QMHIP_ERR_HIP; }
   if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return QMHIP_ERR_ARG; }
   if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return QMHIP_ERR_HIP; }
@@ -196,11 +211,13 @@ void qmhip_destroy(qmhip_ctx* c) {
   if (!c) return; hipSetDevice(c->device); c->bk.sync(); if (c->filler_out) hipFree(c->filler_out); if (c->tick_pin) hipHostFree(c->tick_pin); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); c->hoqp.release();
   for (auto e : c->bk.pool) hipEventDestroy(e); if (c->bk.ev_order) hipEventDestroy(c->bk.ev_order); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
 }
-const char* qmhip_last_error(const qmhip_ctx* c) { QM_GUARD(c); return c ? c->error.c_str() : g_create_error.c_str(); }
+// the text is copied under the context lock into a per-thread buffer: the pointer stays valid (until this THREAD's next qmhip_last_error) even if another thread's
+// failing call on the same context replaces the context's message meanwhile
+const char* qmhip_last_error(const qmhip_ctx* c) { static thread_local std::string copy; QM_GUARD(c); if (!c) return g_create_error.c_str(); copy = c->error; return copy.c_str(); }
 int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
 int qmhip_set_setting(qmhip_ctx* c, int idx, double v) { QM_GUARD(c);
   if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
-  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number, the grid's minimum step a non-negative one"); return QMHIP_ERR_ARG; }
+  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number, the grid's minimum step a non-negative one, ST_RICCATI_STRICT 0 or 1"); return QMHIP_ERR_ARG; }
   if (idx == ST_SOLVER && v == 2.0 && !setting_ok(ST_IPM_DT, c->st[ST_IPM_DT])) { c->fail("qmhip_set_setting: solver 2 needs a positive finite ipm.dt"); return QMHIP_ERR_ARG; }
   if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR) or 2 (the SQP step on the `ipm` block's parameters)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
   hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
@@ -306,7 +323,7 @@ int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oe
   hipSetDevice(c->device); const int nm = c->max_nodes; const QmMpcBuffers& d = c->mpc.d;
   std::vector<int> n_h(B), st_h(B); c->bk.to_host(n_h.data(), d.n_nodes, (size_t)B * 4); c->bk.to_host(st_h.data(), d.status, (size_t)B * 4);
   std::vector<double> si((size_t)B * 4); c->bk.to_host(si.data(), d.step_info, si.size() * 8);
-  for (int b = 0; b < B; ++b) { if (st_h[b] == 0 && si[(size_t)b * 4 + 3] != 0.0) st_h[b] = -4; if (nn) nn[b] = n_h[b]; if (status) status[b] = st_h[b]; }
+  for (int b = 0; b < B; ++b) { if (st_h[b] == 0 && si[(size_t)b * 4 + 3] != 0.0) st_h[b] = (c->st[ST_RICCATI_STRICT] != 0.0) ? -4 : QM_MPC_WARN_PIVOT; /* zeroed pivots: a warning on a valid solution unless strict */ if (nn) nn[b] = n_h[b]; if (status) status[b] = st_h[b]; }
   auto gather_d = [&](const double* dev, int k, double* out) {   // node-major [nmax][B][k] -> instance-major [B][nmax][k]
     if (!out) return; std::vector<double> h((size_t)nm * B * k); c->bk.to_host(h.data(), dev, h.size() * 8);
     for (int b = 0; b < B; ++b) for (int i = 0; i < nm; ++i) memcpy(out + ((size_t)b * nm + i) * k, h.data() + ((size_t)i * B + b) * k, (size_t)k * 8);

@@ -34,7 +34,7 @@ struct QmRiccatiArgs {
   const double* x;                             // [nmax][B][30] (current iterate; event defects, dx0)
   double* stage;                               // [B][nmax][SR_SIZE]  (L, W, y are written here)
   double* dx; double* du;                      // [nmax][B][30]
-  double* step_info;                           // [B][4]: armijo, |dx|², |du|², chol status
+  double* step_info;                           // [B][4]: armijo, |dx|², |du|², 1 if some stage's Huu had a non-positive pivot (zeroed, see rw_stage)
   // baseline performance of the current iterate (sum of K1b's node terms) + arming of the line search, done by the instance's wave before the sweep
   // (what a separate one-wave-per-instance launch did: qm_perf_sum_kernel with with_alpha == 0); perf == nullptr: skipped
   const double* perf; double* base_sum; double* alpha; int* done; double* out_perf; int* open_cnt; int* tickets;
@@ -296,15 +296,19 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
       const double D00 = qm_bcast(Hd[rb], c0), D01 = qm_bcast(Hd[rb], c0 + 1), D02 = qm_bcast(Hd[rb], c0 + 2), D03 = qm_bcast(Hd[rb], c0 + 3);
       const double D11 = qm_bcast(Hd[rb], 16 + c0 + 1), D12 = qm_bcast(Hd[rb], 16 + c0 + 2), D13 = qm_bcast(Hd[rb], 16 + c0 + 3);
       const double D22 = qm_bcast(Hd[rb], 32 + c0 + 2), D23 = qm_bcast(Hd[rb], 32 + c0 + 3), D33 = qm_bcast(Hd[rb], 48 + c0 + 3);
-      const double d0 = D00, rd0 = recip(d0);
+      // A pivot that is NOT positive (the negative-duration interval in front of a gait event: Huu ≈ duration · R) gets a ZERO reciprocal — [upstream, recalled] BLASFEO's
+      // dpotrf kernels under HPIPM's Riccati factorisation store a zero diagonal and a zero reciprocal there instead of failing: its multipliers l_ij, its row of the
+      // trailing update (a2 below) and its rows of W and L⁻¹ (invr below) all vanish, i.e. that reduced input gets K_j = 0, k_j = 0 and the others are solved as if it were
+      // not there.  The flag travels to the instance's status as the warning QM_MPC_WARN_PIVOT (ST_RICCATI_STRICT: as the failure -4).
+      const double d0 = D00, rd0 = (d0 > 0.0) ? recip(d0) : 0.0;
       const double l10 = D01 * rd0, l20 = D02 * rd0, l30 = D03 * rd0;
-      const double d1 = fma(-l10, D01, D11), rd1 = recip(d1);
+      const double d1 = fma(-l10, D01, D11), rd1 = (d1 > 0.0) ? recip(d1) : 0.0;
       const double t12 = fma(-l20, D01, D12), t13 = fma(-l30, D01, D13);            // D12 − l20 l10 d0, D13 − l30 l10 d0
       const double l21 = t12 * rd1, l31 = t13 * rd1;
-      const double d2 = fma(-l21, t12, fma(-l20, D02, D22)), rd2 = recip(d2);
+      const double d2 = fma(-l21, t12, fma(-l20, D02, D22)), rd2 = (d2 > 0.0) ? recip(d2) : 0.0;
       const double t23 = fma(-l31, t12, fma(-l30, D02, D23));                        // D23 − l30 l20 d0 − l31 l21 d1
       const double l32 = t23 * rd2;
-      const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, D03, D33))), rd3 = recip(d3);
+      const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, D03, D33))), rd3 = (d3 > 0.0) ? recip(d3) : 0.0;
       if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) chol_fail = 1;
       // L~⁻¹ of the block (unit lower): its strictly lower entries
       const double M10 = -l10, M21 = -l21, M32 = -l32, M20 = fma(l21, l10, -l20), M31 = fma(l32, l21, -l31), M30 = -(l30 + l31 * M10 + l32 * M20);
@@ -338,7 +342,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
       for (int r = 0; r < 4; ++r) {
         const double d = dsel[I][r]; double inv = __builtin_amdgcn_rsq(d);
         inv = fma(0.5 * inv, fma(-d * inv, inv, 1.0), inv); inv = fma(0.5 * inv, fma(-d * inv, inv, 1.0), inv);
-        invr[I][r] = inv;
+        invr[I][r] = (d > 0.0) ? inv : 0.0;                            // a zeroed pivot: its rows of W and of L⁻¹ are zero
       }
     RWT(3)
     // The forward rollout needs ũ = −L⁻ᵀ (W δx + y): its gain  K = −L⁻ᵀ W  and offset  k = −L⁻ᵀ y  (column 30) are formed HERE, on the matrix core, from the fragments

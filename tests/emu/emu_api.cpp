@@ -115,7 +115,8 @@ void emu_target_download(void* h, int B, double* rt, double* rx, double* last) {
 // qmhip_hoqp_solve on the host emulator: the general HoQp kernel (k_hoqp.h)
 int emu_hoqp(int B, int n_levels, int n, const int* ma, const int* md, const double* A, const double* b, const double* D, const double* f, double* x, int* status) {
   if (!QmHoqpPipeline<EmuBackend>::shapes_ok(n_levels, n, ma, md)) return -1;
-  EmuBackend bk; QmHoqpPipeline<EmuBackend> h(bk); h.solve(B, n_levels, n, ma, md, A, b, D, f, x, status); h.release(); return 0;
+  static EmuBackend bk; static QmHoqpPipeline<EmuBackend> h(bk);      // ONE pipeline for the process, like the context's: successive shapes go through its capacity bookkeeping
+  h.solve(B, n_levels, n, ma, md, A, b, D, f, x, status); return 0;
 }
 void emu_sincos(int n, const double* x, double* sn, double* cs) { for (int i = 0; i < n; ++i) qm_sincos(x[i], sn[i], cs[i]); }
 void emu_frcp(int n, const double* x, double* r) { for (int i = 0; i < n; ++i) r[i] = qm_frcp(x[i]); }

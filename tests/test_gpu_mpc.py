@@ -225,3 +225,31 @@ def test_ipm_solver_slot(blobs, oracle):
     _compare(res, 0, _oracle_solve(oracle, cfg, 0))
     with pytest.raises(api.QmhipError): itf.set_setting(L.ST_SOLVER, 3.0)
     itf.close()
+
+
+def test_degenerate_interval_survives_on_the_device(blobs, oblobs):
+    """-m gpu twin of tests/test_grid_fuzz.py::test_degenerate_interval_survives, FULL matrix: every gait event inside C2's horizon x offsets {-9e-7 ... -1e-12} of a
+    shooting node in front of it.  Through the C ABI on [upstream]'s grid: status == QM_MPC_WARN_PIVOT (a warning, >= 0), integers and node times identical to the oracle's,
+    x* / u* within 1e-6 per block of the oracle on the WHOLE trajectories, and within 5e-6 of the robust-grid solve everywhere but the degenerate interval's input.
+    ST_RICCATI_STRICT = 1 turns the same solve into the hard failure -4 of rounds 1-3."""
+    import pyoracle
+    from qm_control_amd import api, scenarios
+    from test_grid_fuzz import degenerate_cases, check_degenerate_against_robust
+    cfg, cases = degenerate_cases(scenarios.make_config("C2", batch=1, n_intervals=100))
+    B = cfg["B"]; assert B >= 15
+    runs = {}
+    for name, dt_min, strict in (("up", L.QM_GRID_DT_MIN_UPSTREAM, 0.0), ("rob", L.QM_GRID_DT_MIN_ROBUST, 0.0), ("strict", L.QM_GRID_DT_MIN_UPSTREAM, 1.0)):
+        itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=cfg["ref_t"].shape[1], max_events=cfg["ev"].shape[1])
+        itf.set_setting(L.ST_GRID_DT_MIN, dt_min); itf.set_setting(L.ST_RICCATI_STRICT, strict)
+        runs[name] = api.SqpMpc(itf).run(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"]); itf.close()
+    assert (runs["up"]["status"] == L.QM_MPC_WARN_PIVOT).all() and (runs["rob"]["status"] == 0).all() and (runs["strict"]["status"] == -4).all()
+    ost = oblobs[1].copy(); ostrob = ost.copy(); ostrob[L.ST_GRID_DT_MIN] = L.QM_GRID_DT_MIN_ROBUST
+    for b, (k_ev, off) in enumerate(cases):
+        what = "event %d offset %g" % (k_ev, off); dev = {}
+        for name, s in (("up", ost), ("rob", ostrob)):
+            o = pyoracle.Oracle(oblobs[0], s); r = _oracle_solve(o, cfg, b); res = runs[name]; n = len(r["t"])
+            assert r["warn"] == (L.QM_MPC_WARN_PIVOT if name == "up" else 0), what
+            assert res["num_nodes"][b] == n and np.array_equal(res["t"][b, :n], r["t"]) and np.array_equal(res["event"][b, :n], r["ev"]) and np.array_equal(res["mode"][b, :n], r["mode"]), what
+            assert_blocks(res["x"][b, :n], r["x"], "x", TOL, what + " x* vs oracle (%s)" % name); assert_blocks(res["u"][b, :n], r["u"], "u", TOL, what + " u* vs oracle (%s)" % name)
+            dev[name] = dict(t=res["t"][b, :n], ev=res["event"][b, :n], mode=res["mode"][b, :n], x=res["x"][b, :n], u=res["u"][b, :n])
+        check_degenerate_against_robust(dev["up"], dev["rob"], 5e-6, what + " (device)")

@@ -78,3 +78,28 @@ def test_wbc_context_matches_oracle_and_refuses_mpc_calls(blobs, oracle):
     with pytest.raises(api.QmhipError, match="WBC-only"):
         api.SqpMpc(witf).set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
     witf.close(); itf.close()
+
+
+def test_fixed_rate_mpc_loop_never_fails():
+    """60 s of controller time per raster (6000 warm MPC solves each, back to back) through the C ABI from plain C (tests/c_abi_fixed_rate.c): the review's 10 ms raster
+    offset by 1.3 ms, a raster shared with the gait events, and a raster that puts a shooting node 5e-7 s in front of EVERY gait event.  No solve may fail (call error or
+    negative status) — the reference's mpcThread_ answers a failed MPC_BASE::run by stopping the controller (QMController.cpp:327-330); the degenerate stages surface as
+    warnings (status QM_MPC_WARN_PIVOT), one per gait event on the third raster."""
+    exe = os.path.join(ROOT, "tests", "_build", "c_abi_fixed_rate"); os.makedirs(os.path.dirname(exe), exist_ok=True); libdir = os.path.join(ROOT, "qm_control_amd")
+    subprocess.check_call(["gcc", "-O1", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi_fixed_rate.c"),
+                           "-L" + libdir, "-lqmhip", "-Wl,-rpath," + libdir, "-lm", "-o", exe])
+    p = subprocess.run([exe, URDF, TASK, REFI, "60"], capture_output=True, text=True, timeout=900)
+    print(p.stdout)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rows = {}
+    for line in p.stdout.splitlines():
+        k, _, v = line.partition(":"); toks = v.split()
+        if k.startswith("raster_"):
+            rows[k] = {toks[i]: float(toks[i + 1]) for i in range(0, len(toks), 2)}
+    assert len(rows) == 3
+    for k, r in rows.items():
+        assert r["solves"] == 6000 and r["failed"] == 0 and r["call_errors"] == 0, (k, r)
+    assert rows["raster_0"]["warnings"] == 0 and rows["raster_2"]["warnings"] >= 168, rows          # 60 s / 0.35 s = 171 gait events
+    assert rows["raster_2"]["smallest_gap_before_an_event"] < 1e-6
+    with open(os.path.join(ROOT, "gpurun_out", "fixed_rate_report.txt"), "w") as fh:
+        fh.write(p.stdout)

@@ -40,6 +40,33 @@ def test_emulated_general_kernel_on_the_controllers_tasks(blobs, oracle):
         assert (st == 0).all() and np.abs(x - ref[:36]).max() <= 1e-8 * np.abs(ref[:36]).max()
 
 
+def _equality_cascade(rng, n, ma):
+    """one equality-only level with ma rows on n variables (feasible by construction)"""
+    A = rng.normal(size=(ma, n)); return [dict(A=A, b=A @ rng.normal(size=n) if ma <= n else rng.normal(size=ma), D=np.zeros((0, n)), f=np.zeros(0))]
+
+
+def test_emulated_pipeline_reuse_with_fewer_variables_and_more_rows():
+    """advisor finding (round 3): the pipeline sized b / f by rows * n; a later solve with fewer variables but more rows (n = 36, ma = 10 -> n = 10, ma = 36) overran them"""
+    import emu_harness, pyoracle
+    rng = np.random.default_rng(3)
+    for n, ma in ((36, 10), (10, 36), (36, 10), (12, 30)):
+        tasks = _equality_cascade(rng, n, ma)
+        x, st, _ = pyoracle.hoqp(tasks); xe, ste = emu_harness.hoqp(tasks)
+        assert np.array_equal(st, ste) and np.abs(x - xe).max() <= 1e-9 * max(1.0, np.abs(x).max()), (n, ma)
+
+
+@pytest.mark.gpu
+def test_context_reuse_with_fewer_variables_and_more_rows(blobs):
+    import pyoracle
+    from qm_control_amd import api
+    itf = api.QMInterface(blobs=blobs, max_batch=1, max_nodes=8, max_ref_knots=2, max_events=2); hq = api.HoQp(itf); rng = np.random.default_rng(3)
+    for n, ma in ((36, 10), (10, 36), (36, 10), (12, 30)):
+        tasks = _equality_cascade(rng, n, ma)
+        xo, sto, _ = pyoracle.hoqp(tasks); x, st = hq.solve(tasks)
+        assert np.array_equal(np.ravel(st), sto) and np.abs(np.ravel(x) - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max()), (n, ma)
+    itf.close()
+
+
 @pytest.mark.gpu
 def test_general_kernel_batches_vs_oracle(blobs):
     import pyoracle
