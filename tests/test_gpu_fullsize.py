@@ -95,3 +95,34 @@ def test_sample_matches_oracle(full_run, blobs):
         assert np.array_equal(res["t"][b, :n], tr["t"][j, :n]) and np.array_equal(res["event"][b, :n], tr["event"][j, :n]) and np.array_equal(res["mode"][b, :n], tr["mode"][j, :n]), b
         assert_blocks(res["x"][b, :n], tr["x"][j, :n], "x", TOL, "x* of instance %d" % b); assert_blocks(res["u"][b, :n], tr["u"][j, :n], "u", TOL, "u* of instance %d" % b)
         assert_blocks(r["out"][b], w[j], "wbc", TOL, b)
+
+
+def test_c4_global_batch_8192(blobs):
+    """BASELINE.json config 4 at its real size on ONE GPU (the G = 1 point of the strong-scaling curve): 8192 instances, trot, N = 100.  Every status >= 0 — the batch holds
+    one instance (2453, t0 = 0.094999544) whose grid node 17 falls 4.6e-7 s in front of the gait event at 0.35 s: it must come back with the warning QM_MPC_WARN_PIVOT, not
+    fail — and a 64-instance sample INCLUDING that instance matches the oracle on the whole trajectories, the policy at t0 and the WBC output (per block, 1e-6)."""
+    import os
+    import pyoracle
+    from qm_control_amd import api, scenarios
+    B = 8192
+    cfg = scenarios.make_config("C4", batch=B)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=116, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+    wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+    res = mpc.download(); out, qps = wbc.download(B); xd, ud, mode = mpc.evaluatePolicy(cfg["t0"]); ls_trials = res["ls_trials"]; itf.close()
+    assert (res["status"] >= 0).all() and (qps == 0).all() and np.isfinite(out).all()
+    warned = np.nonzero(res["status"] > 0)[0]
+    assert 2453 in warned and len(warned) <= 4 and (res["status"][warned] == L.QM_MPC_WARN_PIVOT).all(), warned
+    assert ls_trials <= 3, ls_trials      # one instance that cannot find a step used to drag the WHOLE batch through all 14 line-search trials (the 14 % loss at B = 8192 of round 3)
+    idx = np.sort(np.random.default_rng(8192).choice(B, 64, replace=False)); idx[np.argmin(np.abs(idx - 2453))] = 2453; idx = np.unique(idx)
+    nm = res["x"].shape[1]
+    bad, xf, uf, w, tr = pyoracle.batch_step(*pyoracle.load_blobs(), min(64, os.cpu_count() or 1), cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx],
+                                             cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"], traj_nodes=nm)
+    assert bad == 0
+    assert_blocks(xd[idx], xf, "x", TOL, "policy x"); assert_blocks(ud[idx], uf, "u", TOL, "policy u")
+    for j, b in enumerate(idx):
+        n = int(tr["num_nodes"][j]); assert n == int(res["num_nodes"][b]), b
+        assert np.array_equal(res["t"][b, :n], tr["t"][j, :n]) and np.array_equal(res["event"][b, :n], tr["event"][j, :n]) and np.array_equal(res["mode"][b, :n], tr["mode"][j, :n]), b
+        assert_blocks(res["x"][b, :n], tr["x"][j, :n], "x", TOL, "x* of instance %d" % b); assert_blocks(res["u"][b, :n], tr["u"][j, :n], "u", TOL, "u* of instance %d" % b)
+        assert_blocks(out[b], w[j], "wbc", TOL, b)

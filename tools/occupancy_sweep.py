@@ -36,12 +36,13 @@ def kernel_ms(itf, step, names, reps=6):
 def main():
     out = {"workload": "C4 (trot, N = 100, seed 1235)", "lds_per_cu": LDS_CU, "lds_padding_sweep_B1024": {}, "batch_sweep": {}}
     sizes = {"lq": 16896, "lq_kin": 31744, "ls_eval": 31744, "riccati": 38272, "wbc": 40752}      # own LDS per workgroup: LQ_LDS_BYTES, LQ_KIN_LDS_BYTES, LS_EVAL_LDS_BYTES, RW_LDS_BYTES, WBC_LDS_BYTES
+    batch_only = "--batch-only" in sys.argv
     cfg, itf, mpc, wbc = engine(1024)
     for _ in range(12): itf.microbench_fp64(True)
     mpc_step = lambda: mpc.solve_resident(cfg["horizon"])
     def wbc_step():
         wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
-    for g, own in sizes.items():
+    for g, own in ({} if batch_only else sizes).items():
         rows = []
         for target in (8, 4, 2, 1):                                   # workgroups (= waves: every kernel here is one wave per workgroup) per CU allowed by LDS
             reg_cap = 4 * GROUPS[g][2]; natural = min(reg_cap, LDS_CU // own)
@@ -58,7 +59,7 @@ def main():
         out["lds_padding_sweep_B1024"]["qm_%s_kernel" % g] = rows
         print(g, rows, flush=True)
     itf.close()
-    for B in (256, 512, 1024, 2048, 4096):
+    for B in (256, 512, 1024, 2048, 4096, 8192):
         cfg, itf, mpc, wbc = engine(B)
         def step():
             wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
@@ -66,7 +67,7 @@ def main():
         itf.synchronize(); t = time.perf_counter()
         for _ in range(10): step()
         itf.synchronize(); dt = (time.perf_counter() - t) / 10
-        out["batch_sweep"][str(B)] = {"instances_per_simd": B / 1024.0, "solver_waves_offered_per_cu": B / 256.0, "ms_per_step_pipelined": round(dt * 1e3, 4), "steps_per_s": round(B / dt),
+        out["batch_sweep"][str(B)] = {"instances_per_simd": B / 1024.0, "solver_waves_offered_per_cu": B / 256.0, "ms_per_step_pipelined": round(dt * 1e3, 4), "steps_per_s": round(B / dt), "ls_trials": int(mpc.download()["ls_trials"]),
                                       "kernel_ms_unpipelined": {k: round(v, 4) for k, v in ms.items()}, "kernel_us_per_instance": {k: round(1e3 * v / B, 4) for k, v in ms.items()}}
         print(B, out["batch_sweep"][str(B)], flush=True)
         itf.close()
