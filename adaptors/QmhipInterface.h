@@ -32,6 +32,9 @@ class QmhipInterface : public QMInterface {
     int maxNodes = 160;      // timeHorizon / sqp.dt + 2 nodes per gait event inside the horizon (K0 reports status -1 when it does not fit)
     int maxRefKnots = 2;     // targetPoseToTargetTrajectories publishes 2 knots (QmTargetTrajectoriesPublisher_node.cpp:44-68)
     int maxEvents = 64;      // events of getModeSchedule(t − T, t + 2T) of the busiest gait
+    bool robustTimeGrid = false;   // false: [upstream] timeDiscretizationWithEvents' dt_min (node schedules bit-equal to OCS2's; a node within 1e-6 s in front of a gait event is kept and
+                                   // its negative-duration stage solved with zeroed pivots, status warning QM_MPC_WARN_PIVOT).  true: ST_GRID_DT_MIN = QM_GRID_DT_MIN_ROBUST — such a node
+                                   // is merged into the event node (no warning, one node less than upstream on those calls)
   };
 
   QmhipInterface(const std::string& taskFile, const std::string& urdfFile, const std::string& referenceFile, DeviceOptions opt)
@@ -42,6 +45,7 @@ class QmhipInterface : public QMInterface {
     if (rc == QMHIP_ERR_FILE) throw std::invalid_argument(qmhip_last_error(nullptr));
     if (rc != QMHIP_OK) throw std::runtime_error(std::string("[QmhipInterface] qmhip_create failed: ") + qmhip_last_error(nullptr));
     ctx_.reset(raw);
+    if (opt.robustTimeGrid && qmhip_set_setting(raw, ST_GRID_DT_MIN, QM_GRID_DT_MIN_ROBUST) != QMHIP_OK) throw std::runtime_error(std::string("[QmhipInterface] qmhip_set_setting: ") + qmhip_last_error(raw));
     // the control thread's own context (include/qmhip.h "Threads"): WbcBase::update runs on the ros_control thread while mpcThread_ is inside MPC_BASE::run
     // (QMController.cpp:128-147 beside :315-333)
     qmhip_ctx* rawWbc = nullptr;

@@ -4,6 +4,16 @@
 // every control tick (QMController.cpp:145-147) and `loadTasksSetting()`.  `update` returns [v̇(24); F(12); τ(18)]; the controller takes tail(18).
 // The joint-acceleration state inputLast_ (WbcBase.cpp:212-213) lives in the device context.  `variant` selects the hierarchy:
 //   0 = HierarchicalWbc (HierarchicalWbc.cpp:18-44, incl. the time < 10 arm-joint branch), 1 = HierarchicalMpcWbc (HierarchicalMpcWbc.cpp:18-34).
+//
+// dynamic_reconfigure.  The reference is tuned through rqt_reconfigure on `<controller>/wbc`: WbcBase's constructor starts a
+// dynamic_reconfigure::Server<qm_wbc::WbcWeightConfig> there (WbcBase.cpp:60-65) whose callback writes the 32 gains into WbcBase's members (WbcBase.cpp:69-116).
+// Server, callback and members are PRIVATE (WbcBase.h:60-62), so a subclass can neither replace the callback nor read the gains — but every
+// dynamic_reconfigure server also publishes each accepted configuration on the latched topic `<ns>/parameter_updates` (dynamic_reconfigure/Config: name / value
+// pairs) [upstream dynamic_reconfigure::Server::updateConfigInternal].  QmhipWbc subscribes to `<controller>/wbc/parameter_updates` and forwards every gain the
+// reference's callback reads to the device (qmhip_wbc_gain_index -> qmhip_set_setting on the WBC context; names it does not read — d_ee_*, da_ee_* — are skipped, as
+// in the reference).  The topic is latched: the configuration the server applied in setCallback (the cfg defaults or the parameter server's values) arrives right
+// after the subscription, so the device starts from the same gains as WbcBase's members; rqt_reconfigure keeps working unchanged.  The subscriber callback runs on
+// the node's spinner thread; qmhip_set_setting serialises with qmhip_wbc_step on the context's lock (include/qmhip.h "Threads").
 #pragma once
 #include <stdexcept>
 #include <string>
@@ -12,7 +22,9 @@
 #ifdef QMHIP_ADAPTOR_STUBS
 #include "stubs/reference_stubs.h"
 #else
+#include <dynamic_reconfigure/Config.h>
 #include <qm_wbc/WbcBase.h>
+#include <ros/ros.h>
 #endif
 
 namespace qm {
@@ -24,6 +36,21 @@ class QmhipWbc : public WbcBase {
       : WbcBase(pinocchioInterface, std::move(info), eeKinematics, armEeKinematics, controllerNh), ctx_(ctx), variant_(variant) {
     if (!ctx_) throw std::invalid_argument("[QmhipWbc] null device context");
     if (qmhip_wbc_reset(ctx_) != QMHIP_OK) throw std::runtime_error(std::string("[QmhipWbc] qmhip_wbc_reset: ") + qmhip_last_error(ctx_));
+    // the base class has just started its server on <controller>/wbc (WbcBase.cpp:60-65): follow its (latched) update topic
+    gainSub_ = controllerNh.subscribe<dynamic_reconfigure::Config>("wbc/parameter_updates", 4, [this](const dynamic_reconfigure::Config::ConstPtr& msg) { applyReconfigure(*msg); });
+  }
+
+  // one configuration of the reference's server -> device gains; returns how many gains were written.  Never throws (it runs in a subscriber callback):
+  // a refused value is counted in gainErrors() and the text kept in lastGainError()
+  int applyReconfigure(const dynamic_reconfigure::Config& config) {
+    int n = 0;
+    for (const auto& d : config.doubles) {
+      const int idx = qmhip_wbc_gain_index(d.name.c_str());
+      if (idx < 0) continue;                                           // d_ee_x ... da_ee_x: not read by WbcBase::dynamicCallback either
+      if (qmhip_set_setting(ctx_, idx, d.value) == QMHIP_OK) ++n; else { ++gainErrors_; lastGainError_ = qmhip_last_error(ctx_); }
+    }
+    ++reconfigureCount_;
+    return n;
   }
 
   ocs2::vector_t update(const ocs2::vector_t& stateDesired, const ocs2::vector_t& inputDesired, const ocs2::vector_t& rbdStateMeasured, size_t mode,
@@ -41,14 +68,18 @@ class QmhipWbc : public WbcBase {
   // task.info's torqueLimitsTask / frictionConeTask blocks (WbcBase.cpp:565-595) were read by qmhip_create from the same file; nothing to load here.
   void loadTasksSetting(const std::string& /*taskFile*/, bool /*verbose*/) override {}
 
-  // dynamic_reconfigure (WbcBase.cpp:69-116 — the base class keeps its own server; a node that wants the gains on the device forwards them here)
+  // a single gain by settings index (tests, nodes without the reconfigure server)
   void setGain(int settingsIndex /* ST_KP_SWING ... ST_KD_EE_ANG, include/qmhip_layout.h */, double value) {
     if (qmhip_set_setting(ctx_, settingsIndex, value) != QMHIP_OK) throw std::runtime_error(std::string("[QmhipWbc] qmhip_set_setting: ") + qmhip_last_error(ctx_));
   }
   const int32_t* lastQpStatus() const { return qpStatus_; }
+  int reconfigureCount() const { return reconfigureCount_; }          // configurations received from <controller>/wbc/parameter_updates
+  int gainErrors() const { return gainErrors_; }
+  const std::string& lastGainError() const { return lastGainError_; }
 
  private:
   qmhip_ctx* ctx_; int variant_; int32_t qpStatus_[3] = {0, 0, 0};
+  ros::Subscriber gainSub_; int reconfigureCount_ = 0, gainErrors_ = 0; std::string lastGainError_;
 };
 
 }  // namespace qm

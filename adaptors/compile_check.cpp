@@ -6,5 +6,7 @@ int qmhip_adaptors_compile_check() {
   ocs2::PrimalSolution p; ocs2::ModeSchedule ms;
   double t[2] = {0, 1}, x[60] = {0}, u[60] = {0}; int32_t ev[2] = {0, 0};
   qm::toPrimalSolution(2, t, ev, x, u, ms, p);
-  return (int)p.timeTrajectory_.size() + s.maxNodes;
+  dynamic_reconfigure::Config cfg; cfg.doubles.push_back({"kp_swing", 350.0});
+  int (qm::QmhipWbc::*apply)(const dynamic_reconfigure::Config&) = &qm::QmhipWbc::applyReconfigure; (void)apply;
+  return (int)p.timeTrajectory_.size() + s.maxNodes + (int)cfg.doubles.size();
 }

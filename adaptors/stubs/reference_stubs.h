@@ -14,8 +14,17 @@
 
 namespace ros {
 struct Publisher {};
-struct NodeHandle { template <class M> Publisher advertise(const std::string&, int) { return Publisher(); } };
+struct Subscriber {};
+struct NodeHandle {
+  template <class M> Publisher advertise(const std::string&, int) { return Publisher(); }
+  // roscpp: subscribe<M>(topic, queue_size, boost::function<void(const boost::shared_ptr<M const>&)>)
+  template <class M, class F> Subscriber subscribe(const std::string&, int, F callback) { if (false) callback(typename M::ConstPtr()); return Subscriber(); }      // type-checks the callback against M::ConstPtr
+};
 }  // namespace ros
+namespace dynamic_reconfigure {                 // dynamic_reconfigure/Config.msg: bools / ints / strs / doubles / groups; the adaptor reads `doubles`
+struct DoubleParameter { std::string name; double value = 0; };
+struct Config { typedef std::shared_ptr<const Config> ConstPtr; std::vector<DoubleParameter> doubles; };
+}  // namespace dynamic_reconfigure
 namespace ocs2_msgs { struct mpc_observation {}; }
 namespace qm_msgs { struct ee_state {}; }
 

@@ -51,6 +51,11 @@ int qmhip_parse_model(const char* urdf_file, const char* task_file, const char* 
                       double* model_blob /*[MB_SIZE]*/, double* settings_blob /*[ST_SIZE]*/);
 int qmhip_export_blobs(const qmhip_ctx* ctx, double* model_blob, double* settings_blob);
 int qmhip_set_setting(qmhip_ctx* ctx, int settings_index, double value);   /* e.g. WBC gains: dynamic_reconfigure callback, WbcBase.cpp:69-116 */
+/* settings index of a WBC gain by the name it carries in the reference's dynamic_reconfigure config (qm_wbc/cfg/wbcWigeht.cfg:7-47, assigned in
+ * WbcBase::dynamicCallback, qm_wbc/src/WbcBase.cpp:69-116): "kp_swing" -> ST_KP_SWING, "baseHeightKp" -> ST_KP_BASE_H, "kp_arm_joint_3" -> ST_KP_ARM_J + 2,
+ * "kd_ee_angular_y" -> ST_KD_EE_ANG + 1, ...; -1 for a name the callback does not read (d_ee_x ... da_ee_x) or an unknown one.  Host-only, no context:
+ * adaptors/QmhipWbc.h feeds every entry of the server's `parameter_updates` message through it into qmhip_set_setting. */
+int qmhip_wbc_gain_index(const char* reconfigure_name);
 
 /* ---- MPC: replaces ocs2::MPC_BASE::run(t, x) on the SqpMpc the reference installs
  *      (qm_controllers/src/QMController.cpp:287-288,315-323) for B independent instances: one multiple-shooting

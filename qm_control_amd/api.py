@@ -19,7 +19,7 @@ from . import layout as L
 MB_SIZE, ST_SIZE = L.MB_SIZE, L.ST_SIZE
 
 EXPORTS = ["qmhip_create", "qmhip_create_from_blobs", "qmhip_create_wbc_context", "qmhip_destroy", "qmhip_last_error", "qmhip_parse_model", "qmhip_export_blobs",
-           "qmhip_set_setting", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_update_references", "qmhip_mpc_solve_resident_warm",
+           "qmhip_set_setting", "qmhip_wbc_gain_index", "qmhip_mpc_step", "qmhip_mpc_upload", "qmhip_mpc_solve_resident", "qmhip_mpc_set_initial", "qmhip_mpc_update_references", "qmhip_mpc_solve_resident_warm",
            "qmhip_mpc_advance_resident", "qmhip_closed_loop_resident", "qmhip_mpc_download", "qmhip_policy_eval",
            "qmhip_wbc_step", "qmhip_wbc_reset", "qmhip_hoqp_solve", "qmhip_control_step_resident", "qmhip_wbc_download", "qmhip_set_profiling",
            "qmhip_get_kernel_ms", "qmhip_reset_kernel_ms", "qmhip_synchronize", "qmhip_last_ls_trials", "qmhip_debug_read", "qmhip_debug_set", "qmhip_debug_get", "qmhip_debug_filler", "qmhip_debug_lq_with_filler", "qmhip_microbench_fp64",
@@ -130,6 +130,15 @@ class QMInterface:
         mb = self.model_blob
         return dict(robotMass=mb[L.MB_ROBOTMASS], centroidalInertiaNominal=mb[L.MB_INOM:L.MB_INOM + 9].reshape(3, 3).copy(), comToBasePositionNominal=mb[L.MB_RNOM:L.MB_RNOM + 3].copy(),
                     qPinocchioNominal=np.concatenate([np.zeros(6), mb[L.MB_QNOM:L.MB_QNOM + 18]]), stateDim=30, inputDim=30, generalizedCoordinatesNum=24, actuatedDofNum=18, numThreeDofContacts=4)
+
+    def set_gain(self, name, value):
+        """one field of the reference's dynamic_reconfigure config qm_wbc::WbcWeightConfig by NAME (WbcBase::dynamicCallback, WbcBase.cpp:69-116); False for a field
+        the callback does not read (d_ee_x ...)"""
+        idx = self.lib.qmhip_wbc_gain_index(name.encode())
+        if idx < 0:
+            return False
+        self.set_setting(idx, value)
+        return True
 
     def set_setting(self, index, value):
         self._check(self.lib.qmhip_set_setting(self.h, C.c_int(index), C.c_double(value)), "qmhip_set_setting")

@@ -215,6 +215,18 @@ void qmhip_destroy(qmhip_ctx* c) {
 // failing call on the same context replaces the context's message meanwhile
 const char* qmhip_last_error(const qmhip_ctx* c) { static thread_local std::string copy; QM_GUARD(c); if (!c) return g_create_error.c_str(); copy = c->error; return copy.c_str(); }
 int qmhip_export_blobs(const qmhip_ctx* c, double* mb, double* st) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; if (mb) memcpy(mb, c->mb, sizeof(c->mb)); if (st) memcpy(st, c->st, sizeof(c->st)); return QMHIP_OK; }
+// name of a field of qm_wbc::WbcWeightConfig (cfg/wbcWigeht.cfg:7-47) -> settings slot of the gain WbcBase::dynamicCallback stores it in (WbcBase.cpp:69-116)
+int qmhip_wbc_gain_index(const char* name) {
+  if (!name) return -1;
+  static const struct { const char* name; int idx; } scalars[] = {{"kp_swing", ST_KP_SWING}, {"kd_swing", ST_KD_SWING}, {"baseHeightKp", ST_KP_BASE_H}, {"baseHeightKd", ST_KD_BASE_H},
+    {"kp_base_linear", ST_KP_BASE_LIN}, {"kd_base_linear", ST_KD_BASE_LIN}, {"kp_base_angular", ST_KP_BASE_ANG}, {"kd_base_angular", ST_KD_BASE_ANG}};
+  for (const auto& e : scalars) if (!strcmp(name, e.name)) return e.idx;
+  static const struct { const char* prefix; int base; } joints[] = {{"kp_arm_joint_", ST_KP_ARM_J}, {"kd_arm_joint_", ST_KD_ARM_J}};
+  for (const auto& e : joints) { const size_t n = strlen(e.prefix); if (!strncmp(name, e.prefix, n) && name[n] >= '1' && name[n] <= '6' && name[n + 1] == 0) return e.base + (name[n] - '1'); }
+  static const struct { const char* prefix; int base; } axes[] = {{"kp_ee_linear_", ST_KP_EE_LIN}, {"kd_ee_linear_", ST_KD_EE_LIN}, {"kp_ee_angular_", ST_KP_EE_ANG}, {"kd_ee_angular_", ST_KD_EE_ANG}};
+  for (const auto& e : axes) { const size_t n = strlen(e.prefix); if (!strncmp(name, e.prefix, n) && name[n] >= 'x' && name[n] <= 'z' && name[n + 1] == 0) return e.base + (name[n] - 'x'); }
+  return -1;
+}
 int qmhip_set_setting(qmhip_ctx* c, int idx, double v) { QM_GUARD(c);
   if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
   if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number, the grid's minimum step a non-negative one, ST_RICCATI_STRICT 0 or 1"); return QMHIP_ERR_ARG; }

@@ -94,3 +94,38 @@ def test_degenerate_vertices_are_resolved(blobs, oracle, gait, inst):
     assert bad == 0
     assert_blocks(out[inst], w[0], "wbc", TOL, inst)
     itf.close()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_reconfigured_gains_reach_the_device(blobs, oblobs, variant):
+    """the rqt_reconfigure path (WbcBase::dynamicCallback, WbcBase.cpp:69-116): gains changed BY NAME mid-run through the C ABI (qmhip_wbc_gain_index ->
+    qmhip_set_setting, what adaptors/QmhipWbc.h does with the server's parameter_updates message) take effect on the next tick and match the oracle run with the same gains;
+    a name the reference's callback does not read changes nothing."""
+    import pyoracle
+    from qm_control_amd import api, layout as L
+    oracle = pyoracle.Oracle(*oblobs)
+    cases = _random_wbc_inputs(oracle, blobs, 12, 41 + variant, 0.05)
+    B = len(cases); arr = lambda k: np.array([c[k] for c in cases])
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=8, max_ref_knots=2, max_events=2); witf = itf.wbc_context()      # the control thread's context, as the adaptor uses it
+    wbc = api.HierarchicalWbc(witf, mpc_variant=bool(variant))
+    def tick():
+        wbc.reset(); wbc.update(arr("xd"), arr("il"), arr("rbd"), arr("mode"), 0.002, arr("time"))
+        return wbc.update(arr("xd"), arr("ud"), arr("rbd"), arr("mode"), 0.002, arr("time"))
+    def oracle_tick(o):
+        outs = []
+        for c in cases:
+            o.wbc_reset(); o.wbc(c["xd"], c["il"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant))
+            outs.append(o.wbc(c["xd"], c["ud"], c["rbd"], c["mode"], 0.002, c["time"], mpc_variant=bool(variant))[0])
+        return np.array(outs)
+    out0, st0 = tick()
+    assert (st0 == 0).all(); assert_blocks(out0, oracle_tick(oracle), "wbc", TOL, "shipped gains")
+    new = {"kp_swing": 200.0, "kd_swing": 20.0, "baseHeightKp": 250.0, "baseHeightKd": 60.0, "kp_base_linear": 300.0, "kd_base_linear": 50.0, "kp_base_angular": 150.0, "kd_base_angular": 90.0,
+           "kp_arm_joint_2": 2500.0, "kd_arm_joint_5": 40.0, "kp_ee_linear_x": 1500.0, "kd_ee_linear_z": 50.0, "kp_ee_angular_y": 900.0, "kd_ee_angular_x": 30.0}
+    for name, v in new.items():
+        assert witf.set_gain(name, v)
+        oracle.set_setting(witf.lib.qmhip_wbc_gain_index(name.encode()), v)
+    assert not witf.set_gain("d_ee_x", 0.3) and not witf.set_gain("da_ee_z", 1.0)          # not read by the reference's callback: no slot
+    out1, st1 = tick()
+    assert (st1 == 0).all(); assert_blocks(out1, oracle_tick(oracle), "wbc", TOL, "reconfigured gains")
+    assert np.abs(out1[:, 36:] - out0[:, 36:]).max() > 1e-3                                  # the gains did change the torques
+    witf.close(); itf.close()

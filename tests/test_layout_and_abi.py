@@ -99,3 +99,34 @@ def test_create_rejects_bad_sizes(blobs):
     for bad in (2, 513):
         with pytest.raises(api.QmhipError, match="bad argument"):
             api.QMInterface(blobs=blobs, max_batch=1, max_nodes=bad)
+
+
+def test_wbc_gain_names_of_the_reconfigure_server():
+    """qmhip_wbc_gain_index: every field WbcBase::dynamicCallback reads (qm_wbc/src/WbcBase.cpp:69-116; declared in qm_wbc/cfg/wbcWigeht.cfg:7-47) maps to its settings
+    slot, the six fields it does not read (d_ee_*, da_ee_*) and unknown names map to -1.  Host-only entry point: no GPU needed."""
+    import ctypes as C
+    from qm_control_amd import api, layout as L
+    lib = api.load_library(); f = lib.qmhip_wbc_gain_index; f.restype = C.c_int; f.argtypes = [C.c_char_p]
+    want = {"kp_swing": L.ST_KP_SWING, "kd_swing": L.ST_KD_SWING, "baseHeightKp": L.ST_KP_BASE_H, "baseHeightKd": L.ST_KD_BASE_H, "kp_base_linear": L.ST_KP_BASE_LIN,
+            "kd_base_linear": L.ST_KD_BASE_LIN, "kp_base_angular": L.ST_KP_BASE_ANG, "kd_base_angular": L.ST_KD_BASE_ANG}
+    for j in range(6):
+        want["kp_arm_joint_%d" % (j + 1)] = L.ST_KP_ARM_J + j; want["kd_arm_joint_%d" % (j + 1)] = L.ST_KD_ARM_J + j
+    for a, ax in enumerate("xyz"):
+        want["kp_ee_linear_" + ax] = L.ST_KP_EE_LIN + a; want["kd_ee_linear_" + ax] = L.ST_KD_EE_LIN + a
+        want["kp_ee_angular_" + ax] = L.ST_KP_EE_ANG + a; want["kd_ee_angular_" + ax] = L.ST_KD_EE_ANG + a
+    assert len(want) == 32 and len(set(want.values())) == 32
+    for name, idx in want.items():
+        assert f(name.encode()) == idx, name
+    for name in ("d_ee_x", "d_ee_y", "d_ee_z", "da_ee_z", "da_ee_y", "da_ee_x", "kp_arm_joint_7", "kp_arm_joint_0", "kp_ee_linear_w", "kp_swing_", "", "kp_arm_joint_11"):
+        assert f(name.encode()) == -1, name
+    assert f(None) == -1
+    # when the reference tree is present (this container, not the GPU box): the cfg file declares exactly these names + the six unread ones, with the blob's defaults
+    cfg = os.path.join("/root/reference", "qm_wbc", "cfg", "wbcWigeht.cfg")
+    if os.path.exists(cfg):
+        import re
+        from qm_control_amd import scenarios
+        st = scenarios.load_blobs()[1]
+        decl = dict((m.group(1), float(m.group(2))) for m in re.finditer(r'gen\.add\("(\w+)",\s*double_t,\s*0,\s*"[^"]*",\s*([-0-9.eE]+)', open(cfg).read()))
+        assert set(want) <= set(decl) and len(decl) == 38
+        for name, idx in want.items():
+            assert st[idx] == decl[name], name
