@@ -15,7 +15,11 @@
 namespace ros {
 struct Publisher {};
 struct Subscriber {};
+inline void init(int&, char**, const std::string&) {}
 struct NodeHandle {
+  NodeHandle() = default;
+  explicit NodeHandle(const std::string&) {}
+  NodeHandle(const NodeHandle&, const std::string&) {}
   template <class M> Publisher advertise(const std::string&, int) { return Publisher(); }
   // roscpp: subscribe<M>(topic, queue_size, boost::function<void(const boost::shared_ptr<M const>&)>)
   template <class M, class F> Subscriber subscribe(const std::string&, int, F callback) { if (false) callback(typename M::ConstPtr()); return Subscriber(); }      // type-checks the callback against M::ConstPtr
@@ -43,12 +47,18 @@ struct vector_t {                               // Eigen::VectorXd stand-in
 using scalar_array_t = std::vector<scalar_t>;
 using vector_array_t = std::vector<vector_t>;
 using size_array_t = std::vector<size_t>;
-struct ModeSchedule { scalar_array_t eventTimes; size_array_t modeSequence; };
-struct TargetTrajectories { scalar_array_t timeTrajectory; vector_array_t stateTrajectory, inputTrajectory; };
-struct ControllerBase { virtual ~ControllerBase() = default; virtual ControllerBase* clone() const = 0; };
+struct ModeSchedule { scalar_array_t eventTimes; size_array_t modeSequence; size_t modeAtTime(scalar_t) const { return modeSequence.empty() ? 0 : modeSequence.front(); } };
+struct TargetTrajectories {
+  TargetTrajectories() = default;
+  TargetTrajectories(scalar_array_t t, vector_array_t x, vector_array_t u) : timeTrajectory(std::move(t)), stateTrajectory(std::move(x)), inputTrajectory(std::move(u)) {}
+  scalar_array_t timeTrajectory; vector_array_t stateTrajectory, inputTrajectory;
+};
+struct ControllerBase { virtual ~ControllerBase() = default; virtual ControllerBase* clone() const = 0; virtual vector_t computeInput(scalar_t t, const vector_t& x) = 0; };
+namespace LinearInterpolation { inline vector_t interpolate(scalar_t, const scalar_array_t&, const vector_array_t& v) { return v.empty() ? vector_t() : v.front(); } }
 struct FeedforwardController : ControllerBase {
   FeedforwardController(scalar_array_t t, vector_array_t u) : t_(std::move(t)), u_(std::move(u)) {}
   FeedforwardController* clone() const override { return new FeedforwardController(*this); }
+  vector_t computeInput(scalar_t, const vector_t&) override { return u_.empty() ? vector_t() : u_.front(); }
   scalar_array_t t_; vector_array_t u_;
 };
 struct PrimalSolution {
@@ -68,6 +78,7 @@ struct ReferenceManagerInterface {
   virtual ~ReferenceManagerInterface() = default;
   virtual const ModeSchedule& getModeSchedule() const = 0;
   virtual const TargetTrajectories& getTargetTrajectories() const = 0;
+  virtual void setTargetTrajectories(TargetTrajectories) {}
 };
 struct SolverSynchronizedModule { virtual ~SolverSynchronizedModule() = default; };
 class SolverBase {                              // ocs2_oc/oc_solver/SolverBase.h
@@ -80,6 +91,7 @@ class SolverBase {                              // ocs2_oc/oc_solver/SolverBase.
   const ReferenceManagerInterface& getReferenceManager() const { return *ref_; }
   void addSynchronizedModule(std::shared_ptr<SolverSynchronizedModule> m) { modules_.push_back(std::move(m)); }
   virtual scalar_t getFinalTime() const = 0;
+  PrimalSolution primalSolution(scalar_t finalTime) const { PrimalSolution p; getPrimalSolution(finalTime, &p); return p; }
   virtual void getPrimalSolution(scalar_t finalTime, PrimalSolution* primalSolutionPtr) const = 0;
   virtual size_t getNumIterations() const = 0;
   virtual const OptimalControlProblem& getOptimalControlProblem() const = 0;
@@ -98,6 +110,8 @@ class MPC_BASE {                                // ocs2_mpc/MPC_BASE.h
  public:
   explicit MPC_BASE(mpc::Settings s) : settings_(std::move(s)) {}
   virtual ~MPC_BASE() = default;
+  virtual void reset() {}
+  virtual bool run(scalar_t currentTime, const vector_t& currentState) { calculateController(currentTime, currentState, currentTime + settings_.timeHorizon_); return true; }
   virtual SolverBase* getSolverPtr() = 0;
   virtual const SolverBase* getSolverPtr() const = 0;
   const mpc::Settings& settings() const { return settings_; }
@@ -108,7 +122,40 @@ class MPC_BASE {                                // ocs2_mpc/MPC_BASE.h
 };
 struct PinocchioInterface {};
 struct CentroidalModelInfo { scalar_t robotMass = 0; };
-struct PinocchioEndEffectorKinematics {};
+struct CentroidalModelPinocchioMapping { explicit CentroidalModelPinocchioMapping(const CentroidalModelInfo&) {} };
+struct PinocchioEndEffectorKinematics {
+  PinocchioEndEffectorKinematics() = default;
+  PinocchioEndEffectorKinematics(const PinocchioInterface&, const CentroidalModelPinocchioMapping&, std::vector<std::string>) {}
+};
+struct Initializer {};
+namespace sqp { struct Settings { int threadPriority = 0; }; }
+class SqpSolverStub final : public SolverBase {     // stands for ocs2::SqpSolver behind SqpMpc::getSolverPtr()
+ public:
+  void reset() override {}
+  scalar_t getFinalTime() const override { return 0; }
+  void getPrimalSolution(scalar_t, PrimalSolution*) const override {}
+  size_t getNumIterations() const override { return 0; }
+  const OptimalControlProblem& getOptimalControlProblem() const override { return problem_; }
+  const PerformanceIndex& getPerformanceIndeces() const override { return perf_; }
+  const std::vector<PerformanceIndex>& getIterationsLog() const override { return log_; }
+  ScalarFunctionQuadraticApproximation getValueFunction(scalar_t, const vector_t&) const override { return {}; }
+  ScalarFunctionQuadraticApproximation getHamiltonian(scalar_t, const vector_t&, const vector_t&) override { return {}; }
+  vector_t getStateInputEqualityConstraintLagrangian(scalar_t, const vector_t&) const override { return {}; }
+ private:
+  void runImpl(scalar_t, const vector_t&, scalar_t) override {}
+  void runImpl(scalar_t, const vector_t&, scalar_t, const ControllerBase*) override {}
+  OptimalControlProblem problem_; PerformanceIndex perf_; std::vector<PerformanceIndex> log_;
+};
+class SqpMpc final : public MPC_BASE {              // ocs2_sqp/SqpMpc.h
+ public:
+  SqpMpc(mpc::Settings mpcSettings, sqp::Settings, const OptimalControlProblem&, const Initializer&) : MPC_BASE(std::move(mpcSettings)) {}
+  SolverBase* getSolverPtr() override { return &solver_; }
+  const SolverBase* getSolverPtr() const override { return &solver_; }
+ protected:
+  void calculateController(scalar_t, const vector_t&, scalar_t) override {}
+ private:
+  SqpSolverStub solver_;
+};
 struct CentroidalModelRbdConversions { CentroidalModelRbdConversions(const PinocchioInterface&, const CentroidalModelInfo&) {} };
 struct RosReferenceManager : ReferenceManagerInterface {
   RosReferenceManager(std::string, std::shared_ptr<ReferenceManagerInterface> p) : p_(std::move(p)) {}
@@ -118,7 +165,13 @@ struct RosReferenceManager : ReferenceManagerInterface {
   std::shared_ptr<ReferenceManagerInterface> p_;
 };
 namespace legged_robot {
-struct GaitSchedule {};
+struct ModeSequenceTemplate { ModeSequenceTemplate(scalar_array_t t, size_array_t m) : switchingTimes(std::move(t)), modeSequence(std::move(m)) {} scalar_array_t switchingTimes; size_array_t modeSequence; };
+struct GaitSchedule {                           // ocs2_legged_robot/gait/GaitSchedule.h
+  GaitSchedule() : tmpl_({0.0, 1.0}, {size_t(15)}) {}
+  GaitSchedule(ModeSchedule initModeSchedule, ModeSequenceTemplate initModeSequenceTemplate, scalar_t phaseTransitionStanceTime) : ms_(std::move(initModeSchedule)), tmpl_(std::move(initModeSequenceTemplate)), t_(phaseTransitionStanceTime) {}
+  ModeSchedule ms_; ModeSequenceTemplate tmpl_; scalar_t t_ = 0;
+};
+struct ModelSettings { std::vector<std::string> contactNames3DoF; struct { std::string eeFrame; } info; };
 struct SwitchedModelReferenceManager : ReferenceManagerInterface { std::shared_ptr<GaitSchedule> getGaitSchedule() { return nullptr; } };
 struct GaitReceiver : SolverSynchronizedModule { GaitReceiver(ros::NodeHandle, std::shared_ptr<GaitSchedule>, const std::string&) {} };
 }  // namespace legged_robot
@@ -132,6 +185,9 @@ class QMInterface {                             // qm_interface/include/qm_inter
   virtual void setupOptimalControlProblem(const std::string&, const std::string&, const std::string&, bool) {}
   const ocs2::OptimalControlProblem& getOptimalControlProblem() const { return problem_; }
   const ocs2::mpc::Settings& mpcSettings() const { return mpcSettings_; }
+  const ocs2::sqp::Settings& sqpSettings() { return sqpSettings_; }
+  const ocs2::legged_robot::ModelSettings& modelSettings() const { return modelSettings_; }
+  const ocs2::Initializer& getInitializer() const { return initializer_; }
   const ocs2::vector_t& getInitialState() const { return initialState_; }
   ocs2::PinocchioInterface& getPinocchioInterface() { return pin_; }
   const ocs2::CentroidalModelInfo& getCentroidalModelInfo() const { return info_; }
@@ -139,6 +195,7 @@ class QMInterface {                             // qm_interface/include/qm_inter
   std::shared_ptr<ocs2::ReferenceManagerInterface> getReferenceManagerPtr() const { return nullptr; }
  private:
   ocs2::OptimalControlProblem problem_; ocs2::mpc::Settings mpcSettings_; ocs2::vector_t initialState_{30}; ocs2::PinocchioInterface pin_; ocs2::CentroidalModelInfo info_;
+  ocs2::sqp::Settings sqpSettings_; ocs2::legged_robot::ModelSettings modelSettings_; ocs2::Initializer initializer_;
 };
 class WbcBase {                                 // qm_wbc/include/qm_wbc/WbcBase.h:26-34
  public:
@@ -147,6 +204,8 @@ class WbcBase {                                 // qm_wbc/include/qm_wbc/WbcBase
   virtual ocs2::vector_t update(const ocs2::vector_t&, const ocs2::vector_t&, const ocs2::vector_t&, size_t, ocs2::scalar_t, ocs2::scalar_t) { return ocs2::vector_t(); }
   virtual void loadTasksSetting(const std::string&, bool) {}
 };
+class HierarchicalWbc : public WbcBase { public: using WbcBase::WbcBase; };        // qm_wbc/include/qm_wbc/HierarchicalWbc.h
+class HierarchicalMpcWbc : public WbcBase { public: using WbcBase::WbcBase; };     // qm_wbc/include/qm_wbc/HierarchicalMpcWbc.h
 class QMController {                            // qm_controllers/include/qm_controllers/QMController.h:37-95 (the members the adaptor touches)
  public:
   virtual ~QMController() = default;

@@ -12,6 +12,14 @@ def test_adaptors_compile_against_stubs():
     assert p.returncode == 0, p.stderr[-3000:]
 
 
+def test_reference_golden_generator_type_checks_against_stubs():
+    """adaptors/tools/dump_reference_goldens.cpp — the program a maintainer compiles in the reference's catkin workspace to produce tests/golden_ref — parses and
+    type-checks against the stand-in declarations (QMInterface, SqpMpc, GaitSchedule, HierarchicalWbc / HierarchicalMpcWbc, PrimalSolution ...)"""
+    p = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-DQMHIP_ADAPTOR_STUBS", "-I" + os.path.join(ROOT, "adaptors"),
+                        os.path.join(ROOT, "adaptors", "tools", "dump_reference_goldens.cpp")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+
+
 def test_adaptors_only_call_declared_entry_points():
     hdr = open(os.path.join(ROOT, "include", "qmhip.h")).read()
     declared = set(re.findall(r"\b(qmhip_\w+)\s*\(", hdr))
