@@ -194,6 +194,8 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
                     if f and v["avg_launch_ms"] > 0 and B == 1024 and args.n_intervals == 100:      # the counters were collected on the default workload
                         v["survey_dense_flop_per_launch"] = v["flop_per_launch"]; v["survey_dense_frac_fp64"] = v["frac_fp64"]
                         v["flop_per_launch"] = f; v["tflops"] = f / (v["avg_launch_ms"] * 1e-3) / 1e12; v["frac_fp64"] = v["tflops"] / FP64_PEAK_TFLOPS
+                    share = fp["kernels"].get(v["kernel"], {}).get("valu_non_f64_share")
+                    if share is not None: v["valu_non_f64_share"] = share      # share of the kernel's vector instructions that are not FP64 arithmetic (addressing, masks, moves): same counter passes
                 if B == 1024 and args.n_intervals == 100: flop_src = "instrumented: SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 + SQ_INSTS_VALU_MFMA_MOPS_F64 per launch, profiles/flops_pmc.json round %s (same command, B=1024; not measured in this run)%s" % (
                     fp.get("round", "?"), " — STALE: collected on kernel sources %s, this tree is %s" % (fp.get("kernel_source_hash"), src_hash) if flops_stale else "")
             except (OSError, KeyError, ValueError):
@@ -240,7 +242,7 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
         if hip:
             line["roofline"] = roofline
             line["fp64_peak_measured"] = {"mfma_f64_16x16x4": peak_mfma, "vector_fma": peak_fma, "unit": "TFLOP/s", "note": "roofline.peak stays the 78.6 TFLOP/s data-sheet figure"}
-            keys = ("avg_launch_ms", "flop_per_launch", "tflops", "frac_fp64", "survey_dense_flop_per_launch", "survey_dense_frac_fp64", "bytes_per_launch", "tbs", "frac_hbm")
+            keys = ("avg_launch_ms", "flop_per_launch", "tflops", "frac_fp64", "survey_dense_flop_per_launch", "survey_dense_frac_fp64", "bytes_per_launch", "tbs", "frac_hbm", "valu_non_f64_share")
             line["roofline_all"] = {k: {kk: v[kk] for kk in keys if kk in v} for k, v in roofs.items()}
             line["kernel_ms_per_step"] = {k: v[0] / 5 for k, v in kms_all.items()}
         line.update(sec)
@@ -341,6 +343,24 @@ def secondary_figures(args, eng, cfg, dist, device, world, rank):
                                                  "cpu_baseline.single_instance_ms"}
         out["latency_ms"] = {"B1_C2": lat1, "B%d_unpipelined" % B: lat_b, "note": "one control step with a device synchronisation after every step (no stream overlap between steps); "
                              "B1_C2 = BASELINE.json config 2 (single instance, trot, N = 100): %.0f Hz" % (1e3 / lat1), "C2_status_ok": r2["ok"]}
+    # (6) PCIe-INCLUSIVE rate: the boundary hands over host buffers (qmhip_mpc_upload / qmhip_mpc_download / qmhip_wbc_download), the headline keeps its inputs resident.
+    #     One whole hand-over per step: upload of (t0, x0, targets, schedule), the step, download of the node arrays + primal solution + WBC output — never `value`
+    if rank == 0:
+        eng.sync(); reps = 3; t = time.perf_counter()
+        for _ in range(reps):
+            mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"]); wbc.reset()
+            mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); r_ = mpc.download(); o_, q_ = wbc.download(B)
+        dt_all = (time.perf_counter() - t) / reps
+        t = time.perf_counter()
+        for _ in range(reps):
+            wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); eng.sync()
+        dt_step = (time.perf_counter() - t) / reps
+        out["pcie_inclusive"] = {"value": B / dt_all, "unit": "steps/s", "ms_per_step": dt_all * 1e3, "ms_step_only_unpipelined": dt_step * 1e3,
+                                 "bytes_in_per_instance": int(8 * (1 + 30 + cfg["ref_t"].shape[1] * 38 + cfg["ev"].shape[1]) + 4 * (cfg["ev"].shape[1] + 1)),
+                                 "bytes_out_per_instance": int(eng.itf.max_nodes * (8 + 4 + 4 + 8 * 60) + 8 * 10 + 4 + 8 * 54 + 12),
+                                 "note": "host -> device inputs, one unpipelined step, device -> host of every output array (node times / tags / modes, x*, u* on max_nodes nodes, perf, WBC output) "
+                                         "through the C ABI's synchronous copies and the host-side node-major -> instance-major gather of qmhip_mpc_download; NOT the headline value"}
+
     return out
 
 

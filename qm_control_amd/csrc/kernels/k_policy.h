@@ -54,3 +54,14 @@ __global__ void qm_policy_measured_kernel(QmPolicyMeasArgs a) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < a.p.B) qm_policy_body(a.p, g); else if (g - a.p.B < a.m.B) qm_measured_body(a.m, g - a.p.B);
 }
+
+// hand-over of the solver's node-major arrays [nmax][B][k] in the C ABI's instance-major layout [B][nmax][k] (qmhip_mpc_download): transposed on the DEVICE into one
+// staging buffer per call, so that the host sees ONE contiguous copy per array instead of B x nmax strided pieces.  Thread per 8-byte word (k doubles, or one int widened)
+struct QmGatherArgs { int B, nmax, k; const double* src_d; const int* src_i; double* dst_d; int* dst_i; };
+__global__ void qm_gather_kernel(QmGatherArgs a) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)a.B * a.nmax * a.k;
+  if (g >= total) return;
+  const int q = (int)(g % a.k); const size_t bi = g / a.k; const int i = (int)(bi % a.nmax), b = (int)(bi / a.nmax);      // destination index (b, i, q): coalesced writes
+  const size_t s = ((size_t)i * a.B + b) * a.k + q;
+  if (a.src_d) a.dst_d[g] = a.src_d[s]; else a.dst_i[g] = a.src_i[s];
+}

@@ -57,6 +57,7 @@ def test_bench_default_line_with_secondaries_and_cpu_baseline():
     # round 3: per-block parity figure, GPU counterparts of the reference's two timers, the strong-scaling point of SURVEY.md §8(d) C4
     assert set(cb["parity_on_sample"]) == {"vdot", "contact_forces", "torques"} and max(cb["parity_on_sample"].values()) < 1e-6
     sg = line["single_instance_ms_gpu"]; assert 0 < sg["wbc_ms_B1"] < sg["mpc_ms_B1"] < 50
+    pi = line["pcie_inclusive"]; assert 0 < pi["value"] < line["value"] * 1.2 and pi["ms_per_step"] > pi["ms_step_only_unpipelined"] > 0      # the hand-over costs time on top of the step
     ss = line["strong_scaling_C4"]; assert ss["scaling"] == "strong" and ss["global_batch"] == 8192 and ss["instances_per_gpu"] == 8192 and ss["value"] > 0
     # round 4: the whole BASELINE config-4 batch solves — no failed instance; the one whose shooting node falls within 1e-6 s in front of a gait event carries the warning
     assert ss["all_status_ok"] and ss["instances_with_failed_mpc_status"] == 0 and ss["instances_with_nonzero_wbc_status"] == 0 and 1 <= ss["instances_with_mpc_warning"] <= 4

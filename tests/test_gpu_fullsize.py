@@ -126,3 +126,31 @@ def test_c4_global_batch_8192(blobs):
         assert np.array_equal(res["t"][b, :n], tr["t"][j, :n]) and np.array_equal(res["event"][b, :n], tr["event"][j, :n]) and np.array_equal(res["mode"][b, :n], tr["mode"][j, :n]), b
         assert_blocks(res["x"][b, :n], tr["x"][j, :n], "x", TOL, "x* of instance %d" % b); assert_blocks(res["u"][b, :n], tr["u"][j, :n], "u", TOL, "u* of instance %d" % b)
         assert_blocks(out[b], w[j], "wbc", TOL, b)
+
+
+def test_c5_batch_512_per_gpu(blobs):
+    """BASELINE.json config 5 at its per-GPU size (4096 instances over 8 GPUs = 512 per GPU): EE-tracking target, trot -> stance -> trot schedule switching, N = 150,
+    a quarter of the instances with the arm on its joint limits.  Every MPC status >= 0, every QP status 0, and a 24-instance sample matches the oracle on the whole
+    trajectories, the policy at t0 and the WBC output (per block, 1e-6)."""
+    import os
+    import pyoracle
+    from qm_control_amd import api, scenarios
+    B = 512
+    cfg = scenarios.make_config("C5", batch=B)
+    itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=192, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+    mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+    mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+    wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+    res = mpc.download(); out, qps = wbc.download(B); xd, ud, mode = mpc.evaluatePolicy(cfg["t0"]); itf.close()
+    assert (res["status"] >= 0).all() and (qps == 0).all() and np.isfinite(out).all() and np.isfinite(res["x"]).all()
+    idx = np.sort(np.random.default_rng(512).choice(B, 24, replace=False)); idx[0] = 0; idx[-1] = B - 1
+    nm = res["x"].shape[1]
+    bad, xf, uf, w, tr = pyoracle.batch_step(*pyoracle.load_blobs(), min(24, os.cpu_count() or 1), cfg["t0"][idx], cfg["horizon"], cfg["x0"][idx], cfg["ref_t"][idx], cfg["ref_x"][idx],
+                                             cfg["ev"][idx], cfg["modes"][idx], cfg["period"], cfg["time"], traj_nodes=nm)
+    assert bad == 0
+    assert_blocks(xd[idx], xf, "x", TOL, "policy x"); assert_blocks(ud[idx], uf, "u", TOL, "policy u")
+    for j, b in enumerate(idx):
+        n = int(tr["num_nodes"][j]); assert n == int(res["num_nodes"][b]), b
+        assert np.array_equal(res["t"][b, :n], tr["t"][j, :n]) and np.array_equal(res["event"][b, :n], tr["event"][j, :n]) and np.array_equal(res["mode"][b, :n], tr["mode"][j, :n]), b
+        assert_blocks(res["x"][b, :n], tr["x"][j, :n], "x", TOL, "x* of instance %d" % b); assert_blocks(res["u"][b, :n], tr["u"][j, :n], "u", TOL, "u* of instance %d" % b)
+        assert_blocks(out[b], w[j], "wbc", TOL, b)
