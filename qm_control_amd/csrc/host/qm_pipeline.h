@@ -53,6 +53,7 @@ struct QmMpcPipeline {
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
   bool ncap_pending = false;   // K0 has been launched and its count not been read yet
+  bool has_m18 = true;         // some horizon of the current grid holds an all-stance phase (K0's conservative flag): K1b's second instance is launched
   std::function<void()> before_lq;   // profiling only (co-residency probe): called right before the LQ kernel is launched
   const int* front_status = nullptr; int front_B = 0;   // sticky status of the device-resident GaitSchedule driving batches of front_B instances (null: schedules come from the host)
   explicit QmMpcPipeline(BK& b) : bk(b) {}
@@ -74,7 +75,7 @@ struct QmMpcPipeline {
     d.alpha = A<double>(Bmax); d.done = A<int>(Bmax); d.xs = A<double>(NB * 30); d.us = A<double>(NB * 30); d.out_perf = A<double>((size_t)Bmax * 10);
     d.prev_n = A<int>(Bmax); d.prev_t = A<double>(NB); d.prev_ev = A<int>(NB);
     d.open_cnt = A<int>(QM_LS_MAX_TRIALS); d.tickets = A<int>(QM_LS_MAX_TRIALS);
-    d.ncap_dev = A<int>(2); { void* hv = nullptr; d.host_ncap_dev = (int*)bk.alloc_mapped(sizeof(int), &hv); d.host_ncap = (volatile int*)hv; d.host_ncap[0] = 0; }
+    d.ncap_dev = A<int>(3); { void* hv = nullptr; d.host_ncap_dev = (int*)bk.alloc_mapped(sizeof(int), &hv); d.host_ncap = (volatile int*)hv; d.host_ncap[0] = 0; }
     { void* hv = nullptr; d.host_open_dev = (int*)bk.alloc_mapped(QM_LS_MAX_TRIALS * sizeof(int), &hv); d.host_open = (volatile int*)hv; for (int i = 0; i < QM_LS_MAX_TRIALS; ++i) d.host_open[i] = 0; }
   }
   void release() {
@@ -128,7 +129,8 @@ struct QmMpcPipeline {
     QmRolloutArgs ro; ro.mb = d.mb; ro.st = d.st; ro.B = B; ro.nmax = d.nmax; ro.mode = 0; ro.trial = 0; ro.n_nodes = d.n_nodes; ro.node_dt = d.node_dt; ro.node_ev = d.node_ev; ro.x0 = d.x0;
     ro.x = d.x; ro.u = d.u; ro.stage = d.stage; ro.alpha = d.alpha; ro.done = d.done; ro.xt = d.xt; ro.ut = d.ut;
     if (ilqr) bk.launch(qm_ilqr_rollout_kernel, B, 64, 0, ro);      // single shooting: the nominal states are the rollout of the initial inputs
-    if (ncap == 0) { if (ncap_pending) bk.wait_flag(d.host_ncap, -1); ncap = ncap_pending ? d.host_ncap[0] : d.nmax; ncap_pending = false; if (ncap < 1 || ncap > d.nmax) ncap = d.nmax; }   // K0 ran first in the stream: published long before K1a is done
+    if (ncap == 0) { if (ncap_pending) bk.wait_flag(d.host_ncap, -1); const int word = ncap_pending ? d.host_ncap[0] : (d.nmax | (1 << 16)); ncap_pending = false;
+                     ncap = word & 0xFFFF; has_m18 = (word >> 16) != 0; if (ncap < 1 || ncap > d.nmax) { ncap = d.nmax; has_m18 = true; } }   // K0 ran first in the stream: published long before K1a is done
     const int nodes_threads = ncap * B;
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
@@ -136,7 +138,8 @@ struct QmMpcPipeline {
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, LQ_KIN_LDS_BYTES, q);
     if (before_lq) before_lq();
     if (d.lqdbg || lq_prof) bk.launch(qm_lq_dbg_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // the instance with debug records / phase cycle stamps (parity tests, profiling)
-    else bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // one wavefront per node; an empty workgroup costs the dispatcher as much as a full one
+    else { bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);      // one wavefront per node: the nodes with m <= 16 reduced inputs (any gait phase with a swing leg) ...
+           if (has_m18) bk.launch(qm_lq_m18_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q); }  // ... and the stance nodes (m = 18): two instances of one body, three waves per SIMD each (k_lq.h)
     QmLsArgs l = ls_args(B); if (ilqr) { l.xt = d.xt; l.ut = d.ut; l.ilqr = 1; }
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
     r.perf = d.perf; r.base_sum = d.base_sum; r.alpha = d.alpha; r.done = d.done; r.out_perf = d.out_perf; r.open_cnt = d.open_cnt; r.tickets = d.tickets;   // baseline merit + arming of the line search

@@ -41,7 +41,7 @@ struct HipBackend {
   void check(hipError_t e, const char* what) { if (e != hipSuccess && error.empty()) error = std::string(what) + ": " + hipGetErrorString(e); }
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
-    if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel || p == (const void*)qm_lq_dbg_kernel) return "lq"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel || p == (const void*)qm_riccati_prof_kernel) return "riccati";
+    if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel || p == (const void*)qm_lq_dbg_kernel) return "lq"; if (p == (const void*)qm_lq_m18_kernel) return "lq_m18"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel || p == (const void*)qm_riccati_prof_kernel) return "riccati";
     if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_ilqr_rollout_kernel) return "rollout"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy"; if (p == (const void*)qm_hoqp_kernel) return "hoqp";
     return "ls_misc";
   }

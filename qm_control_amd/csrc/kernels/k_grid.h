@@ -32,7 +32,7 @@ struct QmGridArgs {
   double* zvel; double* zpos;   // [nmax][B][4]
   double* xref;           // [nmax][B][30]
   double* eeref;          // [nmax][B][7]
-  int* ncap_dev; volatile int* host_ncap;   // optional: {max n_nodes, tickets} on the device; host-visible word the last block publishes the batch's largest node count in
+  int* ncap_dev; volatile int* host_ncap;   // optional: {max n_nodes, tickets, all-stance flag} on the device; host-visible word the last block publishes the batch's largest node count in
                                             // (the per-node launches that follow cover only that many nodes per instance: empty workgroups are not free)
   double* x; double* u;   // [nmax][B][30] initial guess (cold start, or warm start from the previous primal solution)
   // warm start ([upstream ocs2_sqp multiple_shooting::initializeStateInputTrajectories]): previous grid + primal solution; warm == 0 -> cold
@@ -68,7 +68,7 @@ __device__ __forceinline__ void grid_time_segment(const double* ta, int n, doubl
 
 __global__ void qm_grid_kernel(QmGridArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = 0;
+  int n = 0, has18 = 0;
   if (b < a.B) {
   const double* ev = a.ev + (size_t)b * a.nev; const int* modes = a.modes + (size_t)b * (a.nev + 1);
   const double t0 = a.t0[b], tf = t0 + a.horizon, dt = qm_ms_param(a.st, ST_SQP_DT);
@@ -92,13 +92,17 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
   }
   a.n_nodes[b] = n;
   a.status[b] = status;
+  // does the horizon hold a phase with three or four feet on the ground (17 / 18 reduced inputs: K1b's second instance, k_lq.h)?  Conservative: every phase between t0 and tf
+  { const int k0 = grid_find_index(ev, a.nev, t0), k1 = grid_find_index(ev, a.nev, tf);
+    for (int q = k0; q <= k1; ++q) { const int mq = modes[q]; if ((int)mode_flag(mq, 0) + (int)mode_flag(mq, 1) + (int)mode_flag(mq, 2) + (int)mode_flag(mq, 3) >= 3) has18 = 1; } }      // m = 14 + (feet on the ground) > 16
   }
   if (a.ncap_dev) {     // largest node count of the batch -> host (64-thread blocks = one wavefront each; the block that arrives last publishes and re-arms the counters)
-    double m = (double)n;
-    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    double m = (double)n, h = (double)has18;
+    for (int off = 32; off > 0; off >>= 1) { m = fmax(m, __shfl_xor(m, off, 64)); h = fmax(h, __shfl_xor(h, off, 64)); }
     if ((threadIdx.x & 63) == 0) {
-      atomicMax(a.ncap_dev, (int)m); __threadfence();
-      if (atomicAdd(a.ncap_dev + 1, 1) == (int)gridDim.x - 1) { a.host_ncap[0] = atomicMax(a.ncap_dev, 0); a.ncap_dev[0] = 0; a.ncap_dev[1] = 0; __threadfence_system(); }
+      atomicMax(a.ncap_dev, (int)m); if (h > 0.0) atomicOr(a.ncap_dev + 2, 1); __threadfence();
+      // published word: largest node count | (some horizon holds an all-stance phase) << 16
+      if (atomicAdd(a.ncap_dev + 1, 1) == (int)gridDim.x - 1) { const int f18 = atomicOr(a.ncap_dev + 2, 0); a.host_ncap[0] = atomicMax(a.ncap_dev, 0) | (f18 << 16); a.ncap_dev[0] = 0; a.ncap_dev[1] = 0; a.ncap_dev[2] = 0; __threadfence_system(); }
     }
   }
 }

@@ -72,27 +72,27 @@ struct QmLqArgs {
 #define LW_BLOCK 64
 #define LW_TLD 33                   /* odd: the transposed fragment reads (lanes run down a column, stride LW_TLD doubles) then hit 16 different bank pairs; 34 made them 2-way conflicts (K1b − 0.5 %) */
 #define LW_T     0                    /* [32][LW_TLD] hand-over tile (columns from lanes -> fragments) */
-#define LW_V     1088
+#define LW_V     (32 * LW_TLD)
 #define LW_V_X   (LW_V + 0)
 #define LW_V_U   (LW_V + 32)
-#define LW_V_X2  (LW_V + 64)
-#define LW_V_B   (LW_V + 96)          /* b */
-#define LW_V_E   (LW_V + 128)         /* e(16) */
-#define LW_V_PE  (LW_V + 144)         /* Pe(32) */
-#define LW_V_DU  (LW_V + 176)         /* u − unom */
-#define LW_V_G   (LW_V + 208)         /* per contact: Ginv or g data (4 x 12) */
-#define LW_V_EE  (LW_V + 256)         /* g(6) mu(6) qee(4) ref(7) */
-#define LW_V_FR  (LW_V + 280)         /* friction cone terms per contact: p2 dh dhᵀ + p1 ddh (9), p1 dh (3), ds (1) -> 4 x 16 */
-#define LW_V_RV  (LW_V + 344)         /* r */
-#define LW_V_QV  (LW_V + 376)         /* q */
-#define LW_V_RR  (LW_V + 408)         /* r + R Pe */
-#define LW_V_QD  (LW_V + 440)         /* diagonal additions of Q (32) */
-#define LW_V_RD  (LW_V + 472)         /* diagonal additions of R (32) */
-#define LW_K1    (LW_V + 504)
+#define LW_V_B   (LW_V + 64)          /* b */
+#define LW_V_E   (LW_V + 96)          /* e(16) */
+#define LW_V_PE  (LW_V + 112)         /* Pe(32) */
+#define LW_V_DU  (LW_V + 144)         /* u − unom */
+#define LW_V_G   (LW_V + 176)         /* per contact: Ginv or g data (4 x 12) */
+#define LW_V_EE  (LW_V + 224)         /* g(6) mu(6) qee(4) ref(7) */
+#define LW_V_FR  (LW_V + 248)         /* friction cone terms per contact: p2 dh dhᵀ + p1 ddh (9), p1 dh (3), ds (1) -> 4 x 16 */
+#define LW_V_RV  (LW_V + 312)         /* r */
+#define LW_V_QV  (LW_V + 344)         /* q */
+#define LW_V_RR  (LW_V + 376)         /* r + R Pe (before the projection: the lanes' tracking cost) */
+#define LW_V_QD  (LW_V + 408)         /* diagonal additions of Q (32) */
+#define LW_V_RD  (LW_V + 440)         /* diagonal additions of R (32) */
+#define LW_K1    (LW_V + 472)
 #define LW_K2    (LW_K1 + KW_SIZE)
 #define LW_PD    (LW_K2 + KW_SIZE)      /* Pu column descriptors: first source row i0 as double [32], weights [32][3] */
 #define LW_LDS_DOUBLES (LW_PD + 128)
 #define LQ_LDS_BYTES (LW_LDS_DOUBLES * 8)
+static_assert(LQ_LDS_BYTES <= 16384, "ten waves per CU (160 KB of LDS) need at most 16 KB each");
 #define LQ_KIN_LDS_BYTES (64 * 31 * 8)      /* K1a: one 31-double row per thread (the input u): 15.5 KB per wave, eight waves per CU */
 
 // value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column
@@ -113,8 +113,32 @@ __device__ __forceinline__ void lw_get_col30(const qm_d4 (&F)[IT][2], double* v,
 }
 
 // projected cost + record stores; MT = tiles covering the m reduced inputs
+// Bp = Bd Pu (rows 0..11 of the record; a joint row is dt Pu[j], K3 rebuilds it): Bp[row][j] = Σ_k w_k(j) Bdᵀ[i0(j) + k][row] — the tile holds Bdᵀ (rows = inputs).
+// Formed right behind the projected dynamics, so that the discrete-time Jacobians are dead before the cost model is assembled (three waves per SIMD: 168 registers)
 template <int MT>
-__device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu, int m, const qm_d4 (&Bdt)[2][2], const qm_d4 (&PxA)[2][2], const qm_d4 (&PuF)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
+__device__ __forceinline__ void lw_bp(double* S, double* rec, int m, const qm_d4 (&Bdt)[2][2]) {
+  const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
+  double* T = S + LW_T; const double* PD = S + LW_PD;
+  qm_wave_sync();
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 2; ++J)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(16 * I + g + 4 * r) * LW_TLD + 16 * J + c] = Bdt[I][J][r];
+  qm_wave_sync();
+  qm_d4 Bp[1][MT];                                             // rows 0..11 only
+#pragma unroll
+  for (int J = 0; J < MT; ++J) {
+    const int j = 16 * J + c; const int ci0 = (int)PD[j]; const double w0 = PD[32 + 3 * j], w1 = PD[33 + 3 * j], w2 = PD[34 + 3 * j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int row = g + 4 * r; const double* src = T + ci0 * LW_TLD + row; Bp[0][J][r] = w0 * src[0] + w1 * src[LW_TLD] + w2 * src[2 * LW_TLD]; }
+  }
+  qm_frag_store<1, MT, true>(Bp, rec + SR_BP, QM_MMAX, 12, m);
+  qm_wave_sync();
+}
+template <int MT>
+__device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu, int m, const qm_d4 (&PxA)[2][2], const qm_d4 (&PuF)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
   const int l = threadIdx.x & 63;
   qm_d4 Pu[2][MT];
 #pragma unroll
@@ -142,22 +166,14 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
 #pragma unroll
         for (int r = 0; r < 4; ++r) T[(16 * I + g + 4 * r) * LW_TLD + 16 * J + c] = F[I][J][r];
   };
-  // Bp = Bd Pu: Bp[row][j] = Σ_k w_k(j) Bdᵀ[i0(j) + k][row]   (the tile holds Bdᵀ: rows = inputs)
-  qm_wave_sync(); tile_put(Bdt); qm_wave_sync();
-  { qm_d4 Bp[2][MT];
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-      for (int J = 0; J < MT; ++J)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; const double* src = T + ci0[J] * LW_TLD + row; Bp[I][J][r] = cw[J][0] * src[0] + cw[J][1] * src[LW_TLD] + cw[J][2] * src[2 * LW_TLD]; }
-    qm_frag_store<2, MT, true>(Bp, rec + SR_BP, QM_MMAX, 12, m); }        // rows 0..11 only: a joint row is dt Pu[j], K3 rebuilds it (k_riccati.h)
   // [R Px | R Pe + r]: Px rows 12..23 (k-steps 3..5); Pe also has rows 0..11 (column 30 only -> tile column 1, k-steps 0..2)
   qm_d4 RPx[2][2]; qm_frag_zero<2, 2>(RPx);
   qm_gemm_tn<2, 2, 2>(Rm, PxA, RPx, 3, 6, false);
   { qm_d4 Y1[2][1], P1[2][1];
 #pragma unroll
     for (int I = 0; I < 2; ++I) { Y1[I][0] = PxA[I][1]; P1[I][0] = RPx[I][1]; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Y1[0][0][r] = (c == 14) ? S[LW_V_PE + g + 4 * r] : 0.0;
     qm_gemm_tn<2, 2, 1>(Rm, Y1, P1, 0, 3, false);
 #pragma unroll
     for (int I = 0; I < 2; ++I) RPx[I][1] = P1[I][0]; }
@@ -281,7 +297,7 @@ __global__ void __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
 
 // ---- K1b: one wavefront per node ----
 // DBG: the instance that also writes the debug records (a.dbg) and the phase cycle stamps (a.prof) — parity tests and profiling; the product instance has neither branch
-template <bool DBG>
+template <bool DBG, int MT>
 __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   if (!DBG) { a.dbg = nullptr; a.prof = 0; }
   extern __shared__ double qm_smem[];
@@ -299,8 +315,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   const int nn = a.n_nodes[b]; const int ev = a.node_ev[nb];
   const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
   const int nxt = (i + 1 < a.nmax) ? ((i + 1) * a.B + b) : nb;
-  double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_x2 = 0.0, in_ee = 0.0, in_k[4], in_k2[4], in_xref = 0.0, in_qd = 0.0;
-  if (l < 30) { in_xref = a.xref[nb * 30 + l]; in_qd = st[ST_Q + l]; in_x = a.x[nb * 30 + l]; in_u = a.u[nb * 30 + l]; xn = a.x[nxt * 30 + l]; f1 = kr[KR_F1 + l]; f2 = kr[KR_F2 + l]; in_x2 = kr[KR_X2 + l]; }
+  double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_ee = 0.0, in_k[4], in_k2[4], in_xref = 0.0, in_qd = 0.0;
+  if (l < 30) { in_xref = a.xref[nb * 30 + l]; in_qd = st[ST_Q + l]; in_x = a.x[nb * 30 + l]; in_u = a.u[nb * 30 + l]; xn = a.x[nxt * 30 + l]; f1 = kr[KR_F1 + l]; f2 = kr[KR_F2 + l]; }
   if (l >= 32 && l < 39) in_ee = a.eeref[nb * 7 + (l - 32)];
   if (l >= 40 && l < 46) in_ee = kr[KR_EEG + (l - 40)];
   if (l >= 48 && l < 52) in_ee = kr[KR_QEE + (l - 48)];
@@ -323,7 +339,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   for (int idx = l; idx < LW_K1 - LW_V; idx += 64) S[LW_V + idx] = 0.0;
   qm_wave_sync();
   if (terminal) { in_u = 0.0; xn = 0.0; f1 = 0.0; f2 = 0.0; }
-  if (l < 30) { X[l] = in_x; U[l] = in_u; S[LW_V_X2 + l] = in_x2; }
+  if (l < 30) { X[l] = in_x; U[l] = in_u; }
   if (l >= 32 && l < 39) EE[16 + (l - 32)] = in_ee;
   if (l >= 40 && l < 46) EE[l - 40] = in_ee;
   if (l >= 48 && l < 52) EE[12 + (l - 48)] = in_ee;
@@ -341,73 +357,19 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     if (l == 0) { double cN = 0.0; for (int k = 0; k < 6; ++k) cN += 0.5 * EE[6 + k] * EE[k] * EE[k]; rec[SR_SCAL] = 0.0; rec[SR_SCAL + 1] = cN; a.perf[nb * PF_SIZE] = cN; a.perf[nb * PF_SIZE + 1] = 0.0; a.perf[nb * PF_SIZE + 2] = 0.0; }
     return;
   }
-  LQT()
-  // ---- phase I: Jacobian columns -> fragments.  Tile rows 0..15 take [df/dx], rows 16..31 take [df/du] (rows 0..15 of each) ----
-  qm_d4 Ad[2][2], Bdt[2][2];
-  {
-    qm_d4 A1[1][2], B1[1][2], B1t[2][1], A2[1][2], A2t[2][1], B2t[2][1];
-    // one (column, Heun stage) task per lane for the four non-trivial column classes of the flow Jacobian — a wave executes each
-    // divergent class body once: lanes 0-5 dθ-rate columns 3..5, 6-11 zyx columns 9..11, 12-35 leg joints 12..23, 36-59 forces 30..41
-    int fc = 0, fs = l & 1;
-    if (l < 6) fc = 3 + (l >> 1); else if (l < 12) fc = 9 + ((l - 6) >> 1); else if (l < 36) fc = 12 + ((l - 12) >> 1); else fc = 30 + ((l - 36) >> 1);
-    double colf[12];
-    flow_jac_col_wave(mb, U, fs ? K2 : K1, fc, colf);        // lanes 60..63 repeat a force column and drop it
-    const int cc = (fc < 30) ? fc : fc - 30, r0 = (fc < 30) ? 0 : 16;
-    for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
-    qm_wave_sync();
-    if (l < 60 && fs == 0) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = colf[r]; }
-    if (l < 3) T[(6 + l) * LW_TLD + l] = 1.0;                                   // d rdot / d h_lin (both stages)
-    if (l >= 4 && l < 8) T[(16 + 8 + l) * LW_TLD + 8 + l] = 1.0;                // d qdot_j / d u_j rows 12..15 (rows >= 16 are handled analytically)
-    qm_wave_sync();
-    qm_frag_load_tile<1, 2, false>(A1, T, LW_TLD); qm_frag_load_tile<1, 2, false>(B1, T + 16 * LW_TLD, LW_TLD); qm_frag_load_tile<2, 1, true>(B1t, T + 16 * LW_TLD, LW_TLD);   // columns 30, 31 of the tile are zero
-    qm_wave_sync();
-    if (l < 60 && fs == 1) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = colf[r]; }      // same sparsity pattern: no re-zeroing needed
-    qm_wave_sync();
-    qm_frag_load_tile<1, 2, false>(A2, T, LW_TLD); qm_frag_load_tile<2, 1, true>(A2t, T, LW_TLD); qm_frag_load_tile<2, 1, true>(B2t, T + 16 * LW_TLD, LW_TLD);
-    LQT()
-    // A2 A1 (rows < 16): Z = A2ᵀ[0:16, 0:16], Y = A1
-    qm_d4 TA[1][2]; qm_frag_zero<1, 2>(TA);
-    { qm_d4 Z[1][1]; Z[0][0] = A2t[0][0]; qm_gemm_tn<1, 1, 2>(Z, A1, TA, 0, 4, false); }
-    // (A2 B1)ᵀ = B1ᵀ A2ᵀ[0:16, :] + rows >= 16 of A2ᵀ (rows >= 16 of B1 are unit rows)
-    qm_d4 TBt[2][1]; qm_frag_zero<2, 1>(TBt);
-    { qm_d4 Y[1][1]; Y[0][0] = A2t[0][0]; qm_gemm_tn<1, 2, 1>(B1, Y, TBt, 0, 4, false); }
-    TBt[1][0] += A2t[1][0];
-#pragma unroll
-    for (int J = 0; J < 2; ++J)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = g + 4 * r, col = 16 * J + c;
-        Ad[0][J][r] = (col < 30) ? 0.5 * dt * A1[0][J][r] + 0.5 * dt * (A2[0][J][r] + dt * TA[0][J][r]) + ((row == col) ? 1.0 : 0.0) : 0.0;
-        Ad[1][J][r] = (16 + row == col && col < 30) ? 1.0 : 0.0;
-      }
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + g + 4 * r;                                    // input index; column = state row
-        Bdt[I][0][r] = (row < 30) ? 0.5 * dt * B1t[I][0][r] + 0.5 * dt * (B2t[I][0][r] + dt * TBt[I][0][r]) : 0.0;
-        Bdt[I][1][r] = (row == 16 + c && row < 30) ? dt : 0.0;
-      }
-  }
+  // what the prologue's loads are needed for is formed HERE and only the results stay live (three waves per SIMD: 168 registers): the defect b, the tracking terms
+  // of the cost (state weights are diagonal) and u − u_nom
+  double* QD = S + LW_V_QD; double* RD = S + LW_V_RD; double* FR = S + LW_V_FR;
   const double bl = (l < 30) ? X[l] + 0.5 * dt * f1 + 0.5 * dt * f2 - xn : 0.0;
   if (l < 32) S[LW_V_B + l] = bl;
-  qm_wave_sync();
-  // Pin the results of phase I: the discrete-time Jacobians are complete HERE.  Without a use at this point the compiler sinks their arithmetic towards the
-  // products of phase II, keeps the six stage Jacobian fragments alive next to them and spills 100 bytes per lane (the debug stores below used to be that use).
-#pragma unroll
-  for (int I = 0; I < 2; ++I)
-#pragma unroll
-    for (int J = 0; J < 2; ++J) { QM_PIN4(Ad[I][J]); QM_PIN4(Bdt[I][J]); }
-  if (DBG && dbg) {
-    qm_frag_store<2, 2>(Ad, dbg + LQ_DBG_A, 30, 30, 30);
-#pragma unroll
-    for (int I = 0; I < 2; ++I)
-#pragma unroll
-      for (int J = 0; J < 2; ++J)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < 30 && col < 30) dbg[LQ_DBG_B + col * 30 + row] = Bdt[I][J][r]; }
-    if (l < 30) dbg[LQ_DBG_b + l] = bl;
+  if (l < 30) {
+    const double dx = X[l] - in_xref; const double qd = in_qd;
+    S[LW_V_QV + l] = qd * dx; QD[l] = qd; RD[l] = 0.0; S[LW_V_RR + l] = 0.5 * qd * dx * dx;      // the lane's tracking cost waits in the (idle) r + R Pe slot: one register pair less across the Jacobians
+    int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
+    double unom = 0.0; if (l < 12 && (l % 3) == 2 && mode_flag(mode, l / 3) && nst > 0) unom = mb[MB_ROBOTMASS] * 9.81 / nst;
+    S[LW_V_DU + l] = U[l] - unom;
   }
+  qm_wave_sync();
   LQT()
   // ---- phase II: equality rows + closed-form block projection ----
   // rows ordered per contact i = LF,RF,LH,RH: swing -> [F_i = 0 (3)] , stance -> [v_i = 0 (3)] , swing -> [v_iz = zvel_ref (1)]
@@ -474,7 +436,9 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   // row 12 + 3 ch + jj of Px is −(c0 Crow(i0) + c1 Crow(i1) + c2 Crow(i2)) with (c, i) = (Ginv row jj, the leg's 3 velocity rows) for a
   // stance leg and (g_jj / g·g, 0, 0; the normal-velocity row) for a swing leg; [C | e] carries e in column 30.
   qm_d4 PxA[2][2]; qm_frag_zero<2, 2>(PxA);
-  auto px_entry = [&](int row, int col) {
+  // (one row slot at a time, its coefficients shared by the two column tiles, a scheduling barrier between the slots: all 36 LDS reads in flight at once were the
+  //  register peak of this phase)
+  auto px_rows = [&](int row, double& o0, double& o1) {
     const int rr = row - 12, ch = rr / 3, jj = rr - 3 * ch, k = chain_to_contact(ch); const double* gg = G + 12 * k;
     int r0k = 0;
 #pragma unroll
@@ -482,22 +446,22 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     const bool stance = mode_flag(mode, k);
     const double c0 = stance ? gg[3 * jj] : gg[jj], c1 = stance ? gg[3 * jj + 1] : 0.0, c2 = stance ? gg[3 * jj + 2] : 0.0;
     const int i0 = stance ? r0k : r0k + 3, i1 = stance ? r0k + 1 : r0k + 3, i2 = stance ? r0k + 2 : r0k + 3;
-    return -(c0 * Ct[i0 * LW_TLD + col] + c1 * Ct[i1 * LW_TLD + col] + c2 * Ct[i2 * LW_TLD + col]);
+    o0 = -(c0 * Ct[i0 * LW_TLD + c] + c1 * Ct[i1 * LW_TLD + c] + c2 * Ct[i2 * LW_TLD + c]);
+    o1 = -(c0 * Ct[i0 * LW_TLD + 16 + c] + c1 * Ct[i1 * LW_TLD + 16 + c] + c2 * Ct[i2 * LW_TLD + 16 + c]);      // column 31 of [C | e] is zero
   };
-#pragma unroll
-  for (int J = 0; J < 2; ++J) {
-    const int col = 16 * J + c;                               // column 31 of [C | e] is zero
-    PxA[0][J][3] = px_entry(12 + g, col); PxA[1][J][0] = px_entry(16 + g, col); PxA[1][J][1] = px_entry(20 + g, col);
-  }
+  { double o0, o1;
+    px_rows(12 + g, o0, o1); PxA[0][0][3] = o0; PxA[0][1][3] = o1; __builtin_amdgcn_sched_barrier(0);
+    px_rows(16 + g, o0, o1); PxA[1][0][0] = o0; PxA[1][1][0] = o1; __builtin_amdgcn_sched_barrier(0);
+    px_rows(20 + g, o0, o1); PxA[1][0][1] = o0; PxA[1][1][1] = o1; __builtin_amdgcn_sched_barrier(0); }
   if (c == 14) {                                              // Pe rows 0..11: −F of a swing foot
 #pragma unroll
     for (int r = 0; r < 3; ++r) { const int row = g + 4 * r; PxA[0][1][r] = mode_flag(mode, row / 3) ? 0.0 : -U[row]; }
   }
   qm_wave_sync();
   lw_get_col30<2>(PxA, S + LW_V_PE, 30);
+  PxA[0][1][0] = 0.0; PxA[0][1][1] = 0.0; PxA[0][1][2] = 0.0;      // Pe rows 0..11 now live in LW_V_PE only: re-read where they are used (six registers less across the Jacobians)
   const double eq2 = qm_wave_sum((l < nc) ? S[LW_V_E + l] * S[LW_V_E + l] : 0.0);
   const double b2 = qm_wave_sum(bl * bl);
-  qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);      // input cost weights: issued here, consumed in phase III
   // Pu (30 x m) straight into fragments: columns = stance forces (identity triples), swing-leg null spaces (3 x 2 blocks), arm (identity)
   int nst = 0;
 #pragma unroll
@@ -535,6 +499,83 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
       }
   }
   LQT()
+  // ---- phase I: Jacobian columns -> fragments.  Tile rows 0..15 take [df/dx], rows 16..31 take [df/du] (rows 0..15 of each) ----
+  qm_d4 Ad[2][2], Bdt[2][2];
+  {
+    // Live set kept small (three waves per SIMD): stage 1 as A1, B1; of stage 2 first only A2ᵀ[0:16, 0:16] for the two products, then A2 and B2 themselves; B_d is formed
+    // untransposed (16 x 32) and turned into B_dᵀ through the tile once — instead of holding both stages in both layouts (six fragments) at the same time
+    qm_d4 A1[1][2], B1[1][2];
+    // one (column, Heun stage) task per lane for the four non-trivial column classes of the flow Jacobian — a wave executes each
+    // divergent class body once: lanes 0-5 dθ-rate columns 3..5, 6-11 zyx columns 9..11, 12-35 leg joints 12..23, 36-59 forces 30..41
+    int fc = 0, fs = l & 1;
+    if (l < 6) fc = 3 + (l >> 1); else if (l < 12) fc = 9 + ((l - 6) >> 1); else if (l < 36) fc = 12 + ((l - 12) >> 1); else fc = 30 + ((l - 36) >> 1);
+    double colf[12];
+    flow_jac_col(mb, X, U, fs ? K2 : K1, fc, colf);
+    const int cc = (fc < 30) ? fc : fc - 30, r0 = (fc < 30) ? 0 : 16;
+    for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
+    qm_wave_sync();
+    if (l < 60 && fs == 0) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = colf[r]; }
+    if (l < 3) T[(6 + l) * LW_TLD + l] = 1.0;                                   // d rdot / d h_lin (both stages)
+    if (l >= 4 && l < 8) T[(16 + 8 + l) * LW_TLD + 8 + l] = 1.0;                // d qdot_j / d u_j rows 12..15 (rows >= 16 are handled analytically)
+    qm_wave_sync();
+    qm_frag_load_tile<1, 2, false>(A1, T, LW_TLD); qm_frag_load_tile<1, 2, false>(B1, T + 16 * LW_TLD, LW_TLD);   // columns 30, 31 of the tile are zero
+    qm_wave_sync();
+    if (l < 60 && fs == 1) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = colf[r]; }      // same sparsity pattern: no re-zeroing needed
+    qm_wave_sync();
+    LQT()
+    qm_d4 TA[1][2], TB[1][2]; qm_frag_zero<1, 2>(TA); qm_frag_zero<1, 2>(TB);
+    { qm_d4 Z[1][1]; qm_frag_load_tile<1, 1, true>(Z, T, LW_TLD);               // A2ᵀ[0:16, 0:16]
+      qm_gemm_tn<1, 1, 2>(Z, A1, TA, 0, 4, false);                              // A2 A1 (rows < 16)
+      qm_gemm_tn<1, 1, 2>(Z, B1, TB, 0, 4, false); }                            // A2[:, 0:16] B1[0:16, :]; rows >= 16 of B1 are unit rows: + A2[:, 16:32] below
+    {
+      qm_d4 A2[1][2]; qm_frag_load_tile<1, 2, false>(A2, T, LW_TLD);
+      TB[0][1] += A2[0][1];
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = g + 4 * r, col = 16 * J + c;
+          Ad[0][J][r] = (col < 30) ? 0.5 * dt * A1[0][J][r] + 0.5 * dt * (A2[0][J][r] + dt * TA[0][J][r]) + ((row == col) ? 1.0 : 0.0) : 0.0;
+          Ad[1][J][r] = (16 + row == col && col < 30) ? 1.0 : 0.0;
+        }
+    }
+    {
+      qm_d4 B2[1][2]; qm_frag_load_tile<1, 2, false>(B2, T + 16 * LW_TLD, LW_TLD);
+      qm_d4 Bd[1][2];                                                            // rows 0..15 of B_d (state rows), all 32 input columns
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int col = 16 * J + c; Bd[0][J][r] = (col < 30) ? 0.5 * dt * B1[0][J][r] + 0.5 * dt * (B2[0][J][r] + dt * TB[0][J][r]) : 0.0; }
+      qm_wave_sync();
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(g + 4 * r) * LW_TLD + 16 * J + c] = Bd[0][J][r];
+      qm_wave_sync();
+      qm_d4 Bt[2][1]; qm_frag_load_tile<2, 1, true>(Bt, T, LW_TLD);             // B_dᵀ[:, 0:16]
+#pragma unroll
+      for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; Bdt[I][0][r] = Bt[I][0][r]; Bdt[I][1][r] = (row == 16 + c && row < 30) ? dt : 0.0; }
+    }
+  }
+  // Pin the results of phase I: the discrete-time Jacobians are complete HERE.  Without a use at this point the compiler sinks their arithmetic towards the
+  // products of phase II, keeps the six stage Jacobian fragments alive next to them and spills 100 bytes per lane (the debug stores below used to be that use).
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = 0; J < 2; ++J) { QM_PIN4(Ad[I][J]); QM_PIN4(Bdt[I][J]); }
+  if (DBG && dbg) {
+    qm_frag_store<2, 2>(Ad, dbg + LQ_DBG_A, 30, 30, 30);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; if (row < 30 && col < 30) dbg[LQ_DBG_B + col * 30 + row] = Bdt[I][J][r]; }
+    if (l < 30) dbg[LQ_DBG_b + l] = bl;
+  }
+  LQT()
   // projected dynamics  [Ap | bp] = [Ad | b] + Bd [Px | Pe]  (Z = Bdᵀ; Px rows 12..23 -> k-steps 3..5, Pe rows 0..11 -> column tile 1, k-steps 0..2)
   {
     qm_d4 ApA[2][2];
@@ -547,6 +588,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     { qm_d4 Y1[2][1], P1[2][1];
 #pragma unroll
       for (int I = 0; I < 2; ++I) { Y1[I][0] = PxA[I][1]; P1[I][0] = ApA[I][1]; }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) Y1[0][0][r] = (c == 14) ? S[LW_V_PE + g + 4 * r] : 0.0;
       qm_gemm_tn<2, 2, 1>(Bdt, Y1, P1, 0, 3, false);
 #pragma unroll
       for (int I = 0; I < 2; ++I) ApA[I][1] = P1[I][0]; }
@@ -557,17 +600,11 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     // rows 16..29 are joint rows: bp_j = b_j + dt Pe_j, the one non-zero term of the product (the second tile row of [Ap | bp] is never formed)
     if (l >= 16 && l < 30) rec[SR_BPV + l] = fma(dt, S[LW_V_PE + l], S[LW_V_B + l]);
   }
+  lw_bp<MT>(S, rec, m, Bdt);      // Bp = Bd Pu: the last use of the discrete-time Jacobians
   LQT()
   // ---- phase III: cost quadratic model (x dt) ----
-  double cost = 0.0;
-  double* QD = S + LW_V_QD; double* RD = S + LW_V_RD; double* FR = S + LW_V_FR;
-  if (l < 30) {
-    const double dx = X[l] - in_xref; const double qd = in_qd;
-    S[LW_V_QV + l] = qd * dx; QD[l] = qd; RD[l] = 0.0; cost += 0.5 * qd * dx * dx;
-    int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
-    double unom = 0.0; if (l < 12 && (l % 3) == 2 && mode_flag(mode, l / 3) && nst > 0) unom = mb[MB_ROBOTMASS] * 9.81 / nst;
-    S[LW_V_DU + l] = U[l] - unom;
-  }
+  double cost = (l < 30) ? S[LW_V_RR + l] : 0.0;
+  qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);      // input cost weights (L2 / scalar-cache resident table)
   if (l >= 32 && l < 38) EE[6 + (l - 32)] = ((l - 32) < 3 ? st[ST_MU_EE_POS] : st[ST_MU_EE_ORI]);
   qm_wave_sync();
   { // r = R0 (u − unom): a mat-vec on the register fragments — two partial products per lane and register, then a 16-lane DPP row sum
@@ -680,7 +717,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     if (DBG && dbg && col < 30) { for (int r = 0; r < 3; ++r) rec[SR_PX + (g + 4 * r) * 30 + col] = 0.0; rec[SR_PX + (24 + g) * 30 + col] = 0.0; if (g < 2) rec[SR_PX + (28 + g) * 30 + col] = 0.0; }
   }
   double rpe = 0.0;
-  if (m <= 16) lw_project<1>(S, rec, DBG && dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe); else lw_project<2>(S, rec, DBG && dbg != nullptr, m, Bdt, PxA, PuF, Rm, Qa, rpe);
+  lw_project<MT>(S, rec, DBG && dbg != nullptr, m, PxA, PuF, Rm, Qa, rpe);
   // what K3's forward rollout needs to apply Pu without reading it: the swing legs' null-space blocks and the contact mode
   if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
   if (l == 24) rec[SR_MODEF] = (double)mode;
@@ -697,5 +734,17 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     rec[SR_K + 13] = (double)__builtin_amdgcn_s_getreg(63492); rec[SR_K + 14] = (double)__builtin_amdgcn_s_getreg(63508); rec[SR_K + 15] = (double)(tp_[0] - c0_); rec[SR_K + 16] = (double)(c1_ - tp_[np_ - 1]); }
 #undef LQT
 }
-__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_kernel(QmLqArgs a) { qm_lq_body<false>(a); }
-__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_dbg_kernel(QmLqArgs a) { qm_lq_body<true>(a); }      // with debug records (parity tests) / phase cycle stamps (profiling)
+__device__ __forceinline__ int qm_lq_node_mt(const QmLqArgs& a) {
+  const int b = blockIdx.x / a.ncap, i = blockIdx.x - b * a.ncap;
+  const int mode = a.node_mode[i * a.B + b];
+  int nst = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
+  return (3 * nst + 2 * (4 - nst) + 6 <= 16) ? 1 : 2;
+}
+#ifndef QM_LQ_WAVES
+#define QM_LQ_WAVES 3      /* waves per SIMD the two product instances are compiled for */
+#endif
+__global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<false, 1>(a); }
+__global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_m18_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 2) qm_lq_body<false, 2>(a); }
+__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_dbg_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<true, 1>(a); else qm_lq_body<true, 2>(a); }

@@ -86,6 +86,7 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 #define __threadfence_system() ((void)0)
 inline int atomicAdd(int* p, int v) { const int o = *p; *p += v; return o; }
 inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }   /* blocks run one after the other on the host */
+inline int atomicOr(int* p, int v) { const int o = *p; *p |= v; return o; }
 struct double2 { double x, y; };
 inline double2 make_double2(double a, double b) { double2 r; r.x = a; r.y = b; return r; }
 

@@ -184,14 +184,16 @@ def test_lq_records_entrywise(blobs, oracle, name, N, skip):
     assert not bad, (bad, worst)
 
 
-@pytest.mark.parametrize("name,N", [("C2", 26), ("C5", 40), ("C1", 12)])
+@pytest.mark.parametrize("name,N", [("C2", 26), ("C5", 40), ("C1", 12), ("gait:dynamic_walk", 40)])
 def test_product_instances_match_the_instrumented_ones(blobs, oracle, name, N):
     """the LQ and Riccati kernels exist in two instances of one body each — the product's (qm_lq_kernel, qm_riccati_kernel) and the instrumented one the entrywise tests
     read (qm_lq_dbg_kernel with debug records; qm_riccati_prof_kernel, here with skip = 32: counters on, results intact).  Same stage records (bit for bit, apart from the
     fields only the debug instance writes) and the same solution."""
     import emu_harness, lq_record_check as LC
     from qm_control_amd import scenarios
-    cfg = scenarios.make_config(name, batch=1, n_intervals=N)
+    # (C1: stance only, m = 18; C2: trot, m = 16; C5: trot -> stance -> trot; dynamic_walk: three-leg support, m = 17 — the product runs the LQ kernel as two instances,
+    #  m <= 16 and m > 16, the second launched only when K0 flags a phase with three or four feet on the ground)
+    cfg = scenarios.gait_config(name[5:], batch=1, n_intervals=N, seed=3) if name.startswith("gait:") else scenarios.make_config(name, batch=1, n_intervals=N)
     r = _oracle(oracle, cfg); n = len(r["t"])
     outs = []
     for dbg, skip in ((True, 32), (False, 0)):

@@ -2,7 +2,8 @@
 These are the numbers behind DESIGN.md's occupancy notes; crossing an allocation granule here has cost more than most kernel changes gained:
   * a WBC wavefront holds ceil(vgpr / 8) * 8 of its SIMD's 512 registers while the next step's grid kernels run on the other stream — they must fit beside it;
   * the one-wave-per-instance kernels and the LQ kernel must not touch the private segment (rocprofv3's ScratchBytesPerLane);
-  * the LQ kernel runs two waves per SIMD, the thread-per-node kernels four waves per CU (their LDS rows decide that)."""
+  * the two product instances of the LQ kernel run THREE waves per SIMD (round 4: 168 registers, no scratch — any scratch doubles the time of a launch of 110 k
+    one-wave workgroups — and 16 KB of LDS: ten waves per CU), the thread-per-node kernels four waves per CU (their LDS rows decide that)."""
 import os, re, struct, subprocess, tempfile, ctypes as C
 import pytest
 
@@ -31,11 +32,11 @@ def _kernels():
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(READELF)), reason="libqmhip.so / llvm-readelf not available")
 def test_register_and_scratch_budgets():
     k = _kernels(); alloc = lambda name: (k[name]["vgpr"] + 7) // 8 * 8
-    for name in ("qm_wbc_kernel", "qm_sim_kernel", "qm_riccati_kernel", "qm_lq_kernel"):
+    for name in ("qm_wbc_kernel", "qm_sim_kernel", "qm_riccati_kernel", "qm_lq_kernel", "qm_lq_m18_kernel"):
         assert k[name]["scratch"] == 0, (name, k[name])
     assert alloc("qm_wbc_kernel") + alloc("qm_grid_nodes_kernel") <= 512 and alloc("qm_wbc_kernel") + alloc("qm_grid_kernel") <= 512, (k["qm_wbc_kernel"], k["qm_grid_nodes_kernel"])
     assert alloc("qm_wbc_kernel") + alloc("qm_policy_kernel") <= 512
-    assert 2 * alloc("qm_lq_kernel") <= 512, k["qm_lq_kernel"]
+    assert 3 * alloc("qm_lq_kernel") <= 512 and 3 * alloc("qm_lq_m18_kernel") <= 512, (k["qm_lq_kernel"], k["qm_lq_m18_kernel"])
     # the thread-per-node kernels are capped at 256 registers (two waves per SIMD: every wavefront of the benchmark launch resident at once); what does not fit is a
     # handful of spill stores / reloads among ~ 30 k instructions (round 3: 108 B and 352 B per lane; at one wave per SIMD they had 0 / 108 B and were 17 % / 9 % slower)
     assert alloc("qm_lq_kin_kernel") <= 256 and alloc("qm_ls_eval_kernel") <= 256
@@ -47,4 +48,4 @@ def test_lds_budgets_fit_the_intended_waves_per_cu():
     lib = C.CDLL(emu_harness.build())
     cu = 160 * 1024
     lq, ric, kin, ev, wbc, sim = (lib.emu_sizes(i) for i in (3, 4, 6, 7, 8, 9))
-    assert 8 * lq <= cu and 4 * ric <= cu and 8 * kin <= cu and 8 * ev <= cu and 4 * wbc <= cu and 4 * sim <= cu, (lq, ric, kin, ev, wbc, sim)
+    assert 10 * lq <= cu and 4 * ric <= cu and 8 * kin <= cu and 8 * ev <= cu and 4 * wbc <= cu and 4 * sim <= cu, (lq, ric, kin, ev, wbc, sim)
