@@ -77,17 +77,18 @@ struct QmLqArgs {
 #define LW_V_U   (LW_V + 32)
 #define LW_V_B   (LW_V + 64)          /* b */
 #define LW_V_E   (LW_V + 96)          /* e(16) */
-#define LW_V_PE  (LW_V + 112)         /* Pe(32) */
-#define LW_V_DU  (LW_V + 144)         /* u − unom */
-#define LW_V_G   (LW_V + 176)         /* per contact: Ginv or g data (4 x 12) */
-#define LW_V_EE  (LW_V + 224)         /* g(6) mu(6) qee(4) ref(7) */
-#define LW_V_FR  (LW_V + 248)         /* friction cone terms per contact: p2 dh dhᵀ + p1 ddh (9), p1 dh (3), ds (1) -> 4 x 16 */
-#define LW_V_RV  (LW_V + 312)         /* r */
-#define LW_V_QV  (LW_V + 344)         /* q */
-#define LW_V_RR  (LW_V + 376)         /* r + R Pe (before the projection: the lanes' tracking cost) */
-#define LW_V_QD  (LW_V + 408)         /* diagonal additions of Q (32) */
-#define LW_V_RD  (LW_V + 440)         /* diagonal additions of R (32) */
-#define LW_K1    (LW_V + 472)
+#define LW_V_FR  (LW_V + 64)          /* friction cone terms per contact: p2 dh dhᵀ + p1 ddh (9), p1 dh (3), ds (1) -> 4 x 16.  ALIASES b, e and 16 spare doubles: the defect and the
+                                         constraint values are dead once the projected dynamics are stored, the friction terms are formed after that (cost model) */
+#define LW_V_PE  (LW_V + 128)         /* Pe(32) */
+#define LW_V_DU  (LW_V + 160)         /* u − unom */
+#define LW_V_G   (LW_V + 192)         /* per contact: Ginv or g data (4 x 12) */
+#define LW_V_EE  (LW_V + 240)         /* g(6) mu(6) qee(4) ref(7) */
+#define LW_V_RV  (LW_V + 264)         /* r */
+#define LW_V_QV  (LW_V + 296)         /* q */
+#define LW_V_RR  (LW_V + 328)         /* r + R Pe (before the projection: the lanes' tracking cost) */
+#define LW_V_QD  (LW_V + 360)         /* diagonal additions of Q (32) */
+#define LW_V_RD  (LW_V + 392)         /* diagonal additions of R (32) */
+#define LW_K1    (LW_V + 424)
 #define LW_K2    (LW_K1 + KW_SIZE)
 #define LW_PD    (LW_K2 + KW_SIZE)      /* Pu column descriptors: first source row i0 as double [32], weights [32][3] */
 #define LW_LDS_DOUBLES (LW_PD + 128)

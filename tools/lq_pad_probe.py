@@ -14,6 +14,6 @@ for pad in [0, 512, 2048, 4096, 10240, 24576]:
     itf.synchronize(); itf.set_profiling(True); itf.reset_kernel_ms()
     for _ in range(8): mpc.solve_resident(cfg["horizon"])
     itf.synchronize(); itf.set_profiling(False)
-    own = 16384 if "v3" in os.environ["QM_AB_LIB"] else 16896
+    own = {"a.so": 16896, "v5.so": 16000}.get(os.path.basename(os.environ["QM_AB_LIB"]), 16384)
     out[pad] = (160 * 1024 // (own + pad), round(itf.kernel_ms("lq")[0] / itf.kernel_ms("lq")[1], 4))
 print(os.environ["QM_AB_LIB"], json.dumps(out))
