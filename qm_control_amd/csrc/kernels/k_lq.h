@@ -5,18 +5,24 @@
 // OCP of qm_interface/src/QMInterface.cpp:79-142 (SURVEY.md §8 a2–a8, a11; Appendix B.6 steps 2–3):
 //   K1a qm_lq_kin_kernel (one THREAD per node): all scalar kinematics — both Heun/RK2 stages, flow values, EE pose
 //       error — written as a 4 KB "kin record" per node (lanes = instances: no idle lanes, no barriers)
-//   K1b qm_lq_kernel (one WAVEFRONT per node, 64-thread workgroups, 15 KB LDS): every matrix lives in the wave's registers as
+//   K1b qm_lq_kernel / qm_lq_m18_kernel (one WAVEFRONT per node, 64-thread workgroups, 15.6 KB LDS, 168 registers: three waves per SIMD): every matrix lives in the wave's registers as
 //       f64-MFMA D-fragments (qm_dev_common.h), all products are P = Zᵀ Y chains, the vectors ride in column 30 of the 32-wide
 //       tiles, and LDS is only the hand-over point between the lane-per-column analytic Jacobians and the fragments.  No
 //       workgroup barrier anywhere: the 100k nodes of a batch are independent waves.
-//   phase I   analytic Jacobian columns of the flow map, one lane per column.  df/dx and df/du only have 12 (+4 identity)
-//             non-trivial rows (SRBD); RK2 sensitivity composition A_d = I + dt/2 (A1 + A2 + dt A2 A1) and B_dᵀ likewise
-//             (B_d is carried transposed: that is the operand form B_d Px and B_d Pu need), k restricted to the 16 live rows
+//   Order of the phases (round 4 — chosen so that nothing large is live across the two lane-per-column Jacobian evaluations and the kernel fits 168 registers without
+//   scratch, i.e. THREE waves per SIMD; rounds 1–3 ran I before II with A_d, B_dᵀ live across II at 216 registers):
+//   P0        inputs and the kin record -> LDS; what the prologue's loads are needed for (defect b, tracking terms of the cost, u − u_nom) is formed at once
 //   phase II  equality rows (zero force / zero foot velocity / swing normal velocity) and their closed-form block
 //             projection du = Pe + Px dx + Pu ut (D is block structured by construction: each row touches one foot's
-//             force triple or one leg's joint-velocity triple); projected dynamics Ap, Bp, bp streamed to HBM
+//             force triple or one leg's joint-velocity triple): per-contact blocks G, the twelve non-zero rows of Px, Pe, the column descriptors of Pu
+//   phase I   analytic Jacobian columns of the flow map, one lane per column (divergent class bodies: 126 registers against the 166 of the interleaved form).  df/dx and
+//             df/du only have 12 (+4 identity) non-trivial rows (SRBD); RK2 sensitivity composition A_d = I + dt/2 (A1 + A2 + dt A2 A1) and B_d likewise, B_d turned into
+//             B_dᵀ through the tile (that is the operand form B_d Px and B_d Pu need), k restricted to the 16 live rows
+//   then      projected dynamics Ap, Bp, bp streamed to HBM — the last use of A_d, B_dᵀ
 //   phase III cost quadratic model (tracking + arm soft box + friction-cone barrier + EE pose), x dt, and the projected
 //             cost Qp, Pp, Rp, qp, rp (f64 MFMA, k restricted to the 12 rows Px / R Px occupy) streamed to HBM
+//   The body is instantiated per tile count MT of the reduced inputs and runs as TWO product kernels (qm_lq_kernel: m <= 16, qm_lq_m18_kernel: m = 17, 18): one body with a
+//   branch between the two projections at its end made the register allocator carry both paths' worst cases (216 registers).
 // The terminal node only carries the final EE soft constraint (QMInterface.cpp:104).
 #pragma once
 #include "qm_dev_kin.h"

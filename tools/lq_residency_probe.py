@@ -22,7 +22,8 @@ slot = (xcc & 15) * (1 << 20) + (hw & 0xFFFFF)                       # XCC, then
 order = np.lexsort((r0, slot)); ss = slot[order]; a0 = r0[order]; a1 = r1[order]
 gaps = (a0[1:] - a1[:-1])[ss[1:] == ss[:-1]]
 span = r1.max() - r0.min(); nsimd = len(np.unique(slot >> 4))
-names = ["P0 stage inputs", "I jacobian columns", "I RK2 composition", "II constraint rows", "II projector", "II projected dynamics", "III cost model (input / state terms, barriers)", "III EE term, [Q | q], R assembly", "III projected cost + stores"]
+names = ["P0 stage inputs, defect, tracking terms", "II constraint rows", "II projector (G, Px, Pe, Pu descriptors)", "I jacobian columns -> tile", "I RK2 composition, B_d transposed",
+         "projected dynamics + Bp", "III cost model (R0 (u - unom), barriers)", "III EE term, [Q | q], R assembly", "III projected cost + stores"]      # order of the round-4 kernel (constraints before Jacobians)
 print(json.dumps({
     "waves_stamped": int(len(r)), "wave_slots_used": int(len(np.unique(slot))), "simds_used": int(nsimd),
     "shader_clock_GHz_under_K1b": round(float(cyc.sum() / real.sum() * 0.1), 3),
