@@ -81,7 +81,8 @@ struct QmWbcArgs {
 #define WL_WLIST  (WL_W36 + WNV)                  /* [20] ints: working set */
 #define WL_ACC    (WL_G + 18 * 16)                /* chain accumulators: 3 passes x 6 slots x 20 (inside G, after the momentum sums) */
 #define WL_MISC   (WL_WLIST + 12)                 /* q v qd vd w2 (5 x 24), baseAcc(6) */
-#define WL_TOTAL  (WL_MISC + 5 * 24 + 8)
+#define WL_BM     (WL_MISC + 5 * 24 + 8)          /* [21] measured root state for the level-1 tasks: E(9) R(9) al(3) (42 registers less across the level-0 solver) */
+#define WL_TOTAL  (WL_BM + 24)
 /* rigid-body phase only: per-joint subtree composites of the 18 chain lanes (19 x 6 doubles each, lane interleaved), behind the arm Jacobian that is
    being built at the head of the Zp region; spans Zp .. R, all of which the cascade (re)initialises itself — the region is cleared again after the passes */
 #define WL_RBDWS  (WL_ZP + 144)
@@ -333,90 +334,220 @@ __device__ __forceinline__ void wv_Z_times(const double* Zp, int n, const double
   qm_wave_sync();
 }
 
-// min |R z − c|² s.t. E z = e (me working-set rows in WL_EROWS / WL_ERHS), null-space method.  Rc = [R | c] (n x (n+1), ld WTLD,
-// upper triangle valid) is the once-per-level QR factor of G0 = [AZ; sqrt(rho) I | g0]; T (n x (n+1), ld WTLD) is scratch.  lam: multipliers.
-template <bool PROF>
-__device__ __forceinline__ void wv_eq_ls_R(double* S, const double* Rc, double* T, int n, int me, double* zout, long long* tf, int& nfact, double (&g)[WVLD]) {
+// ---- levels >= 1: the equality-constrained solves of the active-set loop on an UPDATED factorisation ----
+// min |R z − c|² s.t. E z = e, E = the working rows.  [R | c] is the once-per-level QR factor of G0 = [A Zp; sqrt(rho) I | g0].  Kept across the iterations:
+//   Q (n x n orthogonal), T = Uᵀ R Q upper triangular with ct = Uᵀ c in column n (U is never needed), L = E Q.
+// The first k = n − me columns of Q span the null space of E; the direction of working row a (in order of addition) is column n−1−a, so L[a][j] = 0 for j < n−1−a
+// (the TQ factorisation of Gill & Murray's null-space active-set methods).  With z = Q y:
+//   y[k..n) from the working rows alone (L is triangular), y[0..k) from the leading k x k triangle of T — a solve is two triangular substitutions and a product with Q;
+//   appending a row rotates the free columns so that the row's free part lands in column k−1, and k−1 row rotations make T triangular again;
+//   dropping working row a moves the directions of the rows behind it one column to the right (one column + one row rotation each), which frees column k.
+// Every step of the active-set loop therefore costs O(n²) — no factorisation is ever repeated (rounds 1–3: a QR of the n x (n − me) reduced matrix per step, 13 k cycles).
+// Layouts: T (ld WTLD) in the first half of G, Q (ld WVLD) where the reflectors used to be, L rows in WL_EROWS, e in WL_ERHS, y in WL_Y; the second half of G holds the
+// new row and the rotation coefficients of an append.
+#define WL_TQ_T   WL_G
+#define WL_TQ_Q   WL_V
+#define WL_TQ_L   WL_EROWS
+#define WL_TQ_CO  (WL_G + WVLD * WTLD)            /* t, alpha, sigma, kappa, free part of t: 5 x 20 */
+#define WL_TQ_ROW (WL_TQ_CO + 100)                /* [18] the row to append (zero beyond n) */
+#define WL_TQ_H   (WL_TQ_ROW + 20)                /* [18] residual / Qᵀ gradient of the multiplier solve */
+// Givens pair with c a + s b = |(a, b)|, −s a + c b = 0 (identity for a null pair); the reciprocal root is the hardware estimate + one third-order correction (qm_house_scalars)
+__device__ __forceinline__ void qm_givens(double a, double b, double& c, double& s) {
+  const double h2 = fma(a, a, b * b); const bool ok = h2 > 0.0; const double x = ok ? h2 : 1.0;
+  const double y0 = __builtin_amdgcn_rsq(x), h = x * y0, e = fma(-h, y0, 1.0), r = fma(y0 * e, fma(0.375, e, 0.5), y0);
+  c = ok ? a * r : 1.0; s = ok ? b * r : 0.0;
+}
+// 1 / x from the hardware estimate (2^-24) and two Newton steps: ≈ 1 ulp, a third of the dependent chain of the IEEE division sequence
+__device__ __forceinline__ double qm_recip(double x) {
+  const double q0 = __builtin_amdgcn_rcp(x), e = fma(-x, q0, 1.0), q1 = fma(fma(e, e, e), q0, q0);
+  return fma(fma(-x, q1, 1.0), q1, q1);
+}
+// 1 / sqrt(x), x > 0 (same correction as qm_givens)
+__device__ __forceinline__ double qm_rsqrt(double x) { const double y0 = __builtin_amdgcn_rsq(x), h = x * y0, e = fma(-h, y0, 1.0); return fma(y0 * e, fma(0.375, e, 0.5), y0); }
+// wv_solve_upper / wv_solve_lower for the factors of the TQ update: every lane loads its whole row UNCONDITIONALLY (`at` must be readable for every (lane row, i < MAXN)) and
+// masks in registers — a load under a wave-uniform condition becomes a scalar branch around each ds_read, which serialises them — and the diagonal is inverted by qm_recip
+template <int MAXN, class At>
+__device__ __forceinline__ double tq_solve_upper(At at, int n, double rj) {
+  const int l = threadIdx.x & 63, lr = (l < n) ? l : 0;
+  double row[MAXN];
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) { const double v = at(lr, i); row[i] = (l < n && i > l && i < n) ? v : 0.0; }
+  const double rinv = (l < n) ? qm_recip(at(lr, lr)) : 0.0; double z = 0.0;
+#pragma unroll
+  for (int i = MAXN - 1; i >= 0; --i) if (i < n) { const double zi = qm_bcast(rj * rinv, i); if (l == i) z = zi; rj -= row[i] * zi; }
+  return z;
+}
+template <int MAXN, class At>
+__device__ __forceinline__ double tq_solve_lower(At at, int n, double rj) {
+  const int l = threadIdx.x & 63, lr = (l < n) ? l : 0;
+  double row[MAXN];
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) { const double v = at(lr, i); row[i] = (l < n && i < l) ? v : 0.0; }
+  const double rinv = (l < n) ? qm_recip(at(lr, lr)) : 0.0; double z = 0.0;
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) if (i < n) { const double zi = qm_bcast(rj * rinv, i); if (l == i) z = zi; rj -= row[i] * zi; }
+  return z;
+}
+// [R | c] has just been left in T by rq_house_tri (strictly lower part zero): Q = I, no working rows; rows n.. of T are cleared (the column sweeps load 18 rows)
+__device__ __forceinline__ void tq_init(double* S, int n) {
   const int l = threadIdx.x & 63;
+  for (int idx = l; idx < WVLD * WVLD; idx += 64) { const int r = idx / WVLD, c = idx - WVLD * r; S[WL_TQ_Q + idx] = (r == c && r < n) ? 1.0 : 0.0; }
+  for (int idx = n * WTLD + l; idx < WVLD * WTLD; idx += 64) S[WL_TQ_T + idx] = 0.0;
+  if (l < 20) S[WL_Y + l] = 0.0;                                          // y is kept zero beyond n, and its free part is cleared before it is solved for: no sum below needs a bound
+  qm_wave_sync();
+}
+// z = Q y for the current working set (me rows): zout[0..n)
+__device__ __forceinline__ void tq_solve(double* S, int n, int me, double* zout) {
+  const int l = threadIdx.x & 63, k = n - me;
+  const double* T = S + WL_TQ_T; const double* Q = S + WL_TQ_Q; double* y = S + WL_Y;
+  if (l < k) y[l] = 0.0;
+  qm_wave_sync();
+  { const int lr = (l < n) ? l : 0;
+    double rhs[2] = {T[lr * WTLD + n], 0.0};
+#pragma unroll
+    for (int j = 0; j < WVLD; ++j) rhs[j & 1] -= T[lr * WTLD + j] * y[j];                 // y[0..k) = 0, y[n..) = 0 (column n of T is ct when n < 18)
+    const double yl = tq_solve_upper<WVLD>([&](int j, int i) { return T[j * WTLD + i]; }, k, (l < k) ? rhs[0] + rhs[1] : 0.0);
+    qm_wave_sync();
+    if (l < k) y[l] = yl;
+    qm_wave_sync();
+  }
+  { const int lr = (l < n) ? l : 0; double sp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < WVLD; ++j) sp[j & 3] += Q[lr * WVLD + j] * y[j];                  // Q and y are zero beyond n
+    if (l < n) zout[l] = (sp[0] + sp[1]) + (sp[2] + sp[3]); }
+  qm_wave_sync();
+}
+// append the row S[WL_TQ_ROW] (zero beyond n) with right-hand side rhs as working row `me` (k = n − me >= 1 free columns before the call)
+template <bool PROF>
+__device__ __forceinline__ void tq_append(double* S, int n, int me, double rhs, long long* tf) {
+  const int l = threadIdx.x & 63, k = n - me;
   long long tl_ = PROF ? (long long)__builtin_readcyclecounter() : 0;
 #define WF(k) { if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tf[k] += now_ - tl_; tl_ = now_; } }
-  if (me == 0) { nfact = -1; wv_backsub_tri<WVLD>(Rc, WTLD, n, zout); return; }
-  double* V = S + WL_V; double* beta = S + WL_BETA; double* R = S + WL_R; double* y = S + WL_Y; const double* e = S + WL_ERHS; double* lam = S + WL_LAM;
-  WF(0)
-  // nfact = number of leading working rows whose factor data (reflectors V / beta, R_E, y1 and this lane's row g of [R | c] Q) are still valid: the active-set loop
-  // appends one row per step most of the time, and everything that belongs to the earlier rows is unchanged by an append (a drop invalidates: nfact = -1)
-  const bool append = (nfact == me - 1);
-  if (append) wv_qr_Et_append(S + WL_EROWS, me, n, V, beta, R, S + WL_HV);
-  else if (nfact != me) wv_qr_Et(S + WL_EROWS, me, n, V, beta, R, S + WL_HV);
-  WF(1)
-  if (append) {                                                          // R_Eᵀ y1 = e: only the new entry (lane m repeats wv_solve_lower's row arithmetic)
-    const int m = me - 1; double rj = (l == m) ? e[m] : 0.0;
-    for (int i = 0; i < m; ++i) rj -= ((l == m) ? R[i * WMAXACT + m] : 0.0) * y[i];
-    if (l == m) y[m] = rj * (1.0 / R[m * WMAXACT + m]);
-  } else if (nfact != me) {
-    const double y1 = wv_solve_lower<WVLD>([&](int j, int i) { return R[i * WMAXACT + j]; }, me, (l < me) ? e[l] : 0.0);   // R_Eᵀ y1 = e
-    if (l < me) y[l] = y1; }
-  WF(2)
-  // T <- T Q (row-wise reflections; lane = row), rhs column untouched
+  double* T = S + WL_TQ_T; double* Q = S + WL_TQ_Q; double* L = S + WL_TQ_L; double* co = S + WL_TQ_CO; const double* drow = S + WL_TQ_ROW; double* y = S + WL_Y;
+  // 1. t = rowᵀ Q (lane = column); co[0..) = t, co[80..) = its free part (zero from column k on)
+  if (l < k) y[l] = 0.0;                                                  // the free part of y is solved for again after the append; cleared, the sum of step 5 needs no bound
+  { const int lc = (l < n) ? l : 0; double sp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < WVLD; ++i) sp[i & 3] += drow[i] * Q[i * WVLD + lc];
+    const double tl = (l < n) ? (sp[0] + sp[1]) + (sp[2] + sp[3]) : 0.0;
+    if (l < 20) { co[l] = tl; co[80 + l] = (l < k) ? tl : 0.0; } }
   qm_wave_sync();
-  {
-    // row l of [R | c] Q in registers, kept across the iterations; V is zero above each pivot, so no index bounds are needed
-    if (!append && nfact != me) {
+  // 2. the rotations (0,1), (1,2), … (k−2,k−1) that carry the free part et = t[0..k) into column k−1 have a closed-form product: with the prefix norms r_j = |et[0..j]|,
+  //    column_j' = alpha_j P_j − sigma_j column_{j+1},  P_j = sum_{c <= j} et_c column_c,  alpha_j = et_{j+1} / (r_j r_{j+1}),  sigma_j = r_j / r_{j+1}   (j < k−1; r_j = 0: unchanged)
+  //    column_{k−1}' = P_{k−1} / r_{k−1};   columns >= k are untouched (kappa = 1).   Lane j computes the coefficients of column j.
+  double rlast, rlinv;
+  { double q4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int i = 0; i < WVLD; ++i) g[i] = (l < n && i >= l && i < n) ? Rc[l * WTLD + i] : 0.0;
-    }
-    for (int k = append ? me - 1 : ((nfact == me) ? me : 0); k < me; ++k) {
-      const double* v = V + k * WVLD; double sq[2] = {0.0, 0.0};
-#pragma unroll
-      for (int i = 0; i < WVLD; ++i) sq[i & 1] += g[i] * v[i];
-      const double sacc = (sq[0] + sq[1]) * beta[k];
-#pragma unroll
-      for (int i = 0; i < WVLD; ++i) g[i] -= sacc * v[i];
-    }
-    nfact = me;
-    double rhs = (l < n) ? Rc[l * WTLD + n] : 0.0;
-#pragma unroll
-    for (int i = 0; i < WVLD; ++i) if (i < me) rhs -= g[i] * y[i];
-    qm_wave_sync();
-    if (l < n) {
-#pragma unroll
-      for (int i = 0; i < WVLD; ++i) if (i < n) T[l * WTLD + i] = g[i];
-      T[l * WTLD + n] = rhs;
-    }
+    for (int i = 0; i < WVLD; ++i) { const double ti = co[80 + i]; q4[i & 3] += (i <= l) ? ti * ti : 0.0; }
+    const double r2 = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    const double tn = co[80 + ((l < 19) ? l + 1 : 0)];                       // et_{l+1} (zero from column k on)
+    const double r2n = fma(tn, tn, r2);
+    const bool pos = r2 > 0.0;
+    const double ij = qm_rsqrt(pos ? r2 : 1.0), in = qm_rsqrt(r2n > 0.0 ? r2n : 1.0);      // 1 / r_j, 1 / r_{j+1}
+    double al = 0.0, sg = 0.0, ka = 1.0;
+    if (l < k - 1) { if (pos) { al = tn * ij * in; sg = r2 * ij * in; ka = 0.0; } }
+    else if (l == k - 1) { al = ij; ka = 0.0; }
+    rlast = qm_bcast(r2 * ij, k - 1); rlinv = qm_bcast(ij, k - 1);
+    if (l < 20) { co[20 + l] = al; co[40 + l] = sg; co[60 + l] = ka; }
   }
   qm_wave_sync();
-  WF(3)
-  if (n - me > 0) wv_ls_qr<18>(T + me, WTLD, n, n - me, S + WL_HV, y + me);
-  WF(4)   // reduced problem on columns me..n-1 (rhs right after them)
-  if (l < n) zout[l] = y[l];
+  WF(4)
+  // 3. columns of T and Q (lane = row: rows of T on lanes 0.., rows of Q on lanes 32..); P runs along the row
+  { const bool isT = l < 32; const int i = isT ? l : l - 32; const bool act = i < n;
+    double* rowp = isT ? T + (act ? i : 0) * WTLD : Q + (act ? i : 0) * WVLD;
+    double x[WVLD + 1];
+#pragma unroll
+    for (int j = 0; j < WVLD; ++j) x[j] = rowp[j];
+    x[WVLD] = 0.0;
+    double P = 0.0;
+#pragma unroll
+    for (int j = 0; j < WVLD; ++j) { P = fma(co[j], x[j], P); const double o = fma(co[20 + j], P, fma(-co[40 + j], x[j + 1], co[60 + j] * x[j])); if (act) rowp[j] = o; }
+  }
   qm_wave_sync();
-  wv_apply_Q(V, beta, me, n, zout);
   WF(5)
-  // multipliers: R_E lam = −(Qᵀ Rᵀ (R z − c))[0:me]
-  double* w = S + WL_W36; double* res = S + WL_HV;
-  // (entries of [R | c] below the diagonal are zeros, z and res are zero padded to 18: static loops, no bounds, two partial sums)
-  if (l >= n && l < WVLD) zout[l] = 0.0;
-  qm_wave_sync();
-  { double sp[2] = {(l < n) ? -Rc[l * WTLD + n] : 0.0, 0.0};
-    const int lr = (l < n) ? l : 0;
+  // 4. T is upper Hessenberg in its first k−1 columns now: rotate rows (j, j+1), j = 0 .. k−2 (lane = column, ct rides in lane n; the pivot pair comes from lane j)
+  { const int c = (l <= n) ? l : 0; double tt[WVLD];
 #pragma unroll
-    for (int k = 0; k < WVLD; ++k) sp[k & 1] += Rc[lr * WTLD + k] * zout[k];
-    if (l < WVLD) res[l] = (l < n) ? sp[0] + sp[1] : 0.0; }
-  qm_wave_sync();
-  { double sp[2] = {0.0, 0.0};
-    const int lc = (l < n) ? l : 0;
+    for (int r = 0; r < WVLD; ++r) tt[r] = T[r * WTLD + c];
 #pragma unroll
-    for (int r = 0; r < WVLD; ++r) sp[r & 1] += Rc[r * WTLD + lc] * res[r];
-    if (l < n) w[l] = sp[0] + sp[1]; }
-  qm_wave_sync();
+    for (int j = 0; j < WVLD - 1; ++j) {
+      if (j < k - 1) {
+        const double a = qm_bcast(tt[j], j), b = qm_bcast(tt[j + 1], j);
+        double cg, sn; qm_givens(a, b, cg, sn);
+        const double u = tt[j], v = tt[j + 1];
+        tt[j] = fma(cg, u, sn * v); tt[j + 1] = (l == j) ? 0.0 : fma(cg, v, -sn * u);
+      }
+    }
+    if (l <= n) {
+#pragma unroll
+      for (int r = 0; r < WVLD; ++r) T[r * WTLD + l] = tt[r];
+    }
+  }
   WF(6)
-  wv_apply_Qt(V, beta, me, n, w);
-  WF(7)
-  { const double lm = wv_solve_upper<WVLD>([&](int j, int i) { return R[j * WMAXACT + i]; }, me, (l < me) ? -w[l] : 0.0);          // R_E lam = −(Qᵀ ∇)[0:me]
-    if (l < me) lam[l] = lm; }
+  // 5. the new working row in the rotated coordinates and its y
+  if (l < WVLD) L[me * WVLD + l] = (l < k - 1) ? 0.0 : (l == k - 1 ? rlast : co[l]);
+  { double sp[2] = {rhs, 0.0};
+#pragma unroll
+    for (int j = 0; j < WVLD; ++j) sp[j & 1] -= co[j] * y[j];                            // y[0..k) = 0
+    qm_wave_sync();
+    if (l == 0) { y[k - 1] = (sp[0] + sp[1]) * rlinv; S[WL_ERHS + me] = rhs; } }
   qm_wave_sync();
-  WF(8)
+  WF(7)
 #undef WF
+}
+// remove working row ad (me rows before the call)
+__device__ __forceinline__ void tq_drop(double* S, int n, int me, int ad) {
+  const int l = threadIdx.x & 63;
+  double* T = S + WL_TQ_T; double* Q = S + WL_TQ_Q; double* L = S + WL_TQ_L; double* y = S + WL_Y; double* e = S + WL_ERHS;
+  // row holders of the column rotations: rows of T on lanes 0..17, rows of Q on 18..35, rows of L on 36..53
+  const int g = (l >= 36) ? 2 : (l >= 18 ? 1 : 0), i = l - 18 * g; const bool act = (g == 2) ? (i < me && l < 54) : (i < n);
+  double* rowp = (g == 0) ? T + (act ? i : 0) * WTLD : (g == 1) ? Q + (act ? i : 0) * WVLD : L + (act ? i : 0) * WVLD;
+  for (int a = ad + 1; a < me; ++a) {
+    const int j = n - 1 - a;                                              // pivot column of row a: moves to j + 1
+    double cg, sn; qm_givens(L[a * WVLD + j + 1], L[a * WVLD + j], cg, sn);
+    qm_wave_sync();
+    if (act) { const double u = rowp[j], v = rowp[j + 1]; rowp[j + 1] = fma(cg, v, sn * u); rowp[j] = (g == 2 && i == a) ? 0.0 : fma(cg, u, -sn * v); }
+    qm_wave_sync();
+    double c2, s2; qm_givens(T[j * WTLD + j], T[(j + 1) * WTLD + j], c2, s2);   // the column rotation left one entry below the diagonal
+    qm_wave_sync();
+    if (l <= n) { const double u = T[j * WTLD + l], v = T[(j + 1) * WTLD + l]; T[j * WTLD + l] = fma(c2, u, s2 * v); T[(j + 1) * WTLD + l] = (l == j) ? 0.0 : fma(c2, v, -s2 * u); }
+    qm_wave_sync();
+  }
+  for (int a = ad; a + 1 < me; ++a) { if (l < WVLD) L[a * WVLD + l] = L[(a + 1) * WVLD + l]; }      // a wave's DS operations retire in order
+  { const bool mv = (l >= ad && l + 1 < me); const double en = mv ? e[l + 1] : 0.0; qm_wave_sync(); if (mv) e[l] = en; }
+  qm_wave_sync();
+  // y of the working rows from the first one on (the rows behind the dropped one changed): equation a reads sum_{a' <= a} L[a][n−1−a'] y[n−1−a'] = e[a]
+  const int m1 = me - 1;
+  if (l < n - m1) y[l] = 0.0;
+  if (m1 > 0) {
+    const double yl = tq_solve_lower<WVLD>([&](int jj, int ii) { return L[jj * WVLD + ((ii < n) ? n - 1 - ii : 0)]; }, m1, (l < m1) ? e[l] : 0.0);
+    qm_wave_sync();
+    if (l < m1) y[n - 1 - l] = yl;
+  }
+  qm_wave_sync();
+}
+// multipliers of the me working rows at the solution of the last tq_solve: grad + Eᵀ lam = 0.  In the rotated coordinates Qᵀ grad = Tᵀ (T y − ct) =: h, whose first k
+// entries vanish, and h[n−1−a] = −sum_{a' >= a} L[a'][n−1−a] lam[a']: a triangular solve from the last working row back
+__device__ __forceinline__ void tq_mult(double* S, int n, int me) {
+  const int l = threadIdx.x & 63, k = n - me;
+  const double* T = S + WL_TQ_T; const double* L = S + WL_TQ_L; const double* y = S + WL_Y; double* h = S + WL_TQ_H; double* lam = S + WL_LAM;
+  if (me == 0) return;
+  { const int lr = (l < n) ? l : 0; double sp[2] = {-T[lr * WTLD + n], 0.0};
+#pragma unroll
+    for (int j = 0; j < WVLD; ++j) sp[j & 1] += T[lr * WTLD + j] * y[j];                  // y is zero beyond n
+    if (l < 20) h[l] = (l >= k && l < n) ? sp[0] + sp[1] : 0.0; }
+  qm_wave_sync();
+  double hj;
+  { const int lc = (l < n) ? l : 0; double sp[2] = {0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < WVLD; ++r) sp[r & 1] += T[r * WTLD + lc] * h[r];
+    hj = sp[0] + sp[1]; }
+  qm_wave_sync();
+  if (l < n) h[l] = hj;
+  qm_wave_sync();
+  const double mu = tq_solve_upper<WVLD>([&](int jj, int ii) { return L[ii * WVLD + n - 1 - jj]; }, me, (l < me) ? h[n - 1 - l] : 0.0);
+  if (l < me) lam[l] = -mu;
+  qm_wave_sync();
 }
 
 // orthonormal null space of AZ (ra x n): Zp (36 x n) <- Zp · Q2, Q2 = Q[:, rank:] from the Householder QR with column pivoting of
@@ -548,8 +679,9 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
   double* S = qm_smem;
   const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
-  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tfine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tnull[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? (long long)__builtin_readcyclecounter() : 0;
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tfine[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tnull[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? (long long)__builtin_readcyclecounter() : 0; long long tfl = tlast;
 #define WT(k) { if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } }
+#define TF(k) { if (PROF) { const long long now_ = (long long)__builtin_readcyclecounter(); tfine[k] += now_ - tfl; tfl = now_; } }
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
   const double* xDes = a.x_des + (size_t)b * 30; const double* uDes = a.u_des + (size_t)b * 30; const double* rbd = a.rbd + (size_t)b * QM_NRBD;
   const int mode = a.mode[b]; const double time = a.time[b];
@@ -629,6 +761,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
       nle[l] = w[0] * NO[0] + w[1] * NO[1] + w[2] * NO[2] + vO[0] * F[0] + vO[1] * F[1] + vO[2] * F[2];
     }
   }
+  if (l == 0) { for (int i = 0; i < 9; ++i) { S[WL_BM + i] = Bm.E[i]; S[WL_BM + 9 + i] = Bm.R[i]; } for (int i = 0; i < 3; ++i) S[WL_BM + 18 + i] = Bm.al[i]; }
   // ---- baseAccDesired (WbcBase.cpp:215-225; SURVEY.md a14 aliasing: A_b SRBD, Adot & A_j full CMM, true COM) ----
   const double* tipsM = tips; const double* tipsD = tips + 27 * 5;
   if (l == 0) {
@@ -676,18 +809,19 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
         if (l == 0) { A[2] = 1.0; bb[0] = baseAcc[2] + st[ST_KP_BASE_H] * (qd[2] - q[2]) + st[ST_KD_BASE_H] * (vd[2] - v[2]); }
         ra = 1;
         if (l == 0) {   // base angular
-          double wMeas[3], wDes[3]; const double thm[3] = {v[3], v[4], v[5]}, thdv[3] = {vd[3], vd[4], vd[5]}; m3_mulv(Bm.E, thm, wMeas); m3_mulv(Bm.E, thdv, wDes);
-          double Rdes[9]; rot_zyx(qd[3], qd[4], qd[5], Rdes); double err[3]; dev_rot_error(Rdes, Bm.R, err);
-          double acc[3]; { const double tdd[3] = {baseAcc[3], baseAcc[4], baseAcc[5]}; m3_mulv(Bm.E, tdd, acc); const double zz[3] = {0.0, 0.0, 1.0}; double t0[3]; v3_cross(zz, wDes, t0);
-            const double c1[3] = {Bm.E[1], Bm.E[4], Bm.E[7]}, c2[3] = {Bm.E[2], Bm.E[5], Bm.E[8]}; double t1[3]; v3_cross(c1, c2, t1); for (int i = 0; i < 3; ++i) acc[i] += thdv[0] * t0[i] + thdv[1] * thdv[2] * t1[i]; }
-          for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) A[(ra + r) * WNV + 3 + k] = Bm.E[3 * r + k]; bb[ra + r] = acc[r] + st[ST_KP_BASE_ANG] * err[r] + st[ST_KD_BASE_ANG] * (wDes[r] - wMeas[r]) - Bm.al[r]; }
+          const double* BmE = S + WL_BM; const double* BmR = BmE + 9; const double* Bmal = BmE + 18;
+          double wMeas[3], wDes[3]; const double thm[3] = {v[3], v[4], v[5]}, thdv[3] = {vd[3], vd[4], vd[5]}; m3_mulv(BmE, thm, wMeas); m3_mulv(BmE, thdv, wDes);
+          double Rdes[9]; rot_zyx(qd[3], qd[4], qd[5], Rdes); double err[3]; dev_rot_error(Rdes, BmR, err);
+          double acc[3]; { const double tdd[3] = {baseAcc[3], baseAcc[4], baseAcc[5]}; m3_mulv(BmE, tdd, acc); const double zz[3] = {0.0, 0.0, 1.0}; double t0[3]; v3_cross(zz, wDes, t0);
+            const double c1[3] = {BmE[1], BmE[4], BmE[7]}, c2[3] = {BmE[2], BmE[5], BmE[8]}; double t1[3]; v3_cross(c1, c2, t1); for (int i = 0; i < 3; ++i) acc[i] += thdv[0] * t0[i] + thdv[1] * thdv[2] * t1[i]; }
+          for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) A[(ra + r) * WNV + 3 + k] = BmE[3 * r + k]; bb[ra + r] = acc[r] + st[ST_KP_BASE_ANG] * err[r] + st[ST_KD_BASE_ANG] * (wDes[r] - wMeas[r]) - Bmal[r]; }
         }
         ra += 3;
         if (a.variant == 0) {
           const double* aM = tipsM + 27 * 4; const double* aD = tipsD + 27 * 4;
           for (int idx = l; idx < 72; idx += 64) { const int r = idx / 24, k = idx - 24 * r; A[(ra + r) * WNV + k] = Jarm[r * 24 + k]; A[(ra + 3 + r) * WNV + k] = (k >= 3 && k < 6) ? 0.0 : Jarm[(3 + r) * 24 + k]; }
           if (l < 3) bb[ra + l] = st[ST_KP_EE_LIN + l] * (TIP_P(aD)[l] - TIP_P(aM)[l]) + st[ST_KD_EE_LIN + l] * (TIP_V(aD)[l] - TIP_V(aM)[l]) - TIP_A(aM)[l];
-          if (l == 0) { double err[3]; dev_rot_error(TIP_R(aD), TIP_R(aM), err); for (int r = 0; r < 3; ++r) bb[ra + 3 + r] = st[ST_KP_EE_ANG + r] * err[r] + st[ST_KD_EE_ANG + r] * (-TIP_W(aM)[r]) - (TIP_AL(aM)[r] - Bm.al[r]); }
+          if (l == 0) { double err[3]; dev_rot_error(TIP_R(aD), TIP_R(aM), err); for (int r = 0; r < 3; ++r) bb[ra + 3 + r] = st[ST_KP_EE_ANG + r] * err[r] + st[ST_KD_EE_ANG + r] * (-TIP_W(aM)[r]) - (TIP_AL(aM)[r] - S[WL_BM + 18 + r]); }
           ra += 6;
         } else {
           if (l < 2) { A[(ra + l) * WNV + l] = 1.0; bb[ra + l] = baseAcc[l] + st[ST_KP_BASE_LIN] * (qd[l] - q[l]) + st[ST_KD_BASE_LIN] * (vd[l] - v[l]); }
@@ -792,7 +926,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
         for (int r = 0; r < WMAXA; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
         rq_house_tri<WMAXA>(d, G, WTLD, n, S + WL_HV);
       }
-      double* Tm = S + WL_G + WVLD * WTLD;               // scratch of wv_eq_ls_R; [R | c] stays in the first 18 x 19 block of G
+      tq_init(S, n);                                     // [R | c] stays in the first 18 x 19 block of G and is updated in place from here on
       double dz[WVLD];                                   // row l of D0 Zp lives in the registers of lane l
 #pragma unroll
       for (int k = 0; k < WVLD; ++k) dz[k] = 0.0;
@@ -836,44 +970,47 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
       qm_wave_sync();
       WT(8)
       int* Wi = (int*)(S + WL_WLIST);                    // working-set list lives in LDS (wave-uniform reads)
-      unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false, vertex = false; double pscale = 0.0; int myslot = -1;   // position of this lane's row in the working set
-      int nfact = -1; double grow[WVLD];                 // factor data of the working set carried from one iteration to the next (wv_eq_ls_R)
-#pragma unroll
-      for (int k = 0; k < WVLD; ++k) grow[k] = 0.0;
+      unsigned long long wmask = 0ull; int nw = 0; int it = 0; bool degenerate = false, vertex = false; double pscale = 0.0;
+      bool atopt = false;                                // z is already the optimum on the working set (a full step has just been taken): nothing to solve, go to the drop test
       for (; it < 100; ++it) {
-        if (myslot >= 0) {
-#pragma unroll
-          for (int k = 0; k < WVLD; ++k) S[WL_EROWS + myslot * WVLD + k] = dz[k];      // dz is zero beyond n: no per-index bound (uniform branches would serialise the LDS traffic)
-          S[WL_ERHS + myslot] = fb[l];
+        double pn = 0.0, zs = 1.0;
+        if (!atopt) {
+          WT(10)
+          TF(8)
+          tq_solve(S, n, nw, zn);
+          TF(0)
+          if (l < n) p[l] = zn[l] - z[l];
+          qm_wave_sync();
+          pn = wv_max((l < n) ? fabs(p[l]) : 0.0); zs = fmax(1.0, wv_max((l < n) ? fabs(z[l]) : 0.0));
+          pscale = fmax(pscale, pn);
+          WT(9)
         }
-        qm_wave_sync();
-        WT(10)
-        wv_eq_ls_R<PROF>(S, G, Tm, n, nw, zn, tfine, nfact, grow);
-        WT(9)
-        if (l < n) p[l] = zn[l] - z[l];
-        qm_wave_sync();
-        const double pn = wv_max((l < n) ? fabs(p[l]) : 0.0), zs = fmax(1.0, wv_max((l < n) ? fabs(z[l]) : 0.0));
-        pscale = fmax(pscale, pn);
 #ifdef QM_WBC_TRACE
-        if (l == 0) { printf("L%d it %d nw %d pn %.3e zs %.3e pscale %.3e W:", level, it, nw, pn, zs, pscale); for (int q2 = 0; q2 < nw; ++q2) printf(" %d(%.2e)", Wi[q2], lam[q2]); printf("\n"); }
+        if (l == 0) { printf("L%d it %d nw %d pn %.3e zs %.3e pscale %.3e W:", level, it, nw, pn, zs, pscale); for (int q2 = 0; q2 < nw; ++q2) printf(" %d", Wi[q2]); printf("\n"); }
 #endif
-        if (pn <= 1e-9 * fmax(zs, pscale) || vertex) {
-          vertex = false;
+        if (atopt || pn <= 1e-9 * fmax(zs, pscale) || vertex) {
+          vertex = false; atopt = false;
           // stationary on the working set: drop a row with a negative multiplier (most negative; lowest constraint index after a degenerate step — Bland)
+          TF(8)
+          tq_mult(S, n, nw);                              // multipliers at zn, the solution of the last solve (== z here)
+          TF(1)
           const double mylam = (l < nw) ? lam[l] : 0.0; const double lscale = fmax(1.0, wv_max(fabs(mylam)));
           const bool cand = (l < nw) && (mylam < -1e-9 * lscale);
           int worst;
-          if (degenerate) { int key = cand ? Wi[l] * 64 + l : (1 << 28); for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; } worst = (key == (1 << 28)) ? -1 : (key & 63); }
-          else { const double lmin = -wv_max(cand ? -mylam : -1e300); int key = (cand && mylam == lmin) ? l : 64; for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; } worst = (key == 64) ? -1 : key; }
+          // (index minima as DPP maxima of small integers held in doubles: a ds_bpermute butterfly costs several times more on a lone wave)
+          if (degenerate) { const int m = (int)wv_max(cand ? (double)(4095 - (Wi[(l < nw) ? l : 0] * 64 + l)) : -1.0); worst = (m < 0) ? -1 : ((4095 - m) & 63); }
+          else { const double lmin = -wv_max(cand ? -mylam : -1e300); const int m = (int)wv_max((cand && mylam == lmin) ? (double)(63 - l) : -1.0); worst = (m < 0) ? -1 : 63 - m; }
           if (worst < 0) break;
           wmask &= ~(1ull << Wi[worst]);
-          if (myslot == worst) myslot = -1; else if (myslot > worst) --myslot;
-          nfact = -1;                                       // the rows behind the dropped one move up: factor again
+          TF(8)
+          tq_drop(S, n, nw, worst);
+          TF(2)
           const int nxt = (l + 1 < nw) ? Wi[l + 1] : 0;
           qm_wave_sync();
           if (l >= worst && l + 1 < nw) Wi[l] = nxt;
           --nw;
           qm_wave_sync();
+          WT(9)
         } else {
           double aa = 1e300;
           if (l < C.nIneq && !((wmask >> l) & 1ull)) {
@@ -884,15 +1021,29 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
           }
           const double amin = -wv_max(-aa);
           double al = 1.0; int block = -1;
-          if (amin < 1.0) { al = amin; int key = (aa == amin) ? l : 64; for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(key, off, 64); key = (o < key) ? o : key; } block = key; }
+          if (amin < 1.0) { al = amin; block = 63 - (int)wv_max((aa == amin) ? (double)(63 - l) : -1.0); }
           qm_wave_sync();
           if (l < n) z[l] += al * p[l];
 #ifdef QM_WBC_TRACE
           if (l == 0) printf("   step al %.6e block %d\n", al, block);
 #endif
           degenerate = (al <= 1e-12);
+          atopt = (block < 0);                            // full step: z = zn; solving the same rows again would return p = 0 and the multipliers of this solve
           if (block >= 0) {
-            if (nw < n && nw < WMAXACT) { if (l == 0) Wi[nw] = block; if (l == block) myslot = nw; wmask |= (1ull << block); ++nw; }
+            if (nw < n && nw < WMAXACT) {
+              if (l == block) {
+#pragma unroll
+                for (int k = 0; k < WVLD; ++k) S[WL_TQ_ROW + k] = dz[k];      // dz is zero beyond n: no per-index bound (uniform branches would serialise the LDS traffic)
+              }
+              if (l == 0) Wi[nw] = block;
+              qm_wave_sync();
+              WT(10)
+              TF(8)
+              tq_append<PROF>(S, n, nw, fb[block], tfine);
+              TF(3)
+              WT(9)
+              wmask |= (1ull << block); ++nw;
+            }
             else if (nw >= n) { if (al <= 1e-12) vertex = true; }   // n rows are active already (the working-set rows are numerically dependent, else p would vanish): the set
                                                                  // cannot grow beyond the dimension.  A step blocked at once means z is a degenerate vertex: decide by the multipliers
                                                                  // (drop by Bland's rule).  After a partial step the same rows are solved again and the remainder ends up here.
@@ -924,6 +1075,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
   if (PROF && a.stop == -2 && l == 0) for (int k = 0; k < 9; ++k) gs[WS_TIME + k] = (double)tfine[k];
   if (PROF && a.stop == -3 && l == 0) for (int k = 0; k < 10; ++k) gs[WS_TIME + k] = (double)tnull[k];
 #undef WT
+#undef TF
   if (PROF && a.dbg) {
     double* d = a.dbg + (size_t)b * WBC_DBG_SIZE;
     if (l < 24) { d[l] = q[l]; d[24 + l] = v[l]; d[48 + l] = qd[l]; d[72 + l] = vd[l]; d[102 + l] = nle[l]; }

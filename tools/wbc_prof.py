@@ -8,8 +8,8 @@ cfg = scenarios.make_config("C4", batch=B)
 itf = api.QMInterface(blobs=scenarios.load_blobs(), max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
 mpc = api.SqpMpc(itf); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
 mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
-for stop, names in ((-1, ["init+rigid_body", "task build + AZ/g0", "L0 G build + active rows", "L0 QR solve", "L0 Z_times/d0_apply/c0c1", "L0 line search", "L0 iteration tail", "null space", "L>=1 factor + DZ", "L>=1 eq_ls_R", "L>=1 iteration rest / level tail", "output"]),
-                    (-2, ["copy T", "qr_Et", "fwd solve y1", "T Q + rhs", "reduced LS", "apply Q", "res/w", "apply Qt", "multipliers"]),
+for stop, names in ((-1, ["init+rigid_body", "task build + AZ/g0", "L0 G build + active rows", "L0 QR solve", "L0 Z_times/d0_apply/c0c1", "L0 line search", "L0 iteration tail", "null space", "L>=1 factor + DZ", "L>=1 solves / appends / drops", "L>=1 iteration rest / level tail", "output"]),
+                    (-2, ["tq_solve", "tq_mult", "tq_drop", "tq_append", "  append 1-2 t, coefficients", "  append 3 column sweep", "  append 4 row rotations", "  append 5 row + y", "(other)"]),
                     (-3, ["L0 load", "L0 pivoted QR", "L0 backward accumulation", "L0 write Zp", "(start -> rigid-body passes)", "L1 load", "L1 pivoted QR", "L1 backward accumulation", "(start -> end of rigid-body passes)", "L1 Zp <- Zp Q2"])):
     itf.debug_set("wbc_stop", stop)
     mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
