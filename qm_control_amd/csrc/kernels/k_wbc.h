@@ -313,7 +313,13 @@ struct WbcCtx {   // everything the D0 block and the torque map need (all wave-u
 // out = D0 x ; lanes cooperate, tau scratch in LDS
 __device__ __forceinline__ void wv_d0_apply(const WbcCtx& c, const double* x, double* tau, double* out) {
   const int l = threadIdx.x & 63;
-  if (l < 18) { double s = 0.0; for (int k = 0; k < 24; ++k) s += c.M[(6 + l) * 24 + k] * x[k]; for (int k = 0; k < 12; ++k) s -= c.Jf[k * 24 + 6 + l] * x[24 + k]; tau[l] = s; out[l] = s; out[18 + l] = -s; }
+  if (l < 18) {                                             // four partial sums: a dependent f64 chain costs ≈ 16 cycles per link on a lone wave
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 24; ++k) s4[k & 3] += c.M[(6 + l) * 24 + k] * x[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s4[k & 3] -= c.Jf[k * 24 + 6 + l] * x[24 + k];
+    const double s = (s4[0] + s4[1]) + (s4[2] + s4[3]); tau[l] = s; out[l] = s; out[18 + l] = -s; }
   if (l >= 36 && l < c.nIneq) {
     const int r = l - 36; double v = 0.0;
     if (r < 5 * c.nc) { const int j = r / 5, q = r - 5 * j; const double* F = x + 24 + 3 * c.contactOf(j); v = (q == 0) ? -F[2] : (q == 1) ? F[0] - c.mu * F[2] : (q == 2) ? -F[0] - c.mu * F[2] : (q == 3) ? F[1] - c.mu * F[2] : -F[1] - c.mu * F[2]; }
@@ -330,7 +336,13 @@ __device__ __forceinline__ double wbc_d0_entry(const WbcCtx& c, int i, int k) { 
 // y(36) = Zp (36 x n) z
 __device__ __forceinline__ void wv_Z_times(const double* Zp, int n, const double* z, double* y) {
   const int l = threadIdx.x & 63;
-  if (l < WNV) { double s = 0.0; if (n == WNV) s = z[l]; else for (int k = 0; k < n; ++k) s += Zp[l * n + k] * z[k]; y[l] = s; }   // level 0: Zp = I
+  if (l < WNV) { double s = 0.0;
+    if (n == WNV) s = z[l];                                 // level 0: Zp = I
+    else { double s4[4] = {0.0, 0.0, 0.0, 0.0};             // n <= 18: static loop, the entries past the row end (the next row's, finite) are masked
+#pragma unroll
+      for (int k = 0; k < WVLD; ++k) { const double zk = Zp[l * n + k] * z[k]; s4[k & 3] += (k < n) ? zk : 0.0; }
+      s = (s4[0] + s4[1]) + (s4[2] + s4[3]); }
+    y[l] = s; }
   qm_wave_sync();
 }
 
@@ -842,8 +854,14 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
     qm_wave_sync();
     // ---- AZ = A Zp, g0 = [b − A xp; 0] ----
     const int n = nz;
-    if (level > 0) for (int idx = l; idx < ra * n; idx += 64) { const int r = idx / n, k = idx - r * n; double s = 0.0; for (int c2 = 0; c2 < WNV; ++c2) s += A[r * WNV + c2] * Zp[c2 * n + k]; AZ[r * WNV + k] = s; }
-    for (int r = l; r < ra + n; r += 64) { double s = 0.0; if (r < ra) { s = bb[r]; for (int c2 = 0; c2 < WNV; ++c2) s -= A[r * WNV + c2] * x[c2]; } g0[r] = s; }
+    if (level > 0) for (int idx = l; idx < ra * n; idx += 64) { const int r = idx / n, k = idx - r * n; double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int c2 = 0; c2 < WNV; ++c2) s4[c2 & 3] += A[r * WNV + c2] * Zp[c2 * n + k];
+      AZ[r * WNV + k] = (s4[0] + s4[1]) + (s4[2] + s4[3]); }
+    for (int r = l; r < ra + n; r += 64) { double s = 0.0; if (r < ra) { double s4[4] = {bb[r], 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c2 = 0; c2 < WNV; ++c2) s4[c2 & 3] -= A[r * WNV + c2] * x[c2];
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]); } g0[r] = s; }
     if (l < WNV) z[l] = 0.0;
     qm_wave_sync();
     const int rows0 = ra + n;
@@ -853,34 +871,51 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
       wv_d0_apply(C, x, tau, Dz);
       if (l < C.nIneq) fb[l] = f0[l] - Dz[l];
       qm_wave_sync();
-      unsigned long long actmask = 0ull; for (int i = 0; i < C.nIneq; ++i) if (0.0 - fb[i] > 0.0) actmask |= (1ull << i);
+      unsigned long long actmask = __ballot((l < C.nIneq) && (0.0 - fb[l] > 0.0));
+      // The task rows do not change over the iterations: [sqrt(rho) I; A | b] is factored ONCE (packed triangle [R0 | c0] in G, a copy kept in the region the levels >= 1
+      // use for their own factors), and an iteration only folds its active soft rows into a fresh copy — 6 dense rows per Householder step instead of 24.  (Rounds 1–3 factored
+      // the whole stack in every iteration; with no active row — the usual first iteration — the solve is the back substitution alone.)
+      double* G0 = S + WL_V;                              // [702] [R0 | c0]
+      for (int idx = l; idx < 702; idx += 64) G[idx] = 0.0;
+      qm_wave_sync();
+      if (l < n) G[wv_tidx(l, l, n, 0)] = sqrt(WRHO);
+      qm_wave_sync();
+      if (ra <= 18) {
+        double d[18];
+#pragma unroll
+        for (int r = 0; r < 18; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
+        rq_house_tri<18>(d, G, 0, n, S + WL_HV);
+      } else {
+        double d[WMAXA];
+#pragma unroll
+        for (int r = 0; r < WMAXA; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
+        rq_house_tri<WMAXA>(d, G, 0, n, S + WL_HV);
+      }
+      for (int idx = l; idx < 702; idx += 64) G0[idx] = G[idx];
+      qm_wave_sync();
+      bool dirty = false;                                 // G holds something else than [R0 | c0]
+      WT(2)
       int it = 0;
       for (; it < 100; ++it) {
-        // least squares [sqrt(rho) I; A | b; active soft rows | fb]: the triangular part sits in G, the dense rows in registers
-        for (int idx = l; idx < 702; idx += 64) G[idx] = 0.0;
-        qm_wave_sync();
-        if (l < n) G[wv_tidx(l, l, n, 0)] = sqrt(WRHO);
         int* alist = (int*)(S + WL_WLIST);
-        if (l == 0) { int na0 = 0; for (int i = 0; i < C.nIneq && na0 < WMAXACT; ++i) if ((actmask >> i) & 1ull) alist[na0++] = i; }
         int na = __popcll(actmask); if (na > WMAXACT) na = WMAXACT;
+        { const int rank = __popcll(actmask & ((1ull << l) - 1ull)); if (((actmask >> l) & 1ull) && rank < WMAXACT) alist[rank] = l; }
+        if (dirty) { for (int idx = l; idx < 702; idx += 64) G[idx] = G0[idx]; dirty = false; }
         qm_wave_sync();
-        if (ra <= 18 && na <= 6) {
-          // the usual case (18 task rows, a handful of active soft rows): 24 dense rows, pivot column broadcast by v_readlane
-          double d[24];
+        if (na > 0) {
+          if (na <= 6) {
+            // the usual case (a handful of active soft rows): pivot column broadcast by v_readlane
+            double d[6];
 #pragma unroll
-          for (int r = 0; r < 18; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
+            for (int q2 = 0; q2 < 6; ++q2) { double v = 0.0; if (q2 < na && l <= n) { const int i = alist[q2]; v = (l == n) ? fb[i] : wbc_d0_entry(C, i, l); } d[q2] = v; }
+            rq_house_tri<6>(d, G, 0, n, S + WL_HV);
+          } else {
+            double d[WMAXACT];
 #pragma unroll
-          for (int q2 = 0; q2 < 6; ++q2) { double v = 0.0; if (q2 < na && l <= n) { const int i = alist[q2]; v = (l == n) ? fb[i] : wbc_d0_entry(C, i, l); } d[18 + q2] = v; }
-          WT(2)
-          rq_house_tri<24>(d, G, 0, n, S + WL_HV);
-        } else {
-          double d[WMAXA + WMAXACT];
-#pragma unroll
-          for (int r = 0; r < WMAXA; ++r) d[r] = (r < ra && l <= n) ? ((l == n) ? g0[r] : AZ[r * WNV + l]) : 0.0;
-#pragma unroll
-          for (int q2 = 0; q2 < WMAXACT; ++q2) { double v = 0.0; if (q2 < na && l <= n) { const int i = alist[q2]; v = (l == n) ? fb[i] : wbc_d0_entry(C, i, l); } d[WMAXA + q2] = v; }
-          WT(2)
-          rq_house_tri<WMAXA + WMAXACT>(d, G, 0, n, S + WL_HV);
+            for (int q2 = 0; q2 < WMAXACT; ++q2) { double v = 0.0; if (q2 < na && l <= n) { const int i = alist[q2]; v = (l == n) ? fb[i] : wbc_d0_entry(C, i, l); } d[q2] = v; }
+            rq_house_tri<WMAXACT>(d, G, 0, n, S + WL_HV);
+          }
+          dirty = true;
         }
         wv_backsub_tri<WNV>(G, 0, n, zn);
         if (l < n) p[l] = zn[l] - z[l];
@@ -889,15 +924,36 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
         wv_Z_times(Zp, n, z, Zz); wv_Z_times(Zp, n, p, Zpv);
         wv_d0_apply(C, Zz, tau, Dz); wv_d0_apply(C, Zpv, tau, Dp);
         double c0p = 0.0, c1p = 0.0;   // smooth part of dphi: c0 + a c1
-        for (int r = l; r < rows0; r += 64) { double gz = -g0[r], gp = 0.0; if (r < ra) { for (int k = 0; k < n; ++k) { gz += AZ[r * WNV + k] * z[k]; gp += AZ[r * WNV + k] * p[k]; } } else { gz += sqrt(WRHO) * z[r - ra]; gp = sqrt(WRHO) * p[r - ra]; } c0p += gz * gp; c1p += gp * gp; }
+        for (int r = l; r < rows0; r += 64) { double gz = -g0[r], gp = 0.0;
+          if (r < ra) { double z2[2] = {0.0, 0.0}, p2[2] = {0.0, 0.0};      // n = 36 here (level 0)
+#pragma unroll
+            for (int k = 0; k < WNV; ++k) { const double ak = AZ[r * WNV + k]; z2[k & 1] += ak * z[k]; p2[k & 1] += ak * p[k]; }
+            gz += z2[0] + z2[1]; gp = p2[0] + p2[1]; }
+          else { gz += sqrt(WRHO) * z[r - ra]; gp = sqrt(WRHO) * p[r - ra]; } c0p += gz * gp; c1p += gp * gp; }
         const double c0 = wv_sum(c0p), c1 = wv_sum(c1p);
         WT(4)
-        // exact line search on the convex piecewise-quadratic phi: bisection on dphi (lane i carries soft row i); the loop stops when the
-        // bracket cannot shrink any more, which leaves the same al as running all 200 halvings
+        // exact line search on the convex piecewise-quadratic phi (lane i carries soft row i): dphi is piecewise LINEAR and non-decreasing, so Newton's iteration on it
+        // — value and slope from one pass over the rows, kept inside the bracket [lo, hi] — lands on the root exactly as soon as a step stays within one linear piece
+        // (the set of rows with a positive residual does not change); rounds 1–3 bisected the bracket down to one ulp, ≈ 52 wave reductions
         const bool mine = (l < C.nIneq); const double myDz = mine ? Dz[l] : 0.0, myDp = mine ? Dp[l] : 0.0, myfb = mine ? fb[l] : 1.0;
-        auto dphi = [&](double al) { const double vv = myDz + al * myDp - myfb; return c0 + al * c1 + wv_sum((vv > 0.0) ? vv * myDp : 0.0); };
+        auto dphi = [&](double a, double& f, double& sl, unsigned long long& msk) { const double vv = myDz + a * myDp - myfb; const bool on = vv > 0.0; msk = __ballot(on);
+          f = c0 + a * c1 + wv_sum(on ? vv * myDp : 0.0); sl = c1 + wv_sum(on ? myDp * myDp : 0.0); };
         double al = 1.0;
-        if (dphi(1.0) > 0.0) { double lo = 0.0, hi = 1.0; for (int bi = 0; bi < 200; ++bi) { const double mid = 0.5 * (lo + hi); if (mid == lo || mid == hi) break; if (dphi(mid) > 0.0) hi = mid; else lo = mid; } al = 0.5 * (lo + hi); }
+        { double f, sl; unsigned long long m0; dphi(1.0, f, sl, m0);
+          if (f > 0.0) {
+            double lo = 0.0, hi = 1.0;
+            for (int bi = 0; bi < 200; ++bi) {
+              double an = al - f / sl; bool newton = true;
+              if (!(an > lo && an < hi)) { an = 0.5 * (lo + hi); newton = false; }
+              if (an == lo || an == hi) { al = an; break; }                      // the bracket cannot shrink any more
+              double fn, sn; unsigned long long mn; dphi(an, fn, sn, mn);
+              if (fn > 0.0) hi = an; else lo = an;
+              const bool done = (newton && mn == m0) || fn == 0.0;
+              al = an; f = fn; sl = sn; m0 = mn;
+              if (done) break;
+            }
+          }
+        }
         WT(5)
         const double pn = wv_max((l < n) ? fabs(al * p[l]) : 0.0);
         if (l < n) z[l] += al * p[l];
