@@ -153,10 +153,14 @@ struct QmMpcPipeline {
       d.host_open[t] = -1;                                 // armed: the launch's last block overwrites it with the count of the instances still searching
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching
       ++ls_trials_run;
+      // The first trial is accepted by every instance most of the time: its apply is enqueued BEHIND the decision before the host knows the outcome, so the device does not
+      // idle through the host's round trip (flag -> launch: 20-30 us per step in the kernel trace).  The apply only reads the iterate and the step and writes the primal
+      // solution — instances still searching get alpha = 0 — so it is simply launched again once the remaining trials are through.
+      if (t == 0) { bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l); }
       bk.wait_flag(d.host_open + t, -1);                   // spin on the host-visible word (a stream synchronisation costs 10-30 us of wake-up latency per step)
       if (d.host_open[t] == 0) break;
     }
-    bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
+    if (ls_trials_run != 1) bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
     if (!last) bk.launch(qm_ls_commit_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
     solved_B = B;
   }
