@@ -58,12 +58,13 @@ def test_line_search_backtracks_like_the_oracle(blobs, oblobs, oracle):
     assert rel_err(e.node_arr("xs", 30)[:n, 0], r["x"]) < TOL
 
 
-def test_wbc_kernel_vs_oracle(blobs, oracle):
+@pytest.mark.parametrize("ncase,seed,amp", [(6, 21, 0.05), (10, 303, 0.5)])      # small and large tracking errors (the large ones saturate torque limits and friction cones: long active-set paths with drops)
+def test_wbc_kernel_vs_oracle(blobs, oracle, ncase, seed, amp):
     import emu_harness
     from test_gpu_wbc import _random_wbc_inputs
-    e = emu_harness.Emu(blobs[0], blobs[1], 8, 8, 2, 2)
+    e = emu_harness.Emu(blobs[0], blobs[1], 16, 8, 2, 2)
     for variant in (0, 1):
-        cases = _random_wbc_inputs(oracle, blobs, 6, 21 + variant, 0.05)
+        cases = _random_wbc_inputs(oracle, blobs, ncase, seed + variant, amp)
         arr = lambda k: np.array([c[k] for c in cases])
         e.wbc_reset(); e.wbc_step(arr("xd"), arr("il"), arr("rbd"), arr("mode"), 0.002, arr("time"), variant)
         out, st, dbg = e.wbc_step(arr("xd"), arr("ud"), arr("rbd"), arr("mode"), 0.002, arr("time"), variant)
