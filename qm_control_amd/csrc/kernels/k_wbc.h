@@ -7,8 +7,10 @@
 //   13 task formulators             -> rows of A_k x = b_k and the structured inequality block D0 x <= f0
 //   HoQp cascade (3 levels)         -> each level is an inequality-constrained least-squares problem
 //        min ½|A Zp z + A xp − b|² + ½ rho |z|² + ½|w|²  s.t.  w >= 0, D Zp z − w <= f − D xp,  Dp Zp z <= fp − Dp xp + wp*
-//      solved exactly by an active-set method on Householder factorisations, lane = matrix column (stands in for
-//      qpOASES, whose return code the reference ignores, HoQp.cpp:143-146; we report qp_status).  rho = 1e-12 (HoQp.cpp:66).
+//      solved exactly, lane = matrix column / row (stands in for qpOASES, whose return code the reference ignores, HoQp.cpp:143-146; we report qp_status).
+//      rho = 1e-12 (HoQp.cpp:66).  Level 0 (own soft rows): Newton on the active set; the task rows are factored once (Householder, rq_house_tri), an iteration folds
+//      its active soft rows into a copy and searches the step length exactly.  Levels >= 1 (hard rows of level 0): primal active set (Nocedal & Wright 16.3) on a TQ
+//      factorisation that is UPDATED by plane rotations when a working row comes or goes (tq_append / tq_drop / tq_solve / tq_mult) — no factorisation is repeated.
 //   updateCmd                        -> tau = [M_j, −J_jᵀ] x + h_j
 // D0 (torque limits ± and friction pyramids) is never materialised: products D0·x use tau(x) and the 5x3 pyramid.
 // Control flow is wave-uniform: every decision is taken on values all 64 lanes read from LDS or get from a wave reduction,
@@ -51,7 +53,7 @@ struct QmWbcArgs {
 #define WL_JF     (WL_NLE + 24)
 #define WL_BB     (WL_JF + 288)                   /* [22] */
 #define WL_AZ     (WL_BB + WMAXA)                 /* [22][36]: level 0 task rows (Zp = I), A Zp at levels >= 1 */
-#define WL_G      (WL_AZ + WMAXA * WNV)           /* 720: level 0 packed triangular [R | c] (702); levels >= 1 [R | c] (18 x 19) + scratch copy;
+#define WL_G      (WL_AZ + WMAXA * WNV)           /* 720: level 0 packed triangular [R | c] (702); levels >= 1 T = [R | c] updated in place (18 x 19) + the append's row / coefficients (WL_TQ_*);
                                                      null-space workspace (A Zp)ᵀ; RBD sums/accumulators before the cascade */
 #define WG_SIZE   720
 #define WL_ZP     (WL_G + WG_SIZE)                /* [36][n], n <= 18 (level 0 works with Zp = I implicitly) */
@@ -69,14 +71,14 @@ struct QmWbcArgs {
 #define WL_DZ     (WL_FB + WMAXINEQ)
 #define WL_DP     (WL_DZ + WMAXINEQ)
 #define WL_TAU    (WL_DP + WMAXINEQ)              /* [18] */
-#define WL_V      (WL_TAU + 24)                   /* [20][18] reflectors of the working-set QR */
+#define WL_V      (WL_TAU + 24)                   /* level 0: copy of the task rows' factor [R0 | c0] (702, spans V .. R); levels >= 1: Q [18][18] of the TQ factorisation */
 #define WL_A      WL_V                            /* [22][36] task rows of levels >= 1: only live while A Zp / g0 are formed, aliases V..EROWS */
 #define WL_BETA   (WL_V + WMAXACT * WVLD)
 #define WL_R      (WL_BETA + WMAXACT)             /* [20][20] */
-#define WL_EROWS  (WL_R + WMAXACT * WMAXACT)      /* [20][18] */
+#define WL_EROWS  (WL_R + WMAXACT * WMAXACT)      /* [20][18] L = E Q: the working rows in the rotated coordinates (before the loop: hand-over tile of D0 Zp) */
 #define WL_ERHS   (WL_EROWS + WMAXACT * WVLD)
 #define WL_LAM    (WL_ERHS + WMAXACT)
-#define WL_Y      (WL_LAM + WMAXACT)              /* [36] */
+#define WL_Y      (WL_LAM + WMAXACT)              /* [36] y = Qᵀ z of the current working set (zero beyond n) */
 #define WL_W36    (WL_Y + WNV)
 #define WL_WLIST  (WL_W36 + WNV)                  /* [20] ints: working set */
 #define WL_ACC    (WL_G + 18 * 16)                /* chain accumulators: 3 passes x 6 slots x 20 (inside G, after the momentum sums) */
@@ -126,39 +128,6 @@ __device__ __forceinline__ bool qm_house_scalars(double nrm2, double g, double& 
 }
 
 // ---- wave-cooperative dense helpers ----
-// Householder QR on REGISTER-resident columns: lane j holds column j in col[0..MR) (rows beyond the matrix are zero); lanes
-// 0..n-1 are the matrix columns, lane n is the right-hand side.  After step k the registers move up one row, so the pivot is
-// always col[0] and every index is static; the pivot column reaches the other lanes through v_readlane (hv is unused, kept for symmetry).
-// Row k of [R | Qᵀ rhs] is written to Rout[k * ldR + l], k <= l <= n.  With Vout the reflectors are kept:
-// Vout[k * ldV + k + i] = v_k[i] (zero above the pivot), beta[k] = 2 / (v·v) (0 for a null column).
-template <int MR>
-__device__ __forceinline__ void rq_house(double (&col)[MR], int nsteps, int n, double* hv, double* Rout, int ldR, double* Vout, int ldV, double* beta, int kstart = 0) {
-  const int l = threadIdx.x & 63;
-  for (int k = kstart; k < nsteps; ++k) {      // kstart > 0: the registers have already moved up kstart rows (wv_qr_Et_append)
-    // the pivot column reaches every lane through v_readlane (MR <= 18 values fit the scalar registers): no LDS round trip in the chain
-    double v[MR];
-#pragma unroll
-    for (int i = 0; i < MR; ++i) v[i] = qm_bcast(col[i], k);
-    double nq[4] = {0.0, 0.0, 0.0, 0.0}, dq[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < MR; ++i) { nq[i & 3] += v[i] * v[i]; if (i > 0) dq[i & 3] += v[i] * col[i]; }
-    const double nrm2 = (nq[0] + nq[1]) + (nq[2] + nq[3]), dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
-    double alpha, vk, b2; const bool ok = qm_house_scalars(nrm2, v[0], alpha, vk, b2);
-    const double s = (dot + vk * col[0]) * b2;
-    const double r0 = (l == k && ok) ? alpha : col[0] - s * vk;
-    if (l >= k && l <= n) Rout[k * ldR + l] = r0;
-    if (Vout && l == k) {
-#pragma unroll
-      for (int i = 0; i < MR; ++i) Vout[k * ldV + k + i] = ok ? (i == 0 ? vk : col[i]) : 0.0;   // entries past the row end are zeros that land above the NEXT row's pivot (Vout must have MR spare slots)
-      beta[k] = b2;
-    }
-    // reflect and move up one row
-#pragma unroll
-    for (int i = 1; i < MR; ++i) col[i - 1] = col[i] - s * v[i];
-    col[MR - 1] = 0.0;
-  }
-  qm_wave_sync();
-}
 // QR of [T; D]: T (n x (n+1), upper triangular with the rhs in column n, LDS, leading dim ldT) stacked on MRD dense rows held
 // by column in registers (lane j: d[0..MRD) = column j of D, lane n = its rhs, unused rows zero).  Step k only touches row k of T
 // and the dense rows, so a least-squares matrix [sqrt(rho) I; A] costs (1 + rows(A)) per column instead of n + rows(A).
@@ -217,18 +186,6 @@ __device__ __forceinline__ double wv_solve_upper(At at, int n, double rj) {
   for (int i = MAXN - 1; i >= 0; --i) if (i < n) { const double zi = qm_bcast(rj * rinv, i); if (l == i) z = zi; rj -= row[i] * zi; }
   return z;
 }
-// lower: L y = r with L = Rᵀ (at(j, i) must return R[i][j]), i = 0 .. n-1, row j holds i < j.
-template <int MAXN, class At>
-__device__ __forceinline__ double wv_solve_lower(At at, int n, double rj) {
-  const int l = threadIdx.x & 63;
-  double row[MAXN];
-#pragma unroll
-  for (int i = 0; i < MAXN; ++i) row[i] = (l < n && i < l) ? at(l, i) : 0.0;
-  const double rinv = (l < n) ? 1.0 / at(l, l) : 0.0; double z = 0.0;
-#pragma unroll
-  for (int i = 0; i < MAXN; ++i) if (i < n) { const double zi = qm_bcast(rj * rinv, i); if (l == i) z = zi; rj -= row[i] * zi; }
-  return z;
-}
 // R z = c on [R | c] held like rq_house_tri leaves it (ld == 0: packed); z -> LDS vector
 template <int MAXN>
 __device__ __forceinline__ void wv_backsub_tri(const double* T, int ld, int n, double* z) {
@@ -237,69 +194,6 @@ __device__ __forceinline__ void wv_backsub_tri(const double* T, int ld, int n, d
   qm_wave_sync();
   if (l < n) z[l] = zl;
   qm_wave_sync();
-}
-// R z = rhs with R = upper triangle of G[0:n, 0:n] (n <= 18); rhs is a strided vector (rhs[i * rs]); z -> LDS vector
-__device__ __forceinline__ void wv_backsub(const double* G, int ld, int n, const double* rhs, int rs, double* z) {
-  const int l = threadIdx.x & 63;
-  const double zl = wv_solve_upper<WVLD>([&](int j, int i) { return G[j * ld + i]; }, n, (l < n) ? rhs[l * rs] : 0.0);
-  qm_wave_sync();
-  if (l < n) z[l] = zl;
-  qm_wave_sync();
-}
-// Householder least squares: min |G[:, :n] z − G[:, n]|
-template <int MR>
-__device__ __forceinline__ void wv_ls_qr(double* G, int ld, int rows, int n, double* hv, double* z) {
-  const int l = threadIdx.x & 63;
-  double col[MR];
-#pragma unroll
-  for (int i = 0; i < MR; ++i) col[i] = (i < rows && l <= n) ? G[i * ld + l] : 0.0;
-  rq_house<MR>(col, n, n, hv, G, ld, nullptr, 0, nullptr);
-  wv_backsub(G, ld, n, G + n, ld, z);
-}
-// Householder QR of Eᵀ (n x me) for E (me x n, ld = WVLD): reflectors V[k][0..n) (zero above k), beta[k], R (me x me upper, ld = WMAXACT).
-// Lane q holds column q of Eᵀ (= row q of E) in registers.
-__device__ __forceinline__ void wv_qr_Et(const double* E, int me, int n, double* V, double* beta, double* R, double* hv) {
-  const int l = threadIdx.x & 63;
-  double col[WVLD];
-#pragma unroll
-  for (int i = 0; i < WVLD; ++i) col[i] = (l < me && i < n) ? E[l * WVLD + i] : 0.0;
-  for (int idx = l; idx < me * WVLD; idx += 64) V[idx] = 0.0;             // reflector entries above the pivot must read as zero
-  rq_house<WVLD>(col, me, me - 1, hv, R, WMAXACT, V, WVLD, beta);
-}
-// The same factorisation after ONE more row has been appended to E (row m = me − 1): the reflectors of the first m columns of Eᵀ do not depend on later columns, so
-// they are applied to the new column — in the lane that holds it, with the arithmetic of rq_house (same partial sums, same order: the result is bit-identical to a
-// factorisation from scratch) — and one Householder step follows.  Costs m reflections of one vector + 1 step instead of me steps over all columns.
-__device__ __forceinline__ void wv_qr_Et_append(const double* E, int me, int n, double* V, double* beta, double* R, double* hv) {
-  const int l = threadIdx.x & 63, m = me - 1;
-  double col[WVLD];
-#pragma unroll
-  for (int i = 0; i < WVLD; ++i) col[i] = (l == m && i < n) ? E[m * WVLD + i] : 0.0;
-  for (int k = 0; k < m; ++k) {
-    const double* vs = V + k * WVLD + k; const double b2 = beta[k];
-    double v[WVLD];
-#pragma unroll
-    for (int i = 0; i < WVLD; ++i) v[i] = vs[i];                          // v[0] = vk; entries past the row end are the zeros rq_house left there
-    double dq[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 1; i < WVLD; ++i) dq[i & 3] += v[i] * col[i];
-    const double dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
-    const double s = (dot + v[0] * col[0]) * b2;
-    if (l == m) R[k * WMAXACT + m] = col[0] - s * v[0];
-#pragma unroll
-    for (int i = 1; i < WVLD; ++i) col[i - 1] = col[i] - s * v[i];
-    col[WVLD - 1] = 0.0;
-  }
-  if (l < m) V[m * WVLD + l] = 0.0;                                      // reflector entries above the pivot must read as zero
-  qm_wave_sync();
-  rq_house<WVLD>(col, me, me - 1, hv, R, WMAXACT, V, WVLD, beta, m);
-}
-__device__ __forceinline__ void wv_apply_Qt(const double* V, const double* beta, int me, int n, double* x) {   // x <- Qᵀ x
-  const int l = threadIdx.x & 63;
-  for (int k = 0; k < me; ++k) { const double* v = V + k * WVLD; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
-}
-__device__ __forceinline__ void wv_apply_Q(const double* V, const double* beta, int me, int n, double* x) {    // x <- Q x
-  const int l = threadIdx.x & 63;
-  for (int k = me - 1; k >= 0; --k) { const double* v = V + k * WVLD; const double s = wv_sum((l >= k && l < n) ? v[l] * x[l] : 0.0) * beta[k]; if (l >= k && l < n) x[l] -= s * v[l]; qm_wave_sync(); }
 }
 
 struct WbcCtx {   // everything the D0 block and the torque map need (all wave-uniform)
