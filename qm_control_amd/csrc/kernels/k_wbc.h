@@ -298,7 +298,7 @@ __device__ __forceinline__ double tq_solve_lower(At at, int n, double rj) {
 __device__ __forceinline__ void tq_init(double* S, int n) {
   const int l = threadIdx.x & 63;
   for (int idx = l; idx < WVLD * WVLD; idx += 64) { const int r = idx / WVLD, c = idx - WVLD * r; S[WL_TQ_Q + idx] = (r == c && r < n) ? 1.0 : 0.0; }
-  for (int idx = n * WTLD + l; idx < WVLD * WTLD; idx += 64) S[WL_TQ_T + idx] = 0.0;
+  for (int idx = l; idx < WVLD * WTLD; idx += 64) { const int r = idx / WTLD, c = idx - WTLD * r; if (r >= n || c > n) S[WL_TQ_T + idx] = 0.0; }   // (entries right of ct are read by the 18-wide sweeps)
   if (l < 20) S[WL_Y + l] = 0.0;                                          // y is kept zero beyond n, and its free part is cleared before it is solved for: no sum below needs a bound
   qm_wave_sync();
 }
