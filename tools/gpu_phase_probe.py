@@ -28,13 +28,13 @@ itf.debug_set("wbc_stop", -1)
 mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
 import numpy as np
 cyc = itf.debug_read("wbc_scratch", (B, 432))
-names = ["init+rigid_body", "task build + AZ/g0", "L0 G build + active rows", "L0 QR solve", "L0 Z_times/d0_apply/c0c1", "L0 line search", "L0 iteration tail", "null space", "L>=1 factor + DZ", "L>=1 eq_ls_R", "L>=1 iteration rest / level tail", "output"]
+names = ["init+rigid_body", "task build + AZ/g0", "L0 G build + active rows", "L0 QR solve", "L0 Z_times/d0_apply/c0c1", "L0 line search", "L0 iteration tail", "null space", "L>=1 factor + DZ", "L>=1 solves / appends / drops", "L>=1 iteration rest / level tail", "output"]
 print(json.dumps({n: float(cyc[:, i].mean()) for i, n in enumerate(names)}, indent=1)); print("total cycles/instance", cyc[:, :12].sum(1).mean())
 itf.debug_set("wbc_stop", 0)
 itf.debug_set("wbc_stop", -2)
 mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
 cyc = itf.debug_read("wbc_scratch", (B, 432))
-fn = ["copy T", "qr_Et", "fwd solve y1", "T Q + rhs", "reduced LS", "apply Q", "res/w", "apply Qt", "multipliers"]
+fn = ["tq_solve", "tq_mult", "tq_drop", "tq_append", "  append 1-2 t, coefficients", "  append 3 column sweep", "  append 4 row rotations", "  append 5 row + y", "(other)"]
 print(json.dumps({n: float(cyc[:, i].mean()) for i, n in enumerate(fn)}, indent=1))
 itf.debug_set("wbc_stop", 0)
 # K1b in-kernel stamps (thread 0 of each node's workgroup)
