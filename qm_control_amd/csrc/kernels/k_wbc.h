@@ -600,12 +600,12 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
   // ---- generalized coordinates of the three passes: measured (q,v), desired (qd,vd), joint-acceleration (qd, w2) ----
   double* q = S + WL_MISC; double* v = q + 24; double* qd = v + 24; double* vd = qd + 24; double* w2 = vd + 24; double* baseAcc = w2 + 24;
   if (l < 3) { q[l] = rbd[3 + l]; q[3 + l] = rbd[l]; v[l] = rbd[27 + l]; }
-  if (l == 3) { const double z = rbd[0], y = rbd[1]; const double sz = sin(z), cz = cos(z), sy = sin(y), cy = cos(y); const double wx = rbd[24], wy = rbd[25], wz = rbd[26]; const double tmp = cz * wx / cy + sz * wy / cy; v[3] = sy * tmp + wz; v[4] = -sz * wx + cz * wy; v[5] = tmp; }
+  if (l == 3) { const double z = rbd[0], y = rbd[1]; double sz, cz, sy, cy; qm_sincos(z, sz, cz); qm_sincos(y, sy, cy); const double wx = rbd[24], wy = rbd[25], wz = rbd[26]; const double tmp = cz * wx / cy + sz * wy / cy; v[3] = sy * tmp + wz; v[4] = -sz * wx + cz * wy; v[5] = tmp; }
   if (l >= 6 && l < 24) { q[l] = rbd[l]; v[l] = rbd[24 + l]; }
   if (l >= 32 && l < 56) qd[l - 32] = xDes[6 + (l - 32)];
   {
     double Kd[KW_LEG];                                 // SRBD quantities at the desired state (every lane: cheap, avoids a broadcast); NOT kept across the
-    kin_base(mb, xDes, Kd);                            // rigid-body passes (21 of them are needed again for baseAccDesired: recomputed there, 42 registers less here)
+    kin_base<true>(mb, xDes, Kd);                      // rigid-body passes (21 of them are needed again for baseAccDesired: recomputed there, 42 registers less here)
     if (l == 0) { double wr[3]; v3_cross(Kd + KW_OM, Kd + KW_RW, wr); for (int k = 0; k < 3; ++k) { vd[k] = xDes[k] + wr[k]; vd[3 + k] = Kd[KW_THD + k]; } }
   }
   if (l >= 6 && l < 24) { vd[l] = uDes[6 + l]; const double* il = a.input_last + (size_t)b * 30; w2[l] = (uDes[6 + l] - il[6 + l]) / a.period; }
@@ -679,7 +679,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
     double cF[3], cH[3]; v3_cross(com, Sd + 10, cF); v3_cross(com, Sa + 4, cH);
     for (int i = 0; i < 3; ++i) { rate[i] -= Sd[10 + i] + Sa[4 + i]; rate[3 + i] -= (Sd[13 + i] - cF[i]) + (Sa[7 + i] - cH[i]); }
     const double ra3[3] = {rate[3], rate[4], rate[5]}; double wdd[3], thdd[3], t[3];
-    double Kd[KW_LEG]; kin_base(mb, xDes, Kd);
+    double Kd[KW_LEG]; kin_base<true>(mb, xDes, Kd);
     m3_mulv(Kd + KW_IINV, ra3, wdd); m3_mulv(Kd + KW_EINV, wdd, thdd); v3_cross(Kd + KW_RW, wdd, t);
     for (int i = 0; i < 3; ++i) { baseAcc[i] = rate[i] / m - t[i]; baseAcc[3 + i] = thdd[i]; }
   }
@@ -717,7 +717,7 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
         if (l == 0) {   // base angular
           const double* BmE = S + WL_BM; const double* BmR = BmE + 9; const double* Bmal = BmE + 18;
           double wMeas[3], wDes[3]; const double thm[3] = {v[3], v[4], v[5]}, thdv[3] = {vd[3], vd[4], vd[5]}; m3_mulv(BmE, thm, wMeas); m3_mulv(BmE, thdv, wDes);
-          double Rdes[9]; rot_zyx(qd[3], qd[4], qd[5], Rdes); double err[3]; dev_rot_error(Rdes, BmR, err);
+          double Rdes[9]; rot_zyx<true>(qd[3], qd[4], qd[5], Rdes); double err[3]; dev_rot_error(Rdes, BmR, err);
           double acc[3]; { const double tdd[3] = {baseAcc[3], baseAcc[4], baseAcc[5]}; m3_mulv(BmE, tdd, acc); const double zz[3] = {0.0, 0.0, 1.0}; double t0[3]; v3_cross(zz, wDes, t0);
             const double c1[3] = {BmE[1], BmE[4], BmE[7]}, c2[3] = {BmE[2], BmE[5], BmE[8]}; double t1[3]; v3_cross(c1, c2, t1); for (int i = 0; i < 3; ++i) acc[i] += thdv[0] * t0[i] + thdv[1] * thdv[2] * t1[i]; }
           for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) A[(ra + r) * WNV + 3 + k] = BmE[3 * r + k]; bb[ra + r] = acc[r] + st[ST_KP_BASE_ANG] * err[r] + st[ST_KD_BASE_ANG] * (wDes[r] - wMeas[r]) - Bmal[r]; }

@@ -72,8 +72,8 @@ __device__ __forceinline__ void qm_sincos(double x, double& sn, double& cs) {
   const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
   sn = (q & 2) ? -ss : ss; cs = ((q + 1) & 2) ? -cc : cc;
 }
-// FAST selects qm_sincos (the MPC's thread-per-node kinematics kernels); the default keeps the library's sin / cos: in the register-capped and the
-// one-wave-per-instance kernels the short inline pair lengthens live ranges enough to cost registers (WBC 441 -> 454: one allocation granule too many, k_grid.h)
+// FAST selects qm_sincos (the MPC's kinematics kernels and, since round 4, the rigid-body passes of the WBC / plant kernels: − 9 k of 117 k cycles per instance; while the WBC sat at
+// 437 of the 440 registers that let the next step's grid kernel run beside it the inline pair cost one allocation granule too many — at 390 it has the room); the default is the library's sin / cos
 template <bool FAST = false>
 __device__ __forceinline__ void rot_axis_angle(const double* a, double q, double* R) {
   double s, c; if (FAST) qm_sincos(q, s, c); else { s = sin(q); c = cos(q); } const double oc = 1.0 - c;

@@ -21,7 +21,7 @@ typedef double RbdSums;
 struct RbdTip { double p[3], R[9], v[3], w[3], a[3], al[3]; };   // frame pose, velocity, bias accelerations
 
 __device__ __forceinline__ void rbd_base(const double* q, const double* v, RbdBase& B) {
-  rot_zyx(q[3], q[4], q[5], B.R); euler_E(q[3], q[4], B.E);
+  rot_zyx<true>(q[3], q[4], q[5], B.R); euler_E<true>(q[3], q[4], B.E);      // qm_sincos: the library's sin / cos pair costs ≈ 10 x the instructions on these one-wave chains
   for (int i = 0; i < 3; ++i) { B.p[i] = q[i]; B.vlin[i] = v[i]; }
   const double thd[3] = {v[3], v[4], v[5]};
   m3_mulv(B.E, thd, B.w);
@@ -118,7 +118,7 @@ __device__ __forceinline__ void rbd_chain(const double* mb, int j0, int frame, c
     for (int e = 0; e < RBD_COMP; ++e) cj[e] = 0.0;
     if (!live) { for (int i = 0; i < 3; ++i) { a[jj][i] = 0.0; o[jj][i] = 0.0; } comp.put(jj, cj); continue; }
     double Rj[9], Rq[9], Rc[9]; m3_mul(Rp, mb + MB_JR + 9 * j, Rj); m3_mulv(Rj, mb + MB_AXIS + 3 * j, a[jj]);
-    rot_axis_angle(mb + MB_AXIS + 3 * j, q[6 + j], Rq); m3_mul(Rj, Rq, Rc);
+    rot_axis_angle<true>(mb + MB_AXIS + 3 * j, q[6 + j], Rq); m3_mul(Rj, Rq, Rc);
     double wa[3]; v3_cross(wp, a[jj], wa);
     double wc[3], alc[3]; for (int i = 0; i < 3; ++i) { wc[i] = wp[i] + a[jj][i] * qd; alc[i] = alp[i] + wa[i] * qd; }
     double c[3], Iw[9], vc[3], ac[3]; body_state(mb, j + 1, Rc, o[jj], vo, wc, ao, alc, c, Iw, vc, ac);
