@@ -348,8 +348,8 @@ __device__ __forceinline__ void tq_append(double* S, int n, int me, double rhs, 
     const double r2 = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     const double tn = co[80 + ((l < 19) ? l + 1 : 0)];                       // et_{l+1} (zero from column k on)
     const double r2n = fma(tn, tn, r2);
-    const bool pos = r2 > 0.0;
-    const double ij = qm_rsqrt(pos ? r2 : 1.0), in = qm_rsqrt(r2n > 0.0 ? r2n : 1.0);      // 1 / r_j, 1 / r_{j+1}
+    const bool pos = r2 > 1.0e-280;                                     // (a prefix of exact zeros is the usual case; squared norms in the denormal range count as zero: error < 1e-140)
+    const double ij = qm_rsqrt(pos ? r2 : 1.0), in = qm_rsqrt(r2n > 1.0e-280 ? r2n : 1.0);  // 1 / r_j, 1 / r_{j+1}
     double al = 0.0, sg = 0.0, ka = 1.0;
     if (l < k - 1) { if (pos) { al = tn * ij * in; sg = r2 * ij * in; ka = 0.0; } }
     else if (l == k - 1) { al = ij; ka = 0.0; }
