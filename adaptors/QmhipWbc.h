@@ -15,6 +15,8 @@
 // after the subscription, so the device starts from the same gains as WbcBase's members; rqt_reconfigure keeps working unchanged.  The subscriber callback runs on
 // the node's spinner thread; qmhip_set_setting serialises with qmhip_wbc_step on the context's lock (include/qmhip.h "Threads").
 #pragma once
+#include <atomic>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -38,6 +40,9 @@ class QmhipWbc : public WbcBase {
     if (qmhip_wbc_reset(ctx_) != QMHIP_OK) throw std::runtime_error(std::string("[QmhipWbc] qmhip_wbc_reset: ") + qmhip_last_error(ctx_));
     // the base class has just started its server on <controller>/wbc (WbcBase.cpp:60-65): follow its (latched) update topic
     gainSub_ = controllerNh.subscribe<dynamic_reconfigure::Config>("wbc/parameter_updates", 4, [this](const dynamic_reconfigure::Config::ConstPtr& msg) { applyReconfigure(*msg); });
+    // Until that latched message is delivered the device runs on the gains of the settings blob (the cfg defaults) while WbcBase's members may already hold the parameter
+    // server's overrides (applied in setCallback): wait — bounded — for the first configuration, so that the first control ticks use the server's gains.
+    for (int k = 0; k < 200 && reconfigureCount_.load() == 0 && ros::ok(); ++k) { ros::spinOnce(); ros::Duration(0.005).sleep(); }
   }
 
   // one configuration of the reference's server -> device gains; returns how many gains were written.  Never throws (it runs in a subscriber callback):
@@ -47,7 +52,7 @@ class QmhipWbc : public WbcBase {
     for (const auto& d : config.doubles) {
       const int idx = qmhip_wbc_gain_index(d.name.c_str());
       if (idx < 0) continue;                                           // d_ee_x ... da_ee_x: not read by WbcBase::dynamicCallback either
-      if (qmhip_set_setting(ctx_, idx, d.value) == QMHIP_OK) ++n; else { ++gainErrors_; lastGainError_ = qmhip_last_error(ctx_); }
+      if (qmhip_set_setting(ctx_, idx, d.value) == QMHIP_OK) ++n; else { const std::string why = qmhip_last_error(ctx_); std::lock_guard<std::mutex> lk(errMutex_); lastGainError_ = why; ++gainErrors_; }
     }
     ++reconfigureCount_;
     return n;
@@ -73,13 +78,14 @@ class QmhipWbc : public WbcBase {
     if (qmhip_set_setting(ctx_, settingsIndex, value) != QMHIP_OK) throw std::runtime_error(std::string("[QmhipWbc] qmhip_set_setting: ") + qmhip_last_error(ctx_));
   }
   const int32_t* lastQpStatus() const { return qpStatus_; }
-  int reconfigureCount() const { return reconfigureCount_; }          // configurations received from <controller>/wbc/parameter_updates
-  int gainErrors() const { return gainErrors_; }
-  const std::string& lastGainError() const { return lastGainError_; }
+  // (written by the subscriber callback on the node's spinner thread, read from any thread: atomics, and the text by value under a mutex)
+  int reconfigureCount() const { return reconfigureCount_.load(); }   // configurations received from <controller>/wbc/parameter_updates
+  int gainErrors() const { return gainErrors_.load(); }
+  std::string lastGainError() const { std::lock_guard<std::mutex> lk(errMutex_); return lastGainError_; }
 
  private:
   qmhip_ctx* ctx_; int variant_; int32_t qpStatus_[3] = {0, 0, 0};
-  ros::Subscriber gainSub_; int reconfigureCount_ = 0, gainErrors_ = 0; std::string lastGainError_;
+  ros::Subscriber gainSub_; std::atomic<int> reconfigureCount_{0}, gainErrors_{0}; mutable std::mutex errMutex_; std::string lastGainError_;
 };
 
 }  // namespace qm

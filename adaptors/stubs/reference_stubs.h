@@ -24,6 +24,9 @@ struct NodeHandle {
   // roscpp: subscribe<M>(topic, queue_size, boost::function<void(const boost::shared_ptr<M const>&)>)
   template <class M, class F> Subscriber subscribe(const std::string&, int, F callback) { if (false) callback(typename M::ConstPtr()); return Subscriber(); }      // type-checks the callback against M::ConstPtr
 };
+inline bool ok() { return false; }                 // roscpp: ros::ok(), ros::spinOnce(), ros::Duration(s).sleep()
+inline void spinOnce() {}
+struct Duration { explicit Duration(double) {} bool sleep() const { return true; } };
 }  // namespace ros
 namespace dynamic_reconfigure {                 // dynamic_reconfigure/Config.msg: bools / ints / strs / doubles / groups; the adaptor reads `doubles`
 struct DoubleParameter { std::string name; double value = 0; };

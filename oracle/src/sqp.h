@@ -217,7 +217,10 @@ inline bool riccatiSolve(SqpResult& R, const Vec& x0, const std::vector<Vec>& x,
       Mat Hux = add(n.Pp, matmul(BtS, n.Ap));
       Vec hu = vadd(n.rp, matvecT(n.Bp, spSb));
       for (int i = 0; i < Huu.r; ++i) for (int j = i + 1; j < Huu.c; ++j) { const double a = 0.5 * (Huu(i, j) + Huu(j, i)); Huu(i, j) = Huu(j, i) = a; }
-      Mat L; if (choleskyZeroPivots(Huu, L) > 0) { if (strict) { R.status = -2; return false; } R.warn |= QM_MPC_WARN_PIVOT; }
+      // benign only on a stage of NON-POSITIVE duration with a finite Huu; a non-positive pivot on a stage of positive duration (Huu genuinely indefinite) or an entry that is
+      // not a number (a NaN in the observation) is the hard failure [upstream: SqpSolver throws on HPIPM's NaN status]
+      bool finite = true; for (int i = 0; i < Huu.r; ++i) for (int j = 0; j < Huu.c; ++j) if (!std::isfinite(Huu(i, j))) finite = false;
+      Mat L; if (choleskyZeroPivots(Huu, L) > 0 || !finite) { if (strict || !finite || n.dt > 0.0) { R.status = -2; return false; } R.warn |= QM_MPC_WARN_PIVOT; }
       n.K = scaled(cholSolve(L, Hux), -1.0); n.kff = vscaled(cholSolve(L, hu), -1.0);
       Mat Snew = add(add(n.Qp, matmulTN(n.Ap, SA)), matmulTN(Hux, n.K));
       for (int i = 0; i < QM_NX; ++i) for (int j = i + 1; j < QM_NX; ++j) { const double a = 0.5 * (Snew(i, j) + Snew(j, i)); Snew(i, j) = Snew(j, i) = a; }
@@ -238,6 +241,7 @@ inline bool riccatiSolve(SqpResult& R, const Vec& x0, const std::vector<Vec>& x,
   }
   armijo += vdot(R.terminal.qp, R.dx[N]);
   R.armijo = armijo;
+  if (!std::isfinite(armijo) || !std::isfinite(trajectoryNorm(R.dx)) || !std::isfinite(trajectoryNorm(R.du))) { R.status = -2; return false; }      // a step that is not finite is a failed solve (the device: -4)
   return true;
 }
 

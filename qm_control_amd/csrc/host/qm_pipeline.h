@@ -42,6 +42,20 @@ struct QmMpcBuffers {
   int* ncap_dev = nullptr; int* host_ncap_dev = nullptr; volatile int* host_ncap = nullptr;
 };
 
+// Status of one instance's solve as the C ABI reports it (qmhip_mpc_download), from K0's status word and K3's step_info[4] = {Armijo metric, |dx|², |du|², pivot flags}.
+// Pivot flags (k_riccati.h): bit 0 = non-positive pivots of Huu on a stage of NON-POSITIVE duration (the interval in front of a gait event: zeroed, the solve is valid ->
+// the warning QM_MPC_WARN_PIVOT, or -4 with ST_RICCATI_STRICT); bit 1 = a non-positive pivot on a stage of positive duration (Huu genuinely indefinite) or a pivot that is
+// not a number.  Bit 1, or a step that is not finite (a NaN in the observation reaches all three sums), is the hard failure -4: [upstream] SqpSolver throws on HPIPM's NaN
+// status, the controller stops (QMController.cpp:315-333) — never a policy made of NaNs behind a "valid solution" status.
+inline int qm_mpc_status(int k0_status, const double* step_info4, bool strict) {
+  if (k0_status != 0) return k0_status;
+  const double* s4 = step_info4; const int pv = (s4[3] == s4[3]) ? (int)s4[3] : 2;
+  const bool finite = (s4[0] - s4[0] == 0.0) && (s4[1] - s4[1] == 0.0) && (s4[2] - s4[2] == 0.0);
+  if (!finite || (pv & 2)) return -4;
+  if (pv & 1) return strict ? -4 : QM_MPC_WARN_PIVOT;
+  return 0;
+}
+
 template <class BK>
 struct QmMpcPipeline {
   BK& bk; QmMpcBuffers d;
@@ -50,6 +64,7 @@ struct QmMpcPipeline {
   int lq_prof = 0;        // profiling only
   int solver = 0;         // 0: multiple-shooting SQP (the reference's SqpMpc), 1: discrete iLQR, 2: the SQP path run on the `ipm` block's parameters (not an interior-point method)
                           // (no hard inequality rows in this OCP: include/qmhip_layout.h, ST_IPM_*); settings slot ST_SOLVER
+  bool speculative_apply = true;   // tests only: false = the first trial's apply waits for the host's decision like every later one (A/B of the invariant below)
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
   bool ncap_pending = false;   // K0 has been launched and its count not been read yet
@@ -156,11 +171,15 @@ struct QmMpcPipeline {
       // The first trial is accepted by every instance most of the time: its apply is enqueued BEHIND the decision before the host knows the outcome, so the device does not
       // idle through the host's round trip (flag -> launch: 20-30 us per step in the kernel trace).  The apply only reads the iterate and the step and writes the primal
       // solution — instances still searching get alpha = 0 — so it is simply launched again once the remaining trials are through.
-      if (t == 0) { bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l); }
+      // INVARIANT this rests on: between the speculative apply and the final one NOTHING reads or writes xs / us, and no trial kernel writes what the apply reads of an instance
+      // that is done — qm_ls_eval / qm_perf_sum / the iLQR trial rollouts read x, u, dx, du (xt, ut) and write perf / alpha / done / xt, ut only, and skip instances with
+      // done != 0, so an accepted instance's xt / ut / alpha stay intact through the later trials.  A new trial kernel that touches xs / us, or a rollout that overwrites a done
+      // instance's xt / ut, breaks it (tests/test_emu_kernels.py::test_speculative_apply_is_idempotent runs mixed batches against the non-speculative order, SQP and iLQR).
+      if (t == 0 && speculative_apply) { bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l); }
       bk.wait_flag(d.host_open + t, -1);                   // spin on the host-visible word (a stream synchronisation costs 10-30 us of wake-up latency per step)
       if (d.host_open[t] == 0) break;
     }
-    if (ls_trials_run != 1) bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
+    if (ls_trials_run != 1 || !speculative_apply) bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
     if (!last) bk.launch(qm_ls_commit_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
     solved_B = B;
   }

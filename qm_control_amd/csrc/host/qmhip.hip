@@ -53,7 +53,7 @@ struct HipBackend {
       if (it == lds_set.end() || it->second < (int)lds) { check(hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); lds_set[p] = (int)lds; }
     }
     const void* kp_ = (const void*)kernel;
-    const bool span = profiling == 1 || (profiling == 2 && (kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_riccati_kernel || kp_ == (const void*)qm_wbc_kernel));
+    const bool span = profiling == 1 || (profiling == 2 && (kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_lq_m18_kernel || kp_ == (const void*)qm_riccati_kernel || kp_ == (const void*)qm_wbc_kernel));      // (lq_m18: launched only on workloads with a phase of three or four stance feet; bench.py prices lq + lq_m18 together)
     Span s; if (span) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); check(hipEventRecord(s.a, cur), "hipEventRecord"); }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, cur, args);
     check(hipGetLastError(), "kernel launch");
@@ -336,7 +336,8 @@ int qmhip_mpc_download(qmhip_ctx* c, int B, int32_t* nn, double* ot, int32_t* oe
   hipSetDevice(c->device); const int nm = c->max_nodes; const QmMpcBuffers& d = c->mpc.d;
   std::vector<int> n_h(B), st_h(B); c->bk.to_host(n_h.data(), d.n_nodes, (size_t)B * 4); c->bk.to_host(st_h.data(), d.status, (size_t)B * 4);
   std::vector<double> si((size_t)B * 4); c->bk.to_host(si.data(), d.step_info, si.size() * 8);
-  for (int b = 0; b < B; ++b) { if (st_h[b] == 0 && si[(size_t)b * 4 + 3] != 0.0) st_h[b] = (c->st[ST_RICCATI_STRICT] != 0.0) ? -4 : QM_MPC_WARN_PIVOT; /* zeroed pivots: a warning on a valid solution unless strict */ if (nn) nn[b] = n_h[b]; if (status) status[b] = st_h[b]; }
+  for (int b = 0; b < B; ++b) { st_h[b] = qm_mpc_status(st_h[b], si.data() + (size_t)b * 4, c->st[ST_RICCATI_STRICT] != 0.0);      /* zeroed pivots of the degenerate stage: a warning; NaN / indefinite: -4 (qm_pipeline.h) */
+    if (nn) nn[b] = n_h[b]; if (status) status[b] = st_h[b]; }
   // node-major [nmax][B][k] -> instance-major [B][nmax][k]: transposed by a kernel into a device staging buffer, copied through pinned memory (one contiguous
   // transfer per array; the per-node host loops this replaces took 20 ms of a 24 ms hand-over at B = 1024, bench.py `pcie_inclusive`)
   const size_t words = (size_t)nm * B * 30;

@@ -93,7 +93,7 @@ __global__ void qm_grid_kernel(QmGridArgs a) {
   a.n_nodes[b] = n;
   a.status[b] = status;
   // does the horizon hold a phase with three or four feet on the ground (17 / 18 reduced inputs: K1b's second instance, k_lq.h)?  Conservative: every phase between t0 and tf
-  { const int k0 = grid_find_index(ev, a.nev, t0), k1 = grid_find_index(ev, a.nev, tf);
+  { const int k0 = grid_find_index(ev, a.nev, t0), k1e = grid_find_index(ev, a.nev, tf + QM_WEAK_EPS), k1 = (k1e < a.nev) ? k1e : a.nev;      // (a PostEvent node looks its mode up at t + weakEpsilon: an event within weakEpsilon behind tf still counts)
     for (int q = k0; q <= k1; ++q) { const int mq = modes[q]; if ((int)mode_flag(mq, 0) + (int)mode_flag(mq, 1) + (int)mode_flag(mq, 2) + (int)mode_flag(mq, 3) >= 3) has18 = 1; } }      // m = 14 + (feet on the ground) > 16
   }
   if (a.ncap_dev) {     // largest node count of the batch -> host (64-thread blocks = one wavefront each; the block that arrives last publishes and re-arms the counters)

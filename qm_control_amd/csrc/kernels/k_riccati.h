@@ -34,7 +34,7 @@ struct QmRiccatiArgs {
   const double* x;                             // [nmax][B][30] (current iterate; event defects, dx0)
   double* stage;                               // [B][nmax][SR_SIZE]  (L, W, y are written here)
   double* dx; double* du;                      // [nmax][B][30]
-  double* step_info;                           // [B][4]: armijo, |dx|², |du|², 1 if some stage's Huu had a non-positive pivot (zeroed, see rw_stage)
+  double* step_info;                           // [B][4]: armijo, |dx|², |du|², pivot flags (as a double): bit 0 = a stage of NON-POSITIVE duration had non-positive pivots of Huu (zeroed, see rw_stage: the warning QM_MPC_WARN_PIVOT), bit 1 = a stage of positive duration had one, or a pivot was not a number (hard failure -4)
   // baseline performance of the current iterate (sum of K1b's node terms) + arming of the line search, done by the instance's wave before the sweep
   // (what a separate one-wave-per-instance launch did: qm_perf_sum_kernel with with_alpha == 0); perf == nullptr: skipped
   const double* perf; double* base_sum; double* alpha; int* done; double* out_perf; int* open_cnt; int* tickets;
@@ -203,12 +203,13 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
   const bool prof = PROF && (skip & 32) != 0; long long tq_ = prof ? (long long)__builtin_readcyclecounter() : 0;
 #define RWT(i) { if (PROF && prof) { const long long t_ = (long long)__builtin_readcyclecounter(); tacc[i] += t_ - tq_; tq_ = t_; } }
   qm_d4 A[2][2], Bm[2][MT], Hux[MT][2], Huu[MT][MT], Sn[2][2];
+  int failbit;                                                    // what a non-positive pivot of this stage means: 1 benign (duration <= 0), 2 hard failure
   {
     // this stage's operands were copied into LDS (asynchronously, global_load_lds) while the previous stage computed
     const double* P = buf + RP_REC; const double* PV = P + RPO_VEC;
     if (md != pc.mode) rw_pu_codes(pc, md);                       // wave-uniform (the mode comes from the node list): a few times per sweep, ahead of the wait
     qm_dma_wait();
-    const double dt = P[RPO_SWG + 25];
+    const double dt = P[RPO_SWG + 25]; failbit = (dt <= 0.0) ? 1 : 2;
     rw_load_A(A, P + RPO_A, P + RPO_PX, PV, dt);                    // [Ap | bp]
     rw_load_B<MT>(Bm, P + RPO_B, P + RPO_SWG, pc, dt, m);
     // [Pp | rp], Rp, [Qp | qp]: K1b left them in fragment order (SR_FRAG) — one LDS load per register, no masks, no per-element addresses
@@ -309,7 +310,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
       const double t23 = fma(-l31, t12, fma(-l30, D02, D23));                        // D23 − l30 l20 d0 − l31 l21 d1
       const double l32 = t23 * rd2;
       const double d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, D03, D33))), rd3 = (d3 > 0.0) ? recip(d3) : 0.0;
-      if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) chol_fail = 1;
+      if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) chol_fail |= failbit;      // bit 0: on a stage of non-positive duration (benign, see above); bit 1: anywhere else or not a number -> hard failure
       // L~⁻¹ of the block (unit lower): its strictly lower entries
       const double M10 = -l10, M21 = -l21, M32 = -l32, M20 = fma(l21, l10, -l20), M31 = fma(l32, l21, -l31), M30 = -(l30 + l31 * M10 + l32 * M20);
       const int ri = c - c0;                                                           // A[i = c][k = g]: row i of the tile against block row k

@@ -118,6 +118,9 @@ int emu_hoqp(int B, int n_levels, int n, const int* ma, const int* md, const dou
   static EmuBackend bk; static QmHoqpPipeline<EmuBackend> h(bk);      // ONE pipeline for the process, like the context's: successive shapes go through its capacity bookkeeping
   h.solve(B, n_levels, n, ma, md, A, b, D, f, x, status); return 0;
 }
+void emu_set_speculative_apply(void* h, int on) { ((EmuCtx*)h)->mpc.speculative_apply = on != 0; }
+// the C ABI's status of an instance from K0's word and K3's step_info (the mapping qmhip_mpc_download applies)
+int emu_mpc_status(int k0_status, const double* step_info4, int strict) { return qm_mpc_status(k0_status, step_info4, strict != 0); }
 void emu_sincos(int n, const double* x, double* sn, double* cs) { for (int i = 0; i < n; ++i) qm_sincos(x[i], sn[i], cs[i]); }
 void emu_frcp(int n, const double* x, double* r) { for (int i = 0; i < n; ++i) r[i] = qm_frcp(x[i]); }
 void emu_log(int n, const double* x, double* r) { for (int i = 0; i < n; ++i) r[i] = qm_log(x[i]); }

@@ -1,5 +1,6 @@
 """The product's device kernels, executed by the host emulator (tests/emu), against the oracle — CPU-only parity.
 Same tolerances as the GPU tests: 1e-6 relative on trajectories / torques, integers bit-exact."""
+import ctypes as C
 import numpy as np
 from qm_control_amd import layout as L
 import pytest
@@ -56,6 +57,31 @@ def test_line_search_backtracks_like_the_oracle(blobs, oblobs, oracle):
     perf = e.buf("out_perf", (10,))
     assert trials == r["ls_trials"] and perf[8] == r["alpha"]
     assert rel_err(e.node_arr("xs", 30)[:n, 0], r["x"]) < TOL
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_speculative_apply_is_idempotent(blobs, solver):
+    """The first trial's apply is enqueued behind its decision before the host knows the outcome and launched again when the search goes on (qm_pipeline.h: the invariant is
+    written there).  A MIXED batch — some instances accept the first trial, others backtrack — must give bit-identical primal solutions with and without the speculative
+    launch, for the SQP and for the discrete iLQR (whose accepted rollouts xt / ut must survive the later trials of the instances still searching)."""
+    import emu_harness
+    from qm_control_amd import scenarios
+    B = 4
+    st = blobs[1].copy()
+    cfg = scenarios.make_config("C5" if solver == 0 else "C3", batch=B, n_intervals=10); cfg["B"] = B
+    # instance 1 starts at rest on the nominal state (accepts the full step), the others are perturbed; the SQP's first instance has its arm far outside the joint limits
+    cfg["x0"][1] = st[L.ST_XINIT:L.ST_XINIT + 30]; cfg["x0"][0, 24:30] += 3.3 if solver == 0 else 0.3; cfg["x0"][2, 12:24] += 0.02; cfg["x0"][3, 9:12] += 0.01
+    outs = []
+    for spec in (1, 0):
+        e = emu_harness.Emu(blobs[0], st, B, 40, cfg["ref_t"].shape[1], cfg["ev"].shape[1]); e.set_solver(solver); e.lib.emu_set_speculative_apply(e.h, C.c_int(spec))
+        trials = e.mpc_step(cfg); n = e.buf("n_nodes", (B,), np.int32).copy()
+        outs.append(dict(trials=trials, alpha=e.buf("out_perf", (B, 10))[:, 8].copy(), done=e.buf("done", (B,), np.int32).copy(), xs=e.node_arr("xs", 30).copy(), us=e.node_arr("us", 30).copy(), n=n))
+    a, b = outs
+    assert a["trials"] == b["trials"] and a["trials"] > 1, (a["trials"], b["trials"])
+    assert (a["alpha"] == 1.0).any() and (a["alpha"] < 1.0).any(), a["alpha"]                   # the batch IS mixed
+    assert np.array_equal(a["alpha"], b["alpha"]) and np.array_equal(a["done"], b["done"])
+    for k in range(B):
+        assert np.array_equal(a["xs"][:a["n"][k], k], b["xs"][:a["n"][k], k]) and np.array_equal(a["us"][:a["n"][k], k], b["us"][:a["n"][k], k]), k
 
 
 @pytest.mark.parametrize("ncase,seed,amp", [(6, 21, 0.05), (10, 303, 0.5)])      # small and large tracking errors (the large ones saturate torque limits and friction cones: long active-set paths with drops)

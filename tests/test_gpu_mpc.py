@@ -227,6 +227,27 @@ def test_ipm_solver_slot(blobs, oracle):
     itf.close()
 
 
+def test_nan_observation_is_a_failed_solve_on_the_device(blobs):
+    """-m gpu twin of tests/test_grid_fuzz.py::test_nan_observation_and_indefinite_stage_are_failures_not_warnings through the C ABI: a NaN in one instance's observation
+    gives THAT instance status -4 (a failure: the adaptor throws, as [upstream] SqpSolver does on HPIPM's NaN status) and leaves its neighbour's solve untouched; a
+    negated input weight (Huu indefinite on stages of positive duration) fails every instance."""
+    from qm_control_amd import api, scenarios
+    B = 2
+    cfg = scenarios.make_config("C3", batch=B, n_intervals=20)
+    kw = dict(max_batch=B, max_nodes=48, max_ref_knots=cfg["ref_t"].shape[1], max_events=cfg["ev"].shape[1])
+    itf = api.QMInterface(blobs=blobs, **kw); mpc = api.SqpMpc(itf)
+    clean = mpc.run(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"]); assert (clean["status"] == 0).all()
+    x0 = cfg["x0"].copy(); x0[0, 7] = np.nan
+    bad = mpc.run(cfg["t0"], x0, cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"])
+    assert bad["status"][0] == -4 and bad["status"][1] == 0, bad["status"]
+    n = clean["num_nodes"][1]; assert np.array_equal(bad["x"][1, :n], clean["x"][1, :n]) and np.array_equal(bad["u"][1, :n], clean["u"][1, :n])
+    itf.close()
+    st = blobs[1].copy(); st[L.ST_R:L.ST_R + 900] *= -1.0
+    itf = api.QMInterface(blobs=(blobs[0], st), **kw)
+    r = api.SqpMpc(itf).run(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"]); itf.close()
+    assert (r["status"] == -4).all(), r["status"]
+
+
 def test_degenerate_interval_survives_on_the_device(blobs, oblobs):
     """-m gpu twin of tests/test_grid_fuzz.py::test_degenerate_interval_survives, FULL matrix: every gait event inside C2's horizon x offsets {-9e-7 ... -1e-12} of a
     shooting node in front of it.  Through the C ABI on [upstream]'s grid: status == QM_MPC_WARN_PIVOT (a warning, >= 0), integers and node times identical to the oracle's,

@@ -140,6 +140,34 @@ def test_strict_pivot_setting_reports_the_failure(oblobs):
         o.mpc_step(cfg["t0"][1], cfg["t0"][1] + cfg["horizon"], cfg["x0"][1])
 
 
+def test_nan_observation_and_indefinite_stage_are_failures_not_warnings(blobs, oblobs):
+    """Only the BENIGN case is a warning (finite non-positive pivots on a stage of non-positive duration).  A NaN in the observation, or a stage of positive duration whose
+    Huu is not positive definite (here: a negated input weight R), must come back as a FAILED solve from the oracle (exception) and from the product (the status mapping of
+    qmhip_mpc_download on the emulated pipeline's K0 status + step_info: -4), never as QM_MPC_WARN_PIVOT with a policy made of NaNs ([upstream] SqpSolver
+    throws on HPIPM's NaN status)."""
+    import ctypes as C
+    import pyoracle
+    from qm_control_amd import scenarios, layout as L
+    B = 2
+    cfg = scenarios.make_config("C3", batch=B, n_intervals=20); cfg["B"] = B
+    status_of = lambda e, b: int(e.lib.emu_mpc_status(C.c_int(int(e.buf("status", (B,), np.int32)[b])), e.buf("step_info", (B, 4))[b].ctypes.data_as(C.POINTER(C.c_double)), C.c_int(0)))
+    # (i) clean solve: status 0
+    e = emu_harness.Emu(blobs[0], blobs[1], B, 48, cfg["ref_t"].shape[1], cfg["ev"].shape[1]); e.mpc_step(cfg)
+    assert [status_of(e, b) for b in range(B)] == [0, 0]
+    # (ii) NaN in instance 0's observation: instance 0 fails, instance 1 is untouched
+    bad = dict(cfg); bad["x0"] = cfg["x0"].copy(); bad["x0"][0, 7] = np.nan
+    e.mpc_step(bad)
+    assert status_of(e, 0) == -4 and status_of(e, 1) == 0, [status_of(e, b) for b in range(B)]
+    o = pyoracle.Oracle(*oblobs); o.set_schedule(cfg["ev"][0], cfg["modes"][0]); o.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
+    with pytest.raises(RuntimeError): o.mpc_step(cfg["t0"][0], cfg["t0"][0] + cfg["horizon"], bad["x0"][0])
+    # (iii) Huu indefinite on stages of POSITIVE duration (negated input weight): hard failure on both sides, although every pivot is finite
+    st = blobs[1].copy(); st[L.ST_R:L.ST_R + 900] *= -1.0; ost = oblobs[1].copy(); ost[L.ST_R:L.ST_R + 900] *= -1.0
+    e2 = emu_harness.Emu(blobs[0], st, B, 48, cfg["ref_t"].shape[1], cfg["ev"].shape[1]); e2.mpc_step(cfg, max_trials=1)
+    assert [status_of(e2, b) for b in range(B)] == [-4, -4] and (e2.buf("step_info", (B, 4))[:, 3].astype(int) & 2).all()
+    o2 = pyoracle.Oracle(oblobs[0], ost); o2.set_schedule(cfg["ev"][0], cfg["modes"][0]); o2.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
+    with pytest.raises(RuntimeError): o2.mpc_step(cfg["t0"][0], cfg["t0"][0] + cfg["horizon"], cfg["x0"][0])
+
+
 @pytest.mark.parametrize("robust", [False, True])
 def test_grid_minimum_step_setting(blobs, oblobs, robust):
     """ST_GRID_DT_MIN: [upstream]'s dt_min (10 limitEpsilon, the ingestion's default) keeps a node that falls 5e-7 s before a gait event; the opt-in robust
