@@ -64,6 +64,7 @@ struct QmMpcPipeline {
   int lq_prof = 0;        // profiling only
   int solver = 0;         // 0: multiple-shooting SQP (the reference's SqpMpc), 1: discrete iLQR, 2: the SQP path run on the `ipm` block's parameters (not an interior-point method)
                           // (no hard inequality rows in this OCP: include/qmhip_layout.h, ST_IPM_*); settings slot ST_SOLVER
+  bool r_blocks = false;           // the input weight R of the settings blob is block diagonal (k_ls.h): the structured instance of the trial-evaluation kernel runs; kept current by note_settings()
   bool speculative_apply = true;   // tests only: false = the first trial's apply waits for the host's decision like every later one (A/B of the invariant below)
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
@@ -79,13 +80,13 @@ struct QmMpcPipeline {
     d.Bmax = Bmax; d.nmax = nmax; d.nref = nref; d.nev = nev;
     const size_t NB = (size_t)nmax * Bmax;
     d.mb = A<double>(MB_SIZE); d.st = A<double>(ST_SIZE);
-    bk.to_device(d.mb, mb_host, MB_SIZE * 8); bk.to_device(d.st, st_host, ST_SIZE * 8);
+    bk.to_device(d.mb, mb_host, MB_SIZE * 8); bk.to_device(d.st, st_host, ST_SIZE * 8); note_settings(st_host);
     d.t0 = A<double>(Bmax); d.x0 = A<double>((size_t)Bmax * 30); d.ref_t = A<double>((size_t)Bmax * nref); d.ref_x = A<double>((size_t)Bmax * nref * QM_NREF);
     d.ev = A<double>((size_t)Bmax * nev); d.modes = A<int>((size_t)Bmax * (nev + 1));
     d.n_nodes = A<int>(Bmax); d.node_t = A<double>(NB); d.node_ts = A<double>(NB); d.node_dt = A<double>(NB); d.node_ev = A<int>(NB); d.node_mode = A<int>(NB);
     d.zvel = A<double>(NB * 4); d.zpos = A<double>(NB * 4); d.xref = A<double>(NB * 30); d.eeref = A<double>(NB * 7); d.status = A<int>(Bmax);
     d.x = A<double>(NB * 30); d.u = A<double>(NB * 30); d.dx = A<double>(NB * 30); d.du = A<double>(NB * 30);
-    d.stage = A<double>(NB * SR_SIZE); d.lqdbg = debug_lq ? A<double>(NB * LQ_DBG_SIZE) : nullptr; d.kin = A<double>(NB * KR_SIZE);
+    d.stage = A<double>(NB * SR_SIZE); d.lqdbg = debug_lq ? A<double>(NB * LQ_DBG_SIZE) : nullptr; d.kin = A<double>((NB + 64) * KR_SIZE);      // (+ 64 records: K1a's waves store whole 64-record blocks, k_lq.h)
     d.perf = A<double>(NB * PF_SIZE); d.base_sum = A<double>((size_t)Bmax * 4); d.perf_sum = A<double>((size_t)Bmax * 4); d.step_info = A<double>((size_t)Bmax * 4);
     d.alpha = A<double>(Bmax); d.done = A<int>(Bmax); d.xs = A<double>(NB * 30); d.us = A<double>(NB * 30); d.out_perf = A<double>((size_t)Bmax * 10);
     d.prev_n = A<int>(Bmax); d.prev_t = A<double>(NB); d.prev_ev = A<int>(NB);
@@ -93,6 +94,7 @@ struct QmMpcPipeline {
     d.ncap_dev = A<int>(3); { void* hv = nullptr; d.host_ncap_dev = (int*)bk.alloc_mapped(sizeof(int), &hv); d.host_ncap = (volatile int*)hv; d.host_ncap[0] = 0; }
     { void* hv = nullptr; d.host_open_dev = (int*)bk.alloc_mapped(QM_LS_MAX_TRIALS * sizeof(int), &hv); d.host_open = (volatile int*)hv; for (int i = 0; i < QM_LS_MAX_TRIALS; ++i) d.host_open[i] = 0; }
   }
+  void note_settings(const double* st_host) { r_blocks = qm_r_is_block_diagonal(st_host); }      // after every change of the settings blob (create, qmhip_set_setting)
   void release() {
     void* ps[] = {d.mb, d.st, d.t0, d.x0, d.ref_t, d.ref_x, d.ev, d.modes, d.n_nodes, d.node_t, d.node_ts, d.node_dt, d.node_ev, d.node_mode, d.zvel, d.zpos, d.xref, d.eeref, d.status,
                   d.x, d.u, d.dx, d.du, d.xt, d.ut, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev, d.open_cnt, d.tickets, d.ncap_dev};
@@ -164,7 +166,8 @@ struct QmMpcPipeline {
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;
       if (ilqr) { ro.mode = 1; ro.trial = t; bk.launch(qm_ilqr_rollout_kernel, B, 64, 0, ro); }      // nonlinear rollout with feedback at the instance's step length
-      bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
+      if (r_blocks) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
+      else bk.launch(qm_ls_eval_dense_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       d.host_open[t] = -1;                                 // armed: the launch's last block overwrites it with the count of the instances still searching
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching
       ++ls_trials_run;

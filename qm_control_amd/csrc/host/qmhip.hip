@@ -42,7 +42,7 @@ struct HipBackend {
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
     if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel || p == (const void*)qm_lq_dbg_kernel) return "lq"; if (p == (const void*)qm_lq_m18_kernel) return "lq_m18"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel || p == (const void*)qm_riccati_prof_kernel) return "riccati";
-    if (p == (const void*)qm_ls_eval_kernel) return "ls_eval"; if (p == (const void*)qm_ilqr_rollout_kernel) return "rollout"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy"; if (p == (const void*)qm_hoqp_kernel) return "hoqp";
+    if (p == (const void*)qm_ls_eval_kernel || p == (const void*)qm_ls_eval_dense_kernel) return "ls_eval"; if (p == (const void*)qm_ilqr_rollout_kernel) return "rollout"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy"; if (p == (const void*)qm_hoqp_kernel) return "hoqp";
     return "ls_misc";
   }
   template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {
@@ -233,7 +233,7 @@ int qmhip_set_setting(qmhip_ctx* c, int idx, double v) { QM_GUARD(c);
   if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number, the grid's minimum step a non-negative one, ST_RICCATI_STRICT 0 or 1"); return QMHIP_ERR_ARG; }
   if (idx == ST_SOLVER && v == 2.0 && !setting_ok(ST_IPM_DT, c->st[ST_IPM_DT])) { c->fail("qmhip_set_setting: solver 2 needs a positive finite ipm.dt"); return QMHIP_ERR_ARG; }
   if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR) or 2 (the SQP step on the `ipm` block's parameters)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
-  hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); return c->hipstate();
+  hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); c->mpc.note_settings(c->st); return c->hipstate();
 }
 
 int qmhip_mpc_upload(qmhip_ctx* c, int B, const double* t0, const double* x0, int n_ref, const double* ref_t, const double* ref_x, int n_ev, const double* ev, const int32_t* modes) { QM_GUARD(c); QM_NEED_MPC(c);

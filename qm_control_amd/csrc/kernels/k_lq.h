@@ -64,15 +64,18 @@ struct QmLqArgs {
 #define LQ_DBG_nc 4667
 #define LQ_DBG_SIZE 4668
 
-// kin record (doubles) per node
+// kin record (doubles) per node, in the order K1a produces it (its stores stream through the record front to back).  Round 5: the second stage's state x2 is no longer
+// stored (nobody read it), the flow values keep their twelve non-trivial rows only (rows 12..29 are the input's joint velocities, which K1b holds anyway) and the
+// second stage's workspace stops in front of the arm block (the arm's pose is a stage-1 quantity): 504 -> 384 doubles = 48 cache lines per node
 #define KR_K1   0
-#define KR_K2   KW_SIZE
-#define KR_F1   (2 * KW_SIZE)
-#define KR_F2   (KR_F1 + 30)
-#define KR_X2   (KR_F2 + 30)
-#define KR_EEG  (KR_X2 + 30)          /* g(6) */
+#define KR_EEG  KW_SIZE               /* g(6)  */
 #define KR_QEE  (KR_EEG + 6)          /* qee(4) */
-#define KR_SIZE (KR_QEE + 4 + 2)
+#define KR_F1   (KR_QEE + 4)          /* rows 0..11 of f(x, u) */
+#define KR_K2   (KR_F1 + 12)          /* base + leg blocks of the second Heun stage (KW_ARM doubles) */
+#define KR_F2   (KR_K2 + KW_ARM)      /* rows 0..11 of f(x + dt f1, u) */
+#define KR_USED (KR_F2 + 12)
+#define KR_SIZE 384
+static_assert(KR_USED <= KR_SIZE && KR_SIZE % 8 == 0, "kin record: whole 64-byte lines");
 
 // LDS carve (doubles) of one wave
 #define LW_BLOCK 64
@@ -100,7 +103,8 @@ struct QmLqArgs {
 #define LW_LDS_DOUBLES (LW_PD + 128)
 #define LQ_LDS_BYTES (LW_LDS_DOUBLES * 8)
 static_assert(LQ_LDS_BYTES <= 16384, "ten waves per CU (160 KB of LDS) need at most 16 KB each");
-#define LQ_KIN_LDS_BYTES (64 * 31 * 8)      /* K1a: one 31-double row per thread (the input u): 15.5 KB per wave, eight waves per CU */
+#define LQ_KIN_TILE (64 * 31)               /* K1a: [64][31] rows — the wave's inputs x (transposed on the way in), then the input u of each thread for the whole kernel ... */
+#define LQ_KIN_LDS_BYTES ((LQ_KIN_TILE + 64 * 9) * 8)      /* ... + the [64][9] hand-over tile of the record stores: 20 KB per wave, seven waves per CU (the benchmark launch has 6.45 per CU) */
 
 // value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column
 __device__ __forceinline__ void lw_set_col30(qm_d4 (&F)[2][2], const double* v) {
@@ -259,47 +263,75 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu
 }
 
 // ---- K1a: scalar kinematics, one thread per (node, instance) ----
-__global__ void __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = g / a.B, b = g - i * a.B;
-  if (i >= a.nmax) return;
-  const int nn = a.n_nodes[b];
-  if (i >= nn) return;
-  const int nb = i * a.B + b; const bool terminal = (i == nn - 1);
-  if (!terminal && a.node_ev[nb] == QM_EV_PRE) return;
-  double* rec = a.kin + (size_t)nb * KR_SIZE; const double* mb = qm_table(a.mb);
-  // x and the kinematics workspace K live in registers; the input u — read-only here — sits in a per-thread LDS row (31-double pitch: conflict free):
-  // x + u + K + two flow values do not fit 512 registers, and what does not fit would otherwise be spilled to scratch memory
-  extern __shared__ double qm_smem[];                  // LQ_KIN_LDS_BYTES
-  double x[30], K[KW_SIZE]; double* u = qm_smem + (threadIdx.x & 63) * 31;
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q];
-  const double* ee = a.eeref + nb * 7;
-  if (terminal) {
-    kin_base<true>(mb, x, K); kin_arm<true>(mb, x, K);
-    _Pragma("unroll") for (int q = 0; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
-    double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq);
-    _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q];
-    return;
+// Thread g = i B + b owns node i of instance b; the 64 threads of a wave own 64 CONSECUTIVE rows of the node-major arrays [nmax][B][.]: one contiguous block of the
+// iterate (64 x 30 doubles) and one contiguous block of kin records (64 x KR_SIZE doubles).  Rounds 1-4 let every thread load its own row and store its own record
+// with 16-byte accesses — each such instruction touches 64 different cache lines (lane stride 240 B / 4 KB): 272 stores x 64 = 17 k partial-line transactions per
+// wave through the CU's one address / tag pipeline, 8 waves per CU, ≈ 140 k cycles of a 310 k-cycle kernel whose arithmetic needs ≈ 30 k per wave.  Round 5: the
+// wave moves its blocks TOGETHER — lanes run over consecutive doubles of the block (full 64-byte lines), thread-private values change hands through LDS:
+//   kin_rows_in    block of 64 x 30 inputs -> a [64][31] LDS tile (row r = thread r's vector)
+//   kin_emit<N>    N values per thread (record doubles [off, off + N)) -> [64][9] tile -> lanes 8 r' + j store double j of an 8-double piece of record 8 k + r'
+// There is no divergence left: every thread of the launch runs the full sequence on whatever its rows hold — PreEvent nodes, nodes behind an instance's last one and
+// the terminal node's leg / second-stage parts produce records (or parts) nobody reads (K1b takes the terminal node's base, arm and end-effector error only); the
+// kin buffer carries 64 records of slack behind the last row so the last wave of a launch needs no bounds either.
+struct KinOut { double* tile; double* wave_rec; int l; };
+__device__ __forceinline__ void kin_rows_in(double* tile, const double* src, size_t row0, size_t nrows, int l) {
+  // 960 pairs of doubles (30 is even: a pair never straddles two rows), 16 bytes per lane: 1 KB = 16 full lines per instruction; three rounds of five (a rolled outer loop keeps
+  // the fifteen row / column / address sets of the two calls from living across the kernel)
+#pragma nounroll
+  for (int t0 = 0; t0 < 15; t0 += 5) {
+    double2 v[5]; int off[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int e = (t0 + k) * 64 + l; const int r = e / 15, c = 2 * (e - r * 15); size_t row = row0 + r; if (row >= nrows) row = nrows - 1; off[k] = r * 31 + c; v[k] = *(const double2*)(src + row * 30 + c); }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { tile[off[k]] = v[k].x; tile[off[k] + 1] = v[k].y; }
   }
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q];
-  const double dt = a.node_dt[nb];
+}
+template <int N> __device__ __forceinline__ void kin_emit(const KinOut& o, int off, const double* v) {
+#pragma unroll
+  for (int p = 0; p < (N + 7) / 8; ++p) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (8 * p + j < N) o.tile[o.l * 9 + j] = v[8 * p + j];
+    qm_wave_sync();
+    const int j = o.l & 7, rr = o.l >> 3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int r = 8 * k + rr; if (8 * p + j < N) o.wave_rec[(size_t)r * KR_SIZE + off + 8 * p + j] = o.tile[r * 9 + j]; }
+    qm_wave_sync();
+  }
+}
+__global__ void __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
+  const int l = threadIdx.x & 63;
+  const size_t g0 = (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
+  size_t g = g0 + l; if (g >= nrows) g = nrows - 1;                             // (rows behind the arrays' end: the last wave of a launch that covers all nmax nodes)
+  const double* mb = qm_table(a.mb);
+  extern __shared__ double qm_smem[];                  // LQ_KIN_LDS_BYTES
+  double* rows = qm_smem; KinOut o; o.tile = qm_smem + LQ_KIN_TILE; o.wave_rec = a.kin + g0 * KR_SIZE; o.l = l;
+  // x and the kinematics workspace K live in registers; the input u — read-only here — stays in its LDS row (31-double pitch: conflict free):
+  // x + u + K + two flow values do not fit 512 registers, and what does not fit would otherwise be spilled to scratch memory
+  double x[30], K[KW_SIZE]; double* u = rows + l * 31;
+  kin_rows_in(rows, a.x, g0, nrows, l); qm_wave_sync();
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = u[q];
+  qm_wave_sync();
+  kin_rows_in(rows, a.u, g0, nrows, l); qm_wave_sync();
+  const double* ee = a.eeref + g * 7; const double dt = a.node_dt[g];
   // Every block of the workspace goes to the record as soon as it is complete and only what the flow map needs (the feet, the base block) stays live: the
-  // kernel then fits 256 registers and one 31-double LDS row per thread, i.e. TWO waves per SIMD — all 1664 wavefronts of the benchmark launch are resident at
-  // once and a wave's dependent chains (≈ 20 cycles per instruction on a lone wave) overlap with its neighbour's
+  // kernel then fits 256 registers, i.e. TWO waves per SIMD — every wavefront of the benchmark launch is resident at once and a wave's dependent chains overlap
+  // with its neighbour's
   kin_base<true>(mb, x, K);
-  _Pragma("unroll") for (int q = 0; q < KW_LEG; ++q) rec[KR_K1 + q] = K[q];
-  _Pragma("unroll") for (int c = 0; c < 4; ++c) { kin_leg<true>(mb, c, x, u, K); _Pragma("unroll") for (int q = 0; q < KW_LEGSZ; ++q) rec[KR_K1 + KW_LEG + KW_LEGSZ * c + q] = K[KW_LEG + KW_LEGSZ * c + q]; __builtin_amdgcn_sched_barrier(0); }
+  kin_emit<KW_LEG>(o, KR_K1, K);
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) { kin_leg<true>(mb, c, x, u, K); kin_emit<KW_LEGSZ>(o, KR_K1 + KW_LEG + KW_LEGSZ * c, K + KW_LEG + KW_LEGSZ * c); __builtin_amdgcn_sched_barrier(0); }
   kin_arm<true>(mb, x, K);
-  _Pragma("unroll") for (int q = KW_ARM; q < KW_SIZE; ++q) rec[KR_K1 + q] = K[q];
-  { double gq[6], qee[4]; ee_error(K, ee, ee + 3, qee, gq); _Pragma("unroll") for (int q = 0; q < 6; ++q) rec[KR_EEG + q] = gq[q]; _Pragma("unroll") for (int q = 0; q < 4; ++q) rec[KR_QEE + q] = qee[q]; }
-  double x2[30], f[12];                                 // the joint part of the flow value is the input's joint velocities (u, in LDS)
-  flow_head_from_kin(mb, x, u, K, f);
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double fq = (q < 12) ? f[q < 12 ? q : 0] : u[q]; x2[q] = x[q] + dt * fq; rec[KR_F1 + q] = fq; rec[KR_X2 + q] = x2[q]; }
+  kin_emit<KW_SIZE - KW_ARM>(o, KR_K1 + KW_ARM, K + KW_ARM);
+  double f[12 + 10];                                    // [0, 10): end-effector error g(6), qee(4); then the twelve non-trivial rows of the flow value (record order)
+  ee_error(K, ee, ee + 3, f + 6, f);
+  flow_head_from_kin(mb, x, u, K, f + 10);
+  kin_emit<22>(o, KR_EEG, f);
+  double x2[30];                                        // the joint part of the flow value is the input's joint velocities (u, in LDS)
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) x2[q] = x[q] + dt * ((q < 12) ? f[10 + (q < 12 ? q : 0)] : u[q]);
   kin_base<true>(mb, x2, K);
-  _Pragma("unroll") for (int q = 0; q < KW_LEG; ++q) rec[KR_K2 + q] = K[q];
-  _Pragma("unroll") for (int c = 0; c < 4; ++c) { kin_leg<true>(mb, c, x2, u, K); _Pragma("unroll") for (int q = 0; q < KW_LEGSZ; ++q) rec[KR_K2 + KW_LEG + KW_LEGSZ * c + q] = K[KW_LEG + KW_LEGSZ * c + q]; __builtin_amdgcn_sched_barrier(0); }
+  kin_emit<KW_LEG>(o, KR_K2, K);
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) { kin_leg<true>(mb, c, x2, u, K); kin_emit<KW_LEGSZ>(o, KR_K2 + KW_LEG + KW_LEGSZ * c, K + KW_LEG + KW_LEGSZ * c); __builtin_amdgcn_sched_barrier(0); }
   flow_head_from_kin(mb, x2, u, K, f);
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) rec[KR_F2 + q] = (q < 12) ? f[q < 12 ? q : 0] : u[q];
+  kin_emit<12>(o, KR_F2, f);
 }
 
 // ---- K1b: one wavefront per node ----
@@ -323,7 +355,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
   const int nxt = (i + 1 < a.nmax) ? ((i + 1) * a.B + b) : nb;
   double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_ee = 0.0, in_k[4], in_k2[4], in_xref = 0.0, in_qd = 0.0;
-  if (l < 30) { in_xref = a.xref[nb * 30 + l]; in_qd = st[ST_Q + l]; in_x = a.x[nb * 30 + l]; in_u = a.u[nb * 30 + l]; xn = a.x[nxt * 30 + l]; f1 = kr[KR_F1 + l]; f2 = kr[KR_F2 + l]; }
+  if (l < 30) { in_xref = a.xref[nb * 30 + l]; in_qd = st[ST_Q + l]; in_x = a.x[nb * 30 + l]; in_u = a.u[nb * 30 + l]; xn = a.x[nxt * 30 + l]; }
+  if (l < 30) { const int lf = (l < 12) ? l : 0; f1 = kr[KR_F1 + lf]; f2 = kr[KR_F2 + lf]; }      // rows 0..11; rows 12..29 of the flow map are the input's joint velocities (selected below)
   if (l >= 32 && l < 39) in_ee = a.eeref[nb * 7 + (l - 32)];
   if (l >= 40 && l < 46) in_ee = kr[KR_EEG + (l - 40)];
   if (l >= 48 && l < 52) in_ee = kr[KR_QEE + (l - 48)];
@@ -367,7 +400,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   // what the prologue's loads are needed for is formed HERE and only the results stay live (three waves per SIMD: 168 registers): the defect b, the tracking terms
   // of the cost (state weights are diagonal) and u − u_nom
   double* QD = S + LW_V_QD; double* RD = S + LW_V_RD; double* FR = S + LW_V_FR;
-  const double bl = (l < 30) ? X[l] + 0.5 * dt * f1 + 0.5 * dt * f2 - xn : 0.0;
+  const double bl = (l < 30) ? X[l] + 0.5 * dt * ((l < 12) ? f1 : U[l]) + 0.5 * dt * ((l < 12) ? f2 : U[l]) - xn : 0.0;
   if (l < 32) S[LW_V_B + l] = bl;
   if (l < 30) {
     const double dx = X[l] - in_xref; const double qd = in_qd;

@@ -35,8 +35,7 @@ struct QmLsArgs {
   const double* xt; const double* ut; int ilqr;
 };
 #define QM_LS_MAX_TRIALS 16
-#define LS_EVAL_LDS_BYTES (64 * 31 * 8)      /* one 31-double row per thread (the trial input): 15.5 KB per wave, eight waves per CU; was */
-#define LS_EVAL_LDS_BYTES_V27 (2 * 64 * 31 * 8)   /* qm_ls_eval_kernel: two 31-double rows per thread = 31 KB per wave: FOUR waves fit a CU's 160 KB (three rows were 46.5 KB: three waves per CU, a SIMD idle) */
+#define LS_EVAL_LDS_BYTES ((64 * 31 + 64) * 8)      /* one 31-double row per thread + the wave's 64 step lengths: 16 KB per wave, eight waves per CU */
 
 // cost value of one intermediate node (a2 + a6 + a7 + a5), not yet × dt; K must hold base, legs and arm
 __device__ __forceinline__ double node_cost_value(const double* mb, const double* st, const double* x, const double* u, const double* K, int mode,
@@ -65,12 +64,29 @@ __device__ __forceinline__ double node_cost_value(const double* mb, const double
 }
 // the terms of an intermediate node's cost that need no kinematics (a2 tracking + input weight, a6 boxes, a7 friction cone), not yet × dt; the same arithmetic,
 // in the same order, as the `intermediate` part of node_cost_value; u − u_nominal lives in registers
-__device__ __forceinline__ double node_cost_value_xu(const double* mb, const double* st, const double* x, const double* u, int mode, const double* xref) {
-  double c = 0.0, du[30];
+// RB: the input weight R has the zero pattern its construction gives it with the shipped task file (QMInterface.cpp:274-299: a diagonal R of task.info, leg block <- Jᵀ R₁₂ J with
+// the block-diagonal feet Jacobian) — diagonal on the twelve force and six arm entries, one 3 x 3 block per leg; the host checks the blob entry by entry (qm_r_is_block_diagonal)
+// and picks the instance.  The structured product adds the same non-zero terms in the same order as the dense one (an exact zero contributes nothing): bit-identical, 54
+// instead of 900 multiply-adds and table entries per node.
+// ctrack: the tracking term  sum_i 1/2 Q_i (x_i − xref_i)^2  summed in index order by the caller (the reference rows come in with the wave's cooperative loads)
+template <bool RB>
+__device__ __forceinline__ double node_cost_value_xu(const double* mb, const double* st, const double* x, const double* u, int mode, double ctrack) {
+  double c = ctrack;
   int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
-  _Pragma("unroll") for (int i = 0; i < 30; ++i) { const double d = x[i] - xref[i]; c += 0.5 * st[ST_Q + i] * d * d; du[i] = u[i]; }
-  if (nst > 0) { _Pragma("unroll") for (int k = 0; k < 4; ++k) if (mode_flag(mode, k)) du[3 * k + 2] -= mb[MB_ROBOTMASS] * 9.81 / nst; }
-  _Pragma("unroll") for (int i = 0; i < 30; ++i) { double s = 0.0; _Pragma("unroll") for (int j = 0; j < 30; ++j) s += st[ST_R + 30 * i + j] * du[j]; c += 0.5 * du[i] * s; }
+  const double wz = mb[MB_ROBOTMASS] * 9.81 / nst;                                   // weight-compensating normal force per stance foot (nst == 0: never selected)
+  // u − u_nominal, entry j (static index): only the normal force of a stance foot has a nominal value.  With the structured R nothing of it is kept: every entry is
+  // formed where its block needs it (the input sits in LDS) — thirty live doubles less across the barrier values below
+#define QM_DU(j) ((((j) < 12) && (((j) % 3) == 2) && nst > 0 && mode_flag(mode, ((j) < 12 ? (j) / 3 : 0))) ? u[j] - wz : u[j])
+  if (RB) {
+    _Pragma("unroll") for (int i = 0; i < 30; ++i) {
+      const int j0 = (i >= 12 && i < 24) ? 12 + 3 * ((i - 12) / 3) : i, j1 = (i >= 12 && i < 24) ? j0 + 3 : i + 1;
+      double s = 0.0; _Pragma("unroll") for (int j = j0; j < j1; ++j) s += st[ST_R + 30 * i + j] * QM_DU(j);
+      c += 0.5 * QM_DU(i) * s; }
+  } else {
+    double du[30]; _Pragma("unroll") for (int i = 0; i < 30; ++i) du[i] = QM_DU(i);
+    _Pragma("unroll") for (int i = 0; i < 30; ++i) { double s = 0.0; _Pragma("unroll") for (int j = 0; j < 30; ++j) s += st[ST_R + 30 * i + j] * du[j]; c += 0.5 * du[i] * s; }
+  }
+#undef QM_DU
   __builtin_amdgcn_sched_barrier(0);
   _Pragma("unroll") for (int i = 0; i < 6; ++i) {
     const double lo = mb[MB_QLO + 12 + i], hi = mb[MB_QHI + 12 + i], z = x[24 + i], mu = st[ST_JPOS_MU], de = st[ST_JPOS_DELTA];
@@ -102,83 +118,125 @@ __device__ __forceinline__ double node_eq_sse(const double* st, const double* x,
   return s;
 }
 
-__global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel(QmLsArgs a) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = g / a.B, b = g - i * a.B;
-  if (i >= a.nmax) return;
+// the wave's 64 consecutive rows of a node-major [nmax][B][30] array -> a [64][31] LDS tile (row r = thread r's vector), lanes running over consecutive doubles of
+// the contiguous block (16 bytes each: whole 64-byte lines; rounds 1-4: every thread loaded its own row, 64 different lines per instruction — see qm_lq_kin_kernel);
+// with `step`: the trial point base + alpha step, alpha per ROW from als[64]
+__device__ __forceinline__ void ls_rows_in(double* tile, const double* base, const double* step, const double* als, size_t row0, size_t nrows, int l) {
+  // three rounds of five 16-byte pieces per lane (a ROLLED outer loop: fully unrolled, the fifteen row / column / address sets of the three calls were kept live across the
+  // whole kernel and spilled)
+#pragma nounroll
+  for (int t0 = 0; t0 < 15; t0 += 5) {
+    double2 v[5], d[5]; int off[5]; double al[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int e = (t0 + k) * 64 + l; const int r = e / 15, c = 2 * (e - r * 15); size_t row = row0 + r; if (row >= nrows) row = nrows - 1;
+      off[k] = r * 31 + c; v[k] = *(const double2*)(base + row * 30 + c);
+      if (step) { d[k] = *(const double2*)(step + row * 30 + c); al[k] = als[r]; } }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { if (step) { v[k].x += al[k] * d[k].x; v[k].y += al[k] * d[k].y; } tile[off[k]] = v[k].x; tile[off[k] + 1] = v[k].y; }
+  }
+}
+// One THREAD per (instance, node), the wave's inputs moved together (ls_rows_in).  No thread leaves before the last cooperative load: a thread without work (its
+// instance has finished the search, a row behind the instance's last node) only helps to move data; the whole wave leaves at once when none of its threads has work.
+template <bool RB> __global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel_t(QmLsArgs a) {
+  const int l = threadIdx.x & 63;
+  const size_t g0 = (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
+  size_t g = g0 + l; const bool inrange = g < nrows; if (!inrange) g = nrows - 1;
+  const int i = (int)(g / a.B), b = (int)(g - (size_t)i * a.B);
   const int n = a.n_nodes[b];
-  if (i >= n || a.done[b] != 0) return;
-  const int nb = i * a.B + b; const double al = a.alpha[b];
+  const bool active = inrange && i < n && a.done[b] == 0;
+  if (__ballot(active) == 0ull) return;
+  const int nb = (int)g; const double al = a.alpha[b];
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
-  extern __shared__ double qm_smem[]; double* qm_ls_u = qm_smem;   // LS_EVAL_LDS_BYTES: [0] the trial input, [1] u − u_nominal of the input cost: the trial input of this thread's node: a per-thread LDS row instead of registers (see qm_lq_kin_kernel)
-  double x[30], K[KW_SIZE]; double* u = qm_ls_u + (threadIdx.x & 63) * 31;
-  if (a.xt) { _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.xt[nb * 30 + q]; }
-  else { _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = a.x[nb * 30 + q] + al * a.dx[nb * 30 + q]; }
-  double* pf = a.perf + (size_t)nb * PF_SIZE;
-  const int ev = a.node_ev[nb];
-  if (i == n - 1) {
-    kin_base<true>(mb, x, K); kin_arm<true>(mb, x, K);
-    pf[0] = node_cost_value(mb, st, x, nullptr, K, 0, nullptr, a.eeref + nb * 7, st[ST_MU_EEF_POS], st[ST_MU_EEF_ORI], false, u); pf[1] = 0.0; pf[2] = 0.0;
-    return;
-  }
-  const int nbn = (i + 1) * a.B + b;
-  if (ev == QM_EV_PRE) {
-    double s = 0.0; _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double xnq = a.xt ? a.xt[nbn * 30 + q] : a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q]; const double d = x[q] - xnq; s += d * d; }
-    pf[0] = 0.0; pf[1] = s; pf[2] = 0.0; return;
-  }
-  if (a.ut) { _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.ut[nb * 30 + q]; }
-  else { _Pragma("unroll") for (int q = 0; q < 30; ++q) u[q] = a.u[nb * 30 + q] + al * a.du[nb * 30 + q]; }
-  const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
+  extern __shared__ double qm_smem[];                  // LS_EVAL_LDS_BYTES: [64][31] rows (the trial state on its way in, then each thread's trial input, at the end the next node's trial state) + alpha[64]
+  double* rows = qm_smem; double* als = qm_smem + 64 * 31; double* u = rows + l * 31;
+  als[l] = al; qm_wave_sync();
+  double x[30], K[KW_SIZE];
+  ls_rows_in(rows, a.xt ? a.xt : a.x, a.xt ? nullptr : a.dx, als, g0, nrows, l); qm_wave_sync();
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = u[q];
+  qm_wave_sync();
+  double ctrack = 0.0;                                   // tracking term of the intermediate cost (a2), index order; the reference rows take the tile on their way through
+  ls_rows_in(rows, a.xref, nullptr, als, g0, nrows, l); qm_wave_sync();
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double d = x[q] - u[q]; ctrack += 0.5 * st[ST_Q + q] * d * d; }
+  qm_wave_sync();
+  ls_rows_in(rows, a.ut ? a.ut : a.u, a.ut ? nullptr : a.du, als, g0, nrows, l); qm_wave_sync();
+  const int ev = a.node_ev[nb]; const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
+  const bool term = (i == n - 1), pre = !term && ev == QM_EV_PRE, reg = active && !term && !pre;
   // Ordered for a SMALL live set (256 registers, one LDS row per thread -> two waves per SIMD, every wavefront of the launch resident at once): first the cost terms
   // that need no kinematics (tracking, input weight, boxes, friction cone), then base -> arm (end-effector term), then the legs ONE AT A TIME, each consumed at once
   // by the equality residual and the flow map's momentum sums — the full workspace K[196] never exists.  A zero-length interval contributes neither cost nor
   // constraint residual and needs no second Heun stage; the guards also split this straight-line kernel into basic blocks, which bounds the scheduler's live ranges.
   double cost = 0.0, eq = 0.0;
-  if (dt > 0.0) cost = node_cost_value_xu(mb, st, x, u, mode, a.xref + nb * 30);
+  if (reg && dt > 0.0) cost = node_cost_value_xu<RB>(mb, st, x, u, mode, ctrack);
   kin_base<true>(mb, x, K);
-  if (dt > 0.0) { kin_arm<true>(mb, x, K); double g[6], qee[4]; ee_error(K, a.eeref + nb * 7, a.eeref + nb * 7 + 3, qee, g); const double mp = st[ST_MU_EE_POS], mo = st[ST_MU_EE_ORI];
-                  for (int r = 0; r < 6; ++r) cost += 0.5 * (r < 3 ? mp : mo) * g[r] * g[r]; }
-  const double mass = mb[MB_ROBOTMASS], im = 1.0 / mass, gain = st[ST_POS_ERR_GAIN];
-  double f1[12], f2[12];
-  { double lin[3] = {0.0, 0.0, -9.81 * mass}, ang[3] = {0.0, 0.0, 0.0};
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {
-      kin_leg<true>(mb, c, x, u, K); const int k = chain_to_contact(c); const double* L = K + KW_LEG + KW_LEGSZ * c;
-      const double d[3] = {L[18] - K[KW_COM], L[19] - K[KW_COM + 1], L[20] - K[KW_COM + 2]};
-      double t[3]; v3_cross(d, u + 3 * k, t);
-      for (int q = 0; q < 3; ++q) { lin[q] += u[3 * k + q]; ang[q] += t[q]; }
-      if (dt > 0.0) {                                       // equality residual of this leg's contact (a8): same terms as node_eq_sse
-        double w[3]; v3_cross(K + KW_OM, d, w); const double v[3] = {x[0] + w[0] + L[21], x[1] + w[1] + L[22], x[2] + w[2] + L[23]}; const double pz = L[20];
-        if (mode_flag(mode, k)) { for (int r = 0; r < 3; ++r) { const double e = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); eq += e * e; } }
-        else {
-          for (int r = 0; r < 3; ++r) eq += u[3 * k + r] * u[3 * k + r];
-          double bb = -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * a.zpos[nb * 4 + k];
-          const double e = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0); eq += e * e;
+  if (active && (term || (reg && dt > 0.0))) {            // end-effector pose term: the intermediate soft constraint, or the final one at the terminal node (its only term)
+    kin_arm<true>(mb, x, K); double g6[6], qee[4]; ee_error(K, a.eeref + nb * 7, a.eeref + nb * 7 + 3, qee, g6);
+    const double mp = term ? st[ST_MU_EEF_POS] : st[ST_MU_EE_POS], mo = term ? st[ST_MU_EEF_ORI] : st[ST_MU_EE_ORI];
+    for (int r = 0; r < 6; ++r) cost += 0.5 * (r < 3 ? mp : mo) * g6[r] * g6[r]; }
+  if (reg) {
+    const double mass = mb[MB_ROBOTMASS], im = 1.0 / mass, gain = st[ST_POS_ERR_GAIN];
+    double f1[12], f2[12];
+    { double lin[3] = {0.0, 0.0, -9.81 * mass}, ang[3] = {0.0, 0.0, 0.0};
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {
+        kin_leg<true>(mb, c, x, u, K); const int k = chain_to_contact(c); const double* L = K + KW_LEG + KW_LEGSZ * c;
+        const double d[3] = {L[18] - K[KW_COM], L[19] - K[KW_COM + 1], L[20] - K[KW_COM + 2]};
+        double t[3]; v3_cross(d, u + 3 * k, t);
+        for (int q = 0; q < 3; ++q) { lin[q] += u[3 * k + q]; ang[q] += t[q]; }
+        if (dt > 0.0) {                                       // equality residual of this leg's contact (a8): same terms as node_eq_sse
+          double w[3]; v3_cross(K + KW_OM, d, w); const double v[3] = {x[0] + w[0] + L[21], x[1] + w[1] + L[22], x[2] + w[2] + L[23]}; const double pz = L[20];
+          if (mode_flag(mode, k)) { for (int r = 0; r < 3; ++r) { const double e = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); eq += e * e; } }
+          else {
+            for (int r = 0; r < 3; ++r) eq += u[3 * k + r] * u[3 * k + r];
+            double bb = -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * a.zpos[nb * 4 + k];
+            const double e = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0); eq += e * e;
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);      // one leg at a time (scheduled together, the four chains' temporaries do not fit)
       }
+      double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
+      for (int q = 0; q < 3; ++q) { f1[q] = lin[q] * im; f1[3 + q] = ang[q] * im; f1[6 + q] = x[q] + wr[q]; f1[9 + q] = K[KW_THD + q]; } }
+    _Pragma("unroll") for (int q = 0; q < 12; ++q) f2[q] = f1[q];
+    if (dt > 0.0) {
+      double x2[30];
+      _Pragma("unroll") for (int q = 0; q < 30; ++q) x2[q] = x[q] + dt * ((q < 12) ? f1[q < 12 ? q : 0] : u[q]);
+      kin_base<true>(mb, x2, K);
+      double lin[3] = {0.0, 0.0, -9.81 * mass}, ang[3] = {0.0, 0.0, 0.0};
+      _Pragma("unroll") for (int c = 0; c < 4; ++c) {
+        kin_leg<true>(mb, c, x2, u, K); const int k = chain_to_contact(c); const double* L = K + KW_LEG + KW_LEGSZ * c;
+        const double d[3] = {L[18] - K[KW_COM], L[19] - K[KW_COM + 1], L[20] - K[KW_COM + 2]};
+        double t[3]; v3_cross(d, u + 3 * k, t);
+        for (int q = 0; q < 3; ++q) { lin[q] += u[3 * k + q]; ang[q] += t[q]; }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
+      for (int q = 0; q < 3; ++q) { f2[q] = lin[q] * im; f2[3 + q] = ang[q] * im; f2[6 + q] = x2[q] + wr[q]; f2[9 + q] = K[KW_THD + q]; }
     }
-    double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
-    for (int q = 0; q < 3; ++q) { f1[q] = lin[q] * im; f1[3 + q] = ang[q] * im; f1[6 + q] = x[q] + wr[q]; f1[9 + q] = K[KW_THD + q]; } }
-  _Pragma("unroll") for (int q = 0; q < 12; ++q) f2[q] = f1[q];
-  if (dt > 0.0) {
-    double x2[30];
-    _Pragma("unroll") for (int q = 0; q < 30; ++q) x2[q] = x[q] + dt * ((q < 12) ? f1[q < 12 ? q : 0] : u[q]);
-    kin_base<true>(mb, x2, K);
-    double lin[3] = {0.0, 0.0, -9.81 * mass}, ang[3] = {0.0, 0.0, 0.0};
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {
-      kin_leg<true>(mb, c, x2, u, K); const int k = chain_to_contact(c); const double* L = K + KW_LEG + KW_LEGSZ * c;
-      const double d[3] = {L[18] - K[KW_COM], L[19] - K[KW_COM + 1], L[20] - K[KW_COM + 2]};
-      double t[3]; v3_cross(d, u + 3 * k, t);
-      for (int q = 0; q < 3; ++q) { lin[q] += u[3 * k + q]; ang[q] += t[q]; }
-    }
-    double wr[3]; v3_cross(K + KW_OM, K + KW_RW, wr);
-    for (int q = 0; q < 3; ++q) { f2[q] = lin[q] * im; f2[3 + q] = ang[q] * im; f2[6 + q] = x2[q] + wr[q]; f2[9 + q] = K[KW_THD + q]; }
+    // the Heun step's end point takes x's place (the joint rows of the flow map are the input's joint velocities in both stages); the input row is free after this
+    _Pragma("unroll") for (int q = 0; q < 30; ++q) {
+      const double fa = (q < 12) ? f1[q < 12 ? q : 0] : u[q], fb = (q < 12) ? f2[q < 12 ? q : 0] : u[q];
+      x[q] = x[q] + 0.5 * dt * fa + 0.5 * dt * fb; }
   }
+  // the next node's trial state (the rows one node further: the same instances, the same step lengths) comes in through the tile the inputs leave; a PreEvent node's
+  // defect is the jump x_i − x_{i+1} (identity jump map), unweighted
+  qm_wave_sync();
+  ls_rows_in(rows, a.xt ? a.xt : a.x, a.xt ? nullptr : a.dx, als, g0 + (size_t)a.B, nrows, l); qm_wave_sync();
   double s = 0.0;
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) {
-    const double xnq = a.xt ? a.xt[nbn * 30 + q] : a.x[nbn * 30 + q] + al * a.dx[nbn * 30 + q];
-    const double fa = (q < 12) ? f1[q < 12 ? q : 0] : u[q], fb = (q < 12) ? f2[q < 12 ? q : 0] : u[q];      // joint rows of the flow map: the input's joint velocities in both stages
-    const double d = x[q] + 0.5 * dt * fa + 0.5 * dt * fb - xnq; s += d * d; }
-  pf[0] = cost * dt; pf[1] = dt * s; pf[2] = dt * eq;
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double d = x[q] - u[q]; s += d * d; }
+  if (!active) return;
+  double* pf = a.perf + (size_t)nb * PF_SIZE;
+  if (term) { pf[0] = cost; pf[1] = 0.0; pf[2] = 0.0; }
+  else if (pre) { pf[0] = 0.0; pf[1] = s; pf[2] = 0.0; }
+  else { pf[0] = cost * dt; pf[1] = dt * s; pf[2] = dt * eq; }
+}
+
+#define qm_ls_eval_kernel qm_ls_eval_kernel_t<true>            /* R block diagonal (the shipped task file) */
+#define qm_ls_eval_dense_kernel qm_ls_eval_kernel_t<false>     /* any R */
+// exact zero pattern of the input weight: diag(12) + four 3 x 3 leg blocks + diag(6)  (host side: which instance of qm_ls_eval to launch)
+inline bool qm_r_is_block_diagonal(const double* st) {
+  for (int i = 0; i < 30; ++i) for (int j = 0; j < 30; ++j) {
+    const bool in = (i >= 12 && i < 24) ? (j >= 12 + 3 * ((i - 12) / 3) && j < 15 + 3 * ((i - 12) / 3)) : (j == i);
+    if (!in && st[ST_R + 30 * i + j] != 0.0) return false; }
+  return true;
 }
 
 // One WAVEFRONT per instance.  Sum of the node terms -> perf_sum[b] = {merit, cost, dynSSE, eqSSE} (lanes stride over the

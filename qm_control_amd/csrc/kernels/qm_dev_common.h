@@ -55,13 +55,18 @@ __device__ __forceinline__ void m3_inv(const double* A, double* R) {   // cofact
   const double id = 1.0 / (A[0] * c00 + A[1] * c10 + A[2] * c20);
   R[0] = c00 * id; R[1] = c01 * id; R[2] = c02 * id; R[3] = c10 * id; R[4] = c11 * id; R[5] = c12 * id; R[6] = c20 * id; R[7] = c21 * id; R[8] = c22 * id;
 }
-// sin and cos of an angle together, ≈ 1 ulp for |x| < 1e5: Cody–Waite reduction x = k π/2 + r with the two-part constant of the classic medium-range path
-// (k π/2_hi is exact for |k| < 2^20), then the minimax kernels on |r| <= π/4 (the standard degree-13 / degree-14 coefficients).  ≈ 35 instructions for the pair;
+// sin and cos of an angle together, ≈ 1 ulp: Cody–Waite reduction x = k π/2 + r, then the minimax kernels on |r| <= π/4 (the standard degree-13 / degree-14
+// coefficients).  ≈ 35 instructions for the pair;
 // the device library's sin() and cos() carry a full-range Payne–Hanek reduction in double-double arithmetic — ≈ 300 instructions EACH — and the thread-per-node
-// kinematics kernels evaluate 36 pairs per node: half of their instruction stream was trigonometry.  Joint and Euler angles never leave a few multiples of π;
-// anything beyond 1e5 takes the library path.
-__device__ __forceinline__ void qm_sincos(double x, double& sn, double& cs) {
-  if (!(fabs(x) < 1.0e5)) { sn = sin(x); cs = cos(x); return; }
+// kinematics kernels evaluate 36 pairs per node.  Joint and Euler angles never leave a few multiples of π: this pair reduces with two Cody–Waite constants (fdlibm's
+// pio2_1 = the first 33 bits of π/2 and pio2_1t = π/2 − pio2_1) and is good for |x| < 2^31: k = rint(2x/π) < 1.4e9 fits an int32, x − k pio2_1 is EXACT under the fma (a
+// multiple of 2^-36 below 1 in magnitude), and the second step rounds once, so the reduced argument carries an absolute error below 7e-17 + k 6.7e-27 < 8e-17 over the whole
+// range.  Round 5: anything beyond (|x| >= 2^31 rad, infinities, NaN) yields NaN — which the solve reports as a failure (status -4) — instead of taking the library path:
+// rounds 1-4 kept `sin(x); cos(x)` behind a branch for |x| >= 1e5, and that never-executed code was INLINED AT EVERY CALL SITE: 19.5 k of the 27 k instructions of
+// qm_lq_kin_kernel, 20.5 k of qm_ls_eval_kernel's 39.8 k, 13.2 k of qm_wbc_kernel's 41.5 k — kernels several times the 64 KB instruction cache two CUs share, with the hot
+// code scattered between the cold blocks.  Results for |x| < 1e5 are bit-identical to rounds 1-4 (same constants, same operations).
+__device__ __forceinline__ void qm_sincos(double xin, double& sn, double& cs) {
+  const double x = (fabs(xin) < 2147483648.0) ? xin : __builtin_nan("");
   const double k = rint(x * 6.36619772367581382433e-01);
   double r = fma(-k, 1.57079632673412561417e+00, x); r = fma(-k, 6.07710050650619224932e-11, r);
   const double z = r * r;

@@ -6,7 +6,7 @@ fragment order (SR_FRAG: whole 16 x 16 tiles, the padding of a 30-wide block inc
 """
 # ---- K1b qm_lq_kernel ----
 LQ_WRITE_DOUBLES = 2665      # rows 0..11 of Ap 360 and Bp 216 (joint rows are e_j + dt Px[j] resp. dt Pu[j]: rebuilt by K3), [Qp | qp] [Pp | rp] Rp in fragment order 768 + 512 + 256 (SR_FRAG; m <= 16), the 12 non-zero rows of Px 360, vectors 108+30, swing blocks 24+2 (Pu is implied by the contact mode)
-LQ_READ_DOUBLES = 620        # kin record (504) + x, u, references, node descriptors
+LQ_READ_DOUBLES = 493        # kin record (377 of the 384-double record: round 5 dropped the stage-2 state, the joint rows of the flow values and the stage-2 arm block; rounds 1-4: 504) + x, u, references, node descriptors
 # ---- K3 qm_riccati_kernel ----
 RICCATI_BWD_READ_DOUBLES = 2576    # rows 0..11 of Ap 360 and Bp 216, the fragment-order operands 1536 (three upper tiles of [Qp | qp], tile row 0 of [Pp | rp], tile (0,0) of Rp; + 448 when m > 16), rows 12..23 of Px 360, bp qp rp 78, swing blocks + mode + dt 26
 RICCATI_BWD_WRITE_DOUBLES = 558    # the gain K = -L^-T W (540) and the offset k = -L^-T y (18), formed on the matrix core for the forward rollout

@@ -22,11 +22,16 @@ def test_sincos_matches_long_double_over_the_range_angles_can_take():
     assert np.abs(s * s + c * c - 1.0).max() < 5e-16
 
 
-def test_sincos_takes_the_library_path_outside_its_range():
-    x = np.array([1.0e5, -3.0e7, 1.0e300, np.inf, np.nan])
-    s, c = _call("emu_sincos", x)
-    assert np.allclose(s[:3], np.sin(x[:3]), rtol=0, atol=1e-15) and np.allclose(c[:3], np.cos(x[:3]), rtol=0, atol=1e-15)
-    assert np.isnan(s[3:]).all() and np.isnan(c[3:]).all()
+def test_sincos_over_its_whole_range_and_nan_beyond():
+    """round 5: no library path — the two-constant reduction holds to |x| < 2^31 (absolute error of the reduced argument < 8e-17, qm_dev_common.h); beyond that, and for
+    infinities / NaN, the pair is NaN (the solve then reports a failure) — the rounds 1-4 fallback `sin(x); cos(x)` was inlined at every call site: most of the kinematics kernels' code"""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-s, s, 100000) for s in (1.0e5, 1.0e7, 2.0e9)] + [[1.0e5, -3.0e7, 2147483647.0, -2147483647.5], np.arange(1, 1300) * 1.0e6 * (np.pi / 2)])
+    s, c = _call("emu_sincos", x); xl = x.astype(np.longdouble)
+    assert np.abs(s - np.sin(xl)).max() < 3e-16 and np.abs(c - np.cos(xl)).max() < 3e-16
+    bad = np.array([2147483648.0, -2147483648.0, 1.0e10, -1.0e300, np.inf, -np.inf, np.nan])
+    s, c = _call("emu_sincos", bad)
+    assert np.isnan(s).all() and np.isnan(c).all()
 
 
 def test_fast_reciprocal_and_log_are_within_an_ulp_or_two():

@@ -35,7 +35,7 @@ def kernel_ms(itf, step, names, reps=6):
 
 def main():
     out = {"workload": "C4 (trot, N = 100, seed 1235)", "lds_per_cu": LDS_CU, "lds_padding_sweep_B1024": {}, "batch_sweep": {}}
-    sizes = {"lq": 16000, "lq_kin": 31744, "ls_eval": 31744, "riccati": 38272, "wbc": 40944}      # own LDS per workgroup: LQ_LDS_BYTES, LQ_KIN_LDS_BYTES, LS_EVAL_LDS_BYTES, RW_LDS_BYTES, WBC_LDS_BYTES
+    sizes = {"lq": 16000, "lq_kin": 20480, "ls_eval": 16384, "riccati": 38272, "wbc": 40944}      # own LDS per workgroup: LQ_LDS_BYTES, LQ_KIN_LDS_BYTES, LS_EVAL_LDS_BYTES, RW_LDS_BYTES, WBC_LDS_BYTES
     batch_only = "--batch-only" in sys.argv
     cfg, itf, mpc, wbc = engine(1024)
     for _ in range(12): itf.microbench_fp64(True)
