@@ -66,9 +66,13 @@ int qmhip_wbc_gain_index(const char* reconfigure_name);
  *      input trajectories (primal solution: input of event nodes copied from the previous node, last input repeated),
  *      perf[10] = baseline{merit,cost,dynSSE,eqSSE}, after-step{...}, step size alpha, armijo metric.
  *      status[b]: 0 ok; < 0 failure: -1 node buffer too small, -2 swing phase not enclosed by stance in the schedule, -3 device gait schedule over capacity,
- *      -4 Riccati not PD (only with ST_RICCATI_STRICT); > 0 WARNING bits on a valid solution: QM_MPC_WARN_PIVOT (1) = a stage's Huu had non-positive pivots, which were
+ *      -4 Riccati failed (indefinite stage of positive duration / NaN; with ST_RICCATI_STRICT also the degenerate stage); > 0 WARNING bits on a valid solution: QM_MPC_WARN_PIVOT (1) = a stage's Huu had non-positive pivots, which were
  *      zeroed ([upstream, recalled] BLASFEO / HPIPM behaviour; qmhip_layout.h) — the stage in front of a gait event when a shooting node falls within weakEpsilon
- *      before it, i.e. about one call in 3700 for an MPC thread on continuous time (QMController.cpp:315-330).  Callers treat status >= 0 as success.
+ *      before it, i.e. about one call in 3700 for an MPC thread on continuous time (QMController.cpp:315-330); on a fixed-rate clock that shares a raster with the gait
+ *      events 3 % ... 12 % of the calls (profiles/r04_fixed_rate_report.txt).  Such a solve lies within 5e-6 (per block) of the solve on the robust grid everywhere but the
+ *      degenerate interval's own input, its policy at t0 within 1e-6 (tests/test_gpu_mpc.py); rastered controllers should set ST_GRID_DT_MIN = QM_GRID_DT_MIN_ROBUST
+ *      (INTEGRATION.md section 3).  Callers treat status >= 0 as success.  -4 also reports: a non-positive pivot on a stage of POSITIVE duration, a pivot or a step that is
+ *      not a finite number (e.g. a NaN in x0) — never a warning.
  *      Solver slot (qmhip_set_setting(ST_SOLVER, .)): 0 the SQP above; 1 a discrete iLQR on the `ddp` block (task.info:33-71); 2 the SAME multiple-shooting step as
  *      slot 0, run with the `ipm` block's parameters (task.info:94-125: ipm.dt / ipmIteration / deltaTol / g_max / g_min, ST_IPM_*).  Slot 2 is NOT an interior-point
  *      method: this OCP has no hard inequality constraints (QMInterface.cpp:79-142 registers friction cones and joint limits as soft costs), so an IpmMpc in the MPC_BASE

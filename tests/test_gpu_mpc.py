@@ -227,6 +227,24 @@ def test_ipm_solver_slot(blobs, oracle):
     itf.close()
 
 
+def test_warned_solve_policy_at_t0_matches_the_robust_grid(blobs):
+    """What the WBC consumes of a solve that carries QM_MPC_WARN_PIVOT — the policy at the observation time (and one control period later) — against the same solve on the
+    robust grid (the degenerate node merged into the event node): <= 1e-6 per block.  Every gait event inside C2's horizon x offsets -9e-7 ... -1e-12."""
+    from qm_control_amd import api, scenarios
+    from test_grid_fuzz import degenerate_cases
+    cfg, cases = degenerate_cases(scenarios.make_config("C2", batch=1, n_intervals=100))
+    B = cfg["B"]; pol = {}
+    for name, dt_min in (("up", L.QM_GRID_DT_MIN_UPSTREAM), ("rob", L.QM_GRID_DT_MIN_ROBUST)):
+        itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=cfg["ref_t"].shape[1], max_events=cfg["ev"].shape[1])
+        itf.set_setting(L.ST_GRID_DT_MIN, dt_min); mpc = api.SqpMpc(itf)
+        res = mpc.run(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"])
+        assert (res["status"] == (L.QM_MPC_WARN_PIVOT if name == "up" else 0)).all(), (name, res["status"])
+        pol[name] = [mpc.evaluatePolicy(cfg["t0"] + d) for d in (0.0, 0.002)]; itf.close()
+    for (xu, uu, mu), (xr, ur, mr) in zip(pol["up"], pol["rob"]):
+        assert np.array_equal(mu, mr)
+        assert_blocks(xu, xr, "x", 1e-6, "policy state at t0: warned solve vs robust grid"); assert_blocks(uu, ur, "u", 1e-6, "policy input at t0: warned solve vs robust grid")
+
+
 def test_nan_observation_is_a_failed_solve_on_the_device(blobs):
     """-m gpu twin of tests/test_grid_fuzz.py::test_nan_observation_and_indefinite_stage_are_failures_not_warnings through the C ABI: a NaN in one instance's observation
     gives THAT instance status -4 (a failure: the adaptor throws, as [upstream] SqpSolver does on HPIPM's NaN status) and leaves its neighbour's solve untouched; a
