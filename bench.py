@@ -376,7 +376,7 @@ def cpu_baseline(cfg, gpu_out, B):
     import pyoracle
     from qm_control_amd import scenarios
     ob = pyoracle.load_blobs()
-    cores = min(os.cpu_count() or 1, 64); S = min(B, 128)
+    cores = min(os.cpu_count() or 1, 64); S = min(B, 512)      # ≈ 15 s of CPU work (≈ 28 ms per instance with the seeded forward mode)
     tb = time.perf_counter()
     bad, _, _, w = pyoracle.batch_step(*ob, cores, cfg["t0"][:S], cfg["horizon"], cfg["x0"][:S], cfg["ref_t"][:S], cfg["ref_x"][:S], cfg["ev"][:S], cfg["modes"][:S], cfg["period"], cfg["time"])
     tcpu = time.perf_counter() - tb
@@ -405,8 +405,9 @@ def cpu_baseline(cfg, gpu_out, B):
             "sample": "first %d instances of the same batch, %d threads over instances (thread count = min(os.cpu_count(), 64)); max rel diff GPU vs oracle on the sample per block: %s" % (S, cores, ", ".join("%s %.1e" % kv for kv in errs.items())),
             "parity_on_sample": errs,
             "single_instance_ms": single,
-            "note": "the oracle is a RESTATEMENT with forward-mode AD Jacobians (Dual<60>) and an O(n^4) Lagrangian mass matrix — much slower than the OCS2 / Pinocchio / HPIPM binary the "
-                    "reference runs (SURVEY.md a11: ~5-10 ms per MPC iteration on 3 cores); it is a reported baseline, never a speed-up claim"}
+            "ad": "seeded forward mode (flow map 33 slots, feet 36, end-effector error 12; bit-identical to the 60-slot evaluation of rounds 1-4, tests/test_oracle.py)",
+            "note": "the oracle is a RESTATEMENT (forward-mode AD Jacobians, an O(n^4) Lagrangian mass matrix in the WBC); since round 5 its single-instance MPC iteration on 3 threads is "
+                    "in the range SURVEY.md a11 expects of the OCS2 / Pinocchio / HPIPM binary the reference runs (~5-10 ms on 3 cores; rounds 1-4: 32 ms).  A reported baseline, never a speed-up claim"}
 
 
 def main():

@@ -60,6 +60,10 @@ class Oracle:
         """worker threads over shooting nodes (LQ approximation, line-search evaluation) — sqp.nThreads of task.info:77"""
         self.lib.qmo_set_threads(C.c_int(n))
 
+    def set_full_seeding(self, on):
+        """tests only (process-wide): True = every Jacobian from the full 60-slot forward mode of rounds 1-4, False = the seeded evaluation (default, oracle/src/ocp.h)"""
+        self.lib.qmo_set_full_seeding(C.c_int(int(bool(on))))
+
     def phase_ms(self):
         """wall time of the last mpc_step: [LQ approximation + projection, Riccati solve, line search] in ms"""
         ms = np.zeros(3); self.lib.qmo_phase_ms(self.h, _p(ms)); return ms

@@ -106,6 +106,8 @@ int qmo_get_step(void* h, double* dx, double* du) {
   return n;
 }
 int qmo_ls_trials(void* h) { return ((Oracle*)h)->R.lsTrials; }
+// tests only: 1 = every Jacobian from the full 60-slot forward mode of rounds 1-4 (the seeded evaluation must reproduce it entry by entry), 0 = seeded (default)
+void qmo_set_full_seeding(int on) { qm_ad_full_seeding = on != 0; }
 int qmo_last_warn(void* h) { return ((Oracle*)h)->R.warn; }      // warning bits of the last (valid) solve: QM_MPC_WARN_PIVOT
 void qmo_phase_ms(void* h, double* ms3) { for (int i = 0; i < 3; ++i) ms3[i] = ((Oracle*)h)->R.phaseMs[i]; }
 // one more SQP iteration on the iterate the last call left (sqp.sqpIteration > 1, [upstream SqpSolver::runImpl loop]); same outputs as qmo_mpc_step

@@ -235,12 +235,51 @@ inline void seedXU(const Vec& x, const Vec& u, D60* xs, D60* us) {
   for (int i = 0; i < QM_NX; ++i) xs[i] = D60::seed(x[i], i);
   for (int i = 0; i < QM_NU; ++i) us[i] = D60::seed(u[i], 30 + i);
 }
+// SEEDED forward mode (round 5).  A dual number carries one derivative slot per seeded INDEPENDENT variable; a variable that is not seeded is a constant of the evaluation,
+// i.e. its Jacobian column is taken to be structurally zero (or is known in closed form and filled in by the caller).  Forward mode propagates every slot independently of the
+// others, so the entries of the seeded columns are bit-identical to those of the full 60-slot evaluation — only the work shrinks (rounds 1-4 pushed 60 slots through every
+// kinematics pass: 83 of the 88 ms of a single-instance MPC iteration).  qm_ad_full_seeding = true restores the full evaluation (tests/test_oracle.py compares the two entry by entry).
+//   flow map:           h (6), zyx (3), leg joints (12), contact forces (12) -> 33 slots; the base position and the arm joints do not enter (com and feet move together; the arm's
+//                       frames are not used), the joint-velocity columns are the identity on rows 12..29
+//   feet pos / vel:     h (6), base pose (6), leg joints (12), leg joint velocities (12) -> 36 slots, ONE kinematics pass for the four feet (rounds 1-4: one per foot)
+//   end-effector error: base pose (6), arm joints (6) -> 12 slots
+static bool qm_ad_full_seeding = false;
+struct SeedPlan { int xs[QM_NX], us[QM_NU]; };       // slot of x_i / u_i, −1: constant
+inline SeedPlan seedPlanFlow() { SeedPlan p; for (int i = 0; i < 30; ++i) { p.xs[i] = -1; p.us[i] = -1; }
+  for (int i = 0; i < 6; ++i) p.xs[i] = i; for (int i = 0; i < 3; ++i) p.xs[9 + i] = 6 + i; for (int i = 0; i < 12; ++i) { p.xs[12 + i] = 9 + i; p.us[i] = 21 + i; } return p; }
+inline SeedPlan seedPlanFeet() { SeedPlan p; for (int i = 0; i < 30; ++i) { p.xs[i] = -1; p.us[i] = -1; }
+  for (int i = 0; i < 24; ++i) p.xs[i] = i; for (int i = 0; i < 12; ++i) p.us[12 + i] = 24 + i; return p; }
+template <int N> inline void seedPlanned(const SeedPlan& sp, const Vec& x, const Vec& u, Dual<N>* xs, Dual<N>* us) {
+  for (int i = 0; i < QM_NX; ++i) xs[i] = (sp.xs[i] >= 0) ? Dual<N>::seed(x[i], sp.xs[i]) : Dual<N>(x[i]);
+  for (int i = 0; i < QM_NU; ++i) us[i] = (sp.us[i] >= 0) ? Dual<N>::seed(u[i], sp.us[i]) : Dual<N>(u[i]);
+}
 // a3: dynamics linearisation by AD (what CppAD does in the reference)
 inline void flowMapLinear(const Model& M, const Vec& x, const Vec& u, Vec& f, Mat& A, Mat& B) {
-  D60 xs[QM_NX], us[QM_NU], dx[QM_NX]; seedXU(x, u, xs, us);
-  flowMap<D60>(M, xs, us, dx);
   f.assign(QM_NX, 0.0); A = Mat(QM_NX, QM_NX); B = Mat(QM_NX, QM_NU);
-  for (int i = 0; i < QM_NX; ++i) { f[i] = dx[i].v; for (int j = 0; j < 30; ++j) { A(i, j) = dx[i].d[j]; B(i, j) = dx[i].d[30 + j]; } }
+  if (qm_ad_full_seeding) {
+    D60 xs[QM_NX], us[QM_NU], dx[QM_NX]; seedXU(x, u, xs, us);
+    flowMap<D60>(M, xs, us, dx);
+    for (int i = 0; i < QM_NX; ++i) { f[i] = dx[i].v; for (int j = 0; j < 30; ++j) { A(i, j) = dx[i].d[j]; B(i, j) = dx[i].d[30 + j]; } }
+    return;
+  }
+  typedef Dual<33> D; static const SeedPlan sp = seedPlanFlow();
+  D xs[QM_NX], us[QM_NU], dx[QM_NX]; seedPlanned<33>(sp, x, u, xs, us);
+  flowMap<D>(M, xs, us, dx);
+  for (int i = 0; i < QM_NX; ++i) {
+    f[i] = dx[i].v;
+    for (int j = 0; j < 30; ++j) { if (sp.xs[j] >= 0) A(i, j) = dx[i].d[sp.xs[j]]; if (sp.us[j] >= 0) B(i, j) = dx[i].d[sp.us[j]]; }
+  }
+  for (int j = 0; j < QM_NJ; ++j) B(12 + j, 12 + j) = 1.0;      // xdot_{12+j} = u_{12+j}
+}
+// feet positions and LOCAL_WORLD_ALIGNED velocities, all four from ONE kinematics pass (same arithmetic per foot as footPosVel)
+template <class T> inline void feetPosVel(const Model& M, const T* x, const T* u, V3<T>* pos, V3<T>* vel) {
+  const T* q = x + 6;
+  Kin<T> k; forwardKinematics(M, q, k);
+  Srbd<T> c; srbd(M, q, c);
+  T v[QM_NQ];
+  baseVelocity(M, c, x, v);
+  for (int j = 0; j < QM_NJ; ++j) v[6 + j] = u[12 + j];
+  for (int i = 0; i < 4; ++i) { V3<T> ang; frameVelocity(M, k, q, v, i, vel[i], ang); pos[i] = k.fp[i]; }
 }
 
 // a8: equality constraints at (t,x,u): rows ordered per foot LF,RF,LH,RH as added in
@@ -250,22 +289,31 @@ inline void equalityConstraints(const Problem& P, double t, const Vec& x, const 
   int nc = 0; for (int i = 0; i < 4; ++i) nc += fl[i] ? 3 : 4;
   e.assign(nc, 0.0); if (linear) { C = Mat(nc, QM_NX); D = Mat(nc, QM_NU); }
   const double gain = M.st[ST_POS_ERR_GAIN];
-  D60 xs[QM_NX], us[QM_NU]; if (linear) seedXU(x, u, xs, us);
+  // derivative of foot quantity `a` with respect to x_j / u_j under the active seeding
+  typedef Dual<36> D36; static const SeedPlan sp = seedPlanFeet();
+  V3<D60> pdF[4], vdF[4]; V3<D36> pdC[4], vdC[4]; V3<double> pv[4], vv[4];
+  if (linear && qm_ad_full_seeding) { D60 xs[QM_NX], us[QM_NU]; seedXU(x, u, xs, us); feetPosVel<D60>(M, xs, us, pdF, vdF); }
+  else if (linear) { D36 xs[QM_NX], us[QM_NU]; seedPlanned<36>(sp, x, u, xs, us); feetPosVel<D36>(M, xs, us, pdC, vdC); }
+  else feetPosVel<double>(M, x.data(), u.data(), pv, vv);
+  const bool full = qm_ad_full_seeding;
+  auto dX = [&](const D60& aF, const D36& aC, int j) { return full ? aF.d[j] : (sp.xs[j] >= 0 ? aC.d[sp.xs[j]] : 0.0); };
+  auto dU = [&](const D60& aF, const D36& aC, int j) { return full ? aF.d[30 + j] : (sp.us[j] >= 0 ? aC.d[sp.us[j]] : 0.0); };
   int r = 0;
   for (int i = 0; i < 4; ++i) {
     if (!fl[i]) {   // ZeroForceConstraint [upstream]
       for (int k = 0; k < 3; ++k) { e[r + k] = u[3 * i + k]; if (linear) D(r + k, 3 * i + k) = 1.0; }
       r += 3;
     }
-    V3<double> p, v; V3<D60> pd, vd;
-    if (linear) { footPosVel<D60>(M, xs, us, i, pd, vd); for (int k = 0; k < 3; ++k) { p[k] = pd[k].v; v[k] = vd[k].v; } }
-    else footPosVel<double>(M, x.data(), u.data(), i, p, v);
+    V3<double> p, v;
+    if (linear) { for (int k = 0; k < 3; ++k) { p[k] = full ? pdF[i][k].v : pdC[i][k].v; v[k] = full ? vdF[i][k].v : vdC[i][k].v; } }
+    else { p = pv[i]; v = vv[i]; }
+    const V3<D60>& pd = pdF[i]; const V3<D60>& vd = vdF[i]; const V3<D36>& pc = pdC[i]; const V3<D36>& vc = vdC[i];
     if (fl[i]) {    // zero velocity: Av = I, b = 0, Ax = diag(0,0,gain) if gain != 0 (QMInterface.cpp:324-339)
       for (int k = 0; k < 3; ++k) {
         e[r + k] = v[k] + ((k == 2 && gain != 0.0) ? gain * p[2] : 0.0);
         if (linear) for (int j = 0; j < 30; ++j) {
-          C(r + k, j) = vd[k].d[j] + ((k == 2 && gain != 0.0) ? gain * pd[2].d[j] : 0.0);
-          D(r + k, j) = vd[k].d[30 + j] + ((k == 2 && gain != 0.0) ? gain * pd[2].d[30 + j] : 0.0);
+          C(r + k, j) = dX(vd[k], vc[k], j) + ((k == 2 && gain != 0.0) ? gain * dX(pd[2], pc[2], j) : 0.0);
+          D(r + k, j) = dU(vd[k], vc[k], j) + ((k == 2 && gain != 0.0) ? gain * dU(pd[2], pc[2], j) : 0.0);
         }
       }
       r += 3;
@@ -273,8 +321,8 @@ inline void equalityConstraints(const Problem& P, double t, const Vec& x, const 
       double b = -P.swing.zVel(i, t); if (gain != 0.0) b -= gain * P.swing.zPos(i, t);
       e[r] = b + v[2] + (gain != 0.0 ? gain * p[2] : 0.0);
       if (linear) for (int j = 0; j < 30; ++j) {
-        C(r, j) = vd[2].d[j] + (gain != 0.0 ? gain * pd[2].d[j] : 0.0);
-        D(r, j) = vd[2].d[30 + j] + (gain != 0.0 ? gain * pd[2].d[30 + j] : 0.0);
+        C(r, j) = dX(vd[2], vc[2], j) + (gain != 0.0 ? gain * dX(pd[2], pc[2], j) : 0.0);
+        D(r, j) = dU(vd[2], vc[2], j) + (gain != 0.0 ? gain * dU(pd[2], pc[2], j) : 0.0);
       }
       r += 1;
     }
@@ -287,11 +335,24 @@ inline void eeSoftCost(const Problem& P, double t, const Vec& x, double muPos, d
   const Model& M = *P.M; double pref[3], qref[4]; P.target.eePose(t, pref, qref);
   double mu[6] = {muPos, muPos, muPos, muOri, muOri, muOri};
   if (!quad) { double g[6]; eePoseError<double>(M, x.data(), pref, qref, g); for (int i = 0; i < 6; ++i) f += 0.5 * mu[i] * g[i] * g[i]; return; }
-  Dual<30> xs[QM_NX], g[6]; for (int i = 0; i < QM_NX; ++i) xs[i] = Dual<30>::seed(x[i], i);
-  eePoseError<Dual<30>>(M, xs, pref, qref, g);
+  if (qm_ad_full_seeding) {
+    Dual<30> xs[QM_NX], g[6]; for (int i = 0; i < QM_NX; ++i) xs[i] = Dual<30>::seed(x[i], i);
+    eePoseError<Dual<30>>(M, xs, pref, qref, g);
+    for (int i = 0; i < 6; ++i) {
+      f += 0.5 * mu[i] * g[i].v * g[i].v;
+      for (int a = 0; a < 30; ++a) { (*gx)[a] += mu[i] * g[i].v * g[i].d[a]; for (int b = 0; b < 30; ++b) (*Hxx)(a, b) += mu[i] * g[i].d[a] * g[i].d[b]; }
+    }
+    return;
+  }
+  // the end-effector pose depends on the base pose (x[6..11]) and the arm joints (x[24..29]) only: 12 slots, the other rows / columns of the Gauss-Newton term are zero
+  Dual<12> xs[QM_NX], g[6]; int var[12];
+  for (int i = 0; i < QM_NX; ++i) xs[i] = Dual<12>(x[i]);
+  for (int k = 0; k < 6; ++k) { var[k] = 6 + k; var[6 + k] = 24 + k; }
+  for (int k = 0; k < 12; ++k) xs[var[k]] = Dual<12>::seed(x[var[k]], k);
+  eePoseError<Dual<12>>(M, xs, pref, qref, g);
   for (int i = 0; i < 6; ++i) {
     f += 0.5 * mu[i] * g[i].v * g[i].v;
-    for (int a = 0; a < 30; ++a) { (*gx)[a] += mu[i] * g[i].v * g[i].d[a]; for (int b = 0; b < 30; ++b) (*Hxx)(a, b) += mu[i] * g[i].d[a] * g[i].d[b]; }
+    for (int a = 0; a < 12; ++a) { (*gx)[var[a]] += mu[i] * g[i].v * g[i].d[a]; for (int b = 0; b < 12; ++b) (*Hxx)(var[a], var[b]) += mu[i] * g[i].d[a] * g[i].d[b]; }
   }
 }
 inline void intermediateCost(const Problem& P, double t, const Vec& x, const Vec& u, bool quad, CostQuad& c) {

@@ -125,10 +125,10 @@ inline void eqConstrainedLS(const Mat& G, const Vec& g, const Mat& E, const Vec&
 }
 
 // min |G y − g|² s.t. C y <= c, from a feasible y: primal active set (Nocedal & Wright alg. 16.3) on the QR-based equality-constrained solves above.
-// status: 0 converged, 1 iteration limit (qpOASES' nWSR = 100, HoQp.cpp:141), 2 working set larger than the problem's dimension
+// status: 0 converged, 1 iteration limit (qpOASES' nWSR = 100, HoQp.cpp:141)
 inline void primalActiveSetLSI(const Mat& G0, const Vec& g0, const Mat& DZ, const Vec& fb, Vec& z, int& status, int& iters) {
   const int n = G0.c, mh = DZ.r;
-  std::vector<int> W; bool degenerate = false; double pscale = 0.0;
+  std::vector<int> W; bool degenerate = false, vertex = false; double pscale = 0.0;
   for (iters = 0; iters < 100; ++iters) {
     Mat E((int)W.size(), n); Vec e(W.size());
     for (size_t a = 0; a < W.size(); ++a) { for (int j = 0; j < n; ++j) E((int)a, j) = DZ(W[a], j); e[a] = fb[W[a]]; }
@@ -136,7 +136,8 @@ inline void primalActiveSetLSI(const Mat& G0, const Vec& g0, const Mat& DZ, cons
     Vec p = vsub(zn, z); double pn = 0; for (double v : p) pn = std::max(pn, std::fabs(v));
     double zs = 1.0; for (double v : z) zs = std::max(zs, std::fabs(v));
     pscale = std::max(pscale, pn);
-    if (pn <= 1e-9 * std::max(zs, pscale)) {      // relative to the largest step seen: the problem's own length scale
+    if (vertex || pn <= 1e-9 * std::max(zs, pscale)) {      // relative to the largest step seen: the problem's own length scale
+      vertex = false;
       // stationary on the working set: drop a row with a negative multiplier (most negative; lowest index after a degenerate step — Bland)
       int worst = -1; double lw = 0.0; double lscale = 1.0; for (double v : lam) lscale = std::max(lscale, std::fabs(v));
       for (size_t a = 0; a < W.size(); ++a) if (lam[a] < -1e-9 * lscale) { if (degenerate) { if (worst < 0 || W[a] < W[worst]) worst = (int)a; } else if (lam[a] < lw) { lw = lam[a]; worst = (int)a; } }
@@ -152,7 +153,10 @@ inline void primalActiveSetLSI(const Mat& G0, const Vec& g0, const Mat& DZ, cons
       degenerate = (alpha <= 1e-12);
       if (block >= 0) {
         if ((int)W.size() < n) W.push_back(block);
-        else { status = 2; break; }                   // more than n independent rows cannot be active
+        else if (alpha <= 1e-12) vertex = true;       // n rows are active already (they are numerically dependent, else p would vanish): the set cannot grow beyond the dimension.
+                                                      // A step blocked at once means z is a degenerate vertex: the multipliers decide (Bland's rule) — what the device kernel does
+                                                      // (k_wbc.h); after a partial step the same rows are simply solved again.  (Rounds 1-4 reported status 2 here: which side of
+                                                      // this branch a stress case lands on depends on rounding, i.e. on the compiler's flags.)
       }
     }
   }

@@ -177,3 +177,26 @@ def test_oracle_matches_golden_fixtures(blobs, oracle):
             r = _solve(oracle, cfg, b)
             assert np.array_equal(r["t"], g["t_%d" % b]) and np.array_equal(r["ev"], g["ev_%d" % b]) and np.array_equal(r["mode"], g["mode_%d" % b])
             assert rel_err(r["x"], g["x_%d" % b]) < 1e-12 and rel_err(r["u"], g["u_%d" % b]) < 1e-12
+
+
+def test_seeded_forward_mode_equals_the_full_one(oracle):
+    """round 5: the oracle's Jacobians come from a SEEDED forward mode — only the independent variables an evaluation depends on carry a derivative slot (flow map 33, feet 36,
+    end-effector error 12 instead of 60 / 60 / 30; oracle/src/ocp.h).  Forward mode propagates the slots independently, so every LQ block must equal the full evaluation's BIT FOR
+    BIT — unprojected model of every node of C2 (trot across events) and of a C5 instance (arm near its limits, EE target moved), and the whole iteration's x*, u*."""
+    from qm_control_amd import scenarios
+    for name, N in (("C2", 30), ("C5", 20)):
+        cfg = scenarios.make_config(name, batch=1, n_intervals=N)
+        oracle.set_schedule(cfg["ev"][0], cfg["modes"][0]); oracle.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
+        runs = {}
+        for full in (True, False):
+            oracle.set_full_seeding(full)
+            try:
+                r = oracle.mpc_step(cfg["t0"][0], cfg["t0"][0] + cfg["horizon"], cfg["x0"][0])
+                runs[full] = (r, [oracle.node_lq(i) for i in range(len(r["t"]) - 1) if r["ev"][i] != 1])
+            finally:
+                oracle.set_full_seeding(False)
+        (ra, la), (rb, lb) = runs[True], runs[False]
+        assert np.array_equal(ra["x"], rb["x"]) and np.array_equal(ra["u"], rb["u"]) and np.array_equal(ra["perf"], rb["perf"]), name
+        for i, (a, b) in enumerate(zip(la, lb)):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (name, i, k)
