@@ -124,7 +124,23 @@
 #define ST_RICCATI_STRICT 1041
 /* MPC status words: 0 ok, < 0 failure (qmhip.h), > 0 warning bits — the solution is valid */
 #define QM_MPC_WARN_PIVOT 1
-#define ST_SIZE       1048  /* 1042..1047 reserved */
+/* hard-inequality interior-point solver (ST_SOLVER = 3): the rest of the `ipm` block (task.info:110-124; defaults [upstream ocs2_ipm ipm::Settings, recalled]
+   where a key is missing).  ST_IPM_MU above is initialBarrierParameter. */
+#define ST_IPM_MU_TARGET      1042 /* ipm.targetBarrierParameter                */
+#define ST_IPM_MU_LINEAR      1043 /* ipm.barrierLinearDecreaseFactor           */
+#define ST_IPM_MU_POWER       1044 /* ipm.barrierSuperlinearDecreasePower       */
+#define ST_IPM_RED_COST_TOL   1045 /* ipm.barrierReductionCostTol               */
+#define ST_IPM_RED_CON_TOL    1046 /* ipm.barrierReductionConstraintTol         */
+#define ST_IPM_FTB_MARGIN     1047 /* ipm.fractionToBoundaryMargin              */
+#define ST_IPM_PRIMAL_FOR_DUAL 1048 /* ipm.usePrimalStepSizeForDual (0 / 1)     */
+#define ST_IPM_SLACK_LB       1049 /* ipm.initialSlackLowerBound                */
+#define ST_IPM_DUAL_LB        1050 /* ipm.initialDualLowerBound                 */
+#define ST_IPM_SLACK_MARGIN   1051 /* ipm.initialSlackMarginRate                */
+#define ST_IPM_DUAL_MARGIN    1052 /* ipm.initialDualMarginRate                 */
+#define ST_SIZE       1056  /* 1053..1055 reserved */
+/* inequality rows of a shooting node under ST_SOLVER = 3, in this order: arm joint position boxes (joint k: lower z − lo, upper hi − z; rows 2k, 2k + 1; 12 rows), arm joint
+   velocity boxes (rows 12 + 2k, 13 + 2k; 12 rows), friction cone of contact c (row 24 + c; inactive — slack 1, dual 0, no contribution — while the foot swings) */
+#define QM_NH 28
 
 /* contact-mode ids: 8*LF + 4*RF + 2*LH + 1*RH (ocs2_legged_robot MotionPhaseDefinition) */
 #define QM_MODE_STANCE 15

@@ -34,7 +34,9 @@ ST = dict(Q=0, R=30, XINIT=930, MU_EE_POS=960, MU_EE_ORI=961, MU_EEF_POS=962, MU
           KD_BASE_H=1001, KP_BASE_LIN=1002, KD_BASE_LIN=1003, KP_BASE_ANG=1004, KD_BASE_ANG=1005,
           KP_ARM_J=1006, KD_ARM_J=1012, KP_EE_LIN=1018, KD_EE_LIN=1021, KP_EE_ANG=1024,
           KD_EE_ANG=1027, SOLVER=1030, DDP_MIN_STEP=1031, DDP_MAX_STEP=1032, DDP_PENALTY=1033,
-          IPM_DT=1034, IPM_ITER=1035, IPM_DELTA_TOL=1036, IPM_G_MAX=1037, IPM_G_MIN=1038, IPM_MU=1039, GRID_DT_MIN=1040, SIZE=1048)
+          IPM_DT=1034, IPM_ITER=1035, IPM_DELTA_TOL=1036, IPM_G_MAX=1037, IPM_G_MIN=1038, IPM_MU=1039, GRID_DT_MIN=1040, RICCATI_STRICT=1041,
+          IPM_MU_TARGET=1042, IPM_MU_LINEAR=1043, IPM_MU_POWER=1044, IPM_RED_COST_TOL=1045, IPM_RED_CON_TOL=1046, IPM_FTB_MARGIN=1047, IPM_PRIMAL_FOR_DUAL=1048,
+          IPM_SLACK_LB=1049, IPM_DUAL_LB=1050, IPM_SLACK_MARGIN=1051, IPM_DUAL_MARGIN=1052, SIZE=1056)
 
 FOOT_FRAMES = ["LF_FOOT", "RF_FOOT", "LH_FOOT", "RH_FOOT"]   # ModelSettings.h:38 (contact order)
 MODE_NAMES = {"FLY": 0, "RH": 1, "LH": 2, "LH_RH": 3, "RF": 4, "RF_RH": 5, "RF_LH": 6,
@@ -412,8 +414,16 @@ def build_settings(task_info_path, model_blob):
     s[ST['GRID_DT_MIN']] = 10.0 * 2.220446049250313e-16      # [upstream] timeDiscretizationWithEvents' default dt_min
     # `ipm` block (task.info:94-125, loaded at QMInterface.cpp:72, never instantiated): the multiple-shooting parameter set of solver 2
     for k, key, dflt in (('IPM_DT', 'ipm.dt', 0.01), ('IPM_ITER', 'ipm.ipmIteration', 10.0), ('IPM_DELTA_TOL', 'ipm.deltaTol', 1e-6), ('IPM_G_MAX', 'ipm.g_max', 1e6), ('IPM_G_MIN', 'ipm.g_min', 1e-6),
-                         ('IPM_MU', 'ipm.initialBarrierParameter', 1e-2)):
+                         ('IPM_MU', 'ipm.initialBarrierParameter', 1e-2), ('IPM_MU_TARGET', 'ipm.targetBarrierParameter', 1e-4), ('IPM_MU_LINEAR', 'ipm.barrierLinearDecreaseFactor', 0.2),
+                         ('IPM_MU_POWER', 'ipm.barrierSuperlinearDecreasePower', 1.5), ('IPM_RED_COST_TOL', 'ipm.barrierReductionCostTol', 1e-3), ('IPM_RED_CON_TOL', 'ipm.barrierReductionConstraintTol', 1e-3),
+                         ('IPM_FTB_MARGIN', 'ipm.fractionToBoundaryMargin', 0.995), ('IPM_SLACK_LB', 'ipm.initialSlackLowerBound', 1e-4), ('IPM_DUAL_LB', 'ipm.initialDualLowerBound', 1e-4),
+                         ('IPM_SLACK_MARGIN', 'ipm.initialSlackMarginRate', 1e-2), ('IPM_DUAL_MARGIN', 'ipm.initialDualMarginRate', 1e-2)):
         s[ST[k]] = gopt(key, dflt)
+    try:
+        v = info_get(t, 'ipm.usePrimalStepSizeForDual')
+    except (KeyError, TypeError):
+        v = ''
+    s[ST['IPM_PRIMAL_FOR_DUAL']] = 1.0 if v == '' else (1.0 if str(v) in ('true', '1') else 0.0)        # a boolean key (hard-inequality IPM, solver 3)
     return s
 
 

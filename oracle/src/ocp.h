@@ -355,7 +355,8 @@ inline void eeSoftCost(const Problem& P, double t, const Vec& x, double muPos, d
     for (int a = 0; a < 12; ++a) { (*gx)[var[a]] += mu[i] * g[i].v * g[i].d[a]; for (int b = 0; b < 12; ++b) (*Hxx)(var[a], var[b]) += mu[i] * g[i].d[a] * g[i].d[b]; }
   }
 }
-inline void intermediateCost(const Problem& P, double t, const Vec& x, const Vec& u, bool quad, CostQuad& c) {
+// softIneq = false: without the relaxed-barrier terms a6 / a7 (the hard-inequality interior-point solver carries the arm boxes and the friction cones as constraints, ipm.h)
+inline void intermediateCost(const Problem& P, double t, const Vec& x, const Vec& u, bool quad, CostQuad& c, bool softIneq = true) {
   const Model& M = *P.M; const double* st = M.st;
   bool fl[4]; modeToFlags(P.ms.modeAt(t), fl);
   c.f = 0.0;
@@ -366,7 +367,7 @@ inline void intermediateCost(const Problem& P, double t, const Vec& x, const Vec
   for (int i = 0; i < QM_NX; ++i) { c.f += 0.5 * st[ST_Q + i] * dx[i] * dx[i]; if (quad) { c.q[i] += st[ST_Q + i] * dx[i]; c.Q(i, i) += st[ST_Q + i]; } }
   for (int i = 0; i < QM_NU; ++i) { double s = 0; for (int j = 0; j < QM_NU; ++j) s += st[ST_R + 30 * i + j] * du[j]; c.f += 0.5 * du[i] * s; if (quad) { c.r[i] += s; for (int j = 0; j < QM_NU; ++j) c.R(i, j) += st[ST_R + 30 * i + j]; } }
   // a6: arm joint position / velocity soft box (QMInterface.cpp:177-259), offset term affects only the value
-  {
+  if (softIneq) {
     Barrier bp{st[ST_JPOS_MU], st[ST_JPOS_DELTA]}, bv{st[ST_JVEL_MU], st[ST_JVEL_DELTA]};
     for (int i = 0; i < 6; ++i) {
       const double lo = M.mb[MB_QLO + 12 + i], hi = M.mb[MB_QHI + 12 + i], z = x[24 + i];
@@ -378,7 +379,7 @@ inline void intermediateCost(const Problem& P, double t, const Vec& x, const Vec
     }
   }
   // a7: friction cone soft constraint per stance foot (QMInterface.cpp:344-358 -> [upstream FrictionConeConstraint])
-  {
+  if (softIneq) {
     Barrier bf{st[ST_FRIC_MU], st[ST_FRIC_DELTA]};
     const double muf = st[ST_FRIC_COEF], reg = st[ST_FRIC_REG], shift = st[ST_FRIC_SHIFT];
     for (int i = 0; i < 4; ++i) if (fl[i]) {

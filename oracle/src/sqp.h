@@ -52,7 +52,7 @@ static const double kLimitEps = 2.220446049250313e-16;     // numeric_traits::li
 // (friction cones / joint limits are soft costs, QMInterface.cpp:79-142) an interior-point iteration has no slack / dual variables and is the SQP step on these parameters
 enum class MsParam { Dt, Iterations, DeltaTol, GMax, GMin };
 inline double msParam(const double* st, MsParam p) {
-  const bool ipm = st[ST_SOLVER] == 2.0;
+  const bool ipm = st[ST_SOLVER] >= 2.0;      // 2: the SQP step on the `ipm` block's parameters; 3: the hard-inequality interior-point method (ipm.h)
   switch (p) {
     case MsParam::Dt: return ipm ? st[ST_IPM_DT] : st[ST_SQP_DT];
     case MsParam::Iterations: return ipm ? st[ST_IPM_ITER] : st[ST_SQP_ITER];
@@ -102,6 +102,8 @@ struct SqpResult {
   std::vector<Vec> dx, du; std::vector<NodeLQ> lq; NodeLQ terminal;
   Performance baseline, after; double alpha = 0; int lsTrials = 0; double armijo = 0; int status = 0;
   int warn = 0;                    // warning bits of a VALID solution: QM_MPC_WARN_PIVOT = some stage's Huu had non-positive pivots, zeroed (riccatiSolve)
+  // hard-inequality interior-point solver (ipm.h): slack / dual of every node's QM_NH inequality rows, their Newton directions, the barrier parameter and the step limits of the last iteration
+  std::vector<Vec> slack, dual, dslack, ddual; double barrier = 0.0, alphaPrimalMax = 1.0, alphaDualMax = 1.0, alphaDual = 0.0;
   double phaseMs[3] = {0, 0, 0};   // wall time of the last iteration: LQ approximation + projection, Riccati solve, line search (the timers ocs2's benchmark prints)
 };
 
@@ -115,7 +117,7 @@ inline Vec rk2Step(const Model& M, const Vec& x, const Vec& u, double dt) {
 }
 
 // K1: setupIntermediateNode
-inline void setupIntermediateNode(const Problem& P, double t, double dt, const Vec& x, const Vec& xn, const Vec& u, NodeLQ& n) {
+inline void setupIntermediateNode(const Problem& P, double t, double dt, const Vec& x, const Vec& xn, const Vec& u, NodeLQ& n, bool softIneq = true) {
   const Model& M = *P.M;
   Vec f1, f2; Mat A1, B1, A2, B2;
   flowMapLinear(M, x, u, f1, A1, B1);
@@ -128,7 +130,7 @@ inline void setupIntermediateNode(const Problem& P, double t, double dt, const V
     for (int j = 0; j < QM_NU; ++j) n.B(i, j) = 0.5 * dt * B1(i, j) + 0.5 * dt * (B2(i, j) + dt * A2B1(i, j));
     n.b[i] = x[i] + 0.5 * dt * f1[i] + 0.5 * dt * f2[i] - xn[i];
   }
-  CostQuad c; intermediateCost(P, t, x, u, true, c);
+  CostQuad c; intermediateCost(P, t, x, u, true, c, softIneq);
   n.c = c.f * dt; n.q = vscaled(c.q, dt); n.r = vscaled(c.r, dt); n.Q = scaled(c.Q, dt); n.R = scaled(c.R, dt); n.P = scaled(c.P, dt);
   equalityConstraints(P, t, x, u, true, n.e, n.C, n.D); n.nc = (int)n.e.size();
   n.dt = dt; n.event = 0;
@@ -248,6 +250,24 @@ inline bool riccatiSolve(SqpResult& R, const Vec& x0, const std::vector<Vec>& x,
 struct SqpResult;
 inline void evaluatePolicy(const SqpResult& R, const ModeSchedule& ms, double t, Vec& x, Vec& u, int& mode);
 
+// initializeStateInputTrajectories: cold start QMInitializer::compute (QMInitializer.cpp:33-41), warm start from `prev` (see sqpIteration); shared with ipm.h
+inline void initialGuess(const Problem& P, const SqpResult& R, const Vec& x0, const SqpResult* prev, std::vector<Vec>& x, std::vector<Vec>& u) {
+  const Model& M = *P.M; const int N = (int)R.grid.size() - 1;
+
+    const bool warm = prev && prev->grid.size() >= 2;
+    const double tend = warm ? prev->grid.back().t : 0.0;
+    x[0] = x0;
+    for (int i = 0; i < N; ++i) {
+      if (R.grid[i].ev == QM_EV_PRE) { u[i] = Vec(QM_NU, 0.0); x[i + 1] = x[i]; continue; }
+      const double time = intervalStart(R.grid[i]), nextTime = intervalEnd(R.grid[i + 1]);
+      if (warm && !(time > tend || nextTime > tend)) {
+        Vec xa, ua, xb, ub; int md; evaluatePolicy(*prev, P.ms, time, xa, ua, md); evaluatePolicy(*prev, P.ms, nextTime, xb, ub, md);
+        u[i] = ua; x[i + 1] = xb;
+      } else { bool fl[4]; modeToFlags(P.ms.modeAt(time), fl); u[i] = weightCompensatingInput(M, fl); x[i + 1] = x[i]; }
+    }
+}
+
+
 // one SQP iteration; initial guess: xInit/uInit if given, else warm start from `prev` (a previous primal solution, may be null /
 // empty -> cold start).  Warm start restates [upstream ocs2_sqp multiple_shooting::initializeStateInputTrajectories]: x_0 = x0; interval i
 // takes u_i = u_prev(intervalStart(i)) and x_{i+1} = x_prev(intervalEnd(i+1)) while the previous solution covers both times, the
@@ -261,19 +281,7 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
   // initializeStateInputTrajectories, cold start: QMInitializer::compute (QMInitializer.cpp:33-41)
   std::vector<Vec> x(N + 1), u(N);
   if (xInit) { x = *xInit; u = *uInit; }
-  else {
-    const bool warm = prev && prev->grid.size() >= 2;
-    const double tend = warm ? prev->grid.back().t : 0.0;
-    x[0] = x0;
-    for (int i = 0; i < N; ++i) {
-      if (R.grid[i].ev == QM_EV_PRE) { u[i] = Vec(QM_NU, 0.0); x[i + 1] = x[i]; continue; }
-      const double time = intervalStart(R.grid[i]), nextTime = intervalEnd(R.grid[i + 1]);
-      if (warm && !(time > tend || nextTime > tend)) {
-        Vec xa, ua, xb, ub; int md; evaluatePolicy(*prev, P.ms, time, xa, ua, md); evaluatePolicy(*prev, P.ms, nextTime, xb, ub, md);
-        u[i] = ua; x[i + 1] = xb;
-      } else { bool fl[4]; modeToFlags(P.ms.modeAt(time), fl); u[i] = weightCompensatingInput(M, fl); x[i + 1] = x[i]; }
-    }
-  }
+  else initialGuess(P, R, x0, prev, x, u);
   // ---- setupQuadraticSubproblem ----
   const auto tq0 = std::chrono::steady_clock::now();
   R.lq.assign(N, NodeLQ()); Performance base;

@@ -280,8 +280,12 @@ bool buildSettingsBlob(const std::string& taskInfo, const double* mb, double* st
   struct KVD { const char* key; int idx; double dflt; };
   const KVD opt[] = {{"ddp.lineSearch.minStepLength", ST_DDP_MIN_STEP, 0.05}, {"ddp.lineSearch.maxStepLength", ST_DDP_MAX_STEP, 1.0}, {"ddp.constraintPenaltyInitialValue", ST_DDP_PENALTY, 2.0},
                      {"ipm.dt", ST_IPM_DT, 0.01}, {"ipm.ipmIteration", ST_IPM_ITER, 10.0}, {"ipm.deltaTol", ST_IPM_DELTA_TOL, 1e-6}, {"ipm.g_max", ST_IPM_G_MAX, 1e6}, {"ipm.g_min", ST_IPM_G_MIN, 1e-6},
-                     {"ipm.initialBarrierParameter", ST_IPM_MU, 1e-2}};
+                     {"ipm.initialBarrierParameter", ST_IPM_MU, 1e-2}, {"ipm.targetBarrierParameter", ST_IPM_MU_TARGET, 1e-4}, {"ipm.barrierLinearDecreaseFactor", ST_IPM_MU_LINEAR, 0.2},
+                     {"ipm.barrierSuperlinearDecreasePower", ST_IPM_MU_POWER, 1.5}, {"ipm.barrierReductionCostTol", ST_IPM_RED_COST_TOL, 1e-3}, {"ipm.barrierReductionConstraintTol", ST_IPM_RED_CON_TOL, 1e-3},
+                     {"ipm.fractionToBoundaryMargin", ST_IPM_FTB_MARGIN, 0.995}, {"ipm.initialSlackLowerBound", ST_IPM_SLACK_LB, 1e-4}, {"ipm.initialDualLowerBound", ST_IPM_DUAL_LB, 1e-4},
+                     {"ipm.initialSlackMarginRate", ST_IPM_SLACK_MARGIN, 1e-2}, {"ipm.initialDualMarginRate", ST_IPM_DUAL_MARGIN, 1e-2}};
   for (const KVD& e : opt) { std::string ignored; if (!infoScalar(t, e.key, st[e.idx], ignored)) st[e.idx] = e.dflt; }
+  { st[ST_IPM_PRIMAL_FOR_DUAL] = 1.0; const INode* n = t.get("ipm.usePrimalStepSizeForDual"); if (n && !n->value.empty()) st[ST_IPM_PRIMAL_FOR_DUAL] = (n->value == "true" || n->value == "1") ? 1.0 : 0.0; }      // a boolean key
   if (!(st[ST_SQP_DT] > 0.0) || !(st[ST_SQP_DT] < 1.0e300)) { err = "INFO: sqp.dt must be a positive finite number"; return false; }   // K0 walks t0 + k dt up to the horizon
   // ipm.dt is validated where it is used: qmhip_set_setting(ST_SOLVER, 2) / (ST_IPM_DT, .) and K0's `sane` guard
   st[ST_GRID_DT_MIN] = QM_GRID_DT_MIN_UPSTREAM;         // [upstream] timeDiscretizationWithEvents' default dt_min = 10 * limitEpsilon
