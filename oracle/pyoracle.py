@@ -159,6 +159,32 @@ class Oracle:
         k = n.value
         return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf, alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h), warn=self.lib.qmo_last_warn(self.h))
 
+    def ipm_step(self, t0, tf, x0, mode="cold"):
+        """one iteration of the hard-inequality interior-point solver (oracle/src/ipm.h); mode: "cold", "warm" (initial guess from the previous solution) or
+        "iterate" (one more iteration on the last call's iterate, slack / dual / barrier kept).  Result dict as mpc_step + barrier, alpha_primal_max, alpha_dual_max, alpha_dual"""
+        x0 = np.ascontiguousarray(x0, float); n = C.c_int(0)
+        nt = np.zeros(self.MAXN); ne = np.zeros(self.MAXN, np.int32); nm = np.zeros(self.MAXN, np.int32)
+        xo = np.zeros((self.MAXN, 30)); uo = np.zeros((self.MAXN, 30)); perf = np.zeros(10)
+        rc = self.lib.qmo_ipm_step(self.h, C.c_int({"cold": 0, "warm": 1, "iterate": 2}[mode]), C.c_double(t0), C.c_double(tf), _p(x0), C.c_int(self.MAXN), C.byref(n), _p(nt), _pi(ne), _pi(nm), _p(xo), _p(uo), _p(perf))
+        if rc != 0:
+            raise RuntimeError("oracle ipm_step failed rc=%d" % rc)
+        k = n.value; info = np.zeros(5); self.lib.qmo_ipm_info(self.h, _p(info))
+        return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf, alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h),
+                    warn=self.lib.qmo_last_warn(self.h), barrier=info[0], alpha_primal_max=info[1], alpha_dual_max=info[2], alpha_dual=info[3])
+
+    def ipm_node(self, i):
+        """interval i of the last ipm_step: slack / dual after the step, directions, linearised inequality rows, dx / du, uncondensed cost blocks"""
+        z = lambda *s: np.zeros(s)
+        d = dict(slack=z(28), dual=z(28), dslack=z(28), ddual=z(28), h=z(28), Hx=z(28, 30), Hu=z(28, 30), on=np.zeros(28, np.int32), dx=z(30), du=z(30), Q=z(30, 30), R=z(30, 30), q=z(30), r=z(30))
+        rc = self.lib.qmo_ipm_node(self.h, C.c_int(i), _p(d["slack"]), _p(d["dual"]), _p(d["dslack"]), _p(d["ddual"]), _p(d["h"]), _p(d["Hx"]), _p(d["Hu"]), _pi(d["on"]), _p(d["dx"]), _p(d["du"]),
+                                   _p(d["Q"]), _p(d["R"]), _p(d["q"]), _p(d["r"]))
+        if rc != 0:
+            raise IndexError(i)
+        return d
+
+    def terminal_lq(self):
+        Q = np.zeros((30, 30)); q = np.zeros(30); self.lib.qmo_terminal_lq(self.h, _p(Q), _p(q)); return dict(Q=Q, q=q)
+
     def node_lq(self, i):
         z = lambda *s: np.zeros(s)
         d = dict(A=z(30, 30), B=z(30, 30), b=z(30), Q=z(30, 30), R=z(30, 30), P=z(30, 30), q=z(30), r=z(30), scal=z(4), C=z(16, 30), D=z(16, 30), e=z(16))

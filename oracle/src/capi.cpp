@@ -2,6 +2,7 @@
 // cpu_baseline leg, __graft_entry__.smoke()).  Nothing under qm_control_amd/ may link or load this.
 #include "sqp.h"
 #include "ilqr.h"
+#include "ipm.h"
 #include "wbc.h"
 #include "sim.h"
 #include <cstdio>
@@ -153,6 +154,41 @@ int qmo_ilqr_step(void* h, int warm, double t0, double tf, const double* x0, int
   perf[8] = R.alpha; perf[9] = R.armijo;
   return 0;
 }
+// hard-inequality interior-point iteration (ipm.h); mode 0: cold, 1: warm from the previous solution, 2: one more iteration on the iterate of the last call (slack / dual / barrier kept)
+static IpmDebug g_ipm_dbg;
+int qmo_ipm_step(void* h, int mode, double t0, double tf, const double* x0, int maxn, int* n_nodes, double* node_t, int* node_ev, int* node_mode, double* xs, double* us, double* perf) {
+  Oracle* o = (Oracle*)h; Vec x0v(x0, x0 + QM_NX);
+  try {
+    if (mode == 2) {
+      if (o->R.grid.size() < 2) return -3;
+      std::vector<Vec> xi = o->R.x, ui(o->R.u.begin(), o->R.u.end() - 1);
+      for (size_t i = 0; i < ui.size(); ++i) if (o->R.grid[i].ev == QM_EV_PRE) ui[i] = Vec(QM_NU, 0.0);
+      ipmIteration(o->P, t0, tf, x0v, &xi, &ui, o->R, nullptr, &g_ipm_dbg);
+    } else { SqpResult prev = o->R; o->R = SqpResult(); ipmIteration(o->P, t0, tf, x0v, nullptr, nullptr, o->R, mode == 1 ? &prev : nullptr, &g_ipm_dbg); }
+  } catch (const std::exception&) { return -2; }
+  const SqpResult& R = o->R; if (R.status != 0) return R.status; const int n = (int)R.grid.size(); if (n > maxn) return -1;
+  *n_nodes = n;
+  for (int i = 0; i < n; ++i) { node_t[i] = R.grid[i].t; node_ev[i] = R.grid[i].ev; node_mode[i] = R.mode[i]; std::memcpy(xs + QM_NX * i, R.x[i].data(), QM_NX * 8); std::memcpy(us + QM_NU * i, R.u[i].data(), QM_NU * 8); }
+  const Performance* pf[2] = {&R.baseline, &R.after};
+  for (int k = 0; k < 2; ++k) { perf[4 * k] = pf[k]->merit; perf[4 * k + 1] = pf[k]->cost; perf[4 * k + 2] = pf[k]->dynSSE; perf[4 * k + 3] = pf[k]->eqSSE; }
+  perf[8] = R.alpha; perf[9] = R.armijo;
+  return 0;
+}
+// info[5] = barrier parameter after the iteration, primal / dual step limits, dual step taken, barrier parameter the iteration ran on (slot 4 filled by the caller's bookkeeping: see pyoracle)
+void qmo_ipm_info(void* h, double* info) { const SqpResult& R = ((Oracle*)h)->R; info[0] = R.barrier; info[1] = R.alphaPrimalMax; info[2] = R.alphaDualMax; info[3] = R.alphaDual; }
+// node i of the last interior-point iteration: slack / dual AFTER the step, their directions, the linearised rows (value, Hx, Hu, active) the step was computed on, dx / du,
+// and the UNCONDENSED cost blocks (the dense KKT check of tests/test_ipm.py assembles the Newton system from these)
+int qmo_ipm_node(void* h, int i, double* slack, double* dual, double* dslack, double* ddual, double* hv, double* Hx, double* Hu, int* on, double* dx, double* du, double* Q, double* Rm, double* q, double* r) {
+  const SqpResult& R = ((Oracle*)h)->R; if (i < 0 || i >= (int)R.slack.size() || i >= (int)g_ipm_dbg.g.size()) return -1;
+  const IneqLin& g = g_ipm_dbg.g[i]; const NodeLQ& n = g_ipm_dbg.lqUncondensed[i];
+  for (int k = 0; k < QM_NH; ++k) { slack[k] = R.slack[i][k]; dual[k] = R.dual[i][k]; dslack[k] = R.dslack[i][k]; ddual[k] = R.ddual[i][k]; hv[k] = g.h[k]; on[k] = g.on[k] ? 1 : 0; }
+  if (g.Hx.a.size()) { std::memcpy(Hx, g.Hx.a.data(), QM_NH * QM_NX * 8); std::memcpy(Hu, g.Hu.a.data(), QM_NH * QM_NU * 8); } else { std::memset(Hx, 0, QM_NH * QM_NX * 8); std::memset(Hu, 0, QM_NH * QM_NU * 8); }
+  std::memcpy(dx, R.dx[i].data(), QM_NX * 8); std::memcpy(du, R.du[i].data(), QM_NU * 8);
+  if (n.Q.a.size()) { std::memcpy(Q, n.Q.a.data(), 900 * 8); std::memcpy(Rm, n.R.a.data(), 900 * 8); std::memcpy(q, n.q.data(), 240); std::memcpy(r, n.r.data(), 240); }
+  return 0;
+}
+// terminal node of the last iteration: Q_N, q_N (final end-effector soft constraint)
+void qmo_terminal_lq(void* h, double* Q, double* q) { const SqpResult& R = ((Oracle*)h)->R; std::memcpy(Q, R.terminal.Qp.a.data(), 900 * 8); std::memcpy(q, R.terminal.qp.data(), 240); }
 void qmo_eval_policy(void* h, double t, double* x, double* u, int* mode) {
   Oracle* o = (Oracle*)h; Vec xv, uv; int m; evaluatePolicy(o->R, o->P.ms, t, xv, uv, m);
   std::memcpy(x, xv.data(), QM_NX * 8); std::memcpy(u, uv.data(), QM_NU * 8); *mode = m;

@@ -1,0 +1,128 @@
+"""The hard-inequality interior-point solver (ST_SOLVER = 3; SURVEY.md section 8 (f) rank 4, task.info:94-125) — oracle/src/ipm.h pinned by an independent dense solve.
+The reference instantiates no IpmMpc and registers cones / joint limits as soft costs only (QMInterface.cpp:116-131), so there is no reference behaviour: PARITY UNPINNED
+by reference data; what pins the restatement here is mathematics — the step of one iteration must solve the primal-dual Newton system of the WHOLE horizon, assembled
+densely in numpy from the unprojected, uncondensed blocks (no condensing, no null-space projection, no Riccati recursion), and the iteration must converge to a point that
+satisfies the perturbed KKT conditions of the barrier problem."""
+import numpy as np
+import pytest
+from qm_control_amd import layout as L
+
+
+def _solver(oblobs, **settings):
+    import pyoracle
+    st = oblobs[1].copy(); st[L.ST_SOLVER] = 3.0
+    for k, v in settings.items(): st[getattr(L, k)] = v
+    return pyoracle.Oracle(oblobs[0], st), st
+
+
+def _problem(o, name, N):
+    from qm_control_amd import scenarios
+    cfg = scenarios.make_config(name, batch=1, n_intervals=N)
+    o.set_schedule(cfg["ev"][0], cfg["modes"][0]); o.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
+    return cfg["t0"][0], cfg["t0"][0] + cfg["horizon"], cfg["x0"][0]
+
+
+def dense_newton_step(o, r, x0, mu):
+    """unknowns per interval i: dx_i (30), du_i (30, regular intervals), ds_i, dlam_i (active rows), nu_i (30: multiplier of the dynamics row), eta_i (nc_i: equality rows);
+    + dx_N.  Stationarity of the Gauss-Newton Lagrangian, linearised dynamics / equalities / inequalities, linearised complementarity."""
+    n = len(r["t"]); N = n - 1
+    lq = [o.node_lq(i) for i in range(N)]; ip = [o.ipm_node(i) for i in range(N)]
+    term = o.terminal_lq() if hasattr(o, "terminal_lq") else None
+    off = {}; k = 0
+    def take(key, m):
+        nonlocal k
+        off[key] = (k, m); k += m
+    for i in range(N):
+        take(("x", i), 30)
+        if not lq[i]["event"]:
+            take(("u", i), 30); a = int(ip[i]["on"].sum()); take(("s", i), a); take(("l", i), a); take(("eta", i), lq[i]["nc"])
+        take(("nu", i), 30)
+    take(("x", N), 30); take(("nu0",), 30)
+    K = np.zeros((k, k)); g = np.zeros(k)
+    sl = lambda key: slice(off[key][0], off[key][0] + off[key][1])
+    row = 0
+    def eq(blocks, rhs):          # Σ blocks[key] @ z[key] = rhs  (rows appended)
+        nonlocal row
+        m = len(rhs)
+        for key, M in blocks: K[row:row + m, sl(key)] += M
+        g[row:row + m] = rhs; row += m
+    I30 = np.eye(30)
+    eq([(("x", 0), I30)], x0 - r["x_before"][0])                                           # dx_0 = x0 − x_0
+    for i in range(N):
+        q = lq[i]; p = ip[i]
+        if q["event"]:
+            eq([(("x", i + 1), I30), (("x", i), -I30)], q["b"]); continue
+        on = p["on"] == 1; Hx = p["Hx"][on]; Hu = p["Hu"][on]; s = p["s_before"][on]; lam = p["l_before"][on]; h = p["h"][on]; nc = q["nc"]
+        eq([(("x", i + 1), I30), (("x", i), -q["A"]), (("u", i), -q["B"])], q["b"])                                    # dynamics
+        eq([(("x", i), q["C"][:nc]), (("u", i), q["D"][:nc])], -q["e"][:nc])                                          # equalities
+        eq([(("x", i), Hx), (("u", i), Hu), (("s", i), -np.eye(on.sum()))], -(h - s))                                   # h + Hx dx + Hu du − (s + ds) = 0
+        eq([(("l", i), np.diag(s)), (("s", i), np.diag(lam))], mu - lam * s)                                            # S dlam + Lam ds = mu − lam ∘ s
+    # stationarity rows.  Multiplier convention: L = cost + Σ nu_iᵀ(A dx_i + B du_i + b − dx_{i+1}) + etaᵀ(C dx + D du + e) − (lam + dlam)ᵀ(...) ; nu0 pairs with the initial condition
+    for i in range(N):
+        q = lq[i]; p = ip[i]
+        prev_nu = ("nu", i - 1) if i > 0 else ("nu0",)
+        if q["event"]:
+            eq([(("nu", i), I30), (prev_nu, -I30)], np.zeros(30)); continue
+        on = p["on"] == 1; Hx = p["Hx"][on]; Hu = p["Hu"][on]; lam = p["l_before"][on]; nc = q["nc"]
+        eq([(("x", i), p["Q"]), (("nu", i), q["A"].T), (prev_nu, -I30), (("eta", i), q["C"][:nc].T), (("l", i), -Hx.T)], -(p["q"] - Hx.T @ lam))
+        eq([(("u", i), p["R"]), (("nu", i), q["B"].T), (("eta", i), q["D"][:nc].T), (("l", i), -Hu.T)], -(p["r"] - Hu.T @ lam))
+    eq([(("x", N), r["terminal_Q"]), (("nu", N - 1), -I30)], -r["terminal_q"])
+    assert row == k, (row, k)
+    z = np.linalg.solve(K, g)
+    return {key: z[sl(key)] for key in off}, lq, ip
+
+
+@pytest.mark.parametrize("name,N,mu", [("C2", 12, 1e-1), ("C5", 10, 1e-2)])
+def test_ipm_step_solves_the_dense_primal_dual_newton_system(oblobs, name, N, mu):
+    o, st = _solver(oblobs, ST_IPM_MU=mu)
+    t0, tf, x0 = _problem(o, name, N)
+    r = o.ipm_step(t0, tf, x0)
+    # the iterate the step was computed on: x_before = x_after − alpha dx (the oracle reports the iterate after the step)
+    n = len(r["t"]); nodes = [o.ipm_node(i) for i in range(n - 1)]
+    r["x_before"] = np.array([r["x"][i] - r["alpha"] * (nodes[i]["dx"] if i < n - 1 else 0.0) for i in range(n)])
+    tq = o.terminal_lq(); r["terminal_Q"], r["terminal_q"] = tq["Q"], tq["q"]
+    for p in nodes:
+        p["s_before"] = p["slack"] - r["alpha"] * p["dslack"]; p["l_before"] = p["dual"] - r["alpha_dual"] * p["ddual"]
+    _ipm_node = o.ipm_node; cache = {i: p for i, p in enumerate(nodes)}; o.ipm_node = lambda i: cache[i]
+    try:
+        z, lq, ip = dense_newton_step(o, r, x0, mu)
+    finally:
+        o.ipm_node = _ipm_node
+    worst = 0.0
+    for i in range(n - 1):
+        if lq[i]["event"]:
+            continue
+        on = ip[i]["on"] == 1
+        for key, val, scale in ((("x", i), ip[i]["dx"], 1.0), (("u", i), ip[i]["du"], 10.0), (("s", i), ip[i]["dslack"][on], 10.0), (("l", i), ip[i]["ddual"][on], 1e-2)):
+            err = np.abs(z[key] - val).max() / max(scale, np.abs(z[key]).max()); worst = max(worst, err)
+            assert err < 1e-7, (name, i, key[0], err)
+    assert r["alpha"] > 0.0 and 0.0 < r["alpha_primal_max"] <= 1.0 and 0.0 < r["alpha_dual_max"] <= 1.0
+
+
+def test_ipm_converges_to_the_perturbed_kkt_point_with_strictly_feasible_cones(oblobs):
+    """iterated on the trot problem with a tight filter (the shipped ipm.g_max = 10 tolerates constraint violations of that size): the iterates reach a point with
+    theta <= 1e-8, slack ∘ dual = mu on every active row (the barrier parameter has reached ipm.targetBarrierParameter), slack = h(x, u), and EVERY friction cone and arm box
+    holds strictly at every node of x*, u*."""
+    # friction coefficient 0.12 (shipped 0.3): the trot problem's acceleration demand (≈ 21 N of tangential force per stance foot at first) does not fit the cone, the constraint must bind
+    o, st = _solver(oblobs, ST_IPM_MU=1e-2, ST_IPM_G_MAX=1e-2, ST_IPM_PRIMAL_FOR_DUAL=1.0, ST_FRIC_COEF=0.12)
+    t0, tf, x0 = _problem(o, "C2", 20)
+    r = o.ipm_step(t0, tf, x0)
+    for it in range(80):          # (stopped AT the perturbed-KKT point: the Gauss-Newton iteration — no constraint curvature in the Hessian, as upstream — is only marginally
+        r = o.ipm_step(t0, tf, x0, mode="iterate")      # stable around a binding cone with this problem's tiny force weights and drifts away again over the next ~ 30 iterations)
+        if r["barrier"] == st[L.ST_IPM_MU_TARGET] and np.sqrt(r["perf"][6] + r["perf"][7]) < 1e-7:
+            break
+    assert r["barrier"] == st[L.ST_IPM_MU_TARGET]
+    theta = np.sqrt(r["perf"][6] + r["perf"][7]); assert theta < 1e-7, theta
+    muf, reg = st[L.ST_FRIC_COEF], st[L.ST_FRIC_REG]; n = len(r["t"]); tight = 0
+    for i in range(n - 1):
+        if r["ev"][i] == 1:
+            continue
+        p = o.ipm_node(i); on = p["on"] == 1; u = r["u"][i]; x = r["x"][i]
+        assert np.abs(p["slack"][on] * p["dual"][on] - r["barrier"]).max() < 1e-7
+        for c in range(4):
+            if (r["mode"][i] >> (3 - c)) & 1:
+                h = muf * u[3 * c + 2] - np.sqrt(u[3 * c] ** 2 + u[3 * c + 1] ** 2 + reg)
+                assert h > 0.0 and abs(h - p["slack"][24 + c]) < 1e-6, (i, c, h); tight += h < 0.1
+        lo, hi = oblobs[0][L.MB_QLO + 12:L.MB_QLO + 18], oblobs[0][L.MB_QHI + 12:L.MB_QHI + 18]
+        assert (x[24:30] > lo).all() and (x[24:30] < hi).all() and (u[24:30] > st[L.ST_JVEL_LO:L.ST_JVEL_LO + 6]).all() and (u[24:30] < st[L.ST_JVEL_HI:L.ST_JVEL_HI + 6]).all()
+    assert tight > 0          # some cone is ACTIVE at the solution (slack of the order of sqrt(mu)): the constraint is doing work
