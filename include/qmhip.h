@@ -74,10 +74,14 @@ int qmhip_wbc_gain_index(const char* reconfigure_name);
  *      (INTEGRATION.md section 3).  Callers treat status >= 0 as success.  -4 also reports: a non-positive pivot on a stage of POSITIVE duration, a pivot or a step that is
  *      not a finite number (e.g. a NaN in x0) — never a warning.
  *      Solver slot (qmhip_set_setting(ST_SOLVER, .)): 0 the SQP above; 1 a discrete iLQR on the `ddp` block (task.info:33-71); 2 the SAME multiple-shooting step as
- *      slot 0, run with the `ipm` block's parameters (task.info:94-125: ipm.dt / ipmIteration / deltaTol / g_max / g_min, ST_IPM_*).  Slot 2 is NOT an interior-point
- *      method: this OCP has no hard inequality constraints (QMInterface.cpp:79-142 registers friction cones and joint limits as soft costs), so an IpmMpc in the MPC_BASE
- *      slot would carry no slack / dual variables; a hard-friction-cone IPM is out of scope.  The reference loads both blocks (QMInterface.cpp:70-72) and
- *      instantiates neither solver. */
+ *      slot 0, run with the `ipm` block's parameters (task.info:94-125: ipm.dt / ipmIteration / deltaTol / g_max / g_min, ST_IPM_*) — kept for compatibility, NOT an
+ *      interior-point method; 3 (round 5) a primal-dual INTERIOR-POINT method with HARD inequality constraints: the friction cone of every stance foot and the arm joint
+ *      position / velocity boxes are constraints h(x, u) >= 0 (QM_NH = 28 rows per node, qmhip_layout.h) instead of relaxed-barrier costs — slack and dual per row,
+ *      condensing into the stage cost, fraction-to-the-boundary step limits, the filter line search on the barrier merit, barrier-parameter update, all on the rest of the
+ *      `ipm` block (ST_IPM_MU ... ST_IPM_DUAL_MARGIN); csrc/kernels/k_ipm.h, oracle/src/ipm.h.  The reference registers cones and limits as soft costs only
+ *      (QMInterface.cpp:79-142) and instantiates no IpmMpc (it loads both blocks, QMInterface.cpp:70-72): slot 3 solves a DIFFERENT problem than the controller's, has no
+ *      reference instance to match, and is checked against the oracle, which is pinned by a dense solve of the horizon's primal-dual Newton system (tests/test_ipm.py).
+ *      Slack / dual / per-instance {barrier, alphaP, alphaD, dual step} can be read through qmhip_debug_read("ipm_s" | "ipm_l" | "ipm_info", ...). */
 int qmhip_mpc_step(qmhip_ctx* ctx, int B, const double* t0, const double* x0 /*[B][30]*/,
                    int n_ref, const double* ref_t /*[B][n_ref]*/, const double* ref_x /*[B][n_ref][37]*/,
                    int n_events, const double* event_times /*[B][n_events]*/, const int32_t* modes /*[B][n_events+1]*/,

@@ -19,6 +19,7 @@
 #include "../kernels/k_riccati.h"
 #include "../kernels/k_ls.h"
 #include "../kernels/k_ilqr.h"
+#include "../kernels/k_ipm.h"
 
 struct QmMpcBuffers {
   int Bmax = 0, nmax = 0, nref = 0, nev = 0;
@@ -34,6 +35,8 @@ struct QmMpcBuffers {
   double* perf = nullptr; double* base_sum = nullptr; double* perf_sum = nullptr; double* step_info = nullptr;
   double* alpha = nullptr; int* done = nullptr; double* xs = nullptr; double* us = nullptr; double* out_perf = nullptr;
   double* xt = nullptr; double* ut = nullptr;   // iLQR trial rollouts [nmax][B][30] (allocated on first use)
+  // interior-point solver (slot 3, k_ipm.h; allocated on first use): slack / dual and their directions [nmax][B][QM_NH], step-limit ratios [nmax][B][2], per-instance info [B][IPM_INFO]
+  double* ipm_s = nullptr; double* ipm_l = nullptr; double* ipm_ds = nullptr; double* ipm_dl = nullptr; double* ipm_ratio = nullptr; double* ipm_info = nullptr;
   // grid of the solve that produced (xs, us): the warm start of the next solve interpolates on it
   int* prev_n = nullptr; double* prev_t = nullptr; int* prev_ev = nullptr;
   // line search: instances still searching after trial t (device counters + their host-visible copy)
@@ -62,10 +65,11 @@ struct QmMpcPipeline {
   int ls_trials_run = 0;
   int riccati_skip = 0;   // profiling only
   int lq_prof = 0;        // profiling only
-  int solver = 0;         // 0: multiple-shooting SQP (the reference's SqpMpc), 1: discrete iLQR, 2: the SQP path run on the `ipm` block's parameters (not an interior-point method)
+  int solver = 0;         // 0: multiple-shooting SQP (the reference's SqpMpc), 1: discrete iLQR, 2: the SQP path run on the `ipm` block's parameters (not an interior-point method), 3: interior-point method with hard cones / boxes (k_ipm.h)
                           // (no hard inequality rows in this OCP: include/qmhip_layout.h, ST_IPM_*); settings slot ST_SOLVER
   bool r_blocks = false;           // the input weight R of the settings blob is block diagonal (k_ls.h): the structured instance of the trial-evaluation kernel runs; kept current by note_settings()
   bool speculative_apply = true;   // tests only: false = the first trial's apply waits for the host's decision like every later one (A/B of the invariant below)
+  bool ipm_fresh = true;  // interior-point solver: the next iteration is the first of its solve (K0 ran): slack / dual / barrier parameter are initialised at the initial iterate
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
   bool ncap_pending = false;   // K0 has been launched and its count not been read yet
@@ -97,7 +101,7 @@ struct QmMpcPipeline {
   void note_settings(const double* st_host) { r_blocks = qm_r_is_block_diagonal(st_host); }      // after every change of the settings blob (create, qmhip_set_setting)
   void release() {
     void* ps[] = {d.mb, d.st, d.t0, d.x0, d.ref_t, d.ref_x, d.ev, d.modes, d.n_nodes, d.node_t, d.node_ts, d.node_dt, d.node_ev, d.node_mode, d.zvel, d.zpos, d.xref, d.eeref, d.status,
-                  d.x, d.u, d.dx, d.du, d.xt, d.ut, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev, d.open_cnt, d.tickets, d.ncap_dev};
+                  d.x, d.u, d.dx, d.du, d.xt, d.ut, d.ipm_s, d.ipm_l, d.ipm_ds, d.ipm_dl, d.ipm_ratio, d.ipm_info, d.stage, d.lqdbg, d.kin, d.perf, d.base_sum, d.perf_sum, d.step_info, d.alpha, d.done, d.xs, d.us, d.out_perf, d.prev_n, d.prev_t, d.prev_ev, d.open_cnt, d.tickets, d.ncap_dev};
     for (void* p : ps) if (p) bk.free(p);
     if (d.host_open) bk.free_mapped((void*)d.host_open);
     if (d.host_ncap) bk.free_mapped((void*)d.host_ncap);
@@ -114,7 +118,7 @@ struct QmMpcPipeline {
   QmLsArgs ls_args(int B) {
     QmLsArgs a; a.mb = d.mb; a.st = d.st; a.B = B; a.nmax = d.nmax; a.n_nodes = d.n_nodes; a.node_ts = d.node_ts; a.node_dt = d.node_dt; a.node_ev = d.node_ev; a.node_mode = d.node_mode;
     a.zvel = d.zvel; a.zpos = d.zpos; a.xref = d.xref; a.eeref = d.eeref; a.x0 = d.x0; a.x = d.x; a.u = d.u; a.dx = d.dx; a.du = d.du; a.alpha = d.alpha; a.done = d.done;
-    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.with_alpha = 0; a.open_cnt = d.open_cnt; a.tickets = d.tickets; a.host_open = (volatile int*)d.host_open_dev; a.xt = nullptr; a.ut = nullptr; a.ilqr = 0;
+    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.with_alpha = 0; a.open_cnt = d.open_cnt; a.tickets = d.tickets; a.host_open = (volatile int*)d.host_open_dev; a.xt = nullptr; a.ut = nullptr; a.ilqr = 0; a.ipm_s = nullptr; a.ipm_ds = nullptr; a.ipm_info = nullptr;
     return a;
   }
 
@@ -132,6 +136,7 @@ struct QmMpcPipeline {
     g.warm = warm ? 1 : 0; g.prev_n = d.prev_n; g.prev_t = d.prev_t; g.prev_ev = d.prev_ev; g.prev_xs = d.xs; g.prev_us = d.us;
     bk.launch(qm_grid_kernel, (B + 63) / 64, 64, 0, g);
     bk.launch(qm_grid_nodes_kernel, (d.nmax * B + 63) / 64, 64, 0, g);
+    ipm_fresh = true;
   }
   // closed loop with a perfect-tracking plant: t0 += dt, x0 <- policy state at the new t0 (uses the grid / primal solution of the last solve)
   void advance(int B, double dt) {
@@ -141,7 +146,16 @@ struct QmMpcPipeline {
   // one SQP iteration on the current iterate (x,u); max_trials bounds the line search (14 reaches alpha_min).  `last`: no further iteration of this solve
   // follows, so the accepted step only has to reach the primal solution (xs, us), not the iterate (x, u) — the next solve starts from xs / us or cold
   void sqp_iteration(int B, int max_trials = 14, bool last = false) {
-    const bool ilqr = solver == 1;
+    const bool ilqr = solver == 1, ipm = solver == 3;
+    QmIpmArgs ia;
+    if (ipm) {
+      const size_t NBm = (size_t)d.nmax * d.Bmax;
+      if (!d.ipm_s) { d.ipm_s = A<double>(NBm * QM_NH); d.ipm_l = A<double>(NBm * QM_NH); d.ipm_ds = A<double>(NBm * QM_NH); d.ipm_dl = A<double>(NBm * QM_NH); d.ipm_ratio = A<double>(NBm * 2); d.ipm_info = A<double>((size_t)d.Bmax * IPM_INFO); }
+      ia.mb = d.mb; ia.st = d.st; ia.B = B; ia.nmax = d.nmax; ia.n_nodes = d.n_nodes; ia.node_ev = d.node_ev; ia.node_mode = d.node_mode; ia.node_dt = d.node_dt; ia.x = d.x; ia.u = d.u; ia.dx = d.dx; ia.du = d.du;
+      ia.s = d.ipm_s; ia.lam = d.ipm_l; ia.ds = d.ipm_ds; ia.dlam = d.ipm_dl; ia.ratio = d.ipm_ratio; ia.info = d.ipm_info; ia.alpha = d.alpha; ia.done = d.done; ia.out_perf = d.out_perf;
+      if (ipm_fresh) bk.launch(qm_ipm_init_kernel, (d.nmax * B + 63) / 64, 64, 0, ia);      // slack / dual at the initial iterate, mu = ipm.initialBarrierParameter (every solve starts over: k_ipm.h)
+      ipm_fresh = false;
+    }
     if (ilqr && !d.xt) { d.xt = A<double>((size_t)d.nmax * d.Bmax * 30); d.ut = A<double>((size_t)d.nmax * d.Bmax * 30); }
     QmRolloutArgs ro; ro.mb = d.mb; ro.st = d.st; ro.B = B; ro.nmax = d.nmax; ro.mode = 0; ro.trial = 0; ro.n_nodes = d.n_nodes; ro.node_dt = d.node_dt; ro.node_ev = d.node_ev; ro.x0 = d.x0;
     ro.x = d.x; ro.u = d.u; ro.stage = d.stage; ro.alpha = d.alpha; ro.done = d.done; ro.xt = d.xt; ro.ut = d.ut;
@@ -152,21 +166,26 @@ struct QmMpcPipeline {
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof; q.ncap = ncap;
+    q.ipm_s = d.ipm_s; q.ipm_l = d.ipm_l; q.ipm_info = d.ipm_info;
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, LQ_KIN_LDS_BYTES, q);
     if (before_lq) before_lq();
-    if (d.lqdbg || lq_prof) bk.launch(qm_lq_dbg_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // the instance with debug records / phase cycle stamps (parity tests, profiling)
+    if (ipm) bk.launch(qm_lq_ipm_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);      // the interior-point instance: condensed inequality rows instead of the soft barrier costs
+    else if (d.lqdbg || lq_prof) bk.launch(qm_lq_dbg_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // the instance with debug records / phase cycle stamps (parity tests, profiling)
     else { bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);      // one wavefront per node: the nodes with m <= 16 reduced inputs (any gait phase with a swing leg) ...
            if (has_m18) bk.launch(qm_lq_m18_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q); }  // ... and the stance nodes (m = 18): two instances of one body, three waves per SIMD each (k_lq.h)
     QmLsArgs l = ls_args(B); if (ilqr) { l.xt = d.xt; l.ut = d.ut; l.ilqr = 1; }
+    if (ipm) { l.ipm_s = d.ipm_s; l.ipm_ds = d.ipm_ds; l.ipm_info = d.ipm_info; }
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;
     r.perf = d.perf; r.base_sum = d.base_sum; r.alpha = d.alpha; r.done = d.done; r.out_perf = d.out_perf; r.open_cnt = d.open_cnt; r.tickets = d.tickets;   // baseline merit + arming of the line search
     if (riccati_skip) bk.launch(qm_riccati_prof_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // instrumented instance: phase skip bits, in-kernel cycle counters (profiling / parity tests only)
     else bk.launch(qm_riccati_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // one wavefront per instance
+    if (ipm) { bk.launch(qm_ipm_dir_kernel, (d.nmax * B + 63) / 64, 64, 0, ia); bk.launch(qm_ipm_alpha_kernel, B, 64, 0, ia); }      // slack / dual directions, fraction to the boundary: the line search starts at alphaP
     ls_trials_run = 0;
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;
       if (ilqr) { ro.mode = 1; ro.trial = t; bk.launch(qm_ilqr_rollout_kernel, B, 64, 0, ro); }      // nonlinear rollout with feedback at the instance's step length
-      if (r_blocks) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
+      if (ipm) bk.launch(qm_ls_eval_ipm_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
+      else if (r_blocks) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       else bk.launch(qm_ls_eval_dense_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       d.host_open[t] = -1;                                 // armed: the launch's last block overwrites it with the count of the instances still searching
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching
@@ -184,6 +203,7 @@ struct QmMpcPipeline {
     }
     if (ls_trials_run != 1 || !speculative_apply) bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
     if (!last) bk.launch(qm_ls_commit_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
+    if (ipm) { bk.launch(qm_ipm_commit_kernel, (int)(((size_t)d.nmax * B * QM_NH + 255) / 256), 256, 0, ia); bk.launch(qm_ipm_barrier_kernel, (B + 63) / 64, 64, 0, ia); }      // accepted slack / dual step, barrier update
     solved_B = B;
   }
 };

@@ -231,8 +231,8 @@ int qmhip_wbc_gain_index(const char* name) {
 int qmhip_set_setting(qmhip_ctx* c, int idx, double v) { QM_GUARD(c);
   if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
   if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number, the grid's minimum step a non-negative one, ST_RICCATI_STRICT 0 or 1"); return QMHIP_ERR_ARG; }
-  if (idx == ST_SOLVER && v == 2.0 && !setting_ok(ST_IPM_DT, c->st[ST_IPM_DT])) { c->fail("qmhip_set_setting: solver 2 needs a positive finite ipm.dt"); return QMHIP_ERR_ARG; }
-  if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR) or 2 (the SQP step on the `ipm` block's parameters)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
+  if (idx == ST_SOLVER && v >= 2.0 && !setting_ok(ST_IPM_DT, c->st[ST_IPM_DT])) { c->fail("qmhip_set_setting: solvers 2 / 3 need a positive finite ipm.dt"); return QMHIP_ERR_ARG; }
+  if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR), 2 (the SQP step on the `ipm` block's parameters) or 3 (interior-point method with hard friction cones / arm boxes)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
   hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); c->mpc.note_settings(c->st); return c->hipstate();
 }
 
@@ -556,7 +556,7 @@ int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) { 
 #define F(n) if (!strcmp(name, #n)) p = d.n;
   if (c->wbc_only) { p = c->wbc.buffer(name); if (!p) { c->fail("qmhip_debug_read: a WBC-only context only has the wbc_* buffers"); return QMHIP_ERR_ARG; } c->bk.to_host(dst, p, bytes); return c->hipstate(); }
   if (!strcmp(name, "sim_rbd")) p = c->sim.s.rbd; if (!strcmp(name, "sim_cmd")) p = c->sim.s.cmd;
-  F(lqdbg) F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
+  F(lqdbg) F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(perf) F(base_sum) F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0) F(ipm_s) F(ipm_l) F(ipm_ds) F(ipm_dl) F(ipm_info)
 #undef F
   if (!p) p = c->wbc.buffer(name);
   if (!p) { c->fail(std::string("qmhip_debug_read: unknown buffer ") + name); return QMHIP_ERR_ARG; }

@@ -47,6 +47,8 @@ struct QmLqArgs {
   double* kin;               // [nmax][B][KR_SIZE] kin records (K1a -> K1b)
   int prof;                  // profiling only: thread 0 leaves phase cycle stamps in the (unused) SR_K field of the record
   int ncap;                  // K1b: nodes per instance covered by the launch (the batch's largest node count, <= nmax)
+  // interior-point instances only (k_ipm.h): slack / dual of the node's QM_NH inequality rows [nmax][B][QM_NH], barrier parameter per instance info[b * 8]
+  const double* ipm_s; const double* ipm_l; const double* ipm_info;
 };
 
 // debug record (unprojected LQ): A(900) B(900) b(30) Q(900) R(900) q(30) r(30) C(16x30) D(16x30) e(16) c nc
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
 
 // ---- K1b: one wavefront per node ----
 // DBG: the instance that also writes the debug records (a.dbg) and the phase cycle stamps (a.prof) — parity tests and profiling; the product instance has neither branch
-template <bool DBG, int MT>
+template <bool DBG, int MT, bool IPM = false>
 __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   if (!DBG) { a.dbg = nullptr; a.prof = 0; }
   extern __shared__ double qm_smem[];
@@ -663,6 +665,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   qm_wave_sync();
   if (l < 30) cost += 0.5 * S[LW_V_DU + l] * S[LW_V_RV + l];
   qm_wave_sync();
+  double ipm_res = 0.0;                                                  // interior-point instance: this lane's (h − s)² terms
   // arm soft box (a6), joint-velocity box, friction cone barrier (a7).  All three are "relaxed barrier of h" evaluations: ONE branch-free
   // body serves lanes 0..11 (variable part of the boxes: lane < 6 position of arm joint l, else velocity), lanes 32..43 (the boxes' constant
   // offsets b(−lo) + b(hi): same code, other arguments) and lanes 16..19 (friction cone of contact l − 16); idle lanes evaluate h = 1.
@@ -675,18 +678,33 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     const double mu = fric ? st[ST_FRIC_MU] : (pos ? st[ST_JPOS_MU] : st[ST_JVEL_MU]), de = fric ? st[ST_FRIC_DELTA] : (pos ? st[ST_JPOS_DELTA] : st[ST_JVEL_DELTA]);
     const double lo = pos ? mb[MB_QLO + 12 + k] : st[ST_JVEL_LO + k], hi = pos ? mb[MB_QHI + 12 + k] : st[ST_JVEL_HI + k], z = pos ? X[24 + k] : U[24 + k];
     const double h1 = boxv ? z - lo : (boxc ? -lo : (fon ? muf * Fz - Tn : 1.0)), h2 = boxv ? hi - z : (boxc ? hi : 1.0);
-    const double v1 = barrier_val(mu, de, h1), v2 = barrier_val(mu, de, h2);
-    double p1, p2, q1, q2; barrier_d12(mu, de, h1, p1, p2); barrier_d12(mu, de, h2, q1, q2);
-    cost += boxv ? v1 + v2 : (boxc ? -(v1 + v2) : (fon ? v1 : 0.0));
+    double v1, v2, p1, p2, q1, q2;
+    if (!IPM) { v1 = barrier_val(mu, de, h1); v2 = barrier_val(mu, de, h2); barrier_d12(mu, de, h1, p1, p2); barrier_d12(mu, de, h2, q1, q2); }
+    else {
+      // interior-point instance (k_ipm.h): rows r1 / r2 of this lane (arm joint k: position rows 2k, 2k + 1, velocity rows 12 + 2k, 13 + 2k; contact: row 24 + kf) carry a slack s and a
+      // dual lam.  CONDENSING puts  lam / s  where the soft cost has its second barrier derivative and  (lam h − mu_b) / s − lam  where it has the first ([upstream
+      // ipm::condenseIneqConstraints]); no constraint curvature, no Hessian shift.  Node merit −mu_b ln s, node constraint term (h − s)² (both summed over the wave below).
+      const bool act = boxv || fon; const int r1 = boxv ? (pos ? 2 * k : 12 + 2 * k) : (24 + kf);
+      const double mub = a.ipm_info[b * 8];
+      const double s1 = act ? a.ipm_s[(size_t)nb * QM_NH + r1] : 1.0, l1 = act ? a.ipm_l[(size_t)nb * QM_NH + r1] : 0.0;
+      const double s2 = boxv ? a.ipm_s[(size_t)nb * QM_NH + r1 + 1] : 1.0, l2 = boxv ? a.ipm_l[(size_t)nb * QM_NH + r1 + 1] : 0.0;
+      // (the condensed rows are NOT weighted by the interval length, the cost blocks they join are multiplied by dt below: hence the 1 / dt)
+      const double i1 = 1.0 / s1, i2 = 1.0 / s2, idt = 1.0 / dt;
+      p2 = l1 * i1 * idt; p1 = ((l1 * h1 - mub) * i1 - l1) * idt; q2 = l2 * i2 * idt; q1 = ((l2 * h2 - mub) * i2 - l2) * idt;
+      if (!act) { p1 = 0.0; p2 = 0.0; } if (!boxv) { q1 = 0.0; q2 = 0.0; }
+      v1 = act ? -mub * log(s1) * idt : 0.0; v2 = boxv ? -mub * log(s2) * idt : 0.0;
+      ipm_res = (act ? (h1 - s1) * (h1 - s1) : 0.0) + (boxv ? (h2 - s2) * (h2 - s2) : 0.0);
+    }
+    cost += IPM ? (v1 + v2) : (boxv ? v1 + v2 : (boxc ? -(v1 + v2) : (fon ? v1 : 0.0)));
     if (boxv) { const double g1 = p1 - q1, g2 = p2 + q2; if (pos) { S[LW_V_QV + 24 + k] += g1; QD[24 + k] += g2; } else { S[LW_V_RV + 24 + k] += g1; RD[24 + k] += g2; } }
     else if (fric) {                                                     // one lane per contact (disjoint 3x3 blocks)
       double* fr = FR + 16 * kf; double ds = 0.0;
       for (int q = 0; q < 13; ++q) fr[q] = 0.0;
       if (fon) {
-        const double shift = st[ST_FRIC_SHIFT], iTn = qm_frcp(Tn), iT3 = iTn * iTn * iTn;
+        const double shift = IPM ? 0.0 : st[ST_FRIC_SHIFT], iTn = IPM ? 1.0 / Tn : qm_frcp(Tn), iT3 = iTn * iTn * iTn;
         const double dh[3] = {-Fx * iTn, -Fy * iTn, muf};
         const double ddh[9] = {-(Fy * Fy + reg) * iT3, Fx * Fy * iT3, 0.0, Fx * Fy * iT3, -(Fx * Fx + reg) * iT3, 0.0, 0.0, 0.0, 0.0};
-        for (int r = 0; r < 3; ++r) { S[LW_V_RV + 3 * kf + r] += p1 * dh[r]; for (int q = 0; q < 3; ++q) fr[3 * r + q] = p2 * dh[r] * dh[q] + p1 * ddh[3 * r + q]; }
+        for (int r = 0; r < 3; ++r) { S[LW_V_RV + 3 * kf + r] += p1 * dh[r]; for (int q = 0; q < 3; ++q) fr[3 * r + q] = p2 * dh[r] * dh[q] + (IPM ? 0.0 : p1 * ddh[3 * r + q]); }
         ds = p1 * (-shift);
       }
       fr[12] = ds;
@@ -712,7 +730,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
       }
   if (l < 30) S[LW_V_RV + l] *= dt;
   const double ctot = qm_wave_sum(cost) * dt;
-  if (l == 0) { a.perf[nb * PF_SIZE] = ctot; a.perf[nb * PF_SIZE + 1] = dt * b2; a.perf[nb * PF_SIZE + 2] = dt * eq2; }
+  const double ineq2 = IPM ? qm_wave_sum(ipm_res) : 0.0;
+  if (l == 0) { a.perf[nb * PF_SIZE] = ctot; a.perf[nb * PF_SIZE + 1] = dt * b2; a.perf[nb * PF_SIZE + 2] = dt * (eq2 + ineq2); }
   // keep Pu safe in registers?  It stays in the tile: the EE term uses its own small staging area (K2 is dead by now)
   double* JT = K2;                                                      // [6][32] J rows, reuse of the stage-2 kin record
   qm_wave_sync();
@@ -787,4 +806,5 @@ __device__ __forceinline__ int qm_lq_node_mt(const QmLqArgs& a) {
 #endif
 __global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<false, 1>(a); }
 __global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_m18_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 2) qm_lq_body<false, 2>(a); }
+__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_ipm_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<false, 1, true>(a); else qm_lq_body<false, 2, true>(a); }      // interior-point instance (solver 3, k_ipm.h)
 __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_dbg_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<true, 1>(a); else qm_lq_body<true, 2>(a); }

@@ -9,6 +9,7 @@
 //                        (u at PreEvent nodes copied from the previous node, last u repeated)
 #pragma once
 #include "qm_dev_kin.h"
+#include "k_ipm.h"
 
 struct QmLsArgs {
   const double* mb; const double* st;
@@ -33,6 +34,8 @@ struct QmLsArgs {
   // discrete iLQR (k_ilqr.h): the trial trajectory is a nonlinear ROLLOUT held in xt / ut (null for the SQP, whose trial point is x + alpha dx, u + alpha du);
   // merit = cost + rho sqrt(eqSSE), accepted when merit(a) < merit(0) + 1e-4 a armijo, a halved down to ddp.lineSearch.minStepLength
   const double* xt; const double* ut; int ilqr;
+  // interior-point solver (k_ipm.h): slack and its direction [nmax][B][QM_NH], per-instance info (barrier parameter at [b * IPM_INFO]); null otherwise
+  const double* ipm_s; const double* ipm_ds; const double* ipm_info;
 };
 #define QM_LS_MAX_TRIALS 16
 #define LS_EVAL_LDS_BYTES ((64 * 31 + 64) * 8)      /* one 31-double row per thread + the wave's 64 step lengths: 16 KB per wave, eight waves per CU */
@@ -69,7 +72,8 @@ __device__ __forceinline__ double node_cost_value(const double* mb, const double
 // and picks the instance.  The structured product adds the same non-zero terms in the same order as the dense one (an exact zero contributes nothing): bit-identical, 54
 // instead of 900 multiply-adds and table entries per node.
 // ctrack: the tracking term  sum_i 1/2 Q_i (x_i − xref_i)^2  summed in index order by the caller (the reference rows come in with the wave's cooperative loads)
-template <bool RB>
+// IPM: without the relaxed-barrier terms a6 / a7 (the interior-point solver carries the arm boxes and the friction cones as constraints)
+template <bool RB, bool IPM = false>
 __device__ __forceinline__ double node_cost_value_xu(const double* mb, const double* st, const double* x, const double* u, int mode, double ctrack) {
   double c = ctrack;
   int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
@@ -87,6 +91,7 @@ __device__ __forceinline__ double node_cost_value_xu(const double* mb, const dou
     _Pragma("unroll") for (int i = 0; i < 30; ++i) { double s = 0.0; _Pragma("unroll") for (int j = 0; j < 30; ++j) s += st[ST_R + 30 * i + j] * du[j]; c += 0.5 * du[i] * s; }
   }
 #undef QM_DU
+  if (IPM) return c;
   __builtin_amdgcn_sched_barrier(0);
   _Pragma("unroll") for (int i = 0; i < 6; ++i) {
     const double lo = mb[MB_QLO + 12 + i], hi = mb[MB_QHI + 12 + i], z = x[24 + i], mu = st[ST_JPOS_MU], de = st[ST_JPOS_DELTA];
@@ -138,7 +143,7 @@ __device__ __forceinline__ void ls_rows_in(double* tile, const double* base, con
 }
 // One THREAD per (instance, node), the wave's inputs moved together (ls_rows_in).  No thread leaves before the last cooperative load: a thread without work (its
 // instance has finished the search, a row behind the instance's last node) only helps to move data; the whole wave leaves at once when none of its threads has work.
-template <bool RB> __global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel_t(QmLsArgs a) {
+template <bool RB, bool IPM = false> __global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel_t(QmLsArgs a) {
   const int l = threadIdx.x & 63;
   const size_t g0 = (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
   size_t g = g0 + l; const bool inrange = g < nrows; if (!inrange) g = nrows - 1;
@@ -167,12 +172,19 @@ template <bool RB> __global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel_t(
   // by the equality residual and the flow map's momentum sums — the full workspace K[196] never exists.  A zero-length interval contributes neither cost nor
   // constraint residual and needs no second Heun stage; the guards also split this straight-line kernel into basic blocks, which bounds the scheduler's live ranges.
   double cost = 0.0, eq = 0.0;
-  if (reg && dt > 0.0) cost = node_cost_value_xu<RB>(mb, st, x, u, mode, ctrack);
+  if (reg && dt > 0.0) cost = node_cost_value_xu<RB, IPM>(mb, st, x, u, mode, ctrack);
   kin_base<true>(mb, x, K);
   if (active && (term || (reg && dt > 0.0))) {            // end-effector pose term: the intermediate soft constraint, or the final one at the terminal node (its only term)
     kin_arm<true>(mb, x, K); double g6[6], qee[4]; ee_error(K, a.eeref + nb * 7, a.eeref + nb * 7 + 3, qee, g6);
     const double mp = term ? st[ST_MU_EEF_POS] : st[ST_MU_EE_POS], mo = term ? st[ST_MU_EEF_ORI] : st[ST_MU_EE_ORI];
     for (int r = 0; r < 6; ++r) cost += 0.5 * (r < 3 ? mp : mo) * g6[r] * g6[r]; }
+  double ipm_cost = 0.0, ipm_res = 0.0;                  // interior-point instance: −mu Σ ln s and Σ (h − s)² of the trial point and its trial slacks s + alpha ds (not × dt / × dt)
+  if (IPM && reg) {
+    const double mub = a.ipm_info[b * IPM_INFO];
+    for (int r = 0; r < QM_NH; ++r) if (ipm_row_on(r, mode)) {
+      const double sr = a.ipm_s[(size_t)nb * QM_NH + r] + al * a.ipm_ds[(size_t)nb * QM_NH + r], h = ipm_row_value(mb, st, x, u, r);
+      ipm_cost -= mub * log(sr); ipm_res += (h - sr) * (h - sr); }
+  }
   if (reg) {
     const double mass = mb[MB_ROBOTMASS], im = 1.0 / mass, gain = st[ST_POS_ERR_GAIN];
     double f1[12], f2[12];
@@ -226,11 +238,12 @@ template <bool RB> __global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel_t(
   double* pf = a.perf + (size_t)nb * PF_SIZE;
   if (term) { pf[0] = cost; pf[1] = 0.0; pf[2] = 0.0; }
   else if (pre) { pf[0] = 0.0; pf[1] = s; pf[2] = 0.0; }
-  else { pf[0] = cost * dt; pf[1] = dt * s; pf[2] = dt * eq; }
+  else { pf[0] = cost * dt + ipm_cost; pf[1] = dt * s; pf[2] = dt * (eq + ipm_res); }
 }
 
 #define qm_ls_eval_kernel qm_ls_eval_kernel_t<true>            /* R block diagonal (the shipped task file) */
 #define qm_ls_eval_dense_kernel qm_ls_eval_kernel_t<false>     /* any R */
+#define qm_ls_eval_ipm_kernel qm_ls_eval_kernel_t<false, true>  /* interior-point solver (slot 3) */
 // exact zero pattern of the input weight: diag(12) + four 3 x 3 leg blocks + diag(6)  (host side: which instance of qm_ls_eval to launch)
 inline bool qm_r_is_block_diagonal(const double* st) {
   for (int i = 0; i < 30; ++i) for (int j = 0; j < 30; ++j) {

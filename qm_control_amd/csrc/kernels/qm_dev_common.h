@@ -314,7 +314,7 @@ __device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* 
 // (the iLQR shares the SQP's grid).  sqp_slot is one of ST_SQP_DT, ST_SQP_ITER, ST_DELTA_TOL, ST_G_MAX, ST_G_MIN — contiguous, in the order of the ipm slots
 static_assert(ST_SQP_ITER - ST_SQP_DT == ST_IPM_ITER - ST_IPM_DT && ST_DELTA_TOL - ST_SQP_DT == ST_IPM_DELTA_TOL - ST_IPM_DT && ST_G_MAX - ST_SQP_DT == ST_IPM_G_MAX - ST_IPM_DT &&
               ST_G_MIN - ST_SQP_DT == ST_IPM_G_MIN - ST_IPM_DT, "qm_ms_param maps sqp slots onto ipm slots by offset: the two blocks of include/qmhip_layout.h must keep the same order");
-__host__ __device__ __forceinline__ double qm_ms_param(const double* st, int sqp_slot) { return (st[ST_SOLVER] == 2.0) ? st[ST_IPM_DT + (sqp_slot - ST_SQP_DT)] : st[sqp_slot]; }
+__host__ __device__ __forceinline__ double qm_ms_param(const double* st, int sqp_slot) { return (st[ST_SOLVER] >= 2.0) ? st[ST_IPM_DT + (sqp_slot - ST_SQP_DT)] : st[sqp_slot]; }      // slot 2 (the SQP step on the `ipm` block) and slot 3 (the interior-point method, k_ipm.h)
 
 // ---- per-node stage record written by K1 (LQ + projection) and read by K3 (Riccati); doubles ----
 // dimensions: nx = 30, projected input dim m <= 18 (stance 18, trot 16); row-major, fixed strides

@@ -48,6 +48,8 @@ int emu_mpc_step_warm(void* h, int B, const double* t0, const double* x0, double
   if (t0) memcpy(d.t0, t0, (size_t)B * 8); if (x0) memcpy(d.x0, x0, (size_t)B * 30 * 8);
   c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B, max_trials); return c->mpc.ls_trials_run;
 }
+// one more iteration on the committed iterate of the last call (sqp.sqpIteration / ipm.ipmIteration > 1: what qmhip_mpc_solve_resident loops over)
+int emu_mpc_iterate(void* h, int B, int max_trials) { EmuCtx* c = (EmuCtx*)h; c->mpc.sqp_iteration(B, max_trials); return c->mpc.ls_trials_run; }
 void emu_advance(void* h, int B, double dt) { ((EmuCtx*)h)->mpc.advance(B, dt); }
 // K0 only: grid, modes, references, initial guess of the uploaded problem
 void emu_grid(void* h, int B, double horizon) { ((EmuCtx*)h)->mpc.grid(B, horizon); }
@@ -58,7 +60,7 @@ void* emu_buffer(void* h, const char* name) {
   { EmuCtx* c = (EmuCtx*)h; if (!strcmp(name, "sim_q")) return (void*)c->sim.s.q; if (!strcmp(name, "sim_v")) return (void*)c->sim.s.v; if (!strcmp(name, "wbc_out")) return (void*)c->wbc.w.out; if (!strcmp(name, "wbc_qp_status")) return (void*)c->wbc.w.qp_status; }
 #define F(n) if (!strcmp(name, #n)) return (void*)d.n;
   F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(lqdbg) F(perf) F(base_sum)
-  F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0)
+  F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0) F(ipm_s) F(ipm_l) F(ipm_ds) F(ipm_dl) F(ipm_info)
 #undef F
   return nullptr;
 }

@@ -139,7 +139,7 @@ inline unsigned long long __ballot(int pred) {
 inline int __shfl(int v, int src, int width) { return (int)__shfl((double)v, src, width); }
 inline int __shfl_xor(int v, int mask, int width = 64) { return (int)__shfl_xor((double)v, mask, width); }
 
-using std::sqrt; using std::sin; using std::cos; using std::fabs; using std::fma; using std::acos; using std::log; using std::fmin; using std::fmax;
+using std::sqrt; using std::sin; using std::cos; using std::fabs; using std::fma; using std::acos; using std::log; using std::fmin; using std::fmax; using std::pow;
 
 namespace emu {
 template <class F> void launch(dim3 grid, dim3 block, F&& body) {

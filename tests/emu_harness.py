@@ -51,6 +51,10 @@ class Emu:
         assert rt.shape[1] == self.nref and ev.shape[1] == self.nev
         return self.lib.emu_mpc_step(self.h, C.c_int(B), _p(t0), _p(x0), _p(rt), _p(rx), _p(ev), _pi(mo), C.c_double(cfg["horizon"]), C.c_int(max_trials))
 
+    def mpc_iterate(self, max_trials=14):
+        """one more iteration on the committed iterate (multi-iteration solves)"""
+        return self.lib.emu_mpc_iterate(self.h, C.c_int(self.B), C.c_int(max_trials))
+
     def set_solver(self, solver):
         self.lib.emu_set_solver(self.h, C.c_int(solver))
 

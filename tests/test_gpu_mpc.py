@@ -223,7 +223,42 @@ def test_ipm_solver_slot(blobs, oracle):
     itf.set_setting(L.ST_SOLVER, 0.0)
     res = mpc.run(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"])
     _compare(res, 0, _oracle_solve(oracle, cfg, 0))
-    with pytest.raises(api.QmhipError): itf.set_setting(L.ST_SOLVER, 3.0)
+    with pytest.raises(api.QmhipError): itf.set_setting(L.ST_SOLVER, 4.0)
+    itf.close()
+
+
+@pytest.mark.parametrize("name,N,fric,iters", [("C2", 100, 0.3, 1), ("C2", 40, 0.12, 3), ("C5", 30, 0.3, 3)])
+def test_ipm_hard_cones(blobs, oblobs, name, N, fric, iters):
+    """qmhip_set_setting(ST_SOLVER, 3): the interior-point method with HARD friction cones and arm position / velocity boxes (the `ipm` block of
+    task.info:94-125) through the C ABI against oracle/src/ipm.h — itself pinned by a dense solve of the horizon's primal-dual Newton system (tests/test_ipm.py): x*, u* 1e-6 per
+    block, integers bit-exact, step lengths / barrier parameter / slack / dual 1e-6, over `iters` iterations of one solve (ipm.ipmIteration); friction coefficient 0.12: a cone
+    that binds; C5: arm within 0.1 rad of its joint limits.  Every slack stays positive, i.e. every iterate is strictly inside the linearised cones and boxes."""
+    import pyoracle
+    from qm_control_amd import api, scenarios
+    cfg = scenarios.make_config(name, batch=2, n_intervals=N)
+    itf = api.QMInterface(blobs=blobs, max_batch=2, max_nodes=N + 16, max_ref_knots=cfg["ref_t"].shape[1], max_events=cfg["ev"].shape[1])
+    ost = oblobs[1].copy()
+    for idx, v in ((L.ST_IPM_MU, 1e-2), (L.ST_FRIC_COEF, fric), (L.ST_IPM_ITER, float(iters)), (L.ST_SOLVER, 3.0)):
+        itf.set_setting(idx, v); ost[idx] = v
+    mpc = api.SqpMpc(itf)
+    res = mpc.run(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"], cfg["horizon"]); assert (res["status"] == 0).all(), res["status"]
+    info = itf.debug_read("ipm_info", (2, 8)); nm = itf.max_nodes
+    s_dev = itf.debug_read("ipm_s", (nm, 2, 28)); l_dev = itf.debug_read("ipm_l", (nm, 2, 28))
+    for b in range(2):
+        o = pyoracle.Oracle(oblobs[0], ost); o.set_schedule(cfg["ev"][b], cfg["modes"][b]); o.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+        for it in range(iters):
+            r = o.ipm_step(cfg["t0"][b], cfg["t0"][b] + cfg["horizon"], cfg["x0"][b], mode="cold" if it == 0 else "iterate")
+        n = len(r["t"]); what = "%s instance %d" % (name, b)
+        assert res["num_nodes"][b] == n and np.array_equal(res["t"][b, :n], r["t"]) and np.array_equal(res["event"][b, :n], r["ev"]) and np.array_equal(res["mode"][b, :n], r["mode"]), what
+        assert_blocks(res["x"][b, :n], r["x"], "x", TOL, what + " x*"); assert_blocks(res["u"][b, :n], r["u"], "u", TOL, what + " u*")
+        assert res["perf"][b, 8] == pytest.approx(r["alpha"], rel=1e-9) and info[b, 1] == pytest.approx(r["alpha_primal_max"], rel=1e-6) and info[b, 2] == pytest.approx(r["alpha_dual_max"], rel=1e-6)
+        assert info[b, 4] == pytest.approx(r["barrier"], rel=1e-12) and np.abs(res["perf"][b, :8] - r["perf"][:8]).max() <= 1e-6 * max(1.0, np.abs(r["perf"][:8]).max()), what
+        for i in range(n - 1):
+            if r["ev"][i] == 1:
+                continue
+            p = o.ipm_node(i); on = p["on"] == 1
+            assert (s_dev[i, b][on] > 0.0).all() and (l_dev[i, b][on] > 0.0).all(), (what, i)
+            assert np.abs(s_dev[i, b][on] - p["slack"][on]).max() <= 1e-6 * max(1.0, np.abs(p["slack"][on]).max()) and np.abs(l_dev[i, b][on] - p["dual"][on]).max() <= 1e-6 * max(1e-3, np.abs(p["dual"][on]).max()), (what, i)
     itf.close()
 
 

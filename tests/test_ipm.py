@@ -126,3 +126,32 @@ def test_ipm_converges_to_the_perturbed_kkt_point_with_strictly_feasible_cones(o
         lo, hi = oblobs[0][L.MB_QLO + 12:L.MB_QLO + 18], oblobs[0][L.MB_QHI + 12:L.MB_QHI + 18]
         assert (x[24:30] > lo).all() and (x[24:30] < hi).all() and (u[24:30] > st[L.ST_JVEL_LO:L.ST_JVEL_LO + 6]).all() and (u[24:30] < st[L.ST_JVEL_HI:L.ST_JVEL_HI + 6]).all()
     assert tight > 0          # some cone is ACTIVE at the solution (slack of the order of sqrt(mu)): the constraint is doing work
+
+
+@pytest.mark.parametrize("name,N,fric", [("C2", 20, 0.3), ("C2", 20, 0.12), ("C5", 16, 0.3)])
+def test_product_ipm_on_the_emulator_vs_oracle(blobs, oblobs, name, N, fric):
+    """the product's interior-point path (k_ipm.h, the IPM instances of K1b / K4, K3 unchanged) on the host emulator against oracle/src/ipm.h: three iterations of one solve —
+    primal solution 1e-6 per block, step lengths and barrier parameter identical, slack / dual 1e-6; friction coefficient 0.12: a cone that binds"""
+    import emu_harness
+    from conftest import assert_blocks
+    from qm_control_amd import scenarios
+    o, ost = _solver(oblobs, ST_IPM_MU=1e-2, ST_FRIC_COEF=fric)
+    st = blobs[1].copy(); st[L.ST_SOLVER] = 3.0; st[L.ST_IPM_MU] = 1e-2; st[L.ST_FRIC_COEF] = fric
+    cfg = scenarios.make_config(name, batch=1, n_intervals=N); cfg["B"] = 1
+    t0, tf, x0 = _problem(o, name, N)
+    e = emu_harness.Emu(blobs[0], st, 1, N + 12, cfg["ref_t"].shape[1], cfg["ev"].shape[1]); e.set_solver(3)
+    for it in range(3):
+        r = o.ipm_step(t0, tf, x0, mode="cold" if it == 0 else "iterate")
+        trials = e.mpc_step(cfg) if it == 0 else e.mpc_iterate()
+        n = len(r["t"]); assert e.buf("n_nodes", (1,), np.int32)[0] == n and e.buf("status", (1,), np.int32)[0] == 0
+        info = e.buf("ipm_info", (1, 8))[0]; perf = e.buf("out_perf", (10,))
+        assert trials == r["ls_trials"] and perf[8] == pytest.approx(r["alpha"], rel=1e-9), (it, trials, r["ls_trials"], perf[8], r["alpha"])
+        assert info[1] == pytest.approx(r["alpha_primal_max"], rel=1e-7) and info[2] == pytest.approx(r["alpha_dual_max"], rel=1e-7) and info[3] == pytest.approx(r["alpha_dual"], rel=1e-7) and info[4] == pytest.approx(r["barrier"], rel=1e-12), (it, info, r)
+        assert np.abs(perf[:8] - r["perf"][:8]).max() <= 1e-7 * max(1.0, np.abs(r["perf"][:8]).max()), (it, perf, r["perf"])
+        assert_blocks(e.node_arr("xs", 30)[:n, 0], r["x"], "x", 1e-6, "it %d" % it); assert_blocks(e.node_arr("us", 30)[:n, 0], r["u"], "u", 1e-6, "it %d" % it)
+        s_dev = e.node_arr("ipm_s", 28)[:n - 1, 0]; l_dev = e.node_arr("ipm_l", 28)[:n - 1, 0]
+        for i in range(n - 1):
+            if r["ev"][i] == 1:
+                continue
+            p = o.ipm_node(i); on = p["on"] == 1
+            assert np.abs(s_dev[i][on] - p["slack"][on]).max() <= 1e-6 * max(1.0, np.abs(p["slack"][on]).max()) and np.abs(l_dev[i][on] - p["dual"][on]).max() <= 1e-6 * max(1e-3, np.abs(p["dual"][on]).max()), (it, i)
