@@ -70,7 +70,7 @@ int qmhip_wbc_gain_index(const char* reconfigure_name);
  *      zeroed ([upstream, recalled] BLASFEO / HPIPM behaviour; qmhip_layout.h) — the stage in front of a gait event when a shooting node falls within weakEpsilon
  *      before it, i.e. about one call in 3700 for an MPC thread on continuous time (QMController.cpp:315-330); on a fixed-rate clock that shares a raster with the gait
  *      events 3 % ... 12 % of the calls (profiles/r04_fixed_rate_report.txt).  Such a solve lies within 5e-6 (per block) of the solve on the robust grid everywhere but the
- *      degenerate interval's own input, its policy at t0 within 1e-6 (tests/test_gpu_mpc.py); rastered controllers should set ST_GRID_DT_MIN = QM_GRID_DT_MIN_ROBUST
+ *      degenerate interval's own input, its policy at t0 within 5e-6 (measured 2.8e-6; tests/test_gpu_mpc.py); rastered controllers should set ST_GRID_DT_MIN = QM_GRID_DT_MIN_ROBUST
  *      (INTEGRATION.md section 3).  Callers treat status >= 0 as success.  -4 also reports: a non-positive pivot on a stage of POSITIVE duration, a pivot or a step that is
  *      not a finite number (e.g. a NaN in x0) — never a warning.
  *      Solver slot (qmhip_set_setting(ST_SOLVER, .)): 0 the SQP above; 1 a discrete iLQR on the `ddp` block (task.info:33-71); 2 the SAME multiple-shooting step as
