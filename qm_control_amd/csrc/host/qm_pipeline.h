@@ -69,6 +69,7 @@ struct QmMpcPipeline {
                           // (no hard inequality rows in this OCP: include/qmhip_layout.h, ST_IPM_*); settings slot ST_SOLVER
   bool r_blocks = false;           // the input weight R of the settings blob is block diagonal (k_ls.h): the structured instance of the trial-evaluation kernel runs; kept current by note_settings()
   bool speculative_apply = true;   // tests only: false = the first trial's apply waits for the host's decision like every later one (A/B of the invariant below)
+  int lq_slices = 1;      // K1a / K1b run the horizon in this many node slices (1: one launch each)
   bool ipm_fresh = true;  // interior-point solver: the next iteration is the first of its solve (K0 ran): slack / dual / barrier parameter are initialised at the initial iterate
   int solved_B = 0;       // batch size of the last completed solve (0: none yet -> a warm start falls back to the cold start)
   int ncap = 0;           // nodes per instance the per-node launches of the current grid cover (0: not read back yet)
@@ -167,12 +168,27 @@ struct QmMpcPipeline {
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof; q.ncap = ncap;
     q.ipm_s = d.ipm_s; q.ipm_l = d.ipm_l; q.ipm_info = d.ipm_info;
+    q.i0 = 0;
+    const int nsl = (ipm || d.lqdbg || lq_prof || lq_slices < 1) ? 1 : (lq_slices > ncap ? ncap : lq_slices);
+    if (nsl > 1) {
+      // node slices: kin records of a slice are written by K1a and read back by K1b before the next slice's records push them out of the memory-side cache
+      if (before_lq) before_lq();
+      for (int sidx = 0; sidx < nsl; ++sidx) {
+        const int a0 = (int)((long long)ncap * sidx / nsl), a1 = (int)((long long)ncap * (sidx + 1) / nsl); if (a1 <= a0) continue;
+        q.i0 = a0; q.ncap = a1 - a0;
+        bk.launch(qm_lq_kin_kernel, ((a1 - a0) * B + 63) / 64, 64, LQ_KIN_LDS_BYTES, q);
+        bk.launch(qm_lq_kernel, B * (a1 - a0), LW_BLOCK, LQ_LDS_BYTES, q);
+        if (has_m18) bk.launch(qm_lq_m18_kernel, B * (a1 - a0), LW_BLOCK, LQ_LDS_BYTES, q);
+      }
+      q.i0 = 0; q.ncap = ncap;
+    } else {
     bk.launch(qm_lq_kin_kernel, (nodes_threads + 63) / 64, 64, LQ_KIN_LDS_BYTES, q);
     if (before_lq) before_lq();
     if (ipm) bk.launch(qm_lq_ipm_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);      // the interior-point instance: condensed inequality rows instead of the soft barrier costs
     else if (d.lqdbg || lq_prof) bk.launch(qm_lq_dbg_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);   // the instance with debug records / phase cycle stamps (parity tests, profiling)
     else { bk.launch(qm_lq_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q);      // one wavefront per node: the nodes with m <= 16 reduced inputs (any gait phase with a swing leg) ...
            if (has_m18) bk.launch(qm_lq_m18_kernel, B * ncap, LW_BLOCK, LQ_LDS_BYTES, q); }  // ... and the stance nodes (m = 18): two instances of one body, three waves per SIMD each (k_lq.h)
+    }
     QmLsArgs l = ls_args(B); if (ilqr) { l.xt = d.xt; l.ut = d.ut; l.ilqr = 1; }
     if (ipm) { l.ipm_s = d.ipm_s; l.ipm_ds = d.ipm_ds; l.ipm_info = d.ipm_info; }
     QmRiccatiArgs r; r.B = B; r.nmax = d.nmax; r.n_nodes = d.n_nodes; r.node_ev = d.node_ev; r.x0 = d.x0; r.x = d.x; r.stage = d.stage; r.dx = d.dx; r.du = d.du; r.step_info = d.step_info; r.skip = riccati_skip;

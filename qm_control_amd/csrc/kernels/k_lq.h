@@ -46,7 +46,8 @@ struct QmLqArgs {
   double* dbg;               // optional [B][nmax][LQ_DBG_SIZE] unprojected LQ data (parity tests); may be null
   double* kin;               // [nmax][B][KR_SIZE] kin records (K1a -> K1b)
   int prof;                  // profiling only: thread 0 leaves phase cycle stamps in the (unused) SR_K field of the record
-  int ncap;                  // K1b: nodes per instance covered by the launch (the batch's largest node count, <= nmax)
+  int ncap;                  // K1b: nodes per instance covered by the launch (the batch's largest node count, <= nmax; with node slices: the slice length)
+  int i0;                    // first node of the launch (node slices: K1a and K1b take the horizon in [i0, i0 + ncap) pieces so that a piece's kin records are consumed while they are still cached)
   // interior-point instances only (k_ipm.h): slack / dual of the node's QM_NH inequality rows [nmax][B][QM_NH], barrier parameter per instance info[b * 8]
   const double* ipm_s; const double* ipm_l; const double* ipm_info;
 };
@@ -302,7 +303,7 @@ template <int N> __device__ __forceinline__ void kin_emit(const KinOut& o, int o
 }
 __global__ void __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
   const int l = threadIdx.x & 63;
-  const size_t g0 = (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
+  const size_t g0 = (size_t)a.i0 * a.B + (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
   size_t g = g0 + l; if (g >= nrows) g = nrows - 1;                             // (rows behind the arrays' end: the last wave of a launch that covers all nmax nodes)
   const double* mb = qm_table(a.mb);
   extern __shared__ double qm_smem[];                  // LQ_KIN_LDS_BYTES
@@ -344,7 +345,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   extern __shared__ double qm_smem[];
   double* S = qm_smem;
   const int l = threadIdx.x & 63, g = l >> 4, c = l & 15;
-  const int b = blockIdx.x / a.ncap, i = blockIdx.x - b * a.ncap;
+  const int b = blockIdx.x / a.ncap, i = a.i0 + blockIdx.x - b * a.ncap;
   const int nb = i * a.B + b;                       // node-major index
   // instrumented instance, profiling on: wave entry in shader-clock cycles and in ticks of the constant 100 MHz reference clock (tools/lq_residency_probe.py)
   const long long c0_ = (DBG && a.prof) ? (long long)__builtin_readcyclecounter() : 0; const long long r0_ = (DBG && a.prof) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
@@ -794,7 +795,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
 #undef LQT
 }
 __device__ __forceinline__ int qm_lq_node_mt(const QmLqArgs& a) {
-  const int b = blockIdx.x / a.ncap, i = blockIdx.x - b * a.ncap;
+  const int b = blockIdx.x / a.ncap, i = a.i0 + blockIdx.x - b * a.ncap;
   const int mode = a.node_mode[i * a.B + b];
   int nst = 0;
 #pragma unroll

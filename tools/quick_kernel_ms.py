@@ -10,6 +10,7 @@ itf = api.QMInterface(blobs=scenarios.load_blobs(), max_batch=B, max_nodes=int(o
 mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
 mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
 MPC_ONLY = bool(os.environ.get("QM_MPC_ONLY"))
+if os.environ.get("QM_LQ_SLICES"): itf.debug_set("lq_slices", int(os.environ["QM_LQ_SLICES"]))
 def step():
     if MPC_ONLY: mpc.solve_resident(cfg["horizon"])       # no WBC on the second stream: per-kernel times without cross-stream waiting
     else: wbc.reset(); mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
