@@ -78,7 +78,7 @@ struct QmLqArgs {
 #define KR_F2   (KR_K2 + KW_ARM)      /* rows 0..11 of f(x + dt f1, u) */
 #define KR_USED (KR_F2 + 12)
 #define KR_SIZE 384
-static_assert(KR_USED <= KR_SIZE && KR_SIZE % 8 == 0, "kin record: whole 64-byte lines");
+static_assert(KR_USED + 7 <= KR_SIZE && KR_SIZE % 8 == 0, "kin record: whole 64-byte lines, room for the last piece's padding");
 
 // LDS carve (doubles) of one wave
 #define LW_BLOCK 64
@@ -293,11 +293,13 @@ template <int N> __device__ __forceinline__ void kin_emit(const KinOut& o, int o
 #pragma unroll
   for (int p = 0; p < (N + 7) / 8; ++p) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (8 * p + j < N) o.tile[o.l * 9 + j] = v[8 * p + j];
+    for (int j = 0; j < 8; ++j) o.tile[o.l * 9 + j] = (8 * p + j < N) ? v[8 * p + j < N ? 8 * p + j : 0] : 0.0;
     qm_wave_sync();
     const int j = o.l & 7, rr = o.l >> 3;
+    // every piece is stored WHOLE (no exec masks: their save / restore pairs were this kernel's scalar-register spills): the zeros behind a block's last value land on the
+    // first doubles of the block that follows in the record — which this wave writes later, in program order — or on the record's padding
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int r = 8 * k + rr; if (8 * p + j < N) o.wave_rec[(size_t)r * KR_SIZE + off + 8 * p + j] = o.tile[r * 9 + j]; }
+    for (int k = 0; k < 8; ++k) { const int r = 8 * k + rr; o.wave_rec[(size_t)r * KR_SIZE + off + 8 * p + j] = o.tile[r * 9 + j]; }
     qm_wave_sync();
   }
 }
@@ -330,10 +332,12 @@ __global__ void __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
   kin_emit<22>(o, KR_EEG, f);
   double x2[30];                                        // the joint part of the flow value is the input's joint velocities (u, in LDS)
   _Pragma("unroll") for (int q = 0; q < 30; ++q) x2[q] = x[q] + dt * ((q < 12) ? f[10 + (q < 12 ? q : 0)] : u[q]);
-  kin_base<true>(mb, x2, K);
+  const double* mb2 = qm_table(a.mb);                   // the second stage reads the model table through its own (opaque) pointer: the first stage's table entries are then
+                                                        // loaded again from the scalar cache instead of being carried across the stage in scalar registers (16 of them were spilled)
+  kin_base<true>(mb2, x2, K);
   kin_emit<KW_LEG>(o, KR_K2, K);
-  _Pragma("unroll") for (int c = 0; c < 4; ++c) { kin_leg<true>(mb, c, x2, u, K); kin_emit<KW_LEGSZ>(o, KR_K2 + KW_LEG + KW_LEGSZ * c, K + KW_LEG + KW_LEGSZ * c); __builtin_amdgcn_sched_barrier(0); }
-  flow_head_from_kin(mb, x2, u, K, f);
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) { kin_leg<true>(mb2, c, x2, u, K); kin_emit<KW_LEGSZ>(o, KR_K2 + KW_LEG + KW_LEGSZ * c, K + KW_LEG + KW_LEGSZ * c); __builtin_amdgcn_sched_barrier(0); }
+  flow_head_from_kin(mb2, x2, u, K, f);
   kin_emit<12>(o, KR_F2, f);
 }
 
