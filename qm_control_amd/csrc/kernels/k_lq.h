@@ -65,7 +65,8 @@ struct QmLqArgs {
 #define LQ_DBG_e 4650
 #define LQ_DBG_c 4666
 #define LQ_DBG_nc 4667
-#define LQ_DBG_SIZE 4668
+#define LQ_DBG_PU 4668       /* [30][18] the null-space basis Pu of this design (K3 rebuilds Pu ut from the contact mode and the swing blocks: the product never stores it) */
+#define LQ_DBG_SIZE 5208
 
 // kin record (doubles) per node, in the order K1a produces it (its stores stream through the record front to back).  Round 5: the second stage's state x2 is no longer
 // stored (nobody read it), the flow values keep their twelve non-trivial rows only (rows 12..29 are the input's joint velocities, which K1b holds anyway) and the
@@ -152,14 +153,14 @@ __device__ __forceinline__ void lw_bp(double* S, double* rec, int m, const qm_d4
   qm_wave_sync();
 }
 template <int MT>
-__device__ __forceinline__ void lw_project(double* S, double* rec, bool store_pu, int m, const qm_d4 (&PxA)[2][2], const qm_d4 (&PuF)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
+__device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_pu, int m, const qm_d4 (&PxA)[2][2], const qm_d4 (&PuF)[2][2], const qm_d4 (&Rm)[2][2], qm_d4 (&Qa)[2][2], double& rpe) {
   const int l = threadIdx.x & 63;
   qm_d4 Pu[2][MT];
 #pragma unroll
   for (int I = 0; I < 2; ++I)
 #pragma unroll
     for (int J = 0; J < MT; ++J) Pu[I][J] = PuF[I][J];
-  if (store_pu) qm_frag_store<2, MT>(Pu, rec + SR_PU, QM_MMAX, 30, m);
+  if (dbg_pu) qm_frag_store<2, MT>(Pu, dbg_pu, QM_MMAX, 30, m);
   // Every column of Pu is a unit vector or three consecutive entries (a swing leg's null-space column): products with Pu are gathers of
   // columns / rows of the other factor, not matrix products.  The other factor goes through the LDS tile once and each lane picks the entries
   // its output elements need (descriptors in LW_PD): ≈ 40 LDS operations per product instead of 8..16 MFMAs of 64 cycles each.
@@ -778,10 +779,9 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   for (int J = 0; J < 2; ++J) {
     const int col = 16 * J + c;
     if (col < 30) { QM_STREAM_ST(rec + SR_PX + (12 + g) * 30 + col, PxA[0][J][3]); QM_STREAM_ST(rec + SR_PX + (16 + g) * 30 + col, PxA[1][J][0]); QM_STREAM_ST(rec + SR_PX + (20 + g) * 30 + col, PxA[1][J][1]); }
-    if (DBG && dbg && col < 30) { for (int r = 0; r < 3; ++r) rec[SR_PX + (g + 4 * r) * 30 + col] = 0.0; rec[SR_PX + (24 + g) * 30 + col] = 0.0; if (g < 2) rec[SR_PX + (28 + g) * 30 + col] = 0.0; }
   }
   double rpe = 0.0;
-  lw_project<MT>(S, rec, DBG && dbg != nullptr, m, PxA, PuF, Rm, Qa, rpe);
+  lw_project<MT>(S, rec, (DBG && dbg != nullptr) ? dbg + LQ_DBG_PU : nullptr, m, PxA, PuF, Rm, Qa, rpe);
   // what K3's forward rollout needs to apply Pu without reading it: the swing legs' null-space blocks and the contact mode
   if (l < 24) rec[SR_SWG + l] = G[12 * (l / 6) + 3 + (l % 6)];
   if (l == 24) rec[SR_MODEF] = (double)mode;

@@ -319,27 +319,32 @@ __host__ __device__ __forceinline__ double qm_ms_param(const double* st, int sqp
 // ---- per-node stage record written by K1 (LQ + projection) and read by K3 (Riccati); doubles ----
 // dimensions: nx = 30, projected input dim m <= 18 (stance 18, trot 16); row-major, fixed strides
 #define QM_MMAX 18
-#define SR_AP   0                      /* [30][30]  A + B Px : rows 0..11 written (joint rows: e_j + dt Px[j]) */
-#define SR_BP   900                    /* [30][18]  B Pu     : rows 0..11 written (joint rows: dt Pu[j])       */
-#define SR_QP   1440                   /* [30][30]  terminal record only (intermediate nodes: SR_FRAG) */
-#define SR_PP   2340                   /* [18][30]  the gain K = −L⁻ᵀ W, written by K3 (Pp itself travels in SR_FRAG) */
-#define SR_RP   2880                   /* [18][18]  unused (Rp travels in SR_FRAG) */
-#define SR_PX   3204                   /* [30][30]  du = Pe + Px dx + Pu ut */
-#define SR_PU   4104                   /* [30][18]  (written only with the debug records: K3 rebuilds Pu ut from SR_SWG / SR_MODEF) */
-#define SR_BPV  4644                   /* [30]      b + B Pe            */
-#define SR_QPV  4674                   /* [30]                          */
-#define SR_RPV  4704                   /* [18]                          */
-#define SR_PE   4722                   /* [30]                          */
-#define SR_K    4752                   /* [18][30]  free (feedback gains are not formed: the reference runs a feedforward policy); profiling stamps use [0, 16) */
-#define SR_SWG   (SR_K + 32)            /* [4][6]    per contact: the 3x2 null-space block of a swing leg's joint velocities (columns of Pu) */
-#define SR_MODEF (SR_K + 56)            /* contact mode of the interval (as double): Pu = {identity columns, SR_SWG blocks} is rebuilt from it */
-#define SR_KFF  5292                   /* [18]  y = L⁻¹ hu (written by K3) */
-#define SR_SCAL 5310                   /* [0]=m (as double) [1]=cp      */
+// Round 5: COMPACT record — only what is written is laid out (rounds 1-4 reserved full 30-row blocks, an unused Rp and a 540-double gain slot: 58.9 KB per node; now 30 KB):
+//   [0, 1094)      what K1b writes row-major and K3's sweeps fetch: Ap rows 0..11 | Bp rows 0..11 | Px rows 12..23 | bp qp rp Pe | k | swing blocks, mode, dt | m, cp
+//   [1152, 1692)   the gain K (written by K3's backward sweep, read by its rollout)
+//   [1792, 3840)   K3's backward operands in fragment order
+// The terminal record's Q_N (30 x 30) overlays the head: a terminal node has no dynamics rows.  Debug-only data (the null-space basis Pu) lives in the debug record (k_lq.h).
+#define SR_AP   0                      /* [12][30]  rows 0..11 of A + B Px (joint rows: e_j + dt Px[j], rebuilt by K3) */
+#define SR_QP   0                      /* [30][30]  TERMINAL record only (intermediate nodes: SR_FRAG); overlays SR_AP / SR_BP / the Px rows */
+#define SR_BP   360                    /* [12][18]  rows 0..11 of B Pu (joint rows: dt Pu[j]) */
+#define SR_PX   216                    /* VIRTUAL base of the [30][30] matrix Px (du = Pe + Px dx + Pu ut): only its rows 12..23 exist, at SR_PX + 360 = 576 ... 935 */
+#define SR_BPV  936                    /* [30]      b + B Pe            */
+#define SR_QPV  966                    /* [30]                          */
+#define SR_RPV  996                    /* [18]                          */
+#define SR_PE   1014                   /* [30]                          */
+#define SR_KFF  1044                   /* [18]  the offset k = −L⁻ᵀ y (written by K3) */
+#define SR_SWG   1064                  /* [4][6]    per contact: the 3x2 null-space block of a swing leg's joint velocities (columns of Pu) */
+#define SR_MODEF 1088                  /* contact mode of the interval (as double), dt, and the constants 1.0, 0.0: Pu = {identity columns, SR_SWG blocks} is rebuilt from it */
+#define SR_SCAL 1092                   /* [0]=m (as double) [1]=cp      */
+#define SR_K    1096                   /* [32] profiling stamps of the instrumented instances only */
+#define SR_PP   1152                   /* [18][30]  the gain K = −L⁻ᵀ W, written by K3 (Pp itself travels in SR_FRAG) */
+static_assert(SR_PX + 360 == SR_BP + 216 && SR_PX + 720 == SR_BPV && SR_MODEF == SR_SWG + 24 && SR_SCAL >= SR_MODEF + 4 && SR_K >= SR_SCAL + 2 && SR_PP >= SR_K + 32 && SR_QP + 900 <= SR_BPV, "stage record fields");
 /* K3's backward operands [Qp | qp], [Pp | rp], Rp in FRAGMENT order: register r of tile t is one contiguous 512-byte row, element (t, r, lane l) at (4 t + r) 64 + l, i.e.
    matrix entry (16 I + (l >> 4) + 4 r, 16 J + (l & 15)) of tile (I, J).  K1b stores its fragments as they are (one unconditional 512-byte store per register, padding
    rows / columns of Pp, Rp zeroed by a select) and K3 reads them back with one LDS load per register: no masks, no per-element addresses on either side.
    The vectors ride in column 30.  m <= 16 (one tile row of reduced inputs) reads the first 1536 doubles only. */
-#define SR_FRAG   5312
+#define SR_FRAG   1792
+static_assert(SR_FRAG >= SR_PP + 540 && SR_FRAG % 128 == 0, "fragment region behind the gain, on a 1 KB boundary");
 #define SR_F_QP    0                    /* tiles (0,0), (0,1), (1,1) of [Qp | qp]: 3 x 256 (the lower-left tile is the mirror image, never formed) */
 #define SR_F_PP    768                  /* tile row 0 of [Pp | rp]: tiles (0,0), (0,1)                                                              */
 #define SR_F_RP    1280                 /* tile (0,0) of Rp                                                                                           */

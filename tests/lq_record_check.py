@@ -55,7 +55,7 @@ def frag_operands(rec, m):
 
 
 def check_interval(rec, dbg, lq, pr, after_riccati=False):
-    """rec: stage record as K1b wrote it (SR_SIZE doubles, debug mode: SR_PU and the zero rows of Px present); dbg: debug record; lq / pr: oracle.node_lq(i) / node_proj(i).
+    """rec: stage record as K1b wrote it (SR_SIZE doubles); dbg: debug record; lq / pr: oracle.node_lq(i) / node_proj(i).
     after_riccati: the record has been through K3, which replaced Pp by the feedback gain K and left the feed-forward k in SR_KFF (ut = K dx + k): those are then
     compared instead, K = T⁻¹ K_o, k = T⁻¹ k_o.  Returns {block name: relative error on the block's own scale}."""
     e = {}
@@ -68,7 +68,8 @@ def check_interval(rec, dbg, lq, pr, after_riccati=False):
     e["C"] = _err(g(DBG["LQ_DBG_C"], 16, 30)[:nc], lq["C"][:nc]); e["D"] = _err(g(DBG["LQ_DBG_D"], 16, 30)[:nc], lq["D"][:nc]); e["e"] = _err(g(DBG["LQ_DBG_e"], 16)[:nc], lq["e"][:nc])
     # ---- projected stage record ----
     s = lambda off, *shape: np.asarray(rec[off:off + int(np.prod(shape))]).reshape(shape)
-    Px = s(SR["SR_PX"], 30, 30); Pu = s(SR["SR_PU"], 30, 18)[:, :m]; Pe = s(SR["SR_PE"], 30)
+    Px = np.zeros((30, 30)); Px[12:24] = s(SR["SR_PX"] + 360, 12, 30)           # only rows 12..23 (leg joint velocities) exist in the record (SR_PX is their virtual base); the others are zero by construction
+    Pu = g(DBG["LQ_DBG_PU"], 30, 18)[:, :m]; Pe = s(SR["SR_PE"], 30)               # Pu: debug record only (K3 rebuilds Pu ut from the mode and the swing blocks)
     Pu_o = pr["Pu"][:, :m]
     T = np.linalg.pinv(Pu_o) @ Pu
     e["Px"] = _err(Px, pr["Px"]); e["Pe"] = _err(Pe, pr["Pe"]); e["range(Pu)"] = _err(Pu_o @ T, Pu)
@@ -78,7 +79,7 @@ def check_interval(rec, dbg, lq, pr, after_riccati=False):
     e["D Pu"] = float(np.abs(Dm @ Pu).max() / max(1.0, np.abs(Dm).max())); e["D Px + C"] = float(np.abs(Dm @ Px + Cm).max() / max(1.0, np.abs(Cm).max())); e["D Pe + e"] = float(np.abs(Dm @ Pe + lq["e"][:nc]).max())
     # rows 0..11 of Ap / Bp are stored; joint rows are rebuilt by K3 as e_j + dt Px[12 + j] and dt Pu[12 + j]
     dt = rec[SR["SR_MODEF"] + 1]
-    Ap = s(SR["SR_AP"], 30, 30).copy(); Bp = s(SR["SR_BP"], 30, 18)[:, :m].copy()
+    Ap = np.zeros((30, 30)); Bp = np.zeros((30, m)); Ap[:12] = s(SR["SR_AP"], 12, 30); Bp[:12] = s(SR["SR_BP"], 12, 18)[:, :m]
     Ap[12:] = np.eye(30)[12:] + dt * Px[12:]; Bp[12:] = dt * Pu[12:]
     e["Ap"] = _err(Ap, pr["Ap"]); e["Bp"] = _err(Bp, pr["Bp"][:, :m] @ T); e["bp"] = _err(s(SR["SR_BPV"], 30), pr["bp"])
     # [Qp | qp], [Pp | rp], Rp: the fragment-order region K3's backward sweep reads (upper tiles of the symmetric blocks; vectors in column 30), which K3 leaves untouched

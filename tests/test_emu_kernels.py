@@ -227,8 +227,7 @@ def test_product_instances_match_the_instrumented_ones(blobs, oracle, name, N):
         e = emu_harness.Emu(blobs[0], blobs[1], 1, n + 3, 2, cfg["ev"].shape[1]); e.set_lq_debug(dbg); e.set_riccati_skip(skip)
         e.mpc_step(cfg)
         outs.append((np.stack([e.stage(0, i) for i in range(n)]), e.node_arr("xs", 30)[:n, 0].copy(), e.node_arr("us", 30)[:n, 0].copy(), e.buf("out_perf", (10,)).copy()))
-    keep = np.ones(LC.SR["SR_SIZE"], bool); keep[LC.SR["SR_PU"]:LC.SR["SR_BPV"]] = False; keep[LC.SR["SR_K"]:LC.SR["SR_K"] + 32] = False      # Pu: debug instance only; SR_K head: cycle stamps
-    px = np.zeros((30, 30), bool); px[12:24] = True; keep[LC.SR["SR_PX"]:LC.SR["SR_PX"] + 900] = px.ravel()                                   # the zero rows of Px likewise
+    keep = np.ones(LC.SR["SR_SIZE"], bool); keep[LC.SR["SR_K"]:LC.SR["SR_K"] + 32] = False      # SR_K: cycle stamps of the instrumented instances
     for i in range(n - 1):
         if r["ev"][i] == 1:
             continue
