@@ -75,9 +75,13 @@ class HipEngine:
         from qm_control_amd import api, scenarios
         self.api = api; self.cfg = cfg; self.B = cfg["B"]
         nm = max_nodes or (cfg["n_intervals"] + 28)
+        import torch
+        torch.cuda.synchronize(local_rank); free0 = torch.cuda.mem_get_info(local_rank)[0]       # device-wide free bytes: sees the library's own hipMalloc calls
+        self.max_nodes = nm
         self.itf = api.QMInterface(blobs=scenarios.load_blobs(), device=local_rank, max_batch=self.B, max_nodes=nm, max_ref_knots=2, max_events=cfg["ev"].shape[1])
         self.mpc = api.SqpMpc(self.itf); self.wbc = api.HierarchicalWbc(self.itf)
         self.upload(cfg)
+        self.itf.synchronize(); self.device_bytes = int(free0 - torch.cuda.mem_get_info(local_rank)[0])    # MEASURED footprint of the contexts + uploaded inputs
         for key in ("riccati_skip", "wbc_stop", "lq_prof", "lq_debug", "lds_pad"):      # profiling-only switches make results meaningless: they must all be off
             assert self.itf.debug_get(key) == 0, key
 
@@ -238,7 +242,8 @@ def run(args, make_engine=HipEngine, backend="nccl", device="cuda"):
             "config": {"workload": "C3/C4: trot gait, horizon N=%d (dt 0.015), %d random initial states per GPU (seed 1235), cold start, 1 SQP iteration + policy eval + 3-level WBC; "
                                    "back-to-back steps, the WBC of a step on its own stream beside the next step's MPC kernels (pipelined THROUGHPUT: the per-kernel times add up to more "
                                    "than ms_per_step; the unpipelined step latency is latency_ms)" % (args.n_intervals, B),
-                       "instances_per_gpu": B, "global_batch": B * world, "parallelism": "shard%d" % world, "all_status_ok": bool(per_rank[:, 4].all()), "ls_trials": res["ls_trials"], "engine": getattr(eng, "name", "?")},
+                       "instances_per_gpu": B, "global_batch": B * world, "parallelism": "shard%d" % world, "all_status_ok": bool(per_rank[:, 4].all()), "ls_trials": res["ls_trials"], "engine": getattr(eng, "name", "?"),
+                       "max_nodes": getattr(eng, "max_nodes", None), "device_gb_measured": round(getattr(eng, "device_bytes", 0) / 1e9, 3)},
             "per_rank": {"seconds": [float(v) for v in per_rank[:, 0]], "lq_ms": [float(v) for v in per_rank[:, 1]], "riccati_ms": [float(v) for v in per_rank[:, 2]],
                          "wbc_ms": [float(v) for v in per_rank[:, 3]], "intervals_per_launch": [int(v) for v in per_rank[:, 5]]},
         }
@@ -303,9 +308,9 @@ def secondary_figures(args, eng, cfg, dist, device, world, rank):
         cfgs = sharding.shard_config(scenarios.make_config("C4", batch=8192, n_intervals=args.n_intervals), rank, world)
         es = HipEngine(cfgs, int(os.environ.get("LOCAL_RANK", "0")))
         es.step(); es.sync()
-        els, _ = timed_region(es, steps_s, dist, device); rs = es.results(); es.close()
+        els, _ = timed_region(es, steps_s, dist, device); rs = es.results(); es_nodes = es.max_nodes; es_gb = round(es.device_bytes / 1e9, 3); es.close()
         out["strong_scaling_C4"] = {"workload": "C4: trot, N = %d, global batch 8192 (seed 1235) in contiguous shards of %d instances per GPU" % (args.n_intervals, Bs), "value": 8192 * steps_s / els,
-                                    "unit": "steps/s", "n_gpus": world, "global_batch": 8192, "instances_per_gpu": Bs, "steps": steps_s, "ms_per_step": els / steps_s * 1e3, "scaling": "strong",
+                                    "unit": "steps/s", "n_gpus": world, "global_batch": 8192, "instances_per_gpu": Bs, "max_nodes": es_nodes, "device_gb_measured": es_gb, "steps": steps_s, "ms_per_step": els / steps_s * 1e3, "scaling": "strong",
                                     "all_status_ok": rs["ok"], "instances_with_failed_mpc_status": rs["n_bad_mpc"], "instances_with_mpc_warning": rs["n_warn_mpc"], "instances_with_nonzero_wbc_status": rs["n_bad_wbc"],
                                     "note": "a warning (status 1 = QM_MPC_WARN_PIVOT) marks an instance whose observation time puts a shooting node within 1e-6 s in front of a gait event "
                                             "(instance 2453 of this batch): the negative-duration stage there is solved with zeroed pivots in product and oracle alike "

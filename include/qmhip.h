@@ -31,8 +31,9 @@ typedef struct qmhip_ctx qmhip_ctx;
  *      WBC constructor / loadTasksSetting (qm_wbc/include/qm_wbc/WbcBase.h:28-34).
  *      Missing files -> QMHIP_ERR_FILE, like the reference's std::invalid_argument (QMInterface.cpp:45,53,61).
  *      3 <= max_nodes <= 512 (horizon nodes incl. event-split nodes; the per-instance node list lives in LDS), else QMHIP_ERR_ARG.
- *      Device memory: ~ 35 KB per (instance, node) — the stage record (30 KB; rounds 1-4: 58.9), the kinematics record (3 KB), iterate / step / reference arrays — i.e. 4.6 GB for
- *      max_batch 1024 x max_nodes 128, 33 GB for BASELINE config 4 on one device (8192 x 116); an allocation that does not fit returns QMHIP_ERR_HIP with the runtime's message. */
+ *      Device memory: ~ 35 KB per (instance, node) — the stage record (30 KB; rounds 1-4: 58.9), the kinematics record (3 KB), iterate / step / reference arrays — measured
+ *      (free device memory around the call, profiles/r05_context_footprint.json): 35.8 KB per (instance, node), 4.7 GB for max_batch 1024 x max_nodes 128, 34 GB for BASELINE config 4 on
+ *      one device at 8192 x 116 (its instances use <= 110 nodes) and 37.5 GB at 8192 x 128; an allocation that does not fit returns QMHIP_ERR_HIP with the runtime's message. */
 int qmhip_create(const char* urdf_file, const char* task_file, const char* reference_file,
                  int device, int max_batch, int max_nodes, int max_ref_knots, int max_events, qmhip_ctx** out);
 /* same, from the flat MODEL / SETTINGS blobs of qmhip_layout.h (no file I/O) */
