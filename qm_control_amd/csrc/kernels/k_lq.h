@@ -558,7 +558,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     int fc = 0, fs = l & 1;
     if (l < 6) fc = 3 + (l >> 1); else if (l < 12) fc = 9 + ((l - 6) >> 1); else if (l < 36) fc = 12 + ((l - 12) >> 1); else fc = 30 + ((l - 36) >> 1);
     double colf[12];
-    flow_jac_col(mb, X, U, fs ? K2 : K1, fc, colf);
+    int kofs = fs ? (int)(K2 - K1) : 0; QM_LANE_OPAQUE(kofs);                  // the lane's stage: one base, immediate offsets
+    flow_jac_col(mb, X, U, K1 + kofs, fc, colf);
     const int cc = (fc < 30) ? fc : fc - 30, r0 = (fc < 30) ? 0 : 16;
     for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
     qm_wave_sync();

@@ -34,6 +34,10 @@ typedef const double __attribute__((address_space(4)))* qm_ctab;
 #ifndef QM_TABLE_OPAQUE                 /* keeps the compiler from folding the two casts back into a plain global pointer */
 #define QM_TABLE_OPAQUE(p) asm volatile("" : "+s"(p))
 #endif
+#ifndef QM_LANE_OPAQUE                  /* a per-lane integer the compiler must treat as unknown: a lane-dependent choice between two LDS arrays is then ONE select of the base and
+                                          plain `ds_read ... offset:imm` accesses, not a select between two absolute addresses at every access (K1b: 66 accesses, 198 instructions) */
+#define QM_LANE_OPAQUE(i) asm volatile("" : "+v"(i))
+#endif
 __device__ __forceinline__ const double* qm_table(const double* p) { qm_ctab c = (qm_ctab)(p); QM_TABLE_OPAQUE(c); return (const double*)c; }
 
 // ---- 3-vector helpers (pointer based so operands may live in LDS, registers or global) ----

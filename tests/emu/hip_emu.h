@@ -27,6 +27,7 @@
 #define QM_MAX_VGPRS(n)            /* register caps mean nothing on the host */
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)   /* instruction-scheduling fence: no meaning on the host */
 #define QM_TABLE_OPAQUE(p)            /* device-only register constraint */
+#define QM_LANE_OPAQUE(i)             /* device-only register constraint */
 #define QM_PIN4(q) ((void)0)             /* device-only scheduling pin */
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };

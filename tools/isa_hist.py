@@ -1,7 +1,7 @@
 """tools/isa_hist.py — static instruction mix of the gfx950 kernels of libqmhip from the compiler's assembly (no GPU needed): per kernel the counts by class
 (FP64 VALU, other VALU, MFMA, SALU, LDS, vector memory) and, with --lines, the source lines that own the most instructions (hipcc -gline-tables-only).
 The dynamic mix (SQ PMC counters, profiles/flops_pmc.json) says how often; this says WHERE.
-usage: python tools/isa_hist.py [--lines N] [kernel ...]      (default kernels: qm_lq_kernel qm_riccati_kernel qm_wbc_kernel)"""
+usage: python tools/isa_hist.py [--other] [--lines N] [kernel ...]      (default kernels: qm_lq_kernel qm_riccati_kernel qm_wbc_kernel)"""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -17,7 +17,8 @@ def classify(op):
 
 
 def main(argv):
-    nlines = 0
+    nlines = 0; by_other = False
+    if argv and argv[0] == '--other': by_other = True; argv = argv[1:]          # rank the lines by their non-FP64 VALU instructions instead of by all instructions
     if argv and argv[0] == '--lines': nlines = int(argv[1]); argv = argv[2:]
     kernels = argv or ['qm_lq_kernel', 'qm_riccati_kernel', 'qm_wbc_kernel']
     with tempfile.TemporaryDirectory() as d:
@@ -37,8 +38,10 @@ def main(argv):
         tot = sum(cls.values()); valu = cls['valu_f64'] + cls['valu_other'] + cls['mfma']
         print('%s: %d instructions %s; non-FP64 share of VALU %.2f' % (name, tot, dict(cls), cls['valu_other'] / max(1, valu)))
         print('   top opcodes: ' + ' '.join('%s:%d' % x for x in ops.most_common(14)))
+        if by_other:
+            per = collections.Counter({k: sum(n for op, n in perop[k].items() if classify(op) == 'valu_other') for k in perop})
         for k, n in per.most_common(nlines):
-            print('   %5d %s:%d  %s' % (n, k[0] if k else None, k[1] if k else 0, ' '.join('%s:%d' % x for x in perop[k].most_common(4))))
+            print('   %5d %s:%d  %s' % (n, k[0] if k else None, k[1] if k else 0, ' '.join('%s:%d' % x for x in perop[k].most_common(5))))
 
 
 if __name__ == '__main__':
