@@ -77,6 +77,31 @@ def test_instances_are_independent(full_run, blobs):
     itf.close()
 
 
+def test_receding_horizon_steps_are_reproducible_and_shard_safe(blobs):
+    """five receding-horizon steps on the device (every solve after the first WARM-started from the shifted previous solution, the observation advanced along the policy):
+    a second run gives bit-identical outputs (no race, no dependence on the order of atomics) and a slice of the batch run on its own equals the batch's rows.  Same-box
+    comparisons of two builds (tools/gpu_ab_accept.sh) and weak scaling over GPUs rest on both; a cold step does not exercise the warm start — one K1a change of round 5 was
+    bitwise invisible on cold steps and showed only from the first warm-started solve on (profiles/r05_build_bisect.txt)"""
+    from qm_control_amd import api, scenarios
+    cfg = scenarios.make_config("C4", batch=256)
+
+    def run(sl):
+        B = sl.stop - sl.start
+        itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+        mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+        mpc.set_problem(cfg["t0"][sl], cfg["x0"][sl], cfg["ref_t"][sl], cfg["ref_x"][sl], cfg["ev"][sl], cfg["modes"][sl])
+        wbc.reset(); mpc.closed_loop_resident(5, 0.01, cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
+        res = mpc.download(); out, qps = wbc.download(B); itf.close()
+        assert (res["status"] >= 0).all() and (qps == 0).all()
+        return res["x"], res["u"], res["t"], out
+
+    full = run(slice(0, 256)); again = run(slice(0, 256)); part = run(slice(96, 160))
+    for a, b, c in zip(full, again, part):
+        assert np.array_equal(a, b)                       # run-to-run
+        assert np.array_equal(a[96:160], c)               # slice == rows of the batch
+    assert not np.array_equal(full[0][:, 0], cfg["x0"])   # the loop did advance the observation (the test is not comparing untouched inputs)
+
+
 def test_sample_matches_oracle(full_run, blobs):
     """64 seeded instances of the full batch against the oracle (64 threads over instances): the WHOLE optimal state / input trajectories (N = 100), node times and
     integer schedules, the policy at t0 and the WBC output — per block, 1e-6"""
