@@ -12,13 +12,29 @@ LIB = os.path.join(ROOT, "qm_control_amd", "libqmhip.so")
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
-def _kernels():
+def _code_object():
     blob = open(LIB, "rb").read(); i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__"); assert i >= 0, "no offload bundle in libqmhip.so"
     n = struct.unpack_from("<Q", blob, i + 24)[0]; p = i + 32; co = None
     for _ in range(n):
         off, size, tl = struct.unpack_from("<QQQ", blob, p); p += 24; triple = blob[p:p + tl].decode(); p += tl
         if "gfx950" in triple: co = blob[i + off:i + off + size]
     assert co, "no gfx950 code object"
+    return co
+
+
+def _code_bytes():
+    """machine-code size of every kernel (symbol table of the gfx950 code object)"""
+    with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+        f.write(_code_object()); f.flush(); syms = subprocess.run([READELF, "-s", "--wide", f.name], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for line in syms.splitlines():
+        m = re.search(r"\s(\d+)\s+FUNC\s+\S+\s+\S+\s+\S+\s+_Z\d+(qm_\w+_kernel)\w*$", line)
+        if m: out[m.group(2)] = max(int(m.group(1)), out.get(m.group(2), 0))
+    return out
+
+
+def _kernels():
+    co = _code_object()
     with tempfile.NamedTemporaryFile(suffix=".elf") as f:
         f.write(co); f.flush(); notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
     out = {}
@@ -44,6 +60,16 @@ def test_register_and_scratch_budgets():
     # the wave's rows moved together through LDS) keeps them at <= 160 / <= 224 B per lane (round 4: 108 / 352 B with 2504 scalar-register spills in K4)
     assert alloc("qm_lq_kin_kernel") <= 256 and alloc("qm_ls_eval_kernel") <= 256
     assert k["qm_lq_kin_kernel"]["scratch"] <= 160 and k["qm_ls_eval_kernel"]["scratch"] <= 224
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(READELF)), reason="libqmhip.so / llvm-readelf not available")
+def test_code_size_of_the_large_kernels():
+    """A wave of the LQ kernel executes nearly all of its code once (few loops), so its code size IS its instruction count: 30.7 KB / 31.8 KB for the two product instances
+    since the lane's choice between the two stages' kinematics arrays is one opaque base (QM_LANE_OPAQUE) — written as `fs ? K2 : K1` the compiler selects between two
+    literal LDS addresses at each of the 66 accesses behind it (+ 1.8 KB, + 1.2 % of the kernel's time, profiles/r05_ab_lane_base.log).  The bounds leave ~ 3 % of room."""
+    b = _code_bytes()
+    assert b["qm_lq_kernel"] <= 31700 and b["qm_lq_m18_kernel"] <= 32800, (b["qm_lq_kernel"], b["qm_lq_m18_kernel"])
+    assert b["qm_riccati_kernel"] <= 45000 and b["qm_wbc_kernel"] <= 185000, (b["qm_riccati_kernel"], b["qm_wbc_kernel"])     # (the WBC exceeds the 64 KB instruction cache by design: DESIGN.md section 7)
 
 
 def test_lds_budgets_fit_the_intended_waves_per_cu():
