@@ -16,6 +16,7 @@
 // the node's spinner thread; qmhip_set_setting serialises with qmhip_wbc_step on the context's lock (include/qmhip.h "Threads").
 #pragma once
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -26,6 +27,7 @@
 #else
 #include <dynamic_reconfigure/Config.h>
 #include <qm_wbc/WbcBase.h>
+#include <ros/callback_queue.h>
 #include <ros/ros.h>
 #endif
 
@@ -39,11 +41,18 @@ class QmhipWbc : public WbcBase {
     if (!ctx_) throw std::invalid_argument("[QmhipWbc] null device context");
     if (qmhip_wbc_reset(ctx_) != QMHIP_OK) throw std::runtime_error(std::string("[QmhipWbc] qmhip_wbc_reset: ") + qmhip_last_error(ctx_));
     // the base class has just started its server on <controller>/wbc (WbcBase.cpp:60-65): follow its (latched) update topic
-    gainSub_ = controllerNh.subscribe<dynamic_reconfigure::Config>("wbc/parameter_updates", 4, [this](const dynamic_reconfigure::Config::ConstPtr& msg) { applyReconfigure(*msg); });
+    // on a PRIVATE callback queue: this constructor runs inside the controller_manager's load-controller service callback, where ros::spinOnce() would run the global
+    // queue's other callbacks re-entrantly, and a controller handle with a custom queue would never deliver to the global one at all
+    gainNh_ = ros::NodeHandle(controllerNh); gainNh_.setCallbackQueue(&gainQueue_);
+    gainSub_ = gainNh_.subscribe<dynamic_reconfigure::Config>("wbc/parameter_updates", 4, [this](const dynamic_reconfigure::Config::ConstPtr& msg) { applyReconfigure(*msg); });
     // Until that latched message is delivered the device runs on the gains of the settings blob (the cfg defaults) while WbcBase's members may already hold the parameter
-    // server's overrides (applied in setCallback): wait — bounded — for the first configuration, so that the first control ticks use the server's gains.
-    for (int k = 0; k < 200 && reconfigureCount_.load() == 0 && ros::ok(); ++k) { ros::spinOnce(); ros::Duration(0.005).sleep(); }
+    // server's overrides (applied in setCallback): wait — bounded in WALL time: under use_sim_time with Gazebo started paused (empty_world*.launch: paused = true) ROS time
+    // stands still and ros::Duration::sleep() would not return — for the first configuration, so that the first control ticks use the server's gains.
+    const ros::WallTime deadline = ros::WallTime::now() + ros::WallDuration(1.0);
+    while (reconfigureCount_.load() == 0 && ros::ok() && ros::WallTime::now() < deadline) gainQueue_.callAvailable(ros::WallDuration(0.005));
+    gainSpinner_.reset(new ros::AsyncSpinner(1, &gainQueue_)); gainSpinner_->start();      // later reconfigure messages: one thread on the private queue (applyReconfigure is thread-safe)
   }
+  ~QmhipWbc() { if (gainSpinner_) gainSpinner_->stop(); }      // (WbcBase declares no virtual destructor, WbcBase.h:23-34: the controller holds the object through a shared_ptr made from the concrete type)
 
   // one configuration of the reference's server -> device gains; returns how many gains were written.  Never throws (it runs in a subscriber callback):
   // a refused value is counted in gainErrors() and the text kept in lastGainError()
@@ -85,7 +94,8 @@ class QmhipWbc : public WbcBase {
 
  private:
   qmhip_ctx* ctx_; int variant_; int32_t qpStatus_[3] = {0, 0, 0};
-  ros::Subscriber gainSub_; std::atomic<int> reconfigureCount_{0}, gainErrors_{0}; mutable std::mutex errMutex_; std::string lastGainError_;
+  ros::CallbackQueue gainQueue_; ros::NodeHandle gainNh_; ros::Subscriber gainSub_; std::unique_ptr<ros::AsyncSpinner> gainSpinner_;      // (the queue outlives everything that refers to it)
+  std::atomic<int> reconfigureCount_{0}, gainErrors_{0}; mutable std::mutex errMutex_; std::string lastGainError_;
 };
 
 }  // namespace qm

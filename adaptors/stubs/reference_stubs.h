@@ -15,11 +15,17 @@
 namespace ros {
 struct Publisher {};
 struct Subscriber {};
+// roscpp: wall-clock time (independent of /clock), a private callback queue and a spinner thread on it
+struct WallDuration { explicit WallDuration(double s = 0) : s_(s) {} bool sleep() const { return true; } double s_; };
+struct WallTime { static WallTime now() { return WallTime(); } WallTime operator+(const WallDuration& d) const { WallTime t; t.s_ = s_ + d.s_; return t; } bool operator<(const WallTime& o) const { return s_ < o.s_; } double s_ = 0; };
+struct CallbackQueue { void callAvailable(WallDuration) {} };
+struct AsyncSpinner { AsyncSpinner(unsigned, CallbackQueue*) {} void start() {} void stop() {} };
 inline void init(int&, char**, const std::string&) {}
 struct NodeHandle {
   NodeHandle() = default;
   explicit NodeHandle(const std::string&) {}
   NodeHandle(const NodeHandle&, const std::string&) {}
+  void setCallbackQueue(CallbackQueue*) {}
   template <class M> Publisher advertise(const std::string&, int) { return Publisher(); }
   // roscpp: subscribe<M>(topic, queue_size, boost::function<void(const boost::shared_ptr<M const>&)>)
   template <class M, class F> Subscriber subscribe(const std::string&, int, F callback) { if (false) callback(typename M::ConstPtr()); return Subscriber(); }      // type-checks the callback against M::ConstPtr
@@ -203,7 +209,6 @@ class QMInterface {                             // qm_interface/include/qm_inter
 class WbcBase {                                 // qm_wbc/include/qm_wbc/WbcBase.h:26-34
  public:
   WbcBase(const ocs2::PinocchioInterface&, ocs2::CentroidalModelInfo, const ocs2::PinocchioEndEffectorKinematics&, const ocs2::PinocchioEndEffectorKinematics&, ros::NodeHandle&) {}
-  virtual ~WbcBase() = default;
   virtual ocs2::vector_t update(const ocs2::vector_t&, const ocs2::vector_t&, const ocs2::vector_t&, size_t, ocs2::scalar_t, ocs2::scalar_t) { return ocs2::vector_t(); }
   virtual void loadTasksSetting(const std::string&, bool) {}
 };

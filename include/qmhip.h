@@ -36,7 +36,8 @@ typedef struct qmhip_ctx qmhip_ctx;
  *      one device at 8192 x 116 (its instances use <= 110 nodes) and 37.5 GB at 8192 x 128; an allocation that does not fit returns QMHIP_ERR_HIP with the runtime's message. */
 int qmhip_create(const char* urdf_file, const char* task_file, const char* reference_file,
                  int device, int max_batch, int max_nodes, int max_ref_knots, int max_events, qmhip_ctx** out);
-/* same, from the flat MODEL / SETTINGS blobs of qmhip_layout.h (no file I/O) */
+/* same, from the flat MODEL / SETTINGS blobs of qmhip_layout.h (no file I/O).  The blobs carry no size stamp: model_blob must hold MB_SIZE and settings_blob ST_SIZE doubles of THIS
+ *      header's layout (a shorter array of an older layout is read past its end); the slots whose garbage would steer a kernel's control flow are range-checked (QMHIP_ERR_MODEL) */
 int qmhip_create_from_blobs(const double* model_blob, const double* settings_blob,
                             int device, int max_batch, int max_nodes, int max_ref_knots, int max_events, qmhip_ctx** out);
 /* WBC-only context for the control thread (see "Threads" above): the parent's model and settings VALUES (copied; later qmhip_set_setting calls go to whichever
@@ -170,8 +171,8 @@ int qmhip_policy_eval(qmhip_ctx* ctx, int B, const double* t, double* x_des /*[B
  *      out[b] = [vdot(24), F(12), tau(18)]; qp_status[b][3] per priority level: 0 ok, 1 iteration limit (qpOASES' nWSR = 100, HoQp.cpp:141), 2 working set larger
  *      than the level's null space (a degenerate vertex).  `variant` selects one of the two hierarchies the reference ships; both put inequality rows into their first
  *      level only, and the cascade kernel is specialised to that shape (slack eliminated analytically at level 0, hard rows below).  The GENERAL stacking of
- *      HoQp.cpp:92-124 — own inequality rows at a lower level, with the reference's current-first / previous-first pairing of stacked rows and slack solutions — cannot
- *      is what qmhip_hoqp_solve below offers on explicit task matrices (a generic kernel); restated in the oracle (oracle/src/wbc.h: solveHoLevel) and pinned against
+ *      HoQp.cpp:92-124 — own inequality rows at a lower level, with the reference's current-first / previous-first pairing of stacked rows and slack solutions — is not
+ *      reachable through this entry point; it is what qmhip_hoqp_solve below offers on explicit task matrices (a generic kernel); restated in the oracle (oracle/src/wbc.h: solveHoLevel) and pinned against
  *      the literal cascade (tests/test_hoqp_literal.py).
  *      The joint-acceleration state `inputLast_` (WbcBase.cpp:212-213) lives in the context per instance;
  *      qmhip_wbc_reset zeroes it.  The call enqueues on the context's WBC stream only and waits for that stream only (pinned staging, asynchronous copies). */

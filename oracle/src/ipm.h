@@ -19,7 +19,7 @@
 //      accepted:  x += alpha dx, u += alpha du, s += alpha ds,  lam += alphaDual dlam with alphaDual = usePrimalStepSizeForDual ? min(alpha, alphaD) : alphaD
 //   4. barrier update [IpmSolver::updateBarrierParameter]: when |merit_before − merit_after| < barrierReductionCostTol and theta_after < barrierReductionConstraintTol:
 //          mu <- max(targetBarrierParameter, min(barrierLinearDecreaseFactor mu, mu ^ barrierSuperlinearDecreasePower))
-// Slack, dual and mu persist across the iterations of a solve (and across warm MPC calls when the grid keeps its node count; otherwise they are re-initialised).
+// Slack, dual and mu persist across the iterations of ONE solve; every solve (cold or warm MPC call) re-initialises them at its initial iterate, as the device does (qm_pipeline.h: ipm_fresh).
 #pragma once
 #include "sqp.h"
 

@@ -41,8 +41,9 @@ struct HipBackend {
   void check(hipError_t e, const char* what) { if (e != hipSuccess && error.empty()) error = std::string(what) + ": " + hipGetErrorString(e); }
   template <class K> const char* name_of(K k) {
     const void* p = (const void*)k;
-    if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel || p == (const void*)qm_lq_dbg_kernel) return "lq"; if (p == (const void*)qm_lq_m18_kernel) return "lq_m18"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel || p == (const void*)qm_riccati_prof_kernel) return "riccati";
-    if (p == (const void*)qm_ls_eval_kernel || p == (const void*)qm_ls_eval_dense_kernel) return "ls_eval"; if (p == (const void*)qm_ilqr_rollout_kernel) return "rollout"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy"; if (p == (const void*)qm_hoqp_kernel) return "hoqp";
+    if (p == (const void*)qm_grid_kernel || p == (const void*)qm_grid_nodes_kernel || p == (const void*)qm_save_grid_kernel || p == (const void*)qm_advance_kernel) return "grid"; if (p == (const void*)qm_lq_kernel || p == (const void*)qm_lq_dbg_kernel || p == (const void*)qm_lq_ipm_kernel) return "lq"; if (p == (const void*)qm_lq_m18_kernel) return "lq_m18"; if (p == (const void*)qm_lq_kin_kernel) return "lq_kin"; if (p == (const void*)qm_riccati_kernel || p == (const void*)qm_riccati_prof_kernel) return "riccati";
+    if (p == (const void*)qm_ls_eval_kernel || p == (const void*)qm_ls_eval_dense_kernel || p == (const void*)qm_ls_eval_ipm_kernel) return "ls_eval";
+    if (p == (const void*)qm_ipm_init_kernel || p == (const void*)qm_ipm_dir_kernel || p == (const void*)qm_ipm_alpha_kernel || p == (const void*)qm_ipm_commit_kernel || p == (const void*)qm_ipm_barrier_kernel) return "ipm"; if (p == (const void*)qm_ilqr_rollout_kernel) return "rollout"; if (p == (const void*)qm_sim_kernel) return "sim"; if (p == (const void*)qm_wbc_kernel || p == (const void*)qm_wbc_prof_kernel) return "wbc"; if (p == (const void*)qm_policy_kernel || p == (const void*)qm_policy_measured_kernel) return "policy"; if (p == (const void*)qm_hoqp_kernel) return "hoqp";
     return "ls_misc";
   }
   template <class K, class A> void launch(K kernel, int grid, int block, size_t lds, const A& args) {
@@ -53,7 +54,7 @@ struct HipBackend {
       if (it == lds_set.end() || it->second < (int)lds) { check(hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); lds_set[p] = (int)lds; }
     }
     const void* kp_ = (const void*)kernel;
-    const bool span = profiling == 1 || (profiling == 2 && (kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_lq_m18_kernel || kp_ == (const void*)qm_riccati_kernel || kp_ == (const void*)qm_wbc_kernel));      // (lq_m18: launched only on workloads with a phase of three or four stance feet; bench.py prices lq + lq_m18 together)
+    const bool span = profiling == 1 || (profiling == 2 && (kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_lq_m18_kernel || kp_ == (const void*)qm_lq_ipm_kernel || kp_ == (const void*)qm_riccati_kernel || kp_ == (const void*)qm_wbc_kernel));      // (lq_m18: launched only on workloads with a phase of three or four stance feet; bench.py prices lq + lq_m18 together)
     Span s; if (span) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); check(hipEventRecord(s.a, cur), "hipEventRecord"); }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, cur, args);
     check(hipGetLastError(), "kernel launch");
@@ -138,7 +139,20 @@ __global__ void qm_bench_mfma_kernel(double* out, int iters) {
 }
 
 // settings whose value the kernels' loop bounds depend on (K0 walks t0 + k dt up to the horizon)
-static bool setting_ok(int idx, double v) { if (idx == ST_SQP_DT || idx == ST_IPM_DT) return v > 0.0 && std::isfinite(v); if (idx == ST_GRID_DT_MIN) return v >= 0.0 && std::isfinite(v); if (idx == ST_RICCATI_STRICT) return v == 0.0 || v == 1.0; return true; }
+static bool setting_ok(int idx, double v) {
+  if (idx == ST_SQP_DT || idx == ST_IPM_DT) return v > 0.0 && std::isfinite(v);
+  if (idx == ST_GRID_DT_MIN) return v >= 0.0 && std::isfinite(v);
+  if (idx == ST_RICCATI_STRICT || idx == ST_IPM_PRIMAL_FOR_DUAL) return v == 0.0 || v == 1.0;
+  // interior-point solver (slot 3, k_ipm.h): the barrier parameter and the slack / dual floors are divided by and go through log(); the margin and the linear factor are fractions
+  if (idx == ST_IPM_MU || idx == ST_IPM_MU_TARGET || idx == ST_IPM_SLACK_LB || idx == ST_IPM_DUAL_LB) return v > 0.0 && std::isfinite(v);
+  if (idx == ST_IPM_FTB_MARGIN || idx == ST_IPM_MU_LINEAR) return v > 0.0 && v < 1.0;
+  if (idx == ST_IPM_MU_POWER) return v > 1.0 && std::isfinite(v);
+  if (idx == ST_IPM_SLACK_MARGIN || idx == ST_IPM_DUAL_MARGIN) return v >= 0.0 && std::isfinite(v);
+  return true;
+}
+// the slots the interior-point solver reads: all of them must hold before solver 3 may run (a blob of the 1048-double layout has zeros there: division by zero in qm_ipm_dir_kernel, log(0) in the merit)
+static const int kIpmSlots[] = {ST_IPM_DT, ST_IPM_MU, ST_IPM_MU_TARGET, ST_IPM_MU_LINEAR, ST_IPM_MU_POWER, ST_IPM_FTB_MARGIN, ST_IPM_PRIMAL_FOR_DUAL, ST_IPM_SLACK_LB, ST_IPM_DUAL_LB, ST_IPM_SLACK_MARGIN, ST_IPM_DUAL_MARGIN};
+static bool ipm_settings_ok(const double* st) { for (int i : kIpmSlots) if (!setting_ok(i, st[i])) return false; return true; }
 
 // ---- co-residency probe (profiling only): a latency-bound stand-in for a narrow (<= 256 VGPR, <= 20 KB LDS) one-wave-per-instance solver wave — chains of
 // dependent f64 MFMAs and FMAs with an LDS round trip per step, ≈ 40 % issue utilisation like qm_riccati_kernel — launched on the second stream beside the
@@ -165,7 +179,8 @@ static int create_common(const double* mb, const double* st, int device, int max
   // a blob of an older layout (no size / version stamp travels with it) would put garbage into the slots added since: check the ones a kernel's control flow depends on
   if (!setting_ok(ST_GRID_DT_MIN, st[ST_GRID_DT_MIN])) { g_create_error = "settings blob: the time grid's minimum step (ST_GRID_DT_MIN) must be a non-negative finite number - is the blob of an older layout (ST_SIZE)?"; return QMHIP_ERR_MODEL; }
   if (st[ST_RICCATI_STRICT] != 0.0 && st[ST_RICCATI_STRICT] != 1.0) { g_create_error = "settings blob: ST_RICCATI_STRICT must be 0 or 1 - is the blob of an older layout (ST_SIZE)?"; return QMHIP_ERR_MODEL; }
-  if (st[ST_SOLVER] != 0.0 && st[ST_SOLVER] != 1.0 && st[ST_SOLVER] != 2.0) { g_create_error = "settings blob: ST_SOLVER must be 0, 1 or 2"; return QMHIP_ERR_MODEL; }
+  if (st[ST_SOLVER] != 0.0 && st[ST_SOLVER] != 1.0 && st[ST_SOLVER] != 2.0 && st[ST_SOLVER] != 3.0) { g_create_error = "settings blob: ST_SOLVER must be 0, 1, 2 or 3"; return QMHIP_ERR_MODEL; }
+  if (st[ST_SOLVER] == 3.0 && !ipm_settings_ok(st)) { g_create_error = "settings blob: ST_SOLVER = 3 needs the ipm block's slots (ST_IPM_*: barrier parameters, slack / dual floors > 0, margin and linear factor in (0, 1), power > 1) - is the blob of an older layout (ST_SIZE)?"; return QMHIP_ERR_MODEL; }
   int ndev = 0; if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_create_error = "no HIP device available (libqmhip has no CPU fallback)"; return QMHIP_ERR_HIP; }
   if (device < 0 || device >= ndev) { g_create_error = "device index out of range"; return QMHIP_ERR_ARG; }
   if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return QMHIP_ERR_HIP; }
@@ -174,7 +189,7 @@ static int create_common(const double* mb, const double* st, int device, int max
   if (hipStreamCreate(&c->bk.stream) != hipSuccess || hipStreamCreate(&c->bk.stream_b) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
   c->bk.cur = c->bk.stream; hipEventCreateWithFlags(&c->bk.ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->bk.ev_wbc, hipEventDisableTiming);
   c->wbc_only = wbc_only;
-  c->mpc.allocate(c->mb, c->st, wbc_only ? 1 : max_batch, max_nodes, max_ref, max_ev, false); c->mpc.solver = (st[ST_SOLVER] == 1.0) ? 1 : ((st[ST_SOLVER] == 2.0) ? 2 : 0);
+  c->mpc.allocate(c->mb, c->st, wbc_only ? 1 : max_batch, max_nodes, max_ref, max_ev, false); c->mpc.solver = (int)st[ST_SOLVER];
   c->wbc.allocate(max_batch);
   if (!wbc_only) c->front.allocate(max_batch);
   { void* h = nullptr; c->bk.check(hipHostMalloc(&h, QmWbcPipeline<HipBackend>::in_bytes(max_batch) + QmWbcPipeline<HipBackend>::out_bytes(max_batch), hipHostMallocDefault), "hipHostMalloc"); c->tick_pin = (char*)h; }
@@ -230,9 +245,10 @@ int qmhip_wbc_gain_index(const char* name) {
 }
 int qmhip_set_setting(qmhip_ctx* c, int idx, double v) { QM_GUARD(c);
   if (!c || idx < 0 || idx >= ST_SIZE) return QMHIP_ERR_ARG;
-  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number, the grid's minimum step a non-negative one, ST_RICCATI_STRICT 0 or 1"); return QMHIP_ERR_ARG; }
+  if (!setting_ok(idx, v)) { c->fail("qmhip_set_setting: sqp.dt / ipm.dt must be a positive finite number, the grid's minimum step a non-negative one, ST_RICCATI_STRICT 0 or 1; ipm block: barrier parameters and slack / dual floors > 0, margin and linear decrease factor in (0, 1), superlinear power > 1, margin rates >= 0"); return QMHIP_ERR_ARG; }
+  if (idx == ST_SOLVER && v == 3.0 && !ipm_settings_ok(c->st)) { c->fail("qmhip_set_setting: solver 3 needs valid ipm settings (ST_IPM_*) - is the settings blob of an older layout?"); return QMHIP_ERR_ARG; }
   if (idx == ST_SOLVER && v >= 2.0 && !setting_ok(ST_IPM_DT, c->st[ST_IPM_DT])) { c->fail("qmhip_set_setting: solvers 2 / 3 need a positive finite ipm.dt"); return QMHIP_ERR_ARG; }
-  if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR), 2 (the SQP step on the `ipm` block's parameters) or 3 (interior-point method with hard friction cones / arm boxes)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; }
+  if (idx == ST_SOLVER) { if (v != 0.0 && v != 1.0 && v != 2.0 && v != 3.0) { c->fail("qmhip_set_setting: ST_SOLVER is 0 (SQP), 1 (discrete iLQR), 2 (the SQP step on the `ipm` block's parameters) or 3 (interior-point method with hard friction cones / arm boxes)"); return QMHIP_ERR_ARG; } c->mpc.solver = (int)v; c->mpc.solved_B = 0; c->have_solution = false; c->mpc.ipm_fresh = true; }      // (a solver switch starts the interior-point state over: slack / dual / barrier parameter of an earlier solve are not carried across)
   hipSetDevice(c->device); c->st[idx] = v; c->bk.to_device(c->mpc.d.st + idx, &v, 8); c->mpc.note_settings(c->st); return c->hipstate();
 }
 

@@ -166,7 +166,7 @@ __device__ __forceinline__ void quat_to_R(const double* q /*xyzw*/, double* R) {
   R[3] = txy + twz; R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
   R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0 - (txx + tyy);
 }
-__global__ void qm_target_kernel(QmTargetArgs a) {
+__global__ void __launch_bounds__(64) qm_target_kernel(QmTargetArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   const int kind = a.kind[b];

@@ -696,7 +696,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
       const double s1 = act ? a.ipm_s[(size_t)nb * QM_NH + r1] : 1.0, l1 = act ? a.ipm_l[(size_t)nb * QM_NH + r1] : 0.0;
       const double s2 = boxv ? a.ipm_s[(size_t)nb * QM_NH + r1 + 1] : 1.0, l2 = boxv ? a.ipm_l[(size_t)nb * QM_NH + r1 + 1] : 0.0;
       // (the condensed rows are NOT weighted by the interval length, the cost blocks they join are multiplied by dt below: hence the 1 / dt)
-      const double i1 = 1.0 / s1, i2 = 1.0 / s2, idt = 1.0 / dt;
+      const double i1 = 1.0 / s1, i2 = 1.0 / s2, idt = (dt != 0.0) ? 1.0 / dt : 0.0;      // (an interval of exactly zero length — a node exactly weakEpsilon in front of a gait event — carries no cost and no condensed rows: inf * 0 would poison R, r and the merit)
       p2 = l1 * i1 * idt; p1 = ((l1 * h1 - mub) * i1 - l1) * idt; q2 = l2 * i2 * idt; q1 = ((l2 * h2 - mub) * i2 - l2) * idt;
       if (!act) { p1 = 0.0; p2 = 0.0; } if (!boxv) { q1 = 0.0; q2 = 0.0; }
       v1 = act ? -mub * log(s1) * idt : 0.0; v2 = boxv ? -mub * log(s2) * idt : 0.0;

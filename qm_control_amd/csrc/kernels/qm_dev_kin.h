@@ -195,7 +195,7 @@ __device__ __forceinline__ void flow_jac_col(const double* mb, const double* x, 
     const int i = (c - 30) / 3, k = (c - 30) - 3 * i;
     col12[k] = im;
     const double* p = kin_foot(K, i); const double d[3] = {p[0] - K[KW_COM], p[1] - K[KW_COM + 1], p[2] - K[KW_COM + 2]};
-    double ek[3] = {0.0, 0.0, 0.0}; ek[k] = 1.0; double t[3]; v3_cross(d, ek, t);
+    const double ek[3] = {(k == 0) ? 1.0 : 0.0, (k == 1) ? 1.0 : 0.0, (k == 2) ? 1.0 : 0.0}; double t[3]; v3_cross(d, ek, t);      // (selects, not ek[k] = 1: a private array indexed by a run-time value lives in the private segment)
     for (int r = 0; r < 3; ++r) col12[3 + r] = t[r] * im;
   }
 }

@@ -10,11 +10,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-6
 
 
-@pytest.fixture(scope="module")
-def full_run(blobs):
+@pytest.fixture(scope="module", params=["C3", "C4"])
+def full_run(blobs, request):
+    """BASELINE.json config 3 (seed 1234) and the first 1024-shard of config 4 (seed 1235), each at 1024 x N = 100: same distribution, different draws"""
     from qm_control_amd import api, scenarios
     B = 1024
-    cfg = scenarios.make_config("C4", batch=B)
+    cfg = scenarios.make_config(request.param, batch=B)
     itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1])
     mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
     mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
