@@ -148,6 +148,12 @@ class Oracle:
         return dict(t=nt[:k].copy(), ev=ne[:k].copy(), mode=nm[:k].copy(), x=xo[:k].copy(), u=uo[:k].copy(), perf=perf,
                     alpha=perf[8], armijo=perf[9], ls_trials=self.lib.qmo_ls_trials(self.h), warn=self.lib.qmo_last_warn(self.h))
 
+    def ls_trace(self):
+        """diagnostics: rows {alpha, merit, theta, filter branch, accepted} of the last SQP iteration's line search; row 0 is the baseline {0, merit, theta0, armijo, -1}"""
+        out = np.zeros((20, 5)); self.lib.qmo_ls_trace.restype = C.c_int
+        k = self.lib.qmo_ls_trace(self.h, _p(out), C.c_int(20))
+        return out[:k].copy()
+
     def ilqr_step(self, t0, tf, x0, warm=False):
         """one discrete iLQR iteration (oracle/src/ilqr.h): same result dict as mpc_step"""
         x0 = np.ascontiguousarray(x0, float); n = C.c_int(0)

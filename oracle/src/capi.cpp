@@ -107,6 +107,8 @@ int qmo_get_step(void* h, double* dx, double* du) {
   return n;
 }
 int qmo_ls_trials(void* h) { return ((Oracle*)h)->R.lsTrials; }
+// diagnostics (tools/warm_ls_histogram.py): rows of 5 doubles, baseline first, then one row per trial (sqp.h: SqpResult::lsTrace); returns the number of rows copied
+int qmo_ls_trace(void* h, double* out, int max_rows) { const std::vector<double>& t = ((Oracle*)h)->R.lsTrace; const int n = (int)(t.size() / 5), k = n < max_rows ? n : max_rows; for (int i = 0; i < 5 * k; ++i) out[i] = t[i]; return k; }
 // tests only: 1 = every Jacobian from the full 60-slot forward mode of rounds 1-4 (the seeded evaluation must reproduce it entry by entry), 0 = seeded (default)
 void qmo_set_full_seeding(int on) { qm_ad_full_seeding = on != 0; }
 int qmo_last_warn(void* h) { return ((Oracle*)h)->R.warn; }      // warning bits of the last (valid) solve: QM_MPC_WARN_PIVOT

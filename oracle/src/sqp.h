@@ -104,6 +104,7 @@ struct SqpResult {
   int warn = 0;                    // warning bits of a VALID solution: QM_MPC_WARN_PIVOT = some stage's Huu had non-positive pivots, zeroed (riccatiSolve)
   // hard-inequality interior-point solver (ipm.h): slack / dual of every node's QM_NH inequality rows, their Newton directions, the barrier parameter and the step limits of the last iteration
   std::vector<Vec> slack, dual, dslack, ddual; double barrier = 0.0, alphaPrimalMax = 1.0, alphaDualMax = 1.0, alphaDual = 0.0;
+  std::vector<double> lsTrace;     // diagnostics: per line-search trial {alpha, merit, theta, filter branch (0: theta > gMax, 1: Armijo, 2: cost-or-constraint decrease), accepted}; [0..4] of the baseline: {0, merit, theta0, armijo, -1}
   double phaseMs[3] = {0, 0, 0};   // wall time of the last iteration: LQ approximation + projection, Riccati solve, line search (the timers ocs2's benchmark prints)
 };
 
@@ -319,6 +320,7 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
   const double theta0 = std::sqrt(base.dynSSE + base.eqSSE);
   const double duNorm = trajectoryNorm(R.du), dxNorm = trajectoryNorm(R.dx);
   double alpha = 1.0; bool accepted = false; std::vector<Vec> xn(N + 1), un(N); Performance pn; R.lsTrials = 0;
+  R.lsTrace.assign({0.0, base.merit, theta0, armijo, -1.0});
   do {
     for (int i = 0; i <= N; ++i) { xn[i] = x[i]; for (int k = 0; k < QM_NX; ++k) xn[i][k] += alpha * R.dx[i][k]; }
     for (int i = 0; i < N; ++i) { un[i] = u[i]; if (R.grid[i].ev != QM_EV_PRE) for (int k = 0; k < QM_NU; ++k) un[i][k] += alpha * R.du[i][k]; }
@@ -327,6 +329,7 @@ inline void sqpIteration(const Problem& P, double t0, double tf, const Vec& x0, 
     if (theta > gMax) accepted = theta < (1.0 - gammaC) * theta0;
     else if (theta < gMin && theta0 < gMin && alpha * armijo < 0.0) accepted = pn.merit < base.merit + armijoFactor * alpha * armijo;
     else accepted = pn.merit < (base.merit - gammaC * theta0) || theta < (1.0 - gammaC) * theta0;
+    { const double br = (theta > gMax) ? 0.0 : ((theta < gMin && theta0 < gMin && alpha * armijo < 0.0) ? 1.0 : 2.0); const double row[5] = {alpha, pn.merit, theta, br, accepted ? 1.0 : 0.0}; R.lsTrace.insert(R.lsTrace.end(), row, row + 5); }
     if (accepted) break;
     alpha *= alphaDecay;
     if (alpha * duNorm < msParam(st, MsParam::DeltaTol) && alpha * dxNorm < msParam(st, MsParam::DeltaTol)) break;

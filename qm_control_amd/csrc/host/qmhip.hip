@@ -509,8 +509,9 @@ int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launche
 }
 int qmhip_reset_kernel_ms(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.acc.clear(); return QMHIP_OK; }
 int qmhip_synchronize(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
-int qmhip_last_ls_trials(const qmhip_ctx* c) { QM_GUARD(c); return c ? c->mpc.ls_trials_run : -1; }
+int qmhip_last_ls_trials(const qmhip_ctx* c) { QM_GUARD(c); if (!c) return -1; hipSetDevice(c->device); return const_cast<qmhip_ctx*>(c)->mpc.ls_trials(); }      // (after a device-side line search: one synchronising read of the trial counters)
 int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { QM_GUARD(c); if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "lq_slices")) { c->mpc.lq_slices = value < 1 ? 1 : value; return QMHIP_OK; } if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; }
+  if (!strcmp(key, "ls_device_tail")) { c->mpc.device_tail = value != 0; return QMHIP_OK; }      // 0: the host-driven line-search trial loop of rounds 1-5 (A/B, tests); 1 (default): the trials after the first in one launch (k_ls.h)
   if (!strncmp(key, "lds_pad:", 8)) {   // profiling only: "lds_pad:<kernel group>" (lq, lq_kin, riccati, ls_eval, wbc, ...) = extra dynamic LDS bytes per workgroup; 0 removes it
     if (value < 0 || value > 160 * 1024) return QMHIP_ERR_ARG; if (value) c->bk.lds_pad[key + 8] = value; else c->bk.lds_pad.erase(key + 8); return QMHIP_OK; }
   if (!strcmp(key, "lq_debug")) {      // parity tests: K1b additionally writes the UNPROJECTED LQ model of every interval (buffer "lqdbg", [B][max_nodes][LQ_DBG_SIZE]) and Pu / the zero rows of Px into the stage record

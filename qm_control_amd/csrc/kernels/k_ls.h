@@ -27,7 +27,8 @@ struct QmLsArgs {
   const double* step_info;              // [B][4]  armijo, |dx|², |du|²
   double* xs; double* us;               // [nmax][B][30] primal solution out
   double* out_perf;                     // [B][10] baseline(4) after(4) alpha armijo
-  int trial;                            // index of the current trial (0-based)
+  int trial;                            // index of the current trial (0-based); qm_ls_tail_kernel: index of its first trial
+  int max_trials;                       // qm_ls_tail_kernel: trials of this line search in all (the tail runs trial, trial + 1, ... < max_trials)
   int with_alpha;                       // perf_sum: 1 = initial-state defect of the trial iterate, 0 = of the base iterate
   int* open_cnt; int* tickets;          // [QM_LS_MAX_TRIALS] instances still searching after trial t / blocks that have passed; zeroed by the baseline sum
   volatile int* host_open;              // [QM_LS_MAX_TRIALS] host-visible copy of open_cnt[t], written by the last block of trial t (the host never copies flags)
@@ -141,44 +142,24 @@ __device__ __forceinline__ void ls_rows_in(double* tile, const double* base, con
     for (int k = 0; k < 5; ++k) { if (step) { v[k].x += al[k] * d[k].x; v[k].y += al[k] * d[k].y; } tile[off[k]] = v[k].x; tile[off[k] + 1] = v[k].y; }
   }
 }
-// One THREAD per (instance, node), the wave's inputs moved together (ls_rows_in).  No thread leaves before the last cooperative load: a thread without work (its
-// instance has finished the search, a row behind the instance's last node) only helps to move data; the whole wave leaves at once when none of its threads has work.
-template <bool RB, bool IPM = false> __global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel_t(QmLsArgs a) {
-  const int l = threadIdx.x & 63;
-  const size_t g0 = (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
-  size_t g = g0 + l; const bool inrange = g < nrows; if (!inrange) g = nrows - 1;
-  const int i = (int)(g / a.B), b = (int)(g - (size_t)i * a.B);
-  const int n = a.n_nodes[b];
-  const bool active = inrange && i < n && a.done[b] == 0;
-  if (__ballot(active) == 0ull) return;
-  const int nb = (int)g; const double al = a.alpha[b];
-  const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
-  extern __shared__ double qm_smem[];                  // LS_EVAL_LDS_BYTES: [64][31] rows (the trial state on its way in, then each thread's trial input, at the end the next node's trial state) + alpha[64]
-  double* rows = qm_smem; double* als = qm_smem + 64 * 31; double* u = rows + l * 31;
-  als[l] = al; qm_wave_sync();
-  double x[30], K[KW_SIZE];
-  ls_rows_in(rows, a.xt ? a.xt : a.x, a.xt ? nullptr : a.dx, als, g0, nrows, l); qm_wave_sync();
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = u[q];
-  qm_wave_sync();
-  double ctrack = 0.0;                                   // tracking term of the intermediate cost (a2), index order; the reference rows take the tile on their way through
-  ls_rows_in(rows, a.xref, nullptr, als, g0, nrows, l); qm_wave_sync();
-  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double d = x[q] - u[q]; ctrack += 0.5 * st[ST_Q + q] * d * d; }
-  qm_wave_sync();
-  ls_rows_in(rows, a.ut ? a.ut : a.u, a.ut ? nullptr : a.du, als, g0, nrows, l); qm_wave_sync();
-  const int ev = a.node_ev[nb]; const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
-  const bool term = (i == n - 1), pre = !term && ev == QM_EV_PRE, reg = active && !term && !pre;
+// Terms of ONE node at the trial point: x[30] (registers) and u (a per-thread LDS row) hold the node's trial state and input, ctrack its tracking cost; on return cost / eq
+// (not yet × dt) and, for a regular node, x = the end point of the Heun step (to be compared with the next node's trial state).  Shared by the thread-per-(node, instance)
+// kernel of the first trial and the per-instance tail kernel of the later ones: the same arithmetic in the same order.
+template <bool RB, bool IPM>
+__device__ __forceinline__ void ls_node_terms(const QmLsArgs& a, const double* mb, const double* st, double (&x)[30], const double* u, const double ctrack, const int nb, const int b, const double al,
+                                               const bool active, const bool term, const bool reg, const double dt, const int mode, double& cost, double& eq, double& ipm_cost, double& ipm_res) {
+  double K[KW_SIZE];
   // Ordered for a SMALL live set (256 registers, one LDS row per thread -> two waves per SIMD, every wavefront of the launch resident at once): first the cost terms
   // that need no kinematics (tracking, input weight, boxes, friction cone), then base -> arm (end-effector term), then the legs ONE AT A TIME, each consumed at once
   // by the equality residual and the flow map's momentum sums — the full workspace K[196] never exists.  A zero-length interval contributes neither cost nor
   // constraint residual and needs no second Heun stage; the guards also split this straight-line kernel into basic blocks, which bounds the scheduler's live ranges.
-  double cost = 0.0, eq = 0.0;
   if (reg && dt > 0.0) cost = node_cost_value_xu<RB, IPM>(mb, st, x, u, mode, ctrack);
   kin_base<true>(mb, x, K);
   if (active && (term || (reg && dt > 0.0))) {            // end-effector pose term: the intermediate soft constraint, or the final one at the terminal node (its only term)
     kin_arm<true>(mb, x, K); double g6[6], qee[4]; ee_error(K, a.eeref + nb * 7, a.eeref + nb * 7 + 3, qee, g6);
     const double mp = term ? st[ST_MU_EEF_POS] : st[ST_MU_EE_POS], mo = term ? st[ST_MU_EEF_ORI] : st[ST_MU_EE_ORI];
     for (int r = 0; r < 6; ++r) cost += 0.5 * (r < 3 ? mp : mo) * g6[r] * g6[r]; }
-  double ipm_cost = 0.0, ipm_res = 0.0;                  // interior-point instance: −mu Σ ln s and Σ (h − s)² of the trial point and its trial slacks s + alpha ds (not × dt / × dt)
+  // interior-point instance: ipm_cost = −mu Σ ln s and ipm_res = Σ (h − s)² of the trial point and its trial slacks s + alpha ds (not × dt / × dt)
   if (IPM && reg) {
     const double mub = a.ipm_info[b * IPM_INFO];
     for (int r = 0; r < QM_NH; ++r) if (ipm_row_on(r, mode)) {
@@ -228,6 +209,35 @@ template <bool RB, bool IPM = false> __global__ void __launch_bounds__(64, 2) qm
       const double fa = (q < 12) ? f1[q < 12 ? q : 0] : u[q], fb = (q < 12) ? f2[q < 12 ? q : 0] : u[q];
       x[q] = x[q] + 0.5 * dt * fa + 0.5 * dt * fb; }
   }
+}
+// One THREAD per (instance, node), the wave's inputs moved together (ls_rows_in).  No thread leaves before the last cooperative load: a thread without work (its
+// instance has finished the search, a row behind the instance's last node) only helps to move data; the whole wave leaves at once when none of its threads has work.
+template <bool RB, bool IPM = false> __global__ void __launch_bounds__(64, 2) qm_ls_eval_kernel_t(QmLsArgs a) {
+  const int l = threadIdx.x & 63;
+  const size_t g0 = (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
+  size_t g = g0 + l; const bool inrange = g < nrows; if (!inrange) g = nrows - 1;
+  const int i = (int)(g / a.B), b = (int)(g - (size_t)i * a.B);
+  const int n = a.n_nodes[b];
+  const bool active = inrange && i < n && a.done[b] == 0;
+  if (__ballot(active) == 0ull) return;
+  const int nb = (int)g; const double al = a.alpha[b];
+  const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
+  extern __shared__ double qm_smem[];                  // LS_EVAL_LDS_BYTES: [64][31] rows (the trial state on its way in, then each thread's trial input, at the end the next node's trial state) + alpha[64]
+  double* rows = qm_smem; double* als = qm_smem + 64 * 31; double* u = rows + l * 31;
+  als[l] = al; qm_wave_sync();
+  double x[30];
+  ls_rows_in(rows, a.xt ? a.xt : a.x, a.xt ? nullptr : a.dx, als, g0, nrows, l); qm_wave_sync();
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) x[q] = u[q];
+  qm_wave_sync();
+  double ctrack = 0.0;                                   // tracking term of the intermediate cost (a2), index order; the reference rows take the tile on their way through
+  ls_rows_in(rows, a.xref, nullptr, als, g0, nrows, l); qm_wave_sync();
+  _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double d = x[q] - u[q]; ctrack += 0.5 * st[ST_Q + q] * d * d; }
+  qm_wave_sync();
+  ls_rows_in(rows, a.ut ? a.ut : a.u, a.ut ? nullptr : a.du, als, g0, nrows, l); qm_wave_sync();
+  const int ev = a.node_ev[nb]; const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
+  const bool term = (i == n - 1), pre = !term && ev == QM_EV_PRE, reg = active && !term && !pre;
+  double cost = 0.0, eq = 0.0, ipm_cost = 0.0, ipm_res = 0.0;
+  ls_node_terms<RB, IPM>(a, mb, st, x, u, ctrack, nb, b, al, active, term, reg, dt, mode, cost, eq, ipm_cost, ipm_res);
   // the next node's trial state (the rows one node further: the same instances, the same step lengths) comes in through the tile the inputs leave; a PreEvent node's
   // defect is the jump x_i − x_{i+1} (identity jump map), unweighted
   qm_wave_sync();
@@ -252,6 +262,25 @@ inline bool qm_r_is_block_diagonal(const double* st) {
   return true;
 }
 
+// Filter line-search decision of ONE instance for the trial at step length al0 with the sums {cost c, dynamics SSE d, equality SSE e} ([upstream ocs2_sqp
+// FilterLinesearch::acceptStep, recalled]): 1 = accepted (done = 1, out_perf), 2 = the search stops without a step (done = 2, alpha = 0), 0 = goes on
+// at alpha[b] = al0 / 2.  One thread per instance calls it (the deciding lane of qm_perf_sum_kernel, thread 0 of a tail block).
+__device__ __forceinline__ int qm_ls_filter_decide(const QmLsArgs& a, const int b, const double al0, const double c, const double d, const double e) {
+  const double gMax = qm_ms_param(a.st, ST_G_MAX), gMin = qm_ms_param(a.st, ST_G_MIN), gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
+  const double* bs = a.base_sum + b * 4; const double ps[4] = {c, c, d, e};
+  const double theta0 = sqrt(bs[2] + bs[3]), theta = sqrt(ps[2] + ps[3]);
+  double al = al0; const double armijo = a.step_info[b * 4];
+  bool acc;
+  if (theta > gMax) acc = theta < (1.0 - gammaC) * theta0;
+  else if (theta < gMin && theta0 < gMin && al * armijo < 0.0) acc = ps[0] < bs[0] + armijoFactor * al * armijo;
+  else acc = ps[0] < (bs[0] - gammaC * theta0) || theta < (1.0 - gammaC) * theta0;
+  if (acc) { a.done[b] = 1; for (int q = 0; q < 4; ++q) a.out_perf[b * 10 + 4 + q] = ps[q]; a.out_perf[b * 10 + 8] = al; return 1; }
+  al *= alphaDecay;
+  const double dxn = sqrt(a.step_info[b * 4 + 1]), dun = sqrt(a.step_info[b * 4 + 2]);
+  if ((al * dun < qm_ms_param(a.st, ST_DELTA_TOL) && al * dxn < qm_ms_param(a.st, ST_DELTA_TOL)) || !(al >= alphaMin)) { a.done[b] = 2; a.alpha[b] = 0.0; return 2; }
+  a.alpha[b] = al;
+  return 0;
+}
 // One WAVEFRONT per instance.  Sum of the node terms -> perf_sum[b] = {merit, cost, dynSSE, eqSSE} (lanes stride over the
 // nodes, DPP wave reduction).  with_alpha == 0: baseline of the current iterate, also arms the line search (alpha = 1, done = 0);
 // with_alpha == 1: the trial point, followed by the filter line-search decision of this instance
@@ -283,20 +312,7 @@ __device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b,
     if (!(an >= a.st[ST_DDP_MIN_STEP])) { a.done[b] = 2; a.alpha[b] = 0.0; return false; }
     a.alpha[b] = an; return true;
   }
-  const double gMax = qm_ms_param(a.st, ST_G_MAX), gMin = qm_ms_param(a.st, ST_G_MIN), gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
-  const double* bs = a.base_sum + b * 4; const double ps[4] = {c, c, d, e};
-  const double theta0 = sqrt(bs[2] + bs[3]), theta = sqrt(ps[2] + ps[3]);
-  double al = al0; const double armijo = a.step_info[b * 4];
-  bool acc;
-  if (theta > gMax) acc = theta < (1.0 - gammaC) * theta0;
-  else if (theta < gMin && theta0 < gMin && al * armijo < 0.0) acc = ps[0] < bs[0] + armijoFactor * al * armijo;
-  else acc = ps[0] < (bs[0] - gammaC * theta0) || theta < (1.0 - gammaC) * theta0;
-  if (acc) { a.done[b] = 1; for (int q = 0; q < 4; ++q) a.out_perf[b * 10 + 4 + q] = ps[q]; a.out_perf[b * 10 + 8] = al; return false; }
-  al *= alphaDecay;
-  const double dxn = sqrt(a.step_info[b * 4 + 1]), dun = sqrt(a.step_info[b * 4 + 2]);
-  if ((al * dun < qm_ms_param(a.st, ST_DELTA_TOL) && al * dxn < qm_ms_param(a.st, ST_DELTA_TOL)) || !(al >= alphaMin)) { a.done[b] = 2; a.alpha[b] = 0.0; return false; }
-  a.alpha[b] = al;
-  return true;
+  return qm_ls_filter_decide(a, b, al0, c, d, e) == 0;
 }
 __global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
   const int b = blockIdx.x, l = threadIdx.x & 63;
@@ -312,6 +328,89 @@ __global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
   }
 }
 
+
+// ---- the trials AFTER the first, on the device (round 6) ----
+// The first trial (alpha = 1) is evaluated for the whole batch by qm_ls_eval + qm_perf_sum.  Rounds 1-5 then let the HOST loop: read the count of the instances still
+// searching, launch both kernels again over the whole batch, spin — one round trip per trial, and every instance paid for the batch's worst one (a warm-started solve needs a
+// second trial on ~ 15 % of its instances and a third on ~ 1 %: the full step of a warm start often does not reduce the constraint violation theta ~ 0.2 > g_max it starts
+// from, tools/warm_ls_histogram.py).  Now ONE launch finishes the search: one 256-thread workgroup per instance, gone at once unless its instance is still searching;
+// it evaluates TWO step lengths side by side (threads 0..127 the nodes at alpha, 128..255 at alpha / 2 — the decisions are taken in the filter's order, the second
+// evaluation is wasted when the first is accepted), sums the node terms exactly as qm_perf_sum does (lane-strided partial sums of one wave + the DPP reduction: a trial's
+// merit is bit-identical to what the two-kernel path computes), decides, repeats until the filter accepts or stops, and writes the accepted step into the primal solution
+// of its own instance (what qm_ls_apply does for the batch).  The host never waits inside the line search.
+#define LS_TAIL_BLOCK 256
+#define LS_TAIL_SLOTS 2
+#define LS_TAIL_NODES (LS_TAIL_BLOCK / LS_TAIL_SLOTS)
+#define LS_TAIL_LDS_DOUBLES(nmax) (LS_TAIL_BLOCK * 31 + LS_TAIL_SLOTS * (nmax) * 3 + LS_TAIL_SLOTS * 4 + 4)      /* input rows | node terms [slot][node][3] | sums [slot][4] | control */
+#define LS_TAIL_LDS_BYTES(nmax) (LS_TAIL_LDS_DOUBLES(nmax) * 8)
+template <bool RB> __global__ void __launch_bounds__(LS_TAIL_BLOCK) qm_ls_tail_kernel_t(QmLsArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x, l = tid & 63;
+  if (b >= a.B || a.done[b] != 0) return;                                      // (uniform over the workgroup; nobody else writes done[b] during this launch)
+  const int n = a.n_nodes[b]; const size_t nrows = (size_t)a.nmax * a.B;
+  const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
+  extern __shared__ double qm_smem[];
+  double* u = qm_smem + tid * 31; double* pfl = qm_smem + LS_TAIL_BLOCK * 31; double* sums = pfl + LS_TAIL_SLOTS * a.nmax * 3; double* ctl = sums + LS_TAIL_SLOTS * 4;
+  const int slot = tid / LS_TAIL_NODES, ni = tid - slot * LS_TAIL_NODES;
+  double al_first = a.alpha[b]; int trial = a.trial, state = 0;
+  __syncthreads();                                                             // every thread has read alpha[b] before thread 0's decisions rewrite it
+  while (trial < a.max_trials) {
+    const double al = slot ? al_first * 0.5 : al_first;                        // (alphaDecay = 0.5: the same product the decision forms)
+    for (int i = ni; i < n; i += LS_TAIL_NODES) {
+      const size_t nb = (size_t)i * a.B + b;
+      double x[30]; double ctrack = 0.0;
+      _Pragma("unroll") for (int q = 0; q < 30; q += 2) { const double2 v = *(const double2*)(a.x + nb * 30 + q), dv = *(const double2*)(a.dx + nb * 30 + q); double v0 = v.x, v1 = v.y; v0 += al * dv.x; v1 += al * dv.y; x[q] = v0; x[q + 1] = v1; }
+      _Pragma("unroll") for (int q = 0; q < 30; q += 2) { const double2 r = *(const double2*)(a.xref + nb * 30 + q); u[q] = r.x; u[q + 1] = r.y; }
+      _Pragma("unroll") for (int q = 0; q < 30; ++q) { const double d = x[q] - u[q]; ctrack += 0.5 * st[ST_Q + q] * d * d; }
+      _Pragma("unroll") for (int q = 0; q < 30; q += 2) { const double2 v = *(const double2*)(a.u + nb * 30 + q), dv = *(const double2*)(a.du + nb * 30 + q); double v0 = v.x, v1 = v.y; v0 += al * dv.x; v1 += al * dv.y; u[q] = v0; u[q + 1] = v1; }
+      const int ev = a.node_ev[nb]; const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
+      const bool term = (i == n - 1), pre = !term && ev == QM_EV_PRE, reg = !term && !pre;
+      double cost = 0.0, eq = 0.0, ipm_cost = 0.0, ipm_res = 0.0;
+      ls_node_terms<RB, false>(a, mb, st, x, u, ctrack, (int)nb, b, al, true, term, reg, dt, mode, cost, eq, ipm_cost, ipm_res);
+      size_t nn = nb + (size_t)a.B; if (nn >= nrows) nn = nrows - 1;         // (the terminal node's row behind the array is never used: clamped like the tile loads)
+      double sq = 0.0;
+      _Pragma("unroll") for (int q = 0; q < 30; q += 2) { const double2 v = *(const double2*)(a.x + nn * 30 + q), dv = *(const double2*)(a.dx + nn * 30 + q); double v0 = v.x, v1 = v.y; v0 += al * dv.x; v1 += al * dv.y;
+                                                          const double d0 = x[q] - v0; sq += d0 * d0; const double d1 = x[q + 1] - v1; sq += d1 * d1; }
+      double* pf = pfl + ((size_t)slot * a.nmax + i) * 3;
+      if (term) { pf[0] = cost; pf[1] = 0.0; pf[2] = 0.0; }
+      else if (pre) { pf[0] = 0.0; pf[1] = sq; pf[2] = 0.0; }
+      else { pf[0] = cost * dt + ipm_cost; pf[1] = dt * sq; pf[2] = dt * (eq + ipm_res); }
+    }
+    __syncthreads();
+    if (ni < 64) {                                                             // the first wave of each slot: qm_perf_sum_body's sums, term by term
+      double c = 0.0, d = 0.0, e = 0.0;
+      for (int i = l; i < n; i += 64) { const double* pf = pfl + ((size_t)slot * a.nmax + i) * 3; c += pf[0]; d += pf[1]; e += pf[2]; }
+      if (l < 30) { const double x0t = a.x[b * 30 + l] + al * a.dx[b * 30 + l]; const double dd = a.x0[(size_t)b * 30 + l] - x0t; d += dd * dd; }
+      c = qm_wave_sum(c); d = qm_wave_sum(d); e = qm_wave_sum(e);
+      if (l == 0) { sums[slot * 4] = c; sums[slot * 4 + 1] = d; sums[slot * 4 + 2] = e; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int stt = 0, used = 0; double aln = al_first;
+      for (int sidx = 0; sidx < LS_TAIL_SLOTS && stt == 0 && trial + sidx < a.max_trials; ++sidx) {
+        const double c = sums[sidx * 4], d = sums[sidx * 4 + 1], e = sums[sidx * 4 + 2];
+        a.perf_sum[b * 4] = c; a.perf_sum[b * 4 + 1] = c; a.perf_sum[b * 4 + 2] = d; a.perf_sum[b * 4 + 3] = e;
+        stt = qm_ls_filter_decide(a, b, aln, c, d, e); ++used;
+        if (stt == 0) { if (a.open_cnt) atomicAdd(a.open_cnt + trial + sidx, 1); aln *= 0.5; }      // (open_cnt[t] > 0: some instance went on to trial t + 1 — how the host learns the number of trials)
+      }
+      ctl[0] = (double)stt; ctl[1] = aln; ctl[2] = (double)(trial + used);
+    }
+    __syncthreads();
+    state = (int)ctl[0]; al_first = ctl[1]; trial = (int)ctl[2];
+    if (state != 0) break;
+  }
+  if (state != 1) return;                                                      // no step (or out of trials): the batch's apply has already written x, u as the primal solution
+  // the accepted step -> primal solution of this instance (qm_ls_apply_kernel's arithmetic); al_first is the accepted step length (not advanced on acceptance)
+  for (int idx = tid; idx < n * 30; idx += LS_TAIL_BLOCK) {
+    const int i = idx / 30, q = idx - 30 * i; const size_t nb = (size_t)i * a.B + b;
+    a.xs[nb * 30 + q] = a.x[nb * 30 + q] + al_first * a.dx[nb * 30 + q];
+    int j = (i == n - 1) ? n - 2 : i; if (j < 0) j = 0;
+    while (j > 0 && a.node_ev[j * a.B + b] == QM_EV_PRE) --j;
+    const size_t jb = (size_t)j * a.B + b; const bool evj = (a.node_ev[jb] == QM_EV_PRE) || n < 2;
+    a.us[nb * 30 + q] = evj ? 0.0 : a.u[jb * 30 + q] + al_first * a.du[jb * 30 + q];
+  }
+}
+#define qm_ls_tail_kernel qm_ls_tail_kernel_t<true>
+#define qm_ls_tail_dense_kernel qm_ls_tail_kernel_t<false>
 
 // one thread per (node, instance, component): consecutive threads touch consecutive doubles
 __global__ void qm_ls_apply_kernel(QmLsArgs a) {

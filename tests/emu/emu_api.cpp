@@ -40,16 +40,16 @@ int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const doubl
   c->mpc.upload_inputs(B, t0, x0, ref_t, ref_x, ev, modes);
   c->mpc.grid(B, horizon);
   c->mpc.sqp_iteration(B, max_trials);
-  return c->mpc.ls_trials_run;
+  return c->mpc.ls_trials();
 }
 // receding horizon: new observation + warm-started iteration / perfect-tracking advance (same calls as the qmhip_* entry points)
 int emu_mpc_step_warm(void* h, int B, const double* t0, const double* x0, double horizon, int max_trials) {
   EmuCtx* c = (EmuCtx*)h; QmMpcBuffers& d = c->mpc.d;
   if (t0) memcpy(d.t0, t0, (size_t)B * 8); if (x0) memcpy(d.x0, x0, (size_t)B * 30 * 8);
-  c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B, max_trials); return c->mpc.ls_trials_run;
+  c->mpc.grid(B, horizon, true); c->mpc.sqp_iteration(B, max_trials); return c->mpc.ls_trials();
 }
 // one more iteration on the committed iterate of the last call (sqp.sqpIteration / ipm.ipmIteration > 1: what qmhip_mpc_solve_resident loops over)
-int emu_mpc_iterate(void* h, int B, int max_trials) { EmuCtx* c = (EmuCtx*)h; c->mpc.sqp_iteration(B, max_trials); return c->mpc.ls_trials_run; }
+int emu_mpc_iterate(void* h, int B, int max_trials) { EmuCtx* c = (EmuCtx*)h; c->mpc.sqp_iteration(B, max_trials); return c->mpc.ls_trials(); }
 void emu_advance(void* h, int B, double dt) { ((EmuCtx*)h)->mpc.advance(B, dt); }
 // K0 only: grid, modes, references, initial guess of the uploaded problem
 void emu_grid(void* h, int B, double horizon) { ((EmuCtx*)h)->mpc.grid(B, horizon); }
@@ -121,6 +121,7 @@ int emu_hoqp(int B, int n_levels, int n, const int* ma, const int* md, const dou
   h.solve(B, n_levels, n, ma, md, A, b, D, f, x, status); return 0;
 }
 void emu_set_speculative_apply(void* h, int on) { ((EmuCtx*)h)->mpc.speculative_apply = on != 0; }
+void emu_set_device_tail(void* h, int on) { ((EmuCtx*)h)->mpc.device_tail = on != 0; }      // qmhip_debug_set("ls_device_tail", .)
 // the C ABI's status of an instance from K0's word and K3's step_info (the mapping qmhip_mpc_download applies)
 int emu_mpc_status(int k0_status, const double* step_info4, int strict) { return qm_mpc_status(k0_status, step_info4, strict != 0); }
 void emu_sincos(int n, const double* x, double* sn, double* cs) { for (int i = 0; i < n; ++i) qm_sincos(x[i], sn[i], cs[i]); }

@@ -84,6 +84,45 @@ def test_speculative_apply_is_idempotent(blobs, solver):
         assert np.array_equal(a["xs"][:a["n"][k], k], b["xs"][:a["n"][k], k]) and np.array_equal(a["us"][:a["n"][k], k], b["us"][:a["n"][k], k]), k
 
 
+@pytest.mark.parametrize("gmax,max_trials", [(None, 14), (1e-9, 14), (1e-9, 4), (1e-9, 2), (1e-9, 1)])
+def test_device_tail_equals_the_host_driven_trial_loop(blobs, oblobs, gmax, max_trials):
+    """Round 6: the line-search trials after the first run in ONE launch without the host (qm_ls_tail_kernel: one workgroup per instance still searching, two step lengths
+    side by side, sums in qm_perf_sum's order).  On a MIXED batch it must reproduce the host-driven trial loop of rounds 1-5 BIT FOR BIT — step lengths, done flags, merit
+    sums, primal solution, number of trials — also when the search is cut off by max_trials in the middle of a pair of step lengths, and the alpha sequence is the oracle's."""
+    import emu_harness, pyoracle
+    from qm_control_amd import scenarios
+    B = 5
+    st = blobs[1].copy()
+    if gmax is not None: st[L.ST_G_MAX] = gmax; st[L.ST_DELTA_TOL] = 1e-12      # a tight filter: long searches (3+ trials: the tail's loop goes round more than once)
+    cfg = scenarios.make_config("C5", batch=B, n_intervals=10); cfg["B"] = B
+    cfg["x0"][1] = st[L.ST_XINIT:L.ST_XINIT + 30]; cfg["x0"][0, 24:30] += 3.3; cfg["x0"][2, 12:24] += 0.02; cfg["x0"][3, 9:12] += 0.01; cfg["x0"][4, 24:30] += 0.3
+    outs = []
+    for tail in (1, 0):
+        e = emu_harness.Emu(blobs[0], st, B, 40, cfg["ref_t"].shape[1], cfg["ev"].shape[1]); e.lib.emu_set_device_tail(e.h, C.c_int(tail))
+        trials = e.mpc_step(cfg, max_trials=max_trials); n = e.buf("n_nodes", (B,), np.int32).copy()
+        outs.append(dict(trials=trials, perf=e.buf("out_perf", (B, 10)).copy(), done=e.buf("done", (B,), np.int32).copy(), alpha=e.buf("alpha", (B,)).copy(), xs=e.node_arr("xs", 30).copy(), us=e.node_arr("us", 30).copy(),
+                         x=e.node_arr("x", 30).copy(), u=e.node_arr("u", 30).copy(), n=n))
+    a, b = outs
+    assert a["trials"] == b["trials"], (a["trials"], b["trials"])
+    assert np.array_equal(a["perf"], b["perf"]) and np.array_equal(a["done"], b["done"]) and np.array_equal(a["alpha"], b["alpha"])
+    for k in range(B):
+        nk = a["n"][k]
+        assert np.array_equal(a["xs"][:nk, k], b["xs"][:nk, k]) and np.array_equal(a["us"][:nk, k], b["us"][:nk, k]), k
+        assert np.array_equal(a["x"][:nk, k], b["x"][:nk, k]) and np.array_equal(a["u"][:nk, k], b["u"][:nk, k]), k      # the committed iterate too
+    if gmax is None:
+        assert a["trials"] > 1 and (a["perf"][:, 8] == 1.0).any() and (a["perf"][:, 8] < 1.0).any(), a["perf"][:, 8]      # the batch IS mixed
+    if max_trials >= 14:
+        # the oracle's step lengths and trial counts, instance by instance
+        o = pyoracle.Oracle(oblobs[0], st)
+        for k in range(B):
+            o.set_schedule(cfg["ev"][k], cfg["modes"][k]); o.set_target(cfg["ref_t"][k], cfg["ref_x"][k])
+            r = o.mpc_step(float(cfg["t0"][k]), float(cfg["t0"][k]) + cfg["horizon"], cfg["x0"][k])
+            assert a["perf"][k, 8] == r["alpha"], (k, a["perf"][k, 8], r["alpha"])
+        if gmax is not None: assert a["trials"] >= 3, a["trials"]
+    else:
+        assert a["trials"] <= max_trials
+
+
 @pytest.mark.parametrize("ncase,seed,amp", [(6, 21, 0.05), (10, 303, 0.5)])      # small and large tracking errors (the large ones saturate torque limits and friction cones: long active-set paths with drops)
 def test_wbc_kernel_vs_oracle(blobs, oracle, ncase, seed, amp):
     import emu_harness

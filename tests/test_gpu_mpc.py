@@ -119,6 +119,45 @@ def test_receding_horizon_closed_loop(blobs, oracle):
     itf.close()
 
 
+def test_device_line_search_tail_equals_the_host_driven_loop(blobs, oracle):
+    """Round 6: after the first trial the line search finishes in ONE launch on the device (qm_ls_tail_kernel, k_ls.h) instead of one host round trip per trial.  On
+    warm-started receding-horizon solves of the benchmark workload (256 instances, N = 100: ~ 15 % of the instances reject the full step, a few take three trials —
+    tools/warm_ls_histogram.py) the tail must give BIT-IDENTICAL results to the host-driven loop of rounds 1-5 (`ls_device_tail` 0): step lengths, merit sums, status, the whole
+    primal solution, the number of trials; and the accepted step lengths are the oracle's on a sample of instances that backtracked."""
+    from qm_control_amd import api, scenarios
+    B, steps, dt_mpc = 256, 5, 0.01
+    cfg = scenarios.make_config("C3", batch=B)
+
+    def run(tail):
+        itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1]); itf.debug_set("ls_device_tail", tail)
+        mpc = api.SqpMpc(itf); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+        outs = []
+        for k in range(steps):
+            if k > 0: mpc.advance(dt_mpc)
+            mpc.solve_resident(cfg["horizon"], warm=(k > 0)); outs.append(mpc.download())
+        itf.close(); return outs
+
+    dev, host = run(1), run(0)
+    for k in range(steps):
+        a, b = dev[k], host[k]
+        assert a["ls_trials"] == b["ls_trials"], (k, a["ls_trials"], b["ls_trials"])
+        for key in ("x", "u", "perf", "status", "t"):
+            assert np.array_equal(a[key], b[key]), (k, key)
+    alphas = np.stack([d["perf"][:, 8] for d in dev])                      # [steps][B] accepted step lengths
+    assert (alphas[0] == 1.0).all() and (alphas[2:] < 1.0).any() and max(d["ls_trials"] for d in dev) >= 2, alphas.min(axis=1)      # the warm solves DO backtrack
+    # the oracle's loop on a sample: the instances with the smallest accepted step lengths + a few that never backtracked
+    order = np.argsort(alphas[1:].min(axis=0)); sample = list(order[:5]) + list(order[-2:])
+    for b in sample:
+        oracle.set_schedule(cfg["ev"][b], cfg["modes"][b]); oracle.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+        t0 = float(cfg["t0"][b]); x0 = cfg["x0"][b]
+        for k in range(steps):
+            if k > 0:
+                t0 += dt_mpc; x0, _, _ = oracle.eval_policy(t0)
+            r = oracle.mpc_step(t0, t0 + cfg["horizon"], x0, warm=(k > 0)); n = len(r["t"])
+            assert dev[k]["perf"][b, 8] == r["alpha"], (b, k, dev[k]["perf"][b, 8], r["alpha"])
+            assert_blocks(dev[k]["x"][b, :n], r["x"], "x", TOL, (b, k)); assert_blocks(dev[k]["u"][b, :n], r["u"], "u", TOL, (b, k))
+
+
 def test_update_references_keeps_the_warm_start(blobs, oracle):
     """what the MPC_BASE adaptor does on every call after the first (adaptors/QmhipMpc.h): new targets / schedule from preSolverRun, new observation,
     warm-started iteration from the PREVIOUS primal solution — qmhip_mpc_update_references must not drop it (qmhip_mpc_upload would)"""
