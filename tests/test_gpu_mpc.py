@@ -122,8 +122,8 @@ def test_receding_horizon_closed_loop(blobs, oracle):
 def test_device_line_search_tail_equals_the_host_driven_loop(blobs, oracle):
     """Round 6: after the first trial the line search finishes in ONE launch on the device (qm_ls_tail_kernel, k_ls.h) instead of one host round trip per trial.  On
     warm-started receding-horizon solves of the benchmark workload (256 instances, N = 100: ~ 15 % of the instances reject the full step, a few take three trials —
-    tools/warm_ls_histogram.py) the tail must give BIT-IDENTICAL results to the host-driven loop of rounds 1-5 (`ls_device_tail` 0): step lengths, merit sums, status, the whole
-    primal solution, the number of trials; and the accepted step lengths are the oracle's on a sample of instances that backtracked."""
+    tools/warm_ls_histogram.py) the tail must give BIT-IDENTICAL results to the host-driven loop of rounds 1-5 (`ls_device_tail` 0): step lengths, status, the whole
+    primal solution, the number of trials (the merit sums to 1e-13); and the accepted step lengths are the oracle's on a sample of instances that backtracked."""
     from qm_control_amd import api, scenarios
     B, steps, dt_mpc = 256, 5, 0.01
     cfg = scenarios.make_config("C3", batch=B)
@@ -141,8 +141,12 @@ def test_device_line_search_tail_equals_the_host_driven_loop(blobs, oracle):
     for k in range(steps):
         a, b = dev[k], host[k]
         assert a["ls_trials"] == b["ls_trials"], (k, a["ls_trials"], b["ls_trials"])
-        for key in ("x", "u", "perf", "status", "t"):
+        for key in ("x", "u", "status", "t"):
             assert np.array_equal(a[key], b[key]), (k, key)
+        # step lengths and Armijo metric bit for bit; the merit sums of a later trial to rounding (the node terms are the same function inlined into two kernels: the compiler's
+        # multiply-add contraction may differ — observed: ONE sum of 256 x 4 off by one unit in the last place over five steps, 1e-22 on 5e-7)
+        assert np.array_equal(a["perf"][:, 8:], b["perf"][:, 8:]) and np.array_equal(a["perf"][:, :4], b["perf"][:, :4]), k
+        assert np.allclose(a["perf"][:, 4:8], b["perf"][:, 4:8], rtol=1e-13, atol=0.0), k
     alphas = np.stack([d["perf"][:, 8] for d in dev])                      # [steps][B] accepted step lengths
     assert (alphas[0] == 1.0).all() and (alphas[2:] < 1.0).any() and max(d["ls_trials"] for d in dev) >= 2, alphas.min(axis=1)      # the warm solves DO backtrack
     # the oracle's loop on a sample: the instances with the smallest accepted step lengths + a few that never backtracked
