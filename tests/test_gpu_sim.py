@@ -193,7 +193,11 @@ def test_readme_end_effector_stability_experiment(blobs):
     stream for 10 s while the end-effector is commanded to hold its pose; EE deviation at most 3.5 mm / 2.6 deg in Gazebo.  The device-resident loop under the same drive:
     with the arm damper of QMController::updateControlLaw off (kd_arm_wbc = 0, a dynamic_reconfigure parameter of the reference, qm_controllers/cfg/weight.cfg:8) the
     end-effector stays within 5 mm / 3 deg while the base travels >= 0.14 m; at the default 0.5 the damper outweighs the WBC's torque on the light wrist links and the
-    deviation is several times that (profiles/r05_readme_experiment.json: the ablation; the plant tracks the MPC's plan within 2 mm in every cell)."""
+    deviation is several times that (profiles/r05_readme_experiment.json: the ablation; the plant tracks the MPC's plan within 2 mm in every cell).
+    WHAT THIS IS NOT (round 6, profiles/r06_readme_experiment.json): a reproduction of the README figure on the reference's own terms.  At the shipped
+    damper (0.5) and the README's travel (0.31 m) no cell comes close (40 mm / 11.6 deg), from no start pose of the end-effector; and even a PERFECT plant deviates 17 mm at 0.30 m
+    of travel, because the shipped cost pulls the elbow back to its default angle — Q(26,26) = 5 against mu_pos = 2000: e = Q (q3 - 0.86) / (mu dx/dq3) = 8.7 mm at 0.2 m, 20.6 mm at
+    0.3 m, measured 8.3 / 17.2 mm; 1.3 mm with that weight at zero.  The cell asserted here is a regression guard of the device loop under the figure's DRIVE, nothing more."""
     import os, sys
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "tools"))
