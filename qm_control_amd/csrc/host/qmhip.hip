@@ -110,6 +110,8 @@ struct qmhip_ctx {
   void* dl_dev = nullptr; void* dl_pin = nullptr; size_t dl_cap = 0;      // staging of qmhip_mpc_download (device transpose buffer + its pinned host mirror), allocated on first use
   char* tick_pin = nullptr;     // pinned host staging of the control-tick path (qmhip_wbc_step): [inputs of max_batch instances | outputs]
   std::string error; int lastB = 0; bool have_solution = false; int front_B = 0; long sim_ticks = 0;
+  int filler_at_lq = 0; int filler_live = 0, filler_lds = 20 * 1024; double* filler_in = nullptr;      // profiling only: footprint of the co-residency stand-in (qmhip_debug_set "filler_live" / "filler_lds")
+  int wbc_defer = 0; int wbc_deferred_B = 0; double wbc_deferred_period = 0.0;      // scheduling experiment (qmhip_debug_set "wbc_defer"): the WBC of step k is launched behind K1a of step k + 1 (flush_wbc at the latest)
   double* filler_out = nullptr; int filler_cap = 0;      // output of the profiling-only filler kernel (co-residency probe)
   bool filler_buffer(int waves) { if (filler_cap >= waves) return true; if (filler_out) hipFree(filler_out); filler_out = nullptr; filler_cap = 0;
                                   if (hipMalloc(&filler_out, (size_t)waves * 64 * 8) != hipSuccess) return false; filler_cap = waves; return true; }
@@ -120,6 +122,8 @@ struct qmhip_ctx {
   // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
   // them (an instance whose line search finds no step just keeps its iterate)
   int sqp_iterations() const { const int n = (int)qm_ms_param(st, ST_SQP_ITER); return n < 1 ? 1 : (n > 50 ? 50 : n); }      // ipm.ipmIteration with solver 2
+  // launch a deferred WBC now, ordered behind everything enqueued on the MPC stream so far
+  void flush_wbc() { if (!wbc_deferred_B) return; const int B = wbc_deferred_B; wbc_deferred_B = 0; bk.wbc_begin(); wbc.step(mpc.d, B, wbc_deferred_period, 0); bk.wbc_end(); }
   int hipstate() { if (!bk.error.empty()) { error = bk.error; bk.error.clear(); return QMHIP_ERR_HIP; } return QMHIP_OK; }
 };
 
@@ -172,6 +176,35 @@ __global__ void __launch_bounds__(64, 2) qm_filler_kernel(double* out, int iters
   out[blockIdx.x * 64 + l] = f + acc[1];
 }
 
+// the same stand-in with a WIDE register footprint (round 6): NLIVE doubles are loaded up front and consumed at the end, so 2 NLIVE vector registers stay allocated for the wave's whole
+// life — NLIVE 153 (386 registers) / 40 KB of LDS is the footprint of today's qm_wbc_kernel, NLIVE 144 (339 registers) / 24 KB the footprint the round-5 review asks of it (344 registers:
+// one 168-register LQ wave fits beside it on a SIMD, four 15.6 KB LQ workgroups beside four of these on a CU).  What the second footprint is worth is measured BEFORE rewriting the WBC.
+template <int NLIVE> __device__ __forceinline__ void qm_filler_wide_body(double* out, const double* in, int iters) {
+  extern __shared__ double qm_smem[];
+  const int l = threadIdx.x & 63;
+  double live[NLIVE];
+#pragma unroll
+  for (int k = 0; k < NLIVE; ++k) live[k] = in[(size_t)k * 64 + l];
+  qm_d4 acc = {0.0, 0.0, 0.0, 0.0}; double a = 1.0 + l * 1e-9, b = 1e-9, f = 1.0;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0); a = acc[0] * 1e-30 + 1.0; }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) f = fma(f, 1.0000001, acc[k & 3] * 1e-30);
+    qm_smem[(l * 7 + i) & 2047] = f; __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    f += qm_smem[(l * 13 + i + 1) & 2047];
+#pragma unroll
+    for (int k = 0; k < NLIVE; ++k) asm volatile("" : "+v"(live[k]));      // every value stays in a register through the loop (no rematerialisation, no sinking of the loads)
+  }
+  double s = f + acc[1];
+#pragma unroll
+  for (int k = 0; k < NLIVE; ++k) s += live[k];
+  out[blockIdx.x * 64 + l] = s;
+}
+
+__global__ void __launch_bounds__(64) qm_filler_wide392_kernel(double* out, const double* in, int iters) { qm_filler_wide_body<153>(out, in, iters); }      // 386 registers (the count is the compiler's: found by trial)
+__global__ void __launch_bounds__(64) qm_filler_wide344_kernel(double* out, const double* in, int iters) { qm_filler_wide_body<144>(out, in, iters); }      // 339 registers
+
 static int create_common(const double* mb, const double* st, int device, int max_batch, int max_nodes, int max_ref, int max_ev, qmhip_ctx** out, bool wbc_only = false) {
   if (!out || max_batch <= 0 || max_nodes < 3 || max_nodes > RW_MAXNODES || max_ref < 1 || max_ev < 1) { g_create_error = "qmhip_create: bad argument (max_nodes must be in [3, 512])"; return QMHIP_ERR_ARG; }
   std::string err; if (!qmio::validateModelBlob(mb, err)) { g_create_error = err; return QMHIP_ERR_MODEL; }
@@ -186,7 +219,11 @@ static int create_common(const double* mb, const double* st, int device, int max
   if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return QMHIP_ERR_HIP; }
   qmhip_ctx* c = new qmhip_ctx(); c->device = device; c->max_batch = max_batch; c->max_nodes = max_nodes; c->max_ref = max_ref; c->max_ev = max_ev;
   memcpy(c->mb, mb, sizeof(c->mb)); memcpy(c->st, st, sizeof(c->st));
-  if (hipStreamCreate(&c->bk.stream) != hipSuccess || hipStreamCreate(&c->bk.stream_b) != hipSuccess) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
+  // (profiling only: QM_WBC_STREAM_PRIORITY = -1 / 0 / 1 creates the WBC stream with the highest / default / lowest priority the device offers; default: no priority given)
+  const char* pr_env = getenv("QM_WBC_STREAM_PRIORITY"); bool sb_ok = true;
+  if (pr_env) { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi); const int want = atoi(pr_env); sb_ok = hipStreamCreateWithPriority(&c->bk.stream_b, hipStreamDefault, want < 0 ? hi : (want > 0 ? lo : 0)) == hipSuccess; }
+  if (!pr_env) { int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo, &hi); sb_ok = hipStreamCreateWithPriority(&c->bk.stream_b, hipStreamDefault, hi) == hipSuccess; }      // the WBC / control-tick stream at the highest priority: its waves get the SIMDs first (- 0.4 % of the pipelined step, profiles/r06_ab_wbc_schedule.log)
+  if (hipStreamCreate(&c->bk.stream) != hipSuccess || !sb_ok) { g_create_error = "hipStreamCreate failed"; delete c; return QMHIP_ERR_HIP; }
   c->bk.cur = c->bk.stream; hipEventCreateWithFlags(&c->bk.ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&c->bk.ev_wbc, hipEventDisableTiming);
   c->wbc_only = wbc_only;
   c->mpc.allocate(c->mb, c->st, wbc_only ? 1 : max_batch, max_nodes, max_ref, max_ev, false); c->mpc.solver = (int)st[ST_SOLVER];
@@ -224,7 +261,7 @@ int qmhip_create_wbc_context(const qmhip_ctx* c, int max_batch, qmhip_ctx** out)
   return create_common(c->mb, c->st, c->device, max_batch, 3, 1, 1, out, true);      // same model / settings values, own device copies, own streams: nothing mutable is shared
 }
 void qmhip_destroy(qmhip_ctx* c) {
-  if (!c) return; hipSetDevice(c->device); c->bk.sync(); if (c->filler_out) hipFree(c->filler_out); if (c->dl_dev) hipFree(c->dl_dev); if (c->dl_pin) hipHostFree(c->dl_pin); if (c->tick_pin) hipHostFree(c->tick_pin); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); c->hoqp.release();
+  if (!c) return; hipSetDevice(c->device); c->bk.sync(); if (c->filler_out) hipFree(c->filler_out); if (c->filler_in) hipFree(c->filler_in); if (c->dl_dev) hipFree(c->dl_dev); if (c->dl_pin) hipHostFree(c->dl_pin); if (c->tick_pin) hipHostFree(c->tick_pin); c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); c->hoqp.release();
   for (auto e : c->bk.pool) hipEventDestroy(e); if (c->bk.ev_order) hipEventDestroy(c->bk.ev_order); hipEventDestroy(c->bk.ev_in); hipEventDestroy(c->bk.ev_wbc); hipStreamDestroy(c->bk.stream); hipStreamDestroy(c->bk.stream_b); delete c;
 }
 // the text is copied under the context lock into a per-thread buffer: the pointer stays valid (until this THREAD's next qmhip_last_error) even if another thread's
@@ -424,7 +461,7 @@ int qmhip_hoqp_solve(qmhip_ctx* c, int B, int n_levels, int n, const int32_t* ma
   hipSetDevice(c->device); c->hoqp.solve(B, n_levels, n, ma, md, A, b, D, f, x, status); return c->hipstate();
 }
 int qmhip_wbc_download(qmhip_ctx* c, int B, double* out, int32_t* qps) { QM_GUARD(c);
-  if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG; hipSetDevice(c->device);
+  if (!c || B <= 0 || B > c->max_batch) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->flush_wbc();
   if (out) c->bk.to_host(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); if (qps) c->bk.to_host(qps, c->wbc.w.qp_status, (size_t)B * 3 * 4);
   return c->hipstate();
 }
@@ -432,7 +469,11 @@ int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double peri
   int rc = qmhip_mpc_solve_resident(c, B, horizon); if (rc) return rc;
   // the WBC goes to its own stream: back-to-back steps overlap WBC(k) — one wave per SIMD whose run time is that of the instance with the most
   // active-set iterations — with the MPC kernels of step k + 1, which fill the SIMDs the finished WBC waves leave behind
+  c->flush_wbc();      // (a deferred WBC the solve's hook has not launched — cannot happen after a solve, kept for safety: its inputs are about to be overwritten)
   c->bk.wbc_inputs_next(); c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time);
+  if (c->wbc_defer) {   // scheduling experiment: WBC(k) goes out behind K1a(k + 1) — the hook fires between the kin and the LQ launch of the next solve — or at the next synchronisation
+    c->wbc_deferred_B = B; c->wbc_deferred_period = period; qmhip_ctx* cc = c; c->mpc.before_lq = [cc]() { cc->flush_wbc(); };
+    return c->hipstate(); }
   c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
   return c->hipstate();
 }
@@ -508,9 +549,12 @@ int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launche
   if (ms) *ms = it == c->bk.acc.end() ? 0.0 : it->second.first; if (launches) *launches = it == c->bk.acc.end() ? 0 : it->second.second; return QMHIP_OK;
 }
 int qmhip_reset_kernel_ms(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.acc.clear(); return QMHIP_OK; }
-int qmhip_synchronize(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.sync(); return c->hipstate(); }
+int qmhip_synchronize(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->flush_wbc(); c->bk.sync(); return c->hipstate(); }
 int qmhip_last_ls_trials(const qmhip_ctx* c) { QM_GUARD(c); if (!c) return -1; hipSetDevice(c->device); return const_cast<qmhip_ctx*>(c)->mpc.ls_trials(); }      // (after a device-side line search: one synchronising read of the trial counters)
 int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { QM_GUARD(c); if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "lq_slices")) { c->mpc.lq_slices = value < 1 ? 1 : value; return QMHIP_OK; } if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; }
+  if (!strcmp(key, "filler_at_lq")) { c->filler_at_lq = value; return QMHIP_OK; }
+  if (!strcmp(key, "filler_live")) { c->filler_live = value; return QMHIP_OK; } if (!strcmp(key, "filler_lds")) { if (value < 16 * 1024 || value > 48 * 1024) return QMHIP_ERR_ARG; c->filler_lds = value; return QMHIP_OK; }      // co-residency stand-in: 0 / 160 / 184 live doubles, LDS bytes (>= 16 KB: the kernel indexes 2048 doubles)
+  if (!strcmp(key, "wbc_defer")) { c->flush_wbc(); c->wbc_defer = value; if (!value) c->mpc.before_lq = nullptr; return QMHIP_OK; }      // scheduling experiment (profiles/r06_ab_wbc_schedule.log)
   if (!strcmp(key, "ls_device_tail")) { c->mpc.device_tail = value != 0; return QMHIP_OK; }      // 0: the host-driven line-search trial loop of rounds 1-5 (A/B, tests); 1 (default): the trials after the first in one launch (k_ls.h)
   if (!strncmp(key, "lds_pad:", 8)) {   // profiling only: "lds_pad:<kernel group>" (lq, lq_kin, riccati, ls_eval, wbc, ...) = extra dynamic LDS bytes per workgroup; 0 removes it
     if (value < 0 || value > 160 * 1024) return QMHIP_ERR_ARG; if (value) c->bk.lds_pad[key + 8] = value; else c->bk.lds_pad.erase(key + 8); return QMHIP_OK; }
@@ -553,9 +597,18 @@ int qmhip_debug_filler(qmhip_ctx* c, int waves, int iters, int wait, double* ms)
   if (!c || waves <= 0 || iters <= 0) return QMHIP_ERR_ARG; hipSetDevice(c->device);
   if (!c->filler_buffer(waves)) { c->fail("hipMalloc of the filler buffer failed"); return QMHIP_ERR_HIP; }
   double* out = c->filler_out;
+  if (!wait && c->filler_at_lq) {      // "filler_at_lq": the stand-in of step k goes out BEHIND K1a of the next solve (between its kin and LQ launches), i.e. beside the LQ kernel only
+    qmhip_ctx* cc = c; c->mpc.before_lq = [cc, waves, iters]() { cc->mpc.before_lq = nullptr; const int keep = cc->filler_at_lq; cc->filler_at_lq = 0; qmhip_debug_filler(cc, waves, iters, 0, nullptr); cc->filler_at_lq = keep; };
+    return QMHIP_OK; }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  if (!wait) { hipEventRecord(c->bk.ev_in, c->bk.stream); hipStreamWaitEvent(c->bk.stream_b, c->bk.ev_in, 0); }      // like the WBC of a control step: starts when everything enqueued on the MPC stream so far is done
   hipEventRecord(e0, c->bk.stream_b);
-  hipLaunchKernelGGL(qm_filler_kernel, dim3(waves), dim3(64), 20 * 1024, c->bk.stream_b, out, iters);
+  if (c->filler_live) {
+    if (!c->filler_in) { if (hipMalloc(&c->filler_in, 192 * 64 * 8) != hipSuccess) { c->fail("hipMalloc failed"); return QMHIP_ERR_HIP; } hipMemset(c->filler_in, 0, 192 * 64 * 8); }
+    const int lds = c->filler_lds;
+    if (c->filler_live >= 184) hipLaunchKernelGGL(qm_filler_wide392_kernel, dim3(waves), dim3(64), lds, c->bk.stream_b, out, c->filler_in, iters);
+    else hipLaunchKernelGGL(qm_filler_wide344_kernel, dim3(waves), dim3(64), lds, c->bk.stream_b, out, c->filler_in, iters);
+  } else hipLaunchKernelGGL(qm_filler_kernel, dim3(waves), dim3(64), c->filler_lds, c->bk.stream_b, out, iters);
   hipEventRecord(e1, c->bk.stream_b);
   if (wait) { hipEventSynchronize(e1); float f = 0; hipEventElapsedTime(&f, e0, e1); if (ms) *ms = f; }
   hipEventDestroy(e0); hipEventDestroy(e1);
