@@ -38,7 +38,7 @@ struct QmRiccatiArgs {
   // baseline performance of the current iterate (sum of K1b's node terms) + arming of the line search, done by the instance's wave before the sweep
   // (what a separate one-wave-per-instance launch did: qm_perf_sum_kernel with with_alpha == 0); perf == nullptr: skipped
   const double* perf; double* base_sum; double* alpha; int* done; double* out_perf; int* open_cnt; int* tickets;
-  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages: results are then
+  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages, 64 lean operand prefetch (rw_prefetch), 128 nothing (the instrumented instance as it is): results are then
                                                // meaningless; 32: results intact, per-phase cycle counts are written to SR_K of each instance's first stage record)
 };
 
@@ -116,10 +116,14 @@ __device__ __forceinline__ void rw_prefetch_seg(const double* rec, double* lds, 
 #pragma unroll
   for (int t = 0; t * 128 < LEN; ++t) qm_dma16((const double*)((const char*)(rec + SRC + 128 * t) + lane_bytes), lds + RP_REC + DST + 128 * t);
 }
-__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds, int m) {
+// lean (profiling only, skip bit 64 of the instrumented instance): three of the twelve fragment chunks are NOT copied — the 360 doubles per stage that packed triangles of the
+// symmetric tiles Qp(0,0), Qp(1,1), Rp would save (round-5 review item 5).  The arithmetic then runs on stale operands (results meaningless); what is measured is the TIME
+// of a backward sweep that moves 7 % fewer bytes and pays nothing for unpacking them: the upper bound of what the packing could gain.
+__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds, int m, bool lean = false) {
   const unsigned lane_bytes = 16u * (threadIdx.x & 63);
   rw_prefetch_seg<SR_AP, RPO_A, 360>(rec, lds, lane_bytes);
   rw_prefetch_seg<SR_BP, RPO_B, 216>(rec, lds, lane_bytes);
+  if (lean) rw_prefetch_seg<SR_FRAG, RPO_Q, SR_F_PP1 - 384>(rec, lds, lane_bytes); else
   rw_prefetch_seg<SR_FRAG, RPO_Q, SR_F_PP1>(rec, lds, lane_bytes);
   if (m > 16) rw_prefetch_seg<SR_FRAG + SR_F_PP1, RPO_Q + SR_F_PP1, SR_F_SIZE - SR_F_PP1>(rec, lds, lane_bytes);      // wave-uniform: the second tile row of the reduced inputs
   rw_prefetch_seg<SR_PX + 360, RPO_PX, 360>(rec, lds, lane_bytes);
@@ -229,7 +233,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 #pragma unroll
       for (int r = 0; r < 4; ++r) { Sn[0][0][r] = F[SR_F_QP + r * 64]; Sn[0][1][r] = F[SR_F_QP + (4 + r) * 64]; Sn[1][1][r] = F[SR_F_QP + (8 + r) * 64]; Sn[1][0][r] = 0.0; } }
     qm_lds_drain();
-    if (nrec) rw_prefetch(nrec, buf, mnext);                        // next regular stage: flies during this stage's products and Cholesky
+    if (nrec) rw_prefetch(nrec, buf, mnext, PROF && (skip & 64));                        // next regular stage: flies during this stage's products and Cholesky
   }
   RWT(0)
   qm_d4 SA[2][2], SB[2][MT];

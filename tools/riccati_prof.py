@@ -12,9 +12,10 @@ mpc.solve_resident(cfg["horizon"]); itf.synchronize()
 import sys as _s
 itf.debug_set("riccati_skip", 32 | int(os.environ.get("RSKIP", "0")))
 mpc.solve_resident(cfg["horizon"]); itf.synchronize()
-nm = 128; SR = 7360
+sys.path.insert(0, os.path.join(ROOT, 'tests')); import lq_record_check as LC
+nm = 128; SR = LC.SR['SR_SIZE']
 stage = itf.debug_read("stage", (B * nm, SR))
-rows = stage[np.arange(B) * nm][:, 4752:4767]
+rows = stage[np.arange(B) * nm][:, LC.SR['SR_K']:LC.SR['SR_K'] + 15]
 names = ["operands LDS->frag (+dma wait)", "5 products", "stage to LDS + columns", "Cholesky loop", "scale, stores, W reload", "WtW", "symmetrise", "BACKWARD total", "FORWARD total", "fwd: loop head + dx store", "fwd: record regs -> LDS", "fwd: next-record fetch issue", "fwd: A dx, W dx", "fwd: triangular solve", "fwd: Pu ut, B ut, du store"]
 print(json.dumps({n: float(rows[:, i].mean()) for i, n in enumerate(names)}, indent=1))
 itf.debug_set("riccati_skip", 0)
