@@ -64,6 +64,9 @@ struct QmMpcPipeline {
   BK& bk; QmMpcBuffers d;
   int ls_trials_run = 0;          // trials of the last line search (the longest of the batch); with the device-side tail it is known only on the device: read through ls_trials()
   bool ls_trials_pending = false; int ls_trials_cap = 0;
+  // policy at t0 from the deciding kernels (k_ls.h): where the step's whole-body controller reads its inputs; enabled per solve by the control-step entry points
+  double* p0_x = nullptr; double* p0_u = nullptr; int* p0_mode = nullptr; bool p0_enable = false; bool p0_done = false;      // p0_done: the last sqp_iteration wrote them
+  bool defer_apply = false; int pending_apply_B = 0; int pending_apply_threads = 0;      // the caller launches the batch's apply itself (apply_pending) — behind the WBC launch of a control step
   bool device_tail = true;        // SQP: the trials after the first run in ONE launch without the host (qm_ls_tail_kernel, k_ls.h); false = the host-driven trial loop of rounds 1-5 (tests, A/B)
   int riccati_skip = 0;   // profiling only
   int lq_prof = 0;        // profiling only
@@ -118,6 +121,9 @@ struct QmMpcPipeline {
     return ls_trials_run;
   }
 
+  // the deferred apply of the last sqp_iteration (defer_apply): x + alpha dx on every node -> the primal solution (xs, us)
+  void apply_pending() { if (!pending_apply_B) return; QmLsArgs l = ls_args(pending_apply_B); bk.launch(qm_ls_apply_kernel, (pending_apply_threads * 30 + 255) / 256, 256, 0, l); pending_apply_B = 0; }
+
   // inputs are HOST pointers (instance-major, as the C ABI receives them)
   void upload_inputs(int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes) {
     bk.to_device(d.t0, t0, (size_t)B * 8); bk.to_device(d.x0, x0, (size_t)B * 30 * 8);
@@ -128,7 +134,7 @@ struct QmMpcPipeline {
   QmLsArgs ls_args(int B) {
     QmLsArgs a; a.mb = d.mb; a.st = d.st; a.B = B; a.nmax = d.nmax; a.n_nodes = d.n_nodes; a.node_ts = d.node_ts; a.node_dt = d.node_dt; a.node_ev = d.node_ev; a.node_mode = d.node_mode;
     a.zvel = d.zvel; a.zpos = d.zpos; a.xref = d.xref; a.eeref = d.eeref; a.x0 = d.x0; a.x = d.x; a.u = d.u; a.dx = d.dx; a.du = d.du; a.alpha = d.alpha; a.done = d.done;
-    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.max_trials = 0; a.with_alpha = 0; a.open_cnt = d.open_cnt; a.tickets = d.tickets; a.host_open = (volatile int*)d.host_open_dev; a.xt = nullptr; a.ut = nullptr; a.ilqr = 0; a.ipm_s = nullptr; a.ipm_ds = nullptr; a.ipm_info = nullptr;
+    a.perf = d.perf; a.perf_sum = d.perf_sum; a.base_sum = d.base_sum; a.step_info = d.step_info; a.xs = d.xs; a.us = d.us; a.out_perf = d.out_perf; a.trial = 0; a.max_trials = 0; a.node_t = d.node_t; a.p0_t = d.t0; a.p0_ev = d.ev; a.p0_modes = d.modes; a.p0_nev = d.nev; a.p0_x = nullptr; a.p0_u = nullptr; a.p0_mode = nullptr; a.with_alpha = 0; a.open_cnt = d.open_cnt; a.tickets = d.tickets; a.host_open = (volatile int*)d.host_open_dev; a.xt = nullptr; a.ut = nullptr; a.ilqr = 0; a.ipm_s = nullptr; a.ipm_ds = nullptr; a.ipm_info = nullptr;
     return a;
   }
 
@@ -205,18 +211,23 @@ struct QmMpcPipeline {
     if (riccati_skip) bk.launch(qm_riccati_prof_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // instrumented instance: phase skip bits, in-kernel cycle counters (profiling / parity tests only)
     else bk.launch(qm_riccati_kernel, B, RW_BLOCK, RW_LDS_BYTES, r);   // one wavefront per instance
     if (ipm) { bk.launch(qm_ipm_dir_kernel, (d.nmax * B + 63) / 64, 64, 0, ia); bk.launch(qm_ipm_alpha_kernel, B, 64, 0, ia); }      // slack / dual directions, fraction to the boundary: the line search starts at alphaP
-    ls_trials_run = 0; ls_trials_pending = false;
+    ls_trials_run = 0; ls_trials_pending = false; p0_done = false;
     if (device_tail && !ilqr && !ipm && max_trials >= 1) {
       // SQP line search without the host: trial 0 over the batch, its apply (instances still searching keep their iterate for now), then ONE launch in which every
       // instance that is still searching finishes its own search and writes its own primal solution (k_ls.h).  Nothing here waits for the device.
       l.trial = 0; l.max_trials = max_trials;
+      if (p0_enable && last && p0_x) { l.p0_x = p0_x; l.p0_u = p0_u; l.p0_mode = p0_mode; p0_done = true; bk.wbc_inputs_next(); }      // (the previous step's WBC has read its inputs before they are rewritten)
       if (r_blocks) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l); else bk.launch(qm_ls_eval_dense_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }
-      if (speculative_apply) bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
       if (max_trials > 1) { QmLsArgs lt = l; lt.trial = 1;
         if (r_blocks) bk.launch(qm_ls_tail_kernel, B, LS_TAIL_BLOCK, LS_TAIL_LDS_BYTES(d.nmax), lt); else bk.launch(qm_ls_tail_dense_kernel, B, LS_TAIL_BLOCK, LS_TAIL_LDS_BYTES(d.nmax), lt); }
-      if (!speculative_apply) bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);      // (tests only: the batch's apply behind the whole search; the tail's own writes are repeated)
       ls_trials_pending = true; ls_trials_cap = max_trials;
+      // the batch's apply reads the FINAL done / alpha of every instance.  A control step launches it behind its WBC (defer_apply): only the policy at t0 — written above by
+      // the deciding kernels — is on the WBC's way, the primal solution on all nodes is not
+      if (defer_apply && last) { pending_apply_B = B; pending_apply_threads = nodes_threads; solved_B = B; return; }
+      bk.launch(qm_ls_apply_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
+      if (!last) bk.launch(qm_ls_commit_kernel, (nodes_threads * 30 + 255) / 256, 256, 0, l);
+      solved_B = B; return;
     } else {
     for (int t = 0; t < max_trials; ++t) {
       l.trial = t;

@@ -122,6 +122,23 @@ struct qmhip_ctx {
   // sqp.sqpIteration (task.info:79, shipped 1): SQP iterations per MPC call [upstream SqpSolver::runImpl loop]; every instance of the batch runs all of
   // them (an instance whose line search finds no step just keeps its iterate)
   int sqp_iterations() const { const int n = (int)qm_ms_param(st, ST_SQP_ITER); return n < 1 ? 1 : (n > 50 ? 50 : n); }      // ipm.ipmIteration with solver 2
+  bool fused_policy = true;      // the policy at t0 comes from the line search's deciding kernels and the batch's apply runs behind the WBC launch (qm_pipeline.h); false: qm_policy_kernel behind the apply (rounds 1-5; qmhip_debug_set "fused_policy")
+  // One control step on resident data, everything enqueued, nothing waited for:
+  //   WBC stream: the synthetic measured state of this step (a function of x0 only) — early, beside the MPC kernels
+  //   MPC stream: K0 .. K4; the kernels that DECIDE the step length also write the policy at t0 (what evaluatePolicy(t0) reads from x + alpha dx)
+  //   WBC stream: waits for that decision, then the WBC;   MPC stream: the batch's apply (the primal solution on every node) runs beside it, then the next step
+  // Rounds 1-5 had apply -> policy kernel -> WBC on the critical path: 2 launches and ~ 60 us of a 2.7 ms step.
+  void control_step(int B, double horizon, double period, double time, bool warm) {
+    bk.stream_order(0, 1); bk.cur = bk.stream_b; wbc.measured_from_x0(mpc.d, B, time); bk.cur = bk.stream;      // (x0 is final on the MPC stream at this point; the previous WBC on this stream has read its rbd)
+    mpc.p0_x = wbc.w.x_des; mpc.p0_u = wbc.w.u_des; mpc.p0_mode = wbc.w.mode;
+    mpc.grid(B, horizon, warm);
+    for (int it = 0, ni = sqp_iterations(); it < ni; ++it) { const bool last_it = it + 1 == ni; mpc.p0_enable = fused_policy && last_it; mpc.defer_apply = fused_policy && last_it; mpc.sqp_iteration(B, 14, last_it); }
+    mpc.p0_enable = false; mpc.defer_apply = false; lastB = B; have_solution = true;
+    if (!mpc.p0_done) { mpc.apply_pending(); bk.wbc_inputs_next(); wbc.policy_eval_at_t0(mpc.d, B); }      // iLQR / interior-point solver / host-driven line search: the policy kernel on the applied primal solution
+    if (wbc_defer) { mpc.apply_pending(); wbc_deferred_B = B; wbc_deferred_period = period; qmhip_ctx* cc = this; mpc.before_lq = [cc]() { cc->flush_wbc(); }; return; }      // (scheduling experiment)
+    bk.wbc_begin(); wbc.step(mpc.d, B, period, 0); bk.wbc_end();
+    mpc.apply_pending();
+  }
   // launch a deferred WBC now, ordered behind everything enqueued on the MPC stream so far
   void flush_wbc() { if (!wbc_deferred_B) return; const int B = wbc_deferred_B; wbc_deferred_B = 0; bk.wbc_begin(); wbc.step(mpc.d, B, wbc_deferred_period, 0); bk.wbc_end(); }
   int hipstate() { if (!bk.error.empty()) { error = bk.error; bk.error.clear(); return QMHIP_ERR_HIP; } return QMHIP_OK; }
@@ -328,9 +345,7 @@ int qmhip_closed_loop_resident(qmhip_ctx* c, int B, int n_steps, double mpc_dt, 
   for (int k = 0; k < n_steps; ++k) {
     if (k > 0) c->mpc.advance(B, mpc_dt);
     if (c->front_B == B) c->gait_schedule(B, horizon);     // device-resident GaitSchedule active: modifyReferences before every MPC call
-    c->mpc.grid(B, horizon, true); for (int it = 0, ni = c->sqp_iterations(); it < ni; ++it) c->mpc.sqp_iteration(B, 14, it + 1 == ni); c->lastB = B; c->have_solution = true;
-    c->bk.wbc_inputs_next(); c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time0 + k * mpc_dt);
-    c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
+    c->control_step(B, horizon, period, time0 + k * mpc_dt, true);
   }
   return c->hipstate();
 }
@@ -466,15 +481,10 @@ int qmhip_wbc_download(qmhip_ctx* c, int B, double* out, int32_t* qps) { QM_GUAR
   return c->hipstate();
 }
 int qmhip_control_step_resident(qmhip_ctx* c, int B, double horizon, double period, double time) { QM_GUARD(c); QM_NEED_MPC(c);
-  int rc = qmhip_mpc_solve_resident(c, B, horizon); if (rc) return rc;
+  if (!c || B <= 0 || B > c->max_batch || !(horizon > 0)) { if (c) c->fail("qmhip_control_step_resident: bad argument"); return QMHIP_ERR_ARG; }
   // the WBC goes to its own stream: back-to-back steps overlap WBC(k) — one wave per SIMD whose run time is that of the instance with the most
   // active-set iterations — with the MPC kernels of step k + 1, which fill the SIMDs the finished WBC waves leave behind
-  c->flush_wbc();      // (a deferred WBC the solve's hook has not launched — cannot happen after a solve, kept for safety: its inputs are about to be overwritten)
-  c->bk.wbc_inputs_next(); c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time);
-  if (c->wbc_defer) {   // scheduling experiment: WBC(k) goes out behind K1a(k + 1) — the hook fires between the kin and the LQ launch of the next solve — or at the next synchronisation
-    c->wbc_deferred_B = B; c->wbc_deferred_period = period; qmhip_ctx* cc = c; c->mpc.before_lq = [cc]() { cc->flush_wbc(); };
-    return c->hipstate(); }
-  c->bk.wbc_begin(); c->wbc.step(c->mpc.d, B, period, 0); c->bk.wbc_end();
+  hipSetDevice(c->device); c->flush_wbc(); c->control_step(B, horizon, period, time, false);
   return c->hipstate();
 }
 
@@ -552,6 +562,7 @@ int qmhip_reset_kernel_ms(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_
 int qmhip_synchronize(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->flush_wbc(); c->bk.sync(); return c->hipstate(); }
 int qmhip_last_ls_trials(const qmhip_ctx* c) { QM_GUARD(c); if (!c) return -1; hipSetDevice(c->device); return const_cast<qmhip_ctx*>(c)->mpc.ls_trials(); }      // (after a device-side line search: one synchronising read of the trial counters)
 int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { QM_GUARD(c); if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "lq_slices")) { c->mpc.lq_slices = value < 1 ? 1 : value; return QMHIP_OK; } if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; }
+  if (!strcmp(key, "fused_policy")) { c->fused_policy = value != 0; return QMHIP_OK; }      // 0: apply -> qm_policy_kernel -> WBC as in rounds 1-5 (A/B, tests)
   if (!strcmp(key, "filler_at_lq")) { c->filler_at_lq = value; return QMHIP_OK; }
   if (!strcmp(key, "filler_live")) { c->filler_live = value; return QMHIP_OK; } if (!strcmp(key, "filler_lds")) { if (value < 16 * 1024 || value > 48 * 1024) return QMHIP_ERR_ARG; c->filler_lds = value; return QMHIP_OK; }      // co-residency stand-in: 0 / 160 / 184 live doubles, LDS bytes (>= 16 KB: the kernel indexes 2048 doubles)
   if (!strcmp(key, "wbc_defer")) { c->flush_wbc(); c->wbc_defer = value; if (!value) c->mpc.before_lq = nullptr; return QMHIP_OK; }      // scheduling experiment (profiles/r06_ab_wbc_schedule.log)

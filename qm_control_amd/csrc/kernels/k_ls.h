@@ -9,6 +9,7 @@
 //                        (u at PreEvent nodes copied from the previous node, last u repeated)
 #pragma once
 #include "qm_dev_kin.h"
+#include "k_grid.h"
 #include "k_ipm.h"
 
 struct QmLsArgs {
@@ -32,6 +33,10 @@ struct QmLsArgs {
   int with_alpha;                       // perf_sum: 1 = initial-state defect of the trial iterate, 0 = of the base iterate
   int* open_cnt; int* tickets;          // [QM_LS_MAX_TRIALS] instances still searching after trial t / blocks that have passed; zeroed by the baseline sum
   volatile int* host_open;              // [QM_LS_MAX_TRIALS] host-visible copy of open_cnt[t], written by the last block of trial t (the host never copies flags)
+  // policy at t0 straight from the line search's decision (round 6; null p0_x: off): what MPC_MRT_Interface::evaluatePolicy(t0) would read from the primal solution
+  // x + alpha dx is written by the kernels that DECIDE alpha (qm_perf_sum for the first trial, qm_ls_tail for the later ones), so that the whole-body controller of the
+  // step can start behind the decision — the batch's apply (xs, us on every node) and the policy kernel leave the critical path (qm_pipeline.h)
+  const double* node_t; const double* p0_t; const double* p0_ev; const int* p0_modes; int p0_nev; double* p0_x; double* p0_u; int* p0_mode;
   // discrete iLQR (k_ilqr.h): the trial trajectory is a nonlinear ROLLOUT held in xt / ut (null for the SQP, whose trial point is x + alpha dx, u + alpha du);
   // merit = cost + rho sqrt(eqSSE), accepted when merit(a) < merit(0) + 1e-4 a armijo, a halved down to ddp.lineSearch.minStepLength
   const double* xt; const double* ut; int ilqr;
@@ -281,6 +286,25 @@ __device__ __forceinline__ int qm_ls_filter_decide(const QmLsArgs& a, const int 
   a.alpha[b] = al;
   return 0;
 }
+// entries of the primal solution of instance b for the step length al (0 when no step is taken) — the arithmetic of qm_ls_apply_kernel, which writes them for every node
+__device__ __forceinline__ double qm_ls_primal_x(const QmLsArgs& a, const int b, const int i, const int q, const double al) { const size_t nb = (size_t)i * a.B + b; return a.x[nb * 30 + q] + al * a.dx[nb * 30 + q]; }
+__device__ __forceinline__ double qm_ls_primal_u(const QmLsArgs& a, const int b, const int n, const int i, const int q, const double al) {
+  int j = (i == n - 1) ? n - 2 : i; if (j < 0) j = 0;                      // input of the primal solution: own node, or the closest earlier non-event node
+  while (j > 0 && a.node_ev[j * a.B + b] == QM_EV_PRE) --j;
+  const size_t jb = (size_t)j * a.B + b; const bool evj = (a.node_ev[jb] == QM_EV_PRE) || n < 2;
+  return evj ? 0.0 : a.u[jb * 30 + q] + al * a.du[jb * 30 + q];
+}
+// evaluatePolicy at t0 ([upstream] linear interpolation of the primal solution, qm_policy_body) on the primal solution the decided step length defines; one wave:
+// lanes 0..29 the state, 32..61 the input, lane 0 the mode of the schedule at t0.  Bit-identical to qm_policy_kernel run behind qm_ls_apply_kernel (same products, same order).
+__device__ __forceinline__ void qm_ls_policy_at_t0(const QmLsArgs& a, const int b, const int l, const double al) {
+  if (!a.p0_x) return;
+  const int n = a.n_nodes[b]; const double t = a.p0_t[b];
+  int idx; double ai; grid_policy_segment(a.node_t, a.node_ev, n, a.B, b, t, &idx, &ai);
+  const int i1 = (n > 1) ? idx + 1 : idx;
+  if (l < 30) a.p0_x[(size_t)b * 30 + l] = ai * qm_ls_primal_x(a, b, idx, l, al) + (1.0 - ai) * qm_ls_primal_x(a, b, i1, l, al);
+  else if (l >= 32 && l < 62) { const int q = l - 32; a.p0_u[(size_t)b * 30 + q] = ai * qm_ls_primal_u(a, b, n, idx, q, al) + (1.0 - ai) * qm_ls_primal_u(a, b, n, i1, q, al); }
+  if (l == 0) a.p0_mode[b] = a.p0_modes[(size_t)b * (a.p0_nev + 1) + grid_find_index(a.p0_ev + (size_t)b * a.p0_nev, a.p0_nev, t)];
+}
 // One WAVEFRONT per instance.  Sum of the node terms -> perf_sum[b] = {merit, cost, dynSSE, eqSSE} (lanes stride over the
 // nodes, DPP wave reduction).  with_alpha == 0: baseline of the current iterate, also arms the line search (alpha = 1, done = 0);
 // with_alpha == 1: the trial point, followed by the filter line-search decision of this instance
@@ -318,6 +342,11 @@ __global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
   const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
   const bool open = qm_perf_sum_body(a, b, l);
+  if (a.with_alpha && a.p0_x) {      // the policy at t0 of what the decision stands at: the accepted step, or the iterate itself while the search goes on / when it gave up (qm_ls_tail overwrites it on acceptance)
+    int acc = 0; double al = 0.0; if (l == 0) { acc = a.done[b] == 1; al = acc ? a.alpha[b] : 0.0; }      // (lane 0 made the decision and reads its own stores)
+    acc = __shfl(acc, 0, 64); al = __shfl(al, 0, 64);
+    qm_ls_policy_at_t0(a, b, l, al);
+  }
   // the host only needs to know whether ANY instance is still searching: count them, and let the block that arrives last publish the count
   // in host-visible memory (one stream synchronisation instead of a flag copy + two)
   if (a.with_alpha && a.open_cnt && l == 0) {
@@ -336,8 +365,9 @@ __global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
 // from, tools/warm_ls_histogram.py).  Now ONE launch finishes the search: one 256-thread workgroup per instance, gone at once unless its instance is still searching;
 // it evaluates TWO step lengths side by side (threads 0..127 the nodes at alpha, 128..255 at alpha / 2 — the decisions are taken in the filter's order, the second
 // evaluation is wasted when the first is accepted), sums the node terms exactly as qm_perf_sum does (lane-strided partial sums of one wave + the DPP reduction: a trial's
-// merit is bit-identical to what the two-kernel path computes), decides, repeats until the filter accepts or stops, and writes the accepted step into the primal solution
-// of its own instance (what qm_ls_apply does for the batch).  The host never waits inside the line search.
+// merit is bit-identical to what the two-kernel path computes), decides, repeats until the filter accepts or stops.  qm_ls_apply_kernel follows for the whole batch (it is no
+// longer speculative: nothing waits for the host); the policy at t0, which is all the step's whole-body controller needs, is written by the deciding kernels.  The host never
+// waits inside the line search.
 #define LS_TAIL_BLOCK 256
 #define LS_TAIL_SLOTS 2
 #define LS_TAIL_NODES (LS_TAIL_BLOCK / LS_TAIL_SLOTS)
@@ -398,16 +428,9 @@ template <bool RB> __global__ void __launch_bounds__(LS_TAIL_BLOCK) qm_ls_tail_k
     state = (int)ctl[0]; al_first = ctl[1]; trial = (int)ctl[2];
     if (state != 0) break;
   }
-  if (state != 1) return;                                                      // no step (or out of trials): the batch's apply has already written x, u as the primal solution
-  // the accepted step -> primal solution of this instance (qm_ls_apply_kernel's arithmetic); al_first is the accepted step length (not advanced on acceptance)
-  for (int idx = tid; idx < n * 30; idx += LS_TAIL_BLOCK) {
-    const int i = idx / 30, q = idx - 30 * i; const size_t nb = (size_t)i * a.B + b;
-    a.xs[nb * 30 + q] = a.x[nb * 30 + q] + al_first * a.dx[nb * 30 + q];
-    int j = (i == n - 1) ? n - 2 : i; if (j < 0) j = 0;
-    while (j > 0 && a.node_ev[j * a.B + b] == QM_EV_PRE) --j;
-    const size_t jb = (size_t)j * a.B + b; const bool evj = (a.node_ev[jb] == QM_EV_PRE) || n < 2;
-    a.us[nb * 30 + q] = evj ? 0.0 : a.u[jb * 30 + q] + al_first * a.du[jb * 30 + q];
-  }
+  // the batch's qm_ls_apply_kernel runs BEHIND this launch (it reads the final done / alpha of every instance); what the whole-body controller of the step needs — the
+  // policy at t0 — is refreshed here for an instance that accepted a shortened step (al_first is the accepted step length: not advanced on acceptance)
+  if (state == 1 && tid < 64) qm_ls_policy_at_t0(a, b, tid, al_first);
 }
 #define qm_ls_tail_kernel qm_ls_tail_kernel_t<true>
 #define qm_ls_tail_dense_kernel qm_ls_tail_kernel_t<false>

@@ -19,12 +19,13 @@ struct EmuBackend {
   void free_mapped(void* p) { ::free(p); }
   void wait_launched() {}
   void wait_flag(volatile int*, int) {}
+  void wbc_inputs_next() {}
   void stream_select(int) {}
   void stream_order(int, int) {}
   void copy_dd(void* d, const void* s, size_t n) { memcpy(d, s, n); }
 };
 
-struct EmuCtx { double* lqdbg_stash = nullptr; EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; QmSimPipeline<EmuBackend> sim; EmuCtx() : mpc(bk), wbc(bk), front(bk), sim(bk) {} };
+struct EmuCtx { bool fused_policy = true; double* lqdbg_stash = nullptr; EmuBackend bk; QmMpcPipeline<EmuBackend> mpc; QmWbcPipeline<EmuBackend> wbc; QmFrontPipeline<EmuBackend> front; QmSimPipeline<EmuBackend> sim; EmuCtx() : mpc(bk), wbc(bk), front(bk), sim(bk) {} };
 
 extern "C" {
 void* emu_create(const double* mb, const double* st, int Bmax, int nmax, int nref, int nev) {
@@ -57,7 +58,8 @@ void emu_upload(void* h, int B, const double* t0, const double* x0, const double
 // raw buffer access for parity tests: name -> pointer
 void* emu_buffer(void* h, const char* name) {
   QmMpcBuffers& d = ((EmuCtx*)h)->mpc.d;
-  { EmuCtx* c = (EmuCtx*)h; if (!strcmp(name, "sim_q")) return (void*)c->sim.s.q; if (!strcmp(name, "sim_v")) return (void*)c->sim.s.v; if (!strcmp(name, "wbc_out")) return (void*)c->wbc.w.out; if (!strcmp(name, "wbc_qp_status")) return (void*)c->wbc.w.qp_status; }
+  { EmuCtx* c = (EmuCtx*)h; if (!strcmp(name, "sim_q")) return (void*)c->sim.s.q; if (!strcmp(name, "sim_v")) return (void*)c->sim.s.v; if (!strcmp(name, "wbc_out")) return (void*)c->wbc.w.out; if (!strcmp(name, "wbc_qp_status")) return (void*)c->wbc.w.qp_status;
+    if (const void* p = c->wbc.buffer(name)) return (void*)p; }      // wbc_x_des, wbc_u_des, wbc_mode, wbc_rbd, ...
 #define F(n) if (!strcmp(name, #n)) return (void*)d.n;
   F(n_nodes) F(node_t) F(node_ts) F(node_dt) F(node_ev) F(node_mode) F(zvel) F(zpos) F(xref) F(eeref) F(status) F(x) F(u) F(dx) F(du) F(stage) F(lqdbg) F(perf) F(base_sum)
   F(perf_sum) F(step_info) F(alpha) F(done) F(xs) F(us) F(out_perf) F(t0) F(x0) F(ipm_s) F(ipm_l) F(ipm_ds) F(ipm_dl) F(ipm_info)
@@ -94,8 +96,13 @@ void emu_wbc_step(void* h, int B, const double* xd, const double* ud, const doub
 }
 // the benchmark's whole control step on resident data (same calls as qmhip_control_step_resident)
 void emu_control_step(void* h, int B, double horizon, double period, double time, double* out, int* status, double* rbd_out) {
-  EmuCtx* c = (EmuCtx*)h; c->mpc.grid(B, horizon); c->mpc.sqp_iteration(B);
-  c->wbc.policy_at_t0_and_measured(c->mpc.d, B, time); c->wbc.step(c->mpc.d, B, period, 0);
+  // as qmhip_control_step_resident: measured state first, the policy at t0 from the line search's deciding kernels, the WBC, then the batch's apply
+  EmuCtx* c = (EmuCtx*)h; c->mpc.grid(B, horizon);
+  c->mpc.p0_x = c->wbc.w.x_des; c->mpc.p0_u = c->wbc.w.u_des; c->mpc.p0_mode = c->wbc.w.mode; c->mpc.p0_enable = c->fused_policy; c->mpc.defer_apply = c->fused_policy;
+  c->wbc.measured_from_x0(c->mpc.d, B, time);
+  c->mpc.sqp_iteration(B, 14, true); c->mpc.p0_enable = false; c->mpc.defer_apply = false;
+  if (!c->mpc.p0_done) c->wbc.policy_eval_at_t0(c->mpc.d, B);
+  c->wbc.step(c->mpc.d, B, period, 0); c->mpc.apply_pending();
   memcpy(out, c->wbc.w.out, (size_t)B * QM_NWBC_OUT * 8); memcpy(status, c->wbc.w.qp_status, (size_t)B * 3 * 4); if (rbd_out) memcpy(rbd_out, c->wbc.w.rbd, (size_t)B * QM_NRBD * 8);
 }
 // reference / gait front-end (same calls as the qmhip_gait_* / qmhip_target_* entry points)
@@ -121,6 +128,7 @@ int emu_hoqp(int B, int n_levels, int n, const int* ma, const int* md, const dou
   h.solve(B, n_levels, n, ma, md, A, b, D, f, x, status); return 0;
 }
 void emu_set_speculative_apply(void* h, int on) { ((EmuCtx*)h)->mpc.speculative_apply = on != 0; }
+void emu_set_fused_policy(void* h, int on) { ((EmuCtx*)h)->fused_policy = on != 0; }      // 0: qm_policy_kernel behind the apply (rounds 1-5)
 void emu_set_device_tail(void* h, int on) { ((EmuCtx*)h)->mpc.device_tail = on != 0; }      // qmhip_debug_set("ls_device_tail", .)
 // the C ABI's status of an instance from K0's word and K3's step_info (the mapping qmhip_mpc_download applies)
 int emu_mpc_status(int k0_status, const double* step_info4, int strict) { return qm_mpc_status(k0_status, step_info4, strict != 0); }

@@ -123,6 +123,33 @@ def test_device_tail_equals_the_host_driven_trial_loop(blobs, oblobs, gmax, max_
         assert a["trials"] <= max_trials
 
 
+@pytest.mark.parametrize("gmax", [None, 1e-9])
+def test_policy_at_t0_from_the_deciding_kernels_equals_the_policy_kernel(blobs, gmax):
+    """Round 6: a control step no longer runs apply -> qm_policy_kernel -> WBC; the kernels that decide the step length (qm_perf_sum, qm_ls_tail) write what
+    evaluatePolicy(t0) reads from x + alpha dx, the WBC starts behind them and the batch's apply follows it.  On a mixed batch (accepting and backtracking instances; with the
+    tight filter some take three or more trials or give up) the WBC inputs, the WBC output and the primal solution must equal the rounds-1-5 order BIT FOR BIT."""
+    import emu_harness
+    from qm_control_amd import scenarios
+    B = 5
+    st = blobs[1].copy()
+    if gmax is not None: st[L.ST_G_MAX] = gmax; st[L.ST_DELTA_TOL] = 1e-12
+    cfg = scenarios.make_config("C5", batch=B, n_intervals=10); cfg["B"] = B
+    cfg["x0"][1] = st[L.ST_XINIT:L.ST_XINIT + 30]; cfg["x0"][0, 24:30] += 3.3; cfg["x0"][2, 12:24] += 0.02; cfg["x0"][3, 9:12] += 0.01; cfg["x0"][4, 24:30] += 0.3
+    outs = []
+    for fused in (1, 0):
+        e = emu_harness.Emu(blobs[0], st, B, 40, cfg["ref_t"].shape[1], cfg["ev"].shape[1]); e.lib.emu_set_fused_policy(e.h, C.c_int(fused))
+        out, qps, rbd = e.control_step(cfg); n = e.buf("n_nodes", (B,), np.int32).copy()
+        outs.append(dict(out=out, qps=qps, rbd=rbd, xd=e.buf("wbc_x_des", (B, 30)).copy(), ud=e.buf("wbc_u_des", (B, 30)).copy(), mode=e.buf("wbc_mode", (B,), np.int32).copy(),
+                         alpha=e.buf("out_perf", (B, 10))[:, 8].copy(), xs=e.node_arr("xs", 30).copy(), us=e.node_arr("us", 30).copy(), n=n))
+    a, b = outs
+    assert (a["alpha"] < 1.0).any() and np.array_equal(a["alpha"], b["alpha"]), a["alpha"]
+    for key in ("xd", "ud", "mode", "rbd", "out", "qps"):
+        assert np.array_equal(a[key], b[key]), key
+    for k in range(B):
+        nk = a["n"][k]; assert np.array_equal(a["xs"][:nk, k], b["xs"][:nk, k]) and np.array_equal(a["us"][:nk, k], b["us"][:nk, k]), k
+    assert np.array_equal(a["xd"], a["xs"][0]) and np.abs(a["ud"]).max() > 0.0      # at t0 the policy IS the first node of the primal solution
+
+
 @pytest.mark.parametrize("ncase,seed,amp", [(6, 21, 0.05), (10, 303, 0.5)])      # small and large tracking errors (the large ones saturate torque limits and friction cones: long active-set paths with drops)
 def test_wbc_kernel_vs_oracle(blobs, oracle, ncase, seed, amp):
     import emu_harness

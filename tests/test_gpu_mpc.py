@@ -162,6 +162,31 @@ def test_device_line_search_tail_equals_the_host_driven_loop(blobs, oracle):
             assert_blocks(dev[k]["x"][b, :n], r["x"], "x", TOL, (b, k)); assert_blocks(dev[k]["u"][b, :n], r["u"], "u", TOL, (b, k))
 
 
+def test_fused_policy_at_t0_equals_the_policy_kernel_on_the_device(blobs):
+    """Round 6: in a control step the kernels that decide the step length write the policy at t0, the WBC starts behind them on its own stream and the batch's apply runs
+    beside it (qmhip.hip: control_step).  Against the rounds-1-5 order (apply -> qm_policy_kernel -> WBC; `fused_policy` 0) on the benchmark workload — a cold step and five
+    warm-started closed-loop steps, where instances backtrack — torques, QP statuses, the policy at t0 and the primal solution must be bit-identical."""
+    from qm_control_amd import api, scenarios
+    B = 256
+    cfg = scenarios.make_config("C3", batch=B)
+
+    def run(fused):
+        itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1]); itf.debug_set("fused_policy", fused)
+        mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+        mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"]); wbc.reset()
+        mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"]); cold = (wbc.download(B), mpc.download(), mpc.evaluatePolicy(cfg["t0"]))
+        wbc.reset(); mpc.closed_loop_resident(5, 0.01, cfg["horizon"], cfg["period"], cfg["time"]); itf.synchronize()
+        warm = (wbc.download(B), mpc.download()); itf.close()
+        return cold, warm
+
+    (c1, w1), (c0, w0) = run(1), run(0)
+    for a, b in ((c1, c0), (w1, w0)):
+        assert np.array_equal(a[0][0], b[0][0]) and np.array_equal(a[0][1], b[0][1]) and (a[0][1] == 0).all()      # WBC output, QP statuses
+        for key in ("x", "u", "perf", "status", "t"): assert np.array_equal(a[1][key], b[1][key]), key
+    for k in range(3): assert np.array_equal(c1[2][k], c0[2][k])
+    assert (w1[1]["perf"][:, 8] < 1.0).any() and w1[1]["ls_trials"] >= 2      # the warm steps did backtrack
+
+
 def test_update_references_keeps_the_warm_start(blobs, oracle):
     """what the MPC_BASE adaptor does on every call after the first (adaptors/QmhipMpc.h): new targets / schedule from preSolverRun, new observation,
     warm-started iteration from the PREVIOUS primal solution — qmhip_mpc_update_references must not drop it (qmhip_mpc_upload would)"""

@@ -30,8 +30,8 @@ def warm(n):
 
 
 for r in range(rounds):
-    for tail in (0, 1):
-        itf.debug_set("ls_device_tail", tail)
+    for tail, fused in ((0, 0), (1, 0), (1, 1)):      # rounds 1-5 | device-side line-search tail | + policy at t0 from the deciding kernels, apply beside the WBC
+        itf.debug_set("ls_device_tail", tail); itf.debug_set("fused_policy", fused)
         c = cold(20); w = warm(10)
-        print(json.dumps({"round": r, "ls_device_tail": tail, "cold_ms_per_step": round(c, 4), "warm_ms_per_step": round(w[0], 4), "warm_ls_trials_last": w[1], "tau_checksum": w[2], "primal_checksum": w[3], "ok": w[4]}), flush=True)
+        print(json.dumps({"round": r, "ls_device_tail": tail, "fused_policy": fused, "cold_ms_per_step": round(c, 4), "warm_ms_per_step": round(w[0], 4), "warm_ls_trials_last": w[1], "tau_checksum": w[2], "primal_checksum": w[3], "ok": w[4]}), flush=True)
 itf.close()
