@@ -240,7 +240,8 @@ int qmhip_closed_loop_sim_pipelined(qmhip_ctx* ctx, int B, int n_ticks, double p
 
 /* ---- instrumentation (ocs2 benchmark::RepeatedTimer analogue, QMController.cpp:145-147,321-323) ----
  * per-kernel HIP-event timing on the stream each kernel runs on; names: "grid","lq_kin","lq","riccati","ls_eval","ls_misc","policy","wbc","sim".
- * enable: 0 off, 1 a span around every launch, 2 only around the three modelled kernels "lq","riccati","wbc" (two event records cost about one launch) */
+ * enable: 0 off, 1 a span around every launch, 2 only around the three modelled kernels "lq","riccati","wbc", 3 only around "lq" — the dominant kernel, all the
+ * bench's timed region carries (two event records cost about one launch) */
 int qmhip_set_profiling(qmhip_ctx* ctx, int enable);
 int qmhip_get_kernel_ms(qmhip_ctx* ctx, const char* name, double* total_ms, int* launches);
 int qmhip_reset_kernel_ms(qmhip_ctx* ctx);

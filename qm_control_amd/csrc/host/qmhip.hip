@@ -30,7 +30,7 @@ struct HipBackend {
   hipStream_t stream_b = nullptr;          // WBC stream: the WBC of step k runs beside the MPC kernels of step k + 1 (the reference runs them in two threads too)
   hipStream_t cur = nullptr;               // stream the next launch / memset goes to
   hipEvent_t ev_in = nullptr, ev_wbc = nullptr; bool wbc_pending = false;
-  int profiling = 0;   // 0 off, 1 HIP-event span around every launch, 2 only around the modelled kernels (lq, riccati, wbc): two event records cost ≈ a launch
+  int profiling = 0;   // 0 off, 1 HIP-event span around every launch, 2 only around the modelled kernels (lq, riccati, wbc), 3 only around the LQ kernel (the dominant one: what the bench's timed region carries): two event records cost ≈ a launch
   std::string error;
   struct Span { std::string name; hipEvent_t a, b; };
   std::vector<Span> spans; std::vector<hipEvent_t> pool;
@@ -54,7 +54,8 @@ struct HipBackend {
       if (it == lds_set.end() || it->second < (int)lds) { check(hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"); lds_set[p] = (int)lds; }
     }
     const void* kp_ = (const void*)kernel;
-    const bool span = profiling == 1 || (profiling == 2 && (kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_lq_m18_kernel || kp_ == (const void*)qm_lq_ipm_kernel || kp_ == (const void*)qm_riccati_kernel || kp_ == (const void*)qm_wbc_kernel));      // (lq_m18: launched only on workloads with a phase of three or four stance feet; bench.py prices lq + lq_m18 together)
+    const bool is_lq_ = kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_lq_m18_kernel || kp_ == (const void*)qm_lq_ipm_kernel;
+    const bool span = profiling == 1 || (profiling == 3 && is_lq_) || (profiling == 2 && (kp_ == (const void*)qm_lq_kernel || kp_ == (const void*)qm_lq_m18_kernel || kp_ == (const void*)qm_lq_ipm_kernel || kp_ == (const void*)qm_riccati_kernel || kp_ == (const void*)qm_wbc_kernel));      // (lq_m18: launched only on workloads with a phase of three or four stance feet; bench.py prices lq + lq_m18 together)
     Span s; if (span) { s.name = name_of(kernel); s.a = ev(); s.b = ev(); check(hipEventRecord(s.a, cur), "hipEventRecord"); }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, cur, args);
     check(hipGetLastError(), "kernel launch");
@@ -553,7 +554,7 @@ int qmhip_closed_loop_sim_pipelined(qmhip_ctx* c, int B, int n_ticks, double per
   return c->hipstate();
 }
 
-int qmhip_set_profiling(qmhip_ctx* c, int en) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.profiling = (en == 2) ? 2 : (en != 0); return QMHIP_OK; }
+int qmhip_set_profiling(qmhip_ctx* c, int en) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; c->bk.resolve(); c->bk.profiling = (en == 2 || en == 3) ? en : (en != 0); return QMHIP_OK; }
 int qmhip_get_kernel_ms(qmhip_ctx* c, const char* name, double* ms, int* launches) { QM_GUARD(c);
   if (!c || !name) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->bk.resolve(); auto it = c->bk.acc.find(name);
   if (ms) *ms = it == c->bk.acc.end() ? 0.0 : it->second.first; if (launches) *launches = it == c->bk.acc.end() ? 0 : it->second.second; return QMHIP_OK;
