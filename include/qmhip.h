@@ -194,7 +194,10 @@ int qmhip_hoqp_solve(qmhip_ctx* ctx, int B, int n_levels, int n, const int32_t* 
                      const double* A, const double* b, const double* D, const double* f, double* x /*[B][n]*/, int32_t* status /*[B][n_levels]*/);
 
 /* ---- whole control step on resident data (benchmark "step"): SQP iteration + policy evaluation at t0 + WBC with
- *      the measured state built from x0 (zero velocities, EE pose by FK) */
+ *      the measured state built from x0 (zero velocities, EE pose by FK).  Everything is enqueued, nothing waited for: the kernels that decide
+ *      the line search's step length also write the policy at t0 (what MPC_MRT_Interface::evaluatePolicy reads from the primal solution at its first node), the WBC starts
+ *      behind them on its own stream, and the primal solution on all nodes (what qmhip_mpc_download / qmhip_policy_eval / the next warm start read) is written beside it.
+ *      Same results as qmhip_mpc_solve_resident + qmhip_policy_eval(t0) + qmhip_wbc_step, bit for bit (tests/test_gpu_mpc.py) */
 int qmhip_control_step_resident(qmhip_ctx* ctx, int B, double horizon, double period, double time);
 int qmhip_wbc_download(qmhip_ctx* ctx, int B, double* out /*[B][54]*/, int32_t* qp_status /*[B][3]*/);
 
@@ -246,6 +249,8 @@ int qmhip_set_profiling(qmhip_ctx* ctx, int enable);
 int qmhip_get_kernel_ms(qmhip_ctx* ctx, const char* name, double* total_ms, int* launches);
 int qmhip_reset_kernel_ms(qmhip_ctx* ctx);
 int qmhip_synchronize(qmhip_ctx* ctx);
+/* line-search trials of the last SQP iteration (the longest search of the batch).  Since round 6 the trials after the first run on the device without the host
+ * (qm_ls_tail_kernel): the count is read back from the device's trial counters on demand — this call synchronises the context's streams */
 int qmhip_last_ls_trials(const qmhip_ctx* ctx);
 /* debug/parity access to a device buffer by name (see QmMpcBuffers); copies `bytes` to host */
 int qmhip_debug_read(qmhip_ctx* ctx, const char* buffer, void* dst, size_t bytes);
