@@ -10,7 +10,7 @@
  * Return value 0 = ok, negative = error (qmhip_last_error gives the text).
  *
  * Threads.  Every entry point that takes a context locks it: calls on ONE context from several threads are safe and run one after another (a blocked
- * caller waits for the other call's host work, e.g. the line search of an MPC solve).  The reference runs the MPC in `mpcThread_` (advanceMpc,
+ * caller waits for the other call's host work, e.g. the launches of an MPC solve — since round 6 the SQP solve only enqueues, its line search no longer waits for the device —).  The reference runs the MPC in `mpcThread_` (advanceMpc,
  * qm_controllers/src/QMController.cpp:315-333) beside the ros_control thread's WbcBase::update (QMController.cpp:128-147); for that layout the control thread
  * gets its OWN context from qmhip_create_wbc_context: own streams, own device copies of the model, own error string — a control tick then never waits for,
  * and is never reordered by, an MPC solve in flight (tests/c_abi_threads.c).  Different contexts share nothing mutable; qmhip_last_error(NULL) is per thread.
