@@ -355,7 +355,11 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   // instrumented instance, profiling on: wave entry in shader-clock cycles and in ticks of the constant 100 MHz reference clock (tools/lq_residency_probe.py)
   const long long c0_ = (DBG && a.prof) ? (long long)__builtin_readcyclecounter() : 0; const long long r0_ = (DBG && a.prof) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   const double* mb = qm_table(a.mb); const double* st = qm_table(a.st);
+#ifdef QM_LQ_FOLD_RECORDS      /* bandwidth experiment only (profiles/r06_ab_lq_write_bound.log): every wave writes its stage record into one of QM_LQ_FOLD_RECORDS slots — the stores stay in cache, the results are meaningless */
+  double* rec = a.stage + ((size_t)(blockIdx.x % QM_LQ_FOLD_RECORDS)) * SR_SIZE;
+#else
   double* rec = a.stage + ((size_t)b * a.nmax + i) * SR_SIZE;
+#endif
   double* dbg = (DBG && a.dbg) ? a.dbg + ((size_t)b * a.nmax + i) * LQ_DBG_SIZE : nullptr;
   const double* kr = a.kin + (size_t)nb * KR_SIZE;
   // every input address depends on (b, i) only: issue all loads before looking at the node's status (one memory round trip)

@@ -302,7 +302,11 @@ __device__ __forceinline__ void qm_frag_load_tile(qm_d4 (&T)[IT][JT], const doub
 }
 // STREAMING data — written once by one kernel, read once by a later one, with gigabytes of other traffic in between (stage records K1b -> K3: 2.8 GB per launch) —
 // is stored with the non-temporal hint (global_store ... nt): the lines do not stay in L2 / MALL at the expense of what IS re-read (measured: K3 − 7 %, step − 3 %)
+#ifdef QM_NO_NT_STORES      /* experiment only */
+#define QM_STREAM_ST(p, v) (*(p) = (double)(v))
+#else
 #define QM_STREAM_ST(p, v) __builtin_nontemporal_store((double)(v), (p))
+#endif
 template <int IT, int JT, bool STREAM = false>
 __device__ __forceinline__ void qm_frag_store(const qm_d4 (&T)[IT][JT], double* dst, int ld, int rows, int cols) {
   const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
