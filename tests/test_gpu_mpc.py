@@ -187,6 +187,40 @@ def test_fused_policy_at_t0_equals_the_policy_kernel_on_the_device(blobs):
     assert (w1[1]["perf"][:, 8] < 1.0).any() and w1[1]["ls_trials"] >= 2      # the warm steps did backtrack
 
 
+@pytest.mark.parametrize("B,max_nodes", [(97, 192), (5, 512)])
+def test_line_search_tail_ragged_batch_and_largest_node_capacity(blobs, oracle, B, max_nodes):
+    """The device-side line-search tail and the fused policy on the shapes the benchmark does not exercise: a batch that is no multiple of the 64-row blocks the
+    thread-per-(node, instance) kernels move together (97), and the largest node capacity (512: the tail's workgroup then carves 88 KB of LDS), on C5 (N = 150, schedule
+    switching, arm near its limits) with a tightened filter and arms started off their references (some far outside the joint limits) so that part of the batch backtracks.  Bit-identical to the host-driven loop + policy kernel, every
+    status valid, and the accepted step lengths and the control step's torques equal the oracle's on a sample."""
+    from qm_control_amd import api, scenarios
+    import pyoracle
+    st = blobs[1].copy(); st[L.ST_G_MAX] = 1e-9; st[L.ST_DELTA_TOL] = 1e-12
+    cfg = scenarios.make_config("C5", batch=B)
+    cfg["x0"][::3, 24:30] += 0.3; cfg["x0"][1::7, 24:30] += 3.3; cfg["x0"][2::5, 12:24] += 0.5      # arms / legs off their references (some arms far outside the joint limits): part of the batch refuses the full step
+
+    def run(tail, fused):
+        itf = api.QMInterface(blobs=(blobs[0], st), max_batch=B, max_nodes=max_nodes, max_ref_knots=2, max_events=cfg["ev"].shape[1])
+        itf.debug_set("ls_device_tail", tail); itf.debug_set("fused_policy", fused)
+        mpc = api.SqpMpc(itf); wbc = api.HierarchicalWbc(itf)
+        mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"]); wbc.reset()
+        mpc.control_step_resident(cfg["horizon"], cfg["period"], cfg["time"])
+        res = mpc.download(); out, qps = wbc.download(B); itf.close()
+        return res, out, qps
+
+    (r1, o1, q1), (r0, o0, q0) = run(1, 1), run(0, 0)
+    assert r1["ls_trials"] == r0["ls_trials"] and r1["ls_trials"] >= 2, (r1["ls_trials"], r0["ls_trials"])
+    for key in ("x", "u", "status", "t", "num_nodes"): assert np.array_equal(r1[key], r0[key]), key
+    assert np.array_equal(r1["perf"][:, 8], r0["perf"][:, 8]) and np.array_equal(o1, o0) and np.array_equal(q1, q0)
+    assert (r1["status"] >= 0).all() and (r1["perf"][:, 8] < 1.0).any() and (r1["perf"][:, 8] == 1.0).any()      # a mixed batch (the WBC of a robot whose arm is 3.3 rad off may report an iteration limit: not asserted)
+    o = pyoracle.Oracle(pyoracle.load_blobs()[0], st)
+    for b in (0, B // 2, B - 1):
+        o.set_schedule(cfg["ev"][b], cfg["modes"][b]); o.set_target(cfg["ref_t"][b], cfg["ref_x"][b])
+        r = o.mpc_step(float(cfg["t0"][b]), float(cfg["t0"][b]) + cfg["horizon"], cfg["x0"][b]); n = len(r["t"])
+        assert r1["perf"][b, 8] == r["alpha"] and r1["num_nodes"][b] == n, (b, r1["perf"][b, 8], r["alpha"])
+        assert_blocks(r1["x"][b, :n], r["x"], "x", TOL, b); assert_blocks(r1["u"][b, :n], r["u"], "u", TOL, b)
+
+
 def test_update_references_keeps_the_warm_start(blobs, oracle):
     """what the MPC_BASE adaptor does on every call after the first (adaptors/QmhipMpc.h): new targets / schedule from preSolverRun, new observation,
     warm-started iteration from the PREVIOUS primal solution — qmhip_mpc_update_references must not drop it (qmhip_mpc_upload would)"""
