@@ -631,6 +631,8 @@ int qmhip_debug_get(const qmhip_ctx* c, const char* key, int* value) { QM_GUARD(
   if (!strcmp(key, "riccati_skip")) { *value = c->mpc.riccati_skip; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { *value = c->wbc.wbc_stop; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { *value = c->mpc.lq_prof; return QMHIP_OK; }
   if (!strcmp(key, "lq_debug")) { *value = c->mpc.d.lqdbg ? 1 : 0; return QMHIP_OK; }
   if (!strcmp(key, "lds_pad")) { *value = (int)c->bk.lds_pad.size(); return QMHIP_OK; }      // number of kernel groups running with padded LDS
+  if (!strcmp(key, "ls_device_tail")) { *value = c->mpc.device_tail ? 1 : 0; return QMHIP_OK; } if (!strcmp(key, "fused_policy")) { *value = c->fused_policy ? 1 : 0; return QMHIP_OK; }      // launch-order switches (A/B, tests): 1 is the product's order
+  if (!strcmp(key, "wbc_defer")) { *value = c->wbc_defer; return QMHIP_OK; } if (!strcmp(key, "filler_at_lq")) { *value = c->filler_at_lq; return QMHIP_OK; }
   return QMHIP_ERR_ARG;
 }
 int qmhip_debug_read(qmhip_ctx* c, const char* name, void* dst, size_t bytes) { QM_GUARD(c);
