@@ -72,7 +72,9 @@ struct QmMpcPipeline {
   int lq_prof = 0;        // profiling only
   int solver = 0;         // 0: multiple-shooting SQP (the reference's SqpMpc), 1: discrete iLQR, 2: the SQP path run on the `ipm` block's parameters (not an interior-point method), 3: interior-point method with hard cones / boxes (k_ipm.h)
                           // (no hard inequality rows in this OCP: include/qmhip_layout.h, ST_IPM_*); settings slot ST_SOLVER
-  bool r_blocks = false;           // the input weight R of the settings blob is block diagonal (k_ls.h): the structured instance of the trial-evaluation kernel runs; kept current by note_settings()
+  bool r_blocks = false;           // the input weight R of the settings blob is block diagonal (k_ls.h): the structured instance of the trial-evaluation kernel and the structured R0 (u − u_nom) of K1b run; kept current by note_settings()
+  bool r_force_dense = false;      // tests / A-B only (qmhip_debug_set "r_dense"): the dense instances run although R is block diagonal — same bits, by construction
+  bool rblk() const { return r_blocks && !r_force_dense; }
   bool speculative_apply = true;   // tests only: false = the first trial's apply waits for the host's decision like every later one (A/B of the invariant below)
   int lq_slices = 1;      // K1a / K1b run the horizon in this many node slices (1: one launch each)
   bool ipm_fresh = true;  // interior-point solver: the next iteration is the first of its solve (K0 ran): slack / dual / barrier parameter are initialised at the initial iterate
@@ -182,7 +184,7 @@ struct QmMpcPipeline {
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof; q.ncap = ncap;
-    q.ipm_s = d.ipm_s; q.ipm_l = d.ipm_l; q.ipm_info = d.ipm_info;
+    q.ipm_s = d.ipm_s; q.ipm_l = d.ipm_l; q.ipm_info = d.ipm_info; q.rb = rblk() ? 1 : 0;
     q.i0 = 0;
     const int nsl = (ipm || d.lqdbg || lq_prof || lq_slices < 1) ? 1 : (lq_slices > ncap ? ncap : lq_slices);
     if (nsl > 1) {
@@ -217,10 +219,10 @@ struct QmMpcPipeline {
       // instance that is still searching finishes its own search and writes its own primal solution (k_ls.h).  Nothing here waits for the device.
       l.trial = 0; l.max_trials = max_trials;
       if (p0_enable && last && p0_x) { l.p0_x = p0_x; l.p0_u = p0_u; l.p0_mode = p0_mode; p0_done = true; bk.wbc_inputs_next(); }      // (the previous step's WBC has read its inputs before they are rewritten)
-      if (r_blocks) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l); else bk.launch(qm_ls_eval_dense_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
+      if (rblk()) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l); else bk.launch(qm_ls_eval_dense_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }
       if (max_trials > 1) { QmLsArgs lt = l; lt.trial = 1;
-        if (r_blocks) bk.launch(qm_ls_tail_kernel, B, LS_TAIL_BLOCK, LS_TAIL_LDS_BYTES(d.nmax), lt); else bk.launch(qm_ls_tail_dense_kernel, B, LS_TAIL_BLOCK, LS_TAIL_LDS_BYTES(d.nmax), lt); }
+        if (rblk()) bk.launch(qm_ls_tail_kernel, B, LS_TAIL_BLOCK, LS_TAIL_LDS_BYTES(d.nmax), lt); else bk.launch(qm_ls_tail_dense_kernel, B, LS_TAIL_BLOCK, LS_TAIL_LDS_BYTES(d.nmax), lt); }
       ls_trials_pending = true; ls_trials_cap = max_trials;
       // the batch's apply reads the FINAL done / alpha of every instance.  A control step launches it behind its WBC (defer_apply): only the policy at t0 — written above by
       // the deciding kernels — is on the WBC's way, the primal solution on all nodes is not
@@ -233,7 +235,7 @@ struct QmMpcPipeline {
       l.trial = t;
       if (ilqr) { ro.mode = 1; ro.trial = t; bk.launch(qm_ilqr_rollout_kernel, B, 64, 0, ro); }      // nonlinear rollout with feedback at the instance's step length
       if (ipm) bk.launch(qm_ls_eval_ipm_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
-      else if (r_blocks) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
+      else if (rblk()) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       else bk.launch(qm_ls_eval_dense_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
       d.host_open[t] = -1;                                 // armed: the launch's last block overwrites it with the count of the instances still searching
       { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }   // trial merit + filter decision + count of the instances still searching

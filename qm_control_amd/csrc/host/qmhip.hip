@@ -563,6 +563,7 @@ int qmhip_reset_kernel_ms(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_
 int qmhip_synchronize(qmhip_ctx* c) { QM_GUARD(c); if (!c) return QMHIP_ERR_ARG; hipSetDevice(c->device); c->flush_wbc(); c->bk.sync(); return c->hipstate(); }
 int qmhip_last_ls_trials(const qmhip_ctx* c) { QM_GUARD(c); if (!c) return -1; hipSetDevice(c->device); return const_cast<qmhip_ctx*>(c)->mpc.ls_trials(); }      // (after a device-side line search: one synchronising read of the trial counters)
 int qmhip_debug_set(qmhip_ctx* c, const char* key, int value) { QM_GUARD(c); if (!c || !key) return QMHIP_ERR_ARG; if (!strcmp(key, "lq_slices")) { c->mpc.lq_slices = value < 1 ? 1 : value; return QMHIP_OK; } if (!strcmp(key, "riccati_skip")) { c->mpc.riccati_skip = value; return QMHIP_OK; } if (!strcmp(key, "wbc_stop")) { c->wbc.wbc_stop = value; return QMHIP_OK; } if (!strcmp(key, "lq_prof")) { c->mpc.lq_prof = value; return QMHIP_OK; }
+  if (!strcmp(key, "r_dense")) { c->mpc.r_force_dense = value != 0; return QMHIP_OK; }      // 1: the dense instances of the trial evaluation and of K1b's R0 (u − u_nom) although R is block diagonal (tests: same bits)
   if (!strcmp(key, "fused_policy")) { c->fused_policy = value != 0; return QMHIP_OK; }      // 0: apply -> qm_policy_kernel -> WBC as in rounds 1-5 (A/B, tests)
   if (!strcmp(key, "filler_at_lq")) { c->filler_at_lq = value; return QMHIP_OK; }
   if (!strcmp(key, "filler_live")) { c->filler_live = value; return QMHIP_OK; } if (!strcmp(key, "filler_lds")) { if (value < 16 * 1024 || value > 48 * 1024) return QMHIP_ERR_ARG; c->filler_lds = value; return QMHIP_OK; }      // co-residency stand-in: 0 / 160 / 184 live doubles, LDS bytes (>= 16 KB: the kernel indexes 2048 doubles)
@@ -632,6 +633,7 @@ int qmhip_debug_get(const qmhip_ctx* c, const char* key, int* value) { QM_GUARD(
   if (!strcmp(key, "lq_debug")) { *value = c->mpc.d.lqdbg ? 1 : 0; return QMHIP_OK; }
   if (!strcmp(key, "lds_pad")) { *value = (int)c->bk.lds_pad.size(); return QMHIP_OK; }      // number of kernel groups running with padded LDS
   if (!strcmp(key, "ls_device_tail")) { *value = c->mpc.device_tail ? 1 : 0; return QMHIP_OK; } if (!strcmp(key, "fused_policy")) { *value = c->fused_policy ? 1 : 0; return QMHIP_OK; }      // launch-order switches (A/B, tests): 1 is the product's order
+  if (!strcmp(key, "r_dense")) { *value = c->mpc.r_force_dense ? 1 : 0; return QMHIP_OK; } if (!strcmp(key, "r_blocks")) { *value = c->mpc.rblk() ? 1 : 0; return QMHIP_OK; }      // r_blocks: the structured instances are the ones that run
   if (!strcmp(key, "wbc_defer")) { *value = c->wbc_defer; return QMHIP_OK; } if (!strcmp(key, "filler_at_lq")) { *value = c->filler_at_lq; return QMHIP_OK; }
   return QMHIP_ERR_ARG;
 }

@@ -26,6 +26,9 @@
 // The terminal node only carries the final EE soft constraint (QMInterface.cpp:104).
 #pragma once
 #include "qm_dev_kin.h"
+#ifndef QM_LQ_RB_ONLY
+#define QM_LQ_RB_ONLY 0      /* instruction counting only (tools/isa_hist.py): 1 compiles K1b without the dense R0 path, i.e. the instruction stream a wave executes with the shipped task file */
+#endif
 
 struct QmLqArgs {
   const double* mb; const double* st;
@@ -50,6 +53,7 @@ struct QmLqArgs {
   int i0;                    // first node of the launch (node slices: K1a and K1b take the horizon in [i0, i0 + ncap) pieces so that a piece's kin records are consumed while they are still cached)
   // interior-point instances only (k_ipm.h): slack / dual of the node's QM_NH inequality rows [nmax][B][QM_NH], barrier parameter per instance info[b * 8]
   const double* ipm_s; const double* ipm_l; const double* ipm_info;
+  int rb;                    // K1b: the input weight R0 of the settings table is block diagonal (diag(12) + four 3 x 3 leg blocks + diag(6): qm_r_is_block_diagonal, k_ls.h — the host checks the table entry by entry)
 };
 
 // debug record (unprojected LQ): A(900) B(900) b(30) Q(900) R(900) q(30) r(30) C(16x30) D(16x30) e(16) c nc
@@ -110,7 +114,9 @@ static_assert(LQ_LDS_BYTES <= 16384, "ten waves per CU (160 KB of LDS) need at m
 #define LQ_KIN_TILE (64 * 31)               /* K1a: [64][31] rows — the wave's inputs x (transposed on the way in), then the input u of each thread for the whole kernel ... */
 #define LQ_KIN_LDS_BYTES ((LQ_KIN_TILE + 64 * 9) * 8)      /* ... + the [64][9] hand-over tile of the record stores: 20 KB per wave, seven waves per CU (the benchmark launch has 6.45 per CU) */
 
-// value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column
+// value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column.  (Lane-conditional reads on purpose: an unconditional read by all 64 lanes +
+// a select — which saves the three scalar instructions of the execution-mask region — measured SLOWER, profiles/r06_ab_lq_regions.log: the scalar unit is idle in this kernel, the
+// LDS pipe is not)
 __device__ __forceinline__ void lw_set_col30(qm_d4 (&F)[2][2], const double* v) {
   const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
 #pragma unroll
@@ -118,15 +124,34 @@ __device__ __forceinline__ void lw_set_col30(qm_d4 (&F)[2][2], const double* v) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14) F[I][1][r] = (row < 30) ? v[row] : 0.0; }
 }
-template <int IT>
+// column 30 of a fragment column -> v[row], rows < rows.  ONE lane-conditional region for all registers: RMIN <= rows <= RMAX are compile-time bounds of `rows`, a register
+// whose rows all lie below RMIN is stored without a test, one whose rows all lie at or above RMAX is not stored at all
+template <int IT, int RMIN, int RMAX>
 __device__ __forceinline__ void lw_get_col30(const qm_d4 (&F)[IT][2], double* v, int rows) {
   const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
+  if (c == 14) {
 #pragma unroll
-  for (int I = 0; I < IT; ++I)
+    for (int I = 0; I < IT; ++I)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14 && row < rows) v[row] = F[I][1][r]; }
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + g + 4 * r;
+        if (16 * I + 4 * r + 3 < RMIN) v[row] = F[I][1][r];
+        else if (16 * I + 4 * r < RMAX) { if (row < rows) v[row] = F[I][1][r]; }
+      }
+  }
 }
 
+// zero fill of N doubles of LDS (N even, 16-byte aligned) with UNROLLED 16-byte stores at immediate offsets: a rolled `for (idx = l; idx < N; idx += 64)` loop of 8-byte
+// stores spends six instructions per store on its counter, compare and branch (K1b cleared its tile twice and its vector area once per node that way: ≈ 250 of a wave's
+// ≈ 5000 dynamic instructions)
+template <int N>
+__device__ __forceinline__ void lw_zero(double* base, int l) {
+  static_assert(N % 2 == 0, "pairs of doubles");
+  double2* b2 = (double2*)base;
+#pragma unroll
+  for (int t = 0; t < (N / 2) / 64; ++t) b2[l + 64 * t] = double2{0.0, 0.0};
+  if ((N / 2) % 64 != 0) { if (l < (N / 2) % 64) b2[l + 64 * ((N / 2) / 64)] = double2{0.0, 0.0}; }
+}
 // projected cost + record stores; MT = tiles covering the m reduced inputs
 // Bp = Bd Pu (rows 0..11 of the record; a joint row is dt Pu[j], K3 rebuilds it): Bp[row][j] = Σ_k w_k(j) Bdᵀ[i0(j) + k][row] — the tile holds Bdᵀ (rows = inputs).
 // Formed right behind the projected dynamics, so that the discrete-time Jacobians are dead before the cost model is assembled (three waves per SIMD: 168 registers)
@@ -192,13 +217,13 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_p
     qm_gemm_tn<2, 2, 1>(Rm, Y1, P1, 0, 3, false);
 #pragma unroll
     for (int I = 0; I < 2; ++I) RPx[I][1] = P1[I][0]; }
-  { const int g = l >> 4, c = l & 15;
+  { const int g = l >> 4, c = l & 15; const double m14 = (c == 14) ? 1.0 : 0.0;      // (slots 30, 31 of r are zero: every lane reads its rows, column 14 adds them — no execution-mask region per register)
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r; if (c == 14 && row < 30) RPx[I][1][r] += S[LW_V_RV + row]; } }
+      for (int r = 0; r < 4; ++r) RPx[I][1][r] = fma(m14, S[LW_V_RV + 16 * I + g + 4 * r], RPx[I][1][r]); }
   qm_wave_sync();
-  lw_get_col30<2>(RPx, S + LW_V_RR, 30);
+  lw_get_col30<2, 30, 30>(RPx, S + LW_V_RR, 30);
   qm_wave_sync();
   rpe = qm_wave_sum((l < 30) ? (S[LW_V_RV + l] + 0.5 * (S[LW_V_RR + l] - S[LW_V_RV + l])) * S[LW_V_PE + l] : 0.0);
   // [Qp | qp] = [Q | q] + Pxᵀ [R Px | rr]
@@ -213,7 +238,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_p
 #pragma unroll
         for (int r = 0; r < 4; ++r) QM_STREAM_ST(frag + SR_F_QP + (4 * (I + J) + r) * 64, Qa[I][J][r]); }
   qm_wave_sync();
-  lw_get_col30<2>(Qa, S + LW_V_QV, 30);
+  lw_get_col30<2, 30, 30>(Qa, S + LW_V_QV, 30);
   // [Pp | rp] = Puᵀ [R Px | rr]: Pp[j][col] = Σ_k w_k(j) [R Px | rr][i0(j) + k][col]
   qm_wave_sync(); tile_put(RPx); qm_wave_sync();
   { qm_d4 Pp[MT][2];
@@ -230,7 +255,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_p
       for (int r = 0; r < 4; ++r) QM_STREAM_ST(frag + SR_F_PP + (4 * J + r) * 64, (g + 4 * r < m) ? Pp[0][J][r] : 0.0);
       if (MT == 2) QM_STREAM_ST(frag + SR_F_PP1 + J * 64, (16 + g < m) ? Pp[MT - 1][J][0] : 0.0);
     }
-    lw_get_col30<MT>(Pp, S + LW_V_RV, m); }
+    lw_get_col30<MT, 14, 18>(Pp, S + LW_V_RV, m); }
   // Rp = Puᵀ (R Pu): first R Pu[i][j] = Σ_k w_k(j) R[i][i0(j) + k], then the rows of that by the same descriptors
   qm_wave_sync(); tile_put(Rm); qm_wave_sync();
   load_col_desc();
@@ -366,14 +391,22 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   const int nn = a.n_nodes[b]; const int ev = a.node_ev[nb];
   const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
   const int nxt = (i + 1 < a.nmax) ? ((i + 1) * a.B + b) : nb;
-  double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_ee = 0.0, in_k[4], in_k2[4], in_xref = 0.0, in_qd = 0.0;
+  double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_ee = 0.0, in_xref = 0.0, in_qd = 0.0;
+  // the two kinematics workspaces of the kin record come in as PAIRS of doubles (16-byte global loads, 16-byte LDS stores: half the instructions of both kinds)
+  static_assert(KR_K1 % 2 == 0 && KR_K2 % 2 == 0 && KR_SIZE % 2 == 0 && KW_SIZE % 2 == 0 && LW_K1 % 2 == 0 && KW_SIZE / 2 <= 128, "kin workspaces: 16-byte aligned, two pairs per lane");
+  double2 in_k[2], in_k2[2];
   if (l < 30) { in_xref = a.xref[nb * 30 + l]; in_qd = st[ST_Q + l]; in_x = a.x[nb * 30 + l]; in_u = a.u[nb * 30 + l]; xn = a.x[nxt * 30 + l]; }
   if (l < 30) { const int lf = (l < 12) ? l : 0; f1 = kr[KR_F1 + lf]; f2 = kr[KR_F2 + lf]; }      // rows 0..11; rows 12..29 of the flow map are the input's joint velocities (selected below)
   if (l >= 32 && l < 39) in_ee = a.eeref[nb * 7 + (l - 32)];
   if (l >= 40 && l < 46) in_ee = kr[KR_EEG + (l - 40)];
   if (l >= 48 && l < 52) in_ee = kr[KR_QEE + (l - 48)];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { const int idx = l + 64 * t; in_k[t] = (idx < KW_SIZE) ? kr[KR_K1 + idx] : 0.0; in_k2[t] = (idx < KW_ARM) ? kr[KR_K2 + idx] : 0.0; }
+  for (int t = 0; t < 2; ++t) {
+    const int p = l + 64 * t;                                          // doubles 2 p, 2 p + 1
+    in_k[t] = (p < KW_SIZE / 2) ? ((const double2*)(kr + KR_K1))[p] : double2{0.0, 0.0};
+    in_k2[t] = (2 * p < KW_ARM) ? ((const double2*)(kr + KR_K2))[p] : double2{0.0, 0.0};      // (the stage-2 workspace ends in front of the arm block, at an odd index: the pair's second half is dropped below)
+    if (2 * p + 1 >= KW_ARM) in_k2[t].y = 0.0;
+  }
   if (i >= nn) return;
   const bool terminal = (i == nn - 1);
   if (!terminal && ev == QM_EV_PRE) {                 // event nodes carry no LQ data (identity jump, handled by K3): only clear their merit terms
@@ -388,7 +421,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   LQT()
   // ---- P0: inputs and the kin record -> LDS ----
   double* T = S + LW_T; double* X = S + LW_V_X; double* U = S + LW_V_U; double* K1 = S + LW_K1; double* K2 = S + LW_K2; double* EE = S + LW_V_EE;
-  for (int idx = l; idx < LW_K1 - LW_V; idx += 64) S[LW_V + idx] = 0.0;
+  static_assert(LW_V % 2 == 0 && (LW_K1 - LW_V) % 2 == 0 && (32 * LW_TLD) % 2 == 0, "16-byte zero fills");
+  lw_zero<LW_K1 - LW_V>(S + LW_V, l);
   qm_wave_sync();
   if (terminal) { in_u = 0.0; xn = 0.0; f1 = 0.0; f2 = 0.0; }
   if (l < 30) { X[l] = in_x; U[l] = in_u; }
@@ -396,7 +430,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   if (l >= 40 && l < 46) EE[l - 40] = in_ee;
   if (l >= 48 && l < 52) EE[12 + (l - 48)] = in_ee;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { const int idx = l + 64 * t; if (idx < KW_SIZE) { K1[idx] = in_k[t]; K2[idx] = terminal ? 0.0 : in_k2[t]; } }
+  for (int t = 0; t < 2; ++t) { const int p = l + 64 * t; if (p < KW_SIZE / 2) { ((double2*)K1)[p] = in_k[t]; ((double2*)K2)[p] = terminal ? double2{0.0, 0.0} : in_k2[t]; } }
   qm_wave_sync();
 
   if (terminal) {
@@ -426,7 +460,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   // ---- phase II: equality rows + closed-form block projection ----
   // rows ordered per contact i = LF,RF,LH,RH: swing -> [F_i = 0 (3)] , stance -> [v_i = 0 (3)] , swing -> [v_iz = zvel_ref (1)]
   // tile rows 0..15 = C (state part), rows 16..31 = D (input part)
-  for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
+  lw_zero<32 * LW_TLD>(T, l);
   qm_wave_sync();
   int row0[4]; int nc = 0; for (int k = 0; k < 4; ++k) { row0[k] = nc; nc += mode_flag(mode, k) ? 3 : 4; }
   const double gain = st[ST_POS_ERR_GAIN];
@@ -496,7 +530,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) if (q < k) r0k += mode_flag(mode, q) ? 3 : 4;
     const bool stance = mode_flag(mode, k);
-    const double c0 = stance ? gg[3 * jj] : gg[jj], c1 = stance ? gg[3 * jj + 1] : 0.0, c2 = stance ? gg[3 * jj + 2] : 0.0;
+    double c0 = gg[stance ? 3 * jj : jj], c1 = gg[3 * jj + 1], c2 = gg[3 * jj + 2]; QM_LOADED(c0); QM_LOADED(c1); QM_LOADED(c2);      // (all three slots exist for either leg state)
+    c1 = stance ? c1 : 0.0; c2 = stance ? c2 : 0.0;
     const int i0 = stance ? r0k : r0k + 3, i1 = stance ? r0k + 1 : r0k + 3, i2 = stance ? r0k + 2 : r0k + 3;
     o0 = -(c0 * Ct[i0 * LW_TLD + c] + c1 * Ct[i1 * LW_TLD + c] + c2 * Ct[i2 * LW_TLD + c]);
     o1 = -(c0 * Ct[i0 * LW_TLD + 16 + c] + c1 * Ct[i1 * LW_TLD + 16 + c] + c2 * Ct[i2 * LW_TLD + 16 + c]);      // column 31 of [C | e] is zero
@@ -510,7 +545,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     for (int r = 0; r < 3; ++r) { const int row = g + 4 * r; PxA[0][1][r] = mode_flag(mode, row / 3) ? 0.0 : -U[row]; }
   }
   qm_wave_sync();
-  lw_get_col30<2>(PxA, S + LW_V_PE, 30);
+  lw_get_col30<2, 30, 30>(PxA, S + LW_V_PE, 30);
   PxA[0][1][0] = 0.0; PxA[0][1][1] = 0.0; PxA[0][1][2] = 0.0;      // Pe rows 0..11 now live in LW_V_PE only: re-read where they are used (six registers less across the Jacobians)
   const double eq2 = qm_wave_sum((l < nc) ? S[LW_V_E + l] * S[LW_V_E + l] : 0.0);
   const double b2 = qm_wave_sum(bl * bl);
@@ -560,12 +595,12 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     // one (column, Heun stage) task per lane for the four non-trivial column classes of the flow Jacobian — a wave executes each
     // divergent class body once: lanes 0-5 dθ-rate columns 3..5, 6-11 zyx columns 9..11, 12-35 leg joints 12..23, 36-59 forces 30..41
     int fc = 0, fs = l & 1;
-    if (l < 6) fc = 3 + (l >> 1); else if (l < 12) fc = 9 + ((l - 6) >> 1); else if (l < 36) fc = 12 + ((l - 12) >> 1); else fc = 30 + ((l - 36) >> 1);
+    fc = (l < 6) ? 3 + (l >> 1) : ((l < 12) ? 9 + ((l - 6) >> 1) : ((l < 36) ? 12 + ((l - 12) >> 1) : 30 + ((l - 36) >> 1)));
     double colf[12];
     int kofs = fs ? (int)(K2 - K1) : 0; QM_LANE_OPAQUE(kofs);                  // the lane's stage: one base, immediate offsets
     flow_jac_col(mb, X, U, K1 + kofs, fc, colf);
     const int cc = (fc < 30) ? fc : fc - 30, r0 = (fc < 30) ? 0 : 16;
-    for (int idx = l; idx < 32 * LW_TLD; idx += 64) T[idx] = 0.0;
+    lw_zero<32 * LW_TLD>(T, l);
     qm_wave_sync();
     if (l < 60 && fs == 0) { for (int r = 0; r < 12; ++r) T[(r0 + r) * LW_TLD + cc] = colf[r]; }
     if (l < 3) T[(6 + l) * LW_TLD + l] = 1.0;                                   // d rdot / d h_lin (both stages)
@@ -660,7 +695,19 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);      // input cost weights (L2 / scalar-cache resident table)
   if (l >= 32 && l < 38) EE[6 + (l - 32)] = ((l - 32) < 3 ? st[ST_MU_EE_POS] : st[ST_MU_EE_ORI]);
   qm_wave_sync();
-  { // r = R0 (u − unom): a mat-vec on the register fragments — two partial products per lane and register, then a 16-lane DPP row sum
+  if (QM_LQ_RB_ONLY || a.rb) {
+    // r = R0 (u − unom) with the block-diagonal R0 of the shipped task file (wave-uniform test): a row has at most three non-zero entries, lane = row.  Bit-identical to the
+    // dense product below: there every lane holds ONE exactly rounded product (the other tile's entry of its column is an exact zero) and the row_shr tree (steps 1, 2, 4, 8)
+    // adds the three of a leg block as  p2 + (p1 + p0)  for the columns 12-14 (lanes 12, 13, 14) and 18-20 (lanes 2, 3, 4 of the second tile) resp.  (p2 + p1) + p0  for
+    // 15-17 (lane 15 of the first tile | lanes 0, 1 of the second: the pair meets first) and 21-23 (lanes 5, 6, 7: 6 and 7 meet first); adding the exact zeros of the other
+    // lanes changes nothing.  A diagonal row reads two exact zeros beside its entry (columns clamped to 27..29 for the last rows).
+#pragma clang fp contract(off)
+    if (l < 30) {
+      const bool blk = l >= 12 && l < 24; const int lb = l / 3, b0 = blk ? 3 * lb : (l < 27 ? l : 27);
+      const double p0 = st[ST_R + 30 * l + b0] * S[LW_V_DU + b0], p1 = st[ST_R + 30 * l + b0 + 1] * S[LW_V_DU + b0 + 1], p2 = st[ST_R + 30 * l + b0 + 2] * S[LW_V_DU + b0 + 2];
+      S[LW_V_RV + l] = (lb & 1) ? (p2 + p1) + p0 : p2 + (p1 + p0);          // leg blocks: lb = 4 .. 7
+    }
+  } else { // r = R0 (u − unom): a mat-vec on the register fragments — two partial products per lane and register, then a 16-lane DPP row sum
     // (as an MFMA it would spend 16 issues of 64 cycles on a single useful column; f64 MFMA and f64 VALU run at the same rate on gfx950)
     const double d0 = S[LW_V_DU + c], d1 = S[LW_V_DU + 16 + c];
 #pragma unroll

@@ -34,6 +34,8 @@ void* emu_create(const double* mb, const double* st, int Bmax, int nmax, int nre
 void emu_set_solver(void* h, int solver) { ((EmuCtx*)h)->mpc.solver = solver; }      // 0 SQP, 1 discrete iLQR (qmhip_set_setting(ST_SOLVER, .))
 // 0: run the PRODUCT instance of the LQ kernel (qm_lq_kernel: no debug records, no cycle stamps); 1 (default): qm_lq_dbg_kernel.  qmhip_debug_set("lq_debug", .)
 void emu_set_lq_debug(void* h, int on) { EmuCtx* c = (EmuCtx*)h; if (!c->lqdbg_stash) c->lqdbg_stash = c->mpc.d.lqdbg; c->mpc.d.lqdbg = on ? c->lqdbg_stash : nullptr; }
+void emu_set_r_dense(void* h, int on) { ((EmuCtx*)h)->mpc.r_force_dense = on != 0; }      // qmhip_debug_set("r_dense", .)
+int emu_r_blocks(void* h) { return ((EmuCtx*)h)->mpc.rblk() ? 1 : 0; }
 void emu_set_riccati_skip(void* h, int mask) { ((EmuCtx*)h)->mpc.riccati_skip = mask; }      // qmhip_debug_set("riccati_skip", .): 20 leaves K1b's stage records untouched
 void emu_destroy(void* h) { EmuCtx* c = (EmuCtx*)h; if (c->lqdbg_stash) c->mpc.d.lqdbg = c->lqdbg_stash; c->mpc.release(); c->wbc.release(); c->front.release(); c->sim.release(); delete c; }
 int emu_mpc_step(void* h, int B, const double* t0, const double* x0, const double* ref_t, const double* ref_x, const double* ev, const int* modes, double horizon, int max_trials) {

@@ -62,6 +62,13 @@ class Emu:
         """False: the PRODUCT instance of the LQ kernel runs (qm_lq_kernel: no debug records); True (default): qm_lq_dbg_kernel"""
         self.lib.emu_set_lq_debug(self.h, C.c_int(int(bool(on))))
 
+    def set_r_dense(self, on):
+        """True: the dense instances of the trial-evaluation kernel and of K1b's R0 (u - u_nom) run although the input weight is block diagonal (qmhip_debug_set "r_dense")"""
+        self.lib.emu_set_r_dense(self.h, C.c_int(int(bool(on))))
+
+    def r_blocks(self):
+        return bool(self.lib.emu_r_blocks(self.h))
+
     def set_riccati_skip(self, mask):
         """profiling / parity switch of the product (qmhip_debug_set "riccati_skip"): 16 | 4 = no backward stage, no rollout -> the stage records stay as K1b wrote them"""
         self.lib.emu_set_riccati_skip(self.h, C.c_int(mask))

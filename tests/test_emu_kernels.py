@@ -300,3 +300,52 @@ def test_product_instances_match_the_instrumented_ones(blobs, oracle, name, N):
         assert np.array_equal(outs[1][0][i][keep], outs[0][0][i][keep]), (i, np.nonzero(outs[1][0][i][keep] != outs[0][0][i][keep])[0][:10])
     assert np.array_equal(outs[1][1], outs[0][1]) and np.array_equal(outs[1][2], outs[0][2]) and np.array_equal(outs[1][3], outs[0][3])
     assert_blocks(outs[1][1], r["x"], "x", TOL); assert_blocks(outs[1][2], r["u"], "u", TOL)
+
+
+@pytest.mark.parametrize("name,N", [("C2", 26), ("gait:dynamic_walk", 30), ("C5", 40)])
+def test_structured_input_weight_paths_equal_the_dense_ones(blobs, name, N):
+    """The shipped input weight R is block diagonal (diag(12) + four 3 x 3 leg blocks + diag(6): QMInterface.cpp:274-299).  The host detects that entry by entry and K1b forms
+    r = R0 (u - u_nom) with at most three terms per row (k_lq.h), the trial evaluation multiplies 54 instead of 900 entries (k_ls.h).  Both are built to give the SAME BITS as the
+    dense instances (the dense sums only ever add exact zeros to the same terms in the same order): stage records, merit terms and the accepted step, dense forced by the debug switch."""
+    import emu_harness, lq_record_check as LC
+    from qm_control_amd import scenarios
+    cfg = scenarios.gait_config(name[5:], batch=1, n_intervals=N, seed=3) if name.startswith("gait:") else scenarios.make_config(name, batch=1, n_intervals=N)
+    outs = []
+    for dense in (False, True):
+        e = emu_harness.Emu(blobs[0], blobs[1], 1, N + 12, 2, cfg["ev"].shape[1]); e.set_lq_debug(False); e.set_r_dense(dense)
+        assert e.r_blocks() == (not dense)
+        e.mpc_step(cfg); e.mpc_iterate()      # the SECOND iteration is the one that counts: a cold start has u = u_nom exactly, R0 (u - u_nom) = 0 whatever the order of the sum
+        n = int(e.buf("n_nodes", (1,), np.int32)[0])
+        assert np.abs(e.node_arr("u", 30)[:n - 1, 0, 12:24]).max() > 1e-3
+        outs.append((np.stack([e.stage(0, i) for i in range(n)]), e.node_arr("xs", 30)[:n, 0].copy(), e.node_arr("us", 30)[:n, 0].copy(), e.buf("out_perf", (10,)).copy(), e.node_arr("node_ev", 1, np.int32)[:n, 0].copy()))
+    ev = outs[0][4]
+    for i in range(len(ev) - 1):
+        if ev[i] == 1:
+            continue
+        assert np.array_equal(outs[0][0][i], outs[1][0][i]), (i, np.nonzero(outs[0][0][i] != outs[1][0][i])[0][:10])
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+
+
+def test_dense_input_weight_runs_the_dense_instances(blobs, oblobs):
+    """An input weight with entries OUTSIDE the shipped block pattern (a coupling between a contact force and an arm joint velocity, and between two legs' joint velocities):
+    the host's check fails, the dense instances of K1b's mat-vec and of the trial evaluation run, and the step still equals the oracle's on the same settings."""
+    import emu_harness, pyoracle
+    from qm_control_amd import scenarios
+    st = np.array(blobs[1], float); ost = np.array(oblobs[1], float)
+    for s_ in (st, ost):
+        R = s_[L.ST_R:L.ST_R + 900].reshape(30, 30)
+        R[2, 25] = R[25, 2] = 1e-4 * np.sqrt(R[2, 2] * R[25, 25]); R[13, 19] = R[19, 13] = 0.05 * np.sqrt(R[13, 13] * R[19, 19])
+    cfg = scenarios.make_config("C2", batch=1, n_intervals=26)
+    o = pyoracle.Oracle(oblobs[0], ost)
+    o.set_schedule(cfg["ev"][0], cfg["modes"][0]); o.set_target(cfg["ref_t"][0], cfg["ref_x"][0])
+    r = o.mpc_step(cfg["t0"][0], cfg["t0"][0] + cfg["horizon"], cfg["x0"][0]); n = len(r["t"])
+    e = emu_harness.Emu(blobs[0], st, 1, n + 3, 2, cfg["ev"].shape[1])
+    assert not e.r_blocks()
+    e.mpc_step(cfg)
+    assert e.buf("status", (1,), np.int32)[0] == 0
+    assert_blocks(e.node_arr("xs", 30)[:n, 0], r["x"], "x", TOL); assert_blocks(e.node_arr("us", 30)[:n, 0], r["u"], "u", TOL)
+    perf = e.buf("out_perf", (10,))
+    assert perf[8] == r["alpha"] and rel_err(perf[:8], r["perf"][:8]) < 1e-9
+    # and the coupling is felt: the same problem with the shipped weight has a different first input
+    e2 = emu_harness.Emu(blobs[0], blobs[1], 1, n + 3, 2, cfg["ev"].shape[1]); e2.mpc_step(cfg)
+    assert np.abs(e2.node_arr("us", 30)[0, 0] - e.node_arr("us", 30)[0, 0]).max() > 1e-9

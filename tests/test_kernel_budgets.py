@@ -68,9 +68,11 @@ def test_register_and_scratch_budgets():
 def test_code_size_of_the_large_kernels():
     """A wave of the LQ kernel executes nearly all of its code once (few loops), so its code size IS its instruction count: 30.7 KB / 31.8 KB for the two product instances
     since the lane's choice between the two stages' kinematics arrays is one opaque base (QM_LANE_OPAQUE) — written as `fs ? K2 : K1` the compiler selects between two
-    literal LDS addresses at each of the 66 accesses behind it (+ 1.8 KB, + 1.2 % of the kernel's time, profiles/r05_ab_lane_base.log).  The bounds leave ~ 3 % of room."""
+    literal LDS addresses at each of the 66 accesses behind it (+ 1.8 KB, + 1.2 % of the kernel's time, profiles/r05_ab_lane_base.log).  Round 6: 30.2 / 31.4 KB INCLUDING the dense
+    R0 (u - u_nom) product a wave no longer executes with the shipped (block-diagonal) input weight (≈ 1 KB; `tools/isa_hist.py` counts the executed stream: 4.84 k instructions,
+    round 5: 5.12 k static + ≈ 0.25 k in the rolled zero-fill loops that are now eight unrolled 16-byte stores).  The bounds leave ~ 3 % of room."""
     b = _code_bytes()
-    assert b["qm_lq_kernel"] <= 31700 and b["qm_lq_m18_kernel"] <= 32800, (b["qm_lq_kernel"], b["qm_lq_m18_kernel"])
+    assert b["qm_lq_kernel"] <= 31200 and b["qm_lq_m18_kernel"] <= 32300, (b["qm_lq_kernel"], b["qm_lq_m18_kernel"])
     assert b["qm_riccati_kernel"] <= 45000 and b["qm_wbc_kernel"] <= 185000, (b["qm_riccati_kernel"], b["qm_wbc_kernel"])     # (the WBC exceeds the 64 KB instruction cache by design: DESIGN.md section 7)
 
 

@@ -1,6 +1,7 @@
 """tools/isa_hist.py — static instruction mix of the gfx950 kernels of libqmhip from the compiler's assembly (no GPU needed): per kernel the counts by class
 (FP64 VALU, other VALU, MFMA, SALU, LDS, vector memory) and, with --lines, the source lines that own the most instructions (hipcc -gline-tables-only).
 The dynamic mix (SQ PMC counters, profiles/flops_pmc.json) says how often; this says WHERE.
+K1b is compiled with QM_LQ_RB_ONLY=1: without the dense R0 (u - u_nom) path a wave does not execute with the shipped block-diagonal input weight, i.e. the executed stream.
 usage: python tools/isa_hist.py [--other] [--lines N] [kernel ...]      (default kernels: qm_lq_kernel qm_riccati_kernel qm_wbc_kernel)"""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +24,7 @@ def main(argv):
     kernels = argv or ['qm_lq_kernel', 'qm_riccati_kernel', 'qm_wbc_kernel']
     with tempfile.TemporaryDirectory() as d:
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-Wno-unused-value', '-Wno-unused-result'] + (['-gline-tables-only'] if nlines else []) +
-                              ['-I' + os.path.join(ROOT, 'include'), '--save-temps', '-c', os.path.join(ROOT, 'qm_control_amd', 'csrc', 'host', 'qmhip.hip'), '-o', os.path.join(d, 'q.o')], cwd=d, stderr=subprocess.DEVNULL)
+                              ['-DQM_LQ_RB_ONLY=1', '-I' + os.path.join(ROOT, 'include'), '--save-temps', '-c', os.path.join(ROOT, 'qm_control_amd', 'csrc', 'host', 'qmhip.hip'), '-o', os.path.join(d, 'q.o')], cwd=d, stderr=subprocess.DEVNULL)
         s = open(os.path.join(d, 'qmhip-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
     files = {int(m.group(1)): (m.group(3) or m.group(2)).split('/')[-1] for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', s)}
     for name in kernels:
