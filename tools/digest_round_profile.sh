@@ -16,4 +16,5 @@ if [ -d gpurun_out/pmc_flops_a ]; then
   python tools/flops_pmc_digest.py profiles/${rnd}_pmc_flops_a_${tag}.csv profiles/${rnd}_pmc_flops_b_${tag}.csv "${rnd} ${tag}" 32 profiles/flops_pmc.json
 fi
 if [ -d gpurun_out/pmc_sq ]; then python tools/rocpd_pmc_summary.py "$(newest gpurun_out/pmc_sq)" profiles/${rnd}_pmc_sq_activity_${tag}.csv > /dev/null; fi
+if [ -d gpurun_out/pmc_lds ]; then python tools/rocpd_pmc_summary.py "$(newest gpurun_out/pmc_lds)" profiles/${rnd}_pmc_lds_mix_${tag}.csv > /dev/null; fi
 cp gpurun_out/bench.json profiles/${rnd}_bench_${tag}.json

@@ -23,3 +23,7 @@ ls -R gpurun_out | head -60
 rm -rf gpurun_out/pmc_sq
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --kernel-trace -d gpurun_out/pmc_sq -- $B --steps 3 --warmup 1 > gpurun_out/pmc_sq.log 2>&1
 tail -3 gpurun_out/pmc_sq.log
+# LDS pipe and instruction mix (round 6: K1b turned out to be sensitive to LDS instructions and vector instructions, not to scalar ones — profiles/r06_ab_lq_regions.log)
+rm -rf gpurun_out/pmc_lds
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace -d gpurun_out/pmc_lds -- $B --steps 3 --warmup 1 > gpurun_out/pmc_lds.log 2>&1
+tail -3 gpurun_out/pmc_lds.log
