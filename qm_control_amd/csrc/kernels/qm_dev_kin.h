@@ -323,7 +323,9 @@ __device__ __forceinline__ void foot_vel_jac_col_wave(const double* mb, const do
     const double qd = u[12 + 3 * chain + jj]; const double* aj = L + 3 * jj;
     const double dj[3] = {p[0] - L[9 + 3 * jj], p[1] - L[10 + 3 * jj], p[2] - L[11 + 3 * jj]};
     double t1[3], t2[3], t3[3], t4[3], t0[3];
-    v3_cross(al, aj, t1); v3_cross(t1, dj, t2); v3_cross(al, dj, t3); v3_cross(aj, t3, t4); v3_cross(aj, dp, t0);
+    v3_cross(aj, dp, t0);
+    if (jj == 0) { for (int r = 0; r < 3; ++r) acc[r] += qd * t0[r]; continue; }      // l >= 0: joint 0 is never behind the lane's joint — the four products of the other branch are not formed at all
+    v3_cross(al, aj, t1); v3_cross(t1, dj, t2); v3_cross(al, dj, t3); v3_cross(aj, t3, t4);
     for (int r = 0; r < 3; ++r) acc[r] += qd * ((jj > l) ? t2[r] + t4[r] : t0[r]);
   }
   for (int r = 0; r < 3; ++r) dv[r] = (cls == 0) ? a[r] : (cls == 1) ? b[r] : (cls == 2) ? acc[r] : dp[r];
