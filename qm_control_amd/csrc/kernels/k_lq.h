@@ -114,9 +114,8 @@ static_assert(LQ_LDS_BYTES <= 16384, "ten waves per CU (160 KB of LDS) need at m
 #define LQ_KIN_TILE (64 * 31)               /* K1a: [64][31] rows — the wave's inputs x (transposed on the way in), then the input u of each thread for the whole kernel ... */
 #define LQ_KIN_LDS_BYTES ((LQ_KIN_TILE + 64 * 9) * 8)      /* ... + the [64][9] hand-over tile of the record stores: 20 KB per wave, seven waves per CU (the benchmark launch has 6.45 per CU) */
 
-// value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column.  (Lane-conditional reads on purpose: an unconditional read by all 64 lanes +
-// a select — which saves the three scalar instructions of the execution-mask region — measured SLOWER, profiles/r06_ab_lq_regions.log: the scalar unit is idle in this kernel, the
-// LDS pipe is not)
+// value v[row] placed in column 30 (tile J = 1, lane column 14) of a two-tile-high fragment column.  (One lane-conditional region; the forms without one — an unconditional read
+// pinned by an empty asm + a select, or an addition through a selected address — measured slower resp. cost more instructions here, profiles/r06_ab_lq_regions.log)
 __device__ __forceinline__ void lw_set_col30(qm_d4 (&F)[2][2], const double* v) {
   const int g = (threadIdx.x & 63) >> 4, c = threadIdx.x & 15;
 #pragma unroll
@@ -770,6 +769,13 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   }
   qm_wave_sync();
   const double dsum = FR[12] + FR[28] + FR[44] + FR[60];
+  if (l < 30) { QD[l] += dsum; RD[l] += dsum; }      // the diagonals as they are added below, once per row instead of once per fragment register
+  qm_wave_sync();
+  // PREDICATION BY ADDRESS.  "Lane-conditional value from LDS" is written below as an unconditional read through a SELECTED ADDRESS — the value's slot, or a slot that holds
+  // zero — followed by a plain addition (x + 0.0 is x): one v_cndmask_b32 on the address per register.  Written as `cond ? LDS[i] : 0.0` the compiler sinks the read into a
+  // lane-conditional region (s_and_saveexec / s_cbranch_execz / s_or + the wait inside it) per register; 0 / 1 masks multiplied in cost a register pair each (two such sites
+  // together spill).  Same bits; R assembly + Q assembly + the EE rows: K1b − 3 % (profiles/r06_ab_lq_regions.log)
+  const double* const ZS = X + 30;                   // a double that holds zero (slots 30, 31 of the state vector are never written)
   LQT()
   // R = (R0 + diag + friction blocks + shift) dt
 #pragma unroll
@@ -778,13 +784,10 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     for (int J = 0; J < 2; ++J)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + g + 4 * r, col = 16 * J + c; double v = Rm[I][J][r];
-        if (row < 30 && col < 30) {
-          if (row == col) v += RD[row] + dsum;
-          if (row < 12 && col < 12 && row / 3 == col / 3) v += FR[16 * (row / 3) + 3 * (row % 3) + (col % 3)];
-          v *= dt;
-        } else v = 0.0;
-        Rm[I][J][r] = v;
+        const int rl = g + 4 * r; double v = Rm[I][J][r];
+        if (I == J) { const double* pd = (rl == c && (I == 0 || rl < 14)) ? RD + 16 * I + rl : ZS; v += *pd; }
+        if (I == 0 && J == 0 && r < 3) { const int rb = rl / 3; const double* pf = (c / 3 == rb) ? FR + 16 * rb + 3 * (rl - 3 * rb) + (c % 3) : ZS; v += *pf; }
+        Rm[I][J][r] = v * dt;
       }
   if (l < 30) S[LW_V_RV + l] *= dt;
   const double ctot = qm_wave_sum(cost) * dt;
@@ -803,13 +806,27 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
 #pragma unroll
     for (int J = 0; J < 2; ++J)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = g + 4 * r, col = 16 * J + c; const double jv = (row < 6 && col < 30) ? JT[row * 32 + col] : 0.0; Jz[0][J][r] = jv; Jy[0][J][r] = (row < 6) ? ((col < 30) ? EE[6 + row] * jv : ((col == 30) ? EE[6 + row] * EE[row] : 0.0)) : 0.0; }
+      for (int r = 0; r < 4; ++r) {
+        double jv = 0.0, jy = 0.0;
+        if (r < 2) {
+          const int row = g + 4 * r, col = 16 * J + c; const bool live = (r == 0) || g < 2; const double* const ZJ = X + 30;
+          const double mu = EE[6 + row];
+          jv = *(live ? JT + row * 32 + col : ZJ);
+          if (J == 1) { const double ge = *((c == 14 && live) ? EE + row : ZJ); jy = mu * (jv + ge); } else jy = mu * jv;
+        }
+        Jz[0][J][r] = jv; Jy[0][J][r] = jy;
+      }
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
       for (int J = 0; J < 2; ++J)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; Qa[I][J][r] = (row < 30) ? ((row == col) ? QD[row] + dsum : ((col == 30) ? S[LW_V_QV + row] : 0.0)) : 0.0; }
+        for (int r = 0; r < 4; ++r) {
+          const int rl = g + 4 * r, row = 16 * I + rl; double v = 0.0;
+          if (I == J) { const double* pd = (rl == c && (I == 0 || rl < 14)) ? QD + row : ZS; v = *pd; }
+          if (J == 1) { const double* pq = (c == 14) ? S + LW_V_QV + row : ZS; v += *pq; }
+          Qa[I][J][r] = v;
+        }
     qm_gemm_tn<1, 2, 2>(Jz, Jy, Qa, 0, 2, false);
 #pragma unroll
     for (int I = 0; I < 2; ++I)
