@@ -111,15 +111,23 @@ __device__ __forceinline__ void rw_load(qm_d4 (&T)[IT][JT], const double* src, i
 // 1 KB chunk: a segment's last chunk runs past the segment's end into the fields that follow it in the record (all sources end inside the record) and lands in
 // the segment's padding in LDS — no per-chunk lane mask.  The lane's byte offset 16 l is one 32-bit register for all of them, the chunk's address a wave-uniform
 // base (scalar registers): global_load_lds with scalar base + vector offset instead of a 64-bit vector address per instruction.
+// (round 6: four chunks share one global base and one LDS base — the instruction's immediate offset moves both sides, qm_dma16_at)
 template <int SRC, int DST, int LEN>
-__device__ __forceinline__ void rw_prefetch_seg(const double* rec, double* lds, unsigned lane_bytes) {
+__device__ __forceinline__ void rw_prefetch_seg(const double* rec, qm_lds_ptr lds, unsigned lane_bytes) {
 #pragma unroll
-  for (int t = 0; t * 128 < LEN; ++t) qm_dma16((const double*)((const char*)(rec + SRC + 128 * t) + lane_bytes), lds + RP_REC + DST + 128 * t);
+  for (int t0 = 0; t0 * 128 < LEN; t0 += 4) {
+    const char* g = (const char*)(rec + SRC + 128 * t0) + lane_bytes; const qm_lds_ptr l3 = lds + 8 * (RP_REC + DST + 128 * t0);
+    qm_dma16_at<0>(g, l3);
+    if ((t0 + 1) * 128 < LEN) qm_dma16_at<1024>(g, l3);
+    if ((t0 + 2) * 128 < LEN) qm_dma16_at<2048>(g, l3);
+    if ((t0 + 3) * 128 < LEN) qm_dma16_at<3072>(g, l3);
+  }
 }
 // lean (profiling only, skip bit 64 of the instrumented instance): three of the twelve fragment chunks are NOT copied — the 360 doubles per stage that packed triangles of the
 // symmetric tiles Qp(0,0), Qp(1,1), Rp would save (round-5 review item 5).  The arithmetic then runs on stale operands (results meaningless); what is measured is the TIME
 // of a backward sweep that moves 7 % fewer bytes and pays nothing for unpacking them: the upper bound of what the packing could gain.
-__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds, int m, bool lean = false) {
+__device__ __forceinline__ void rw_prefetch(const double* rec, double* lds_generic, int m, bool lean = false) {
+  const qm_lds_ptr lds = qm_lds(lds_generic);
   const unsigned lane_bytes = 16u * (threadIdx.x & 63);
   rw_prefetch_seg<SR_AP, RPO_A, 360>(rec, lds, lane_bytes);
   rw_prefetch_seg<SR_BP, RPO_B, 216>(rec, lds, lane_bytes);
@@ -494,7 +502,9 @@ __device__ __forceinline__ void qm_riccati_body(QmRiccatiArgs a) {
     const double* nrec = (kn >= 0) ? a.stage + ((size_t)b * a.nmax + kn) * SR_SIZE : nullptr;
     const int m = mlist(k), mnext = (kn >= 0) ? mlist(kn) : 0;
     if (m <= 16) rw_stage<1, PROF>(rec, m, nrec, mnext, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
+#ifndef QM_RW_ONLY_MT1
     else rw_stage<2, PROF>(rec, m, nrec, mnext, buf, S, sv, a.skip, chol_fail, tacc, pc, modelist(k));
+#endif
   }
   const long long tback = PROF ? (long long)__builtin_readcyclecounter() : 0;
   // L, W, y were stored by other lanes than the ones that read them back below
@@ -513,10 +523,21 @@ __device__ __forceinline__ void qm_riccati_body(QmRiccatiArgs a) {
   int fsrc[RF_NLOAD];
 #pragma unroll
   for (int t = 0; t < RF_NLOAD; ++t) { const int e = 2 * (t * 64 + l); fsrc[t] = (e < RF_TOTAL) ? rf_src(e) : -1; }
-  auto fetch = [&](int k, int which) {
-    const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE; double* F = buf + (which ? RF_F1 : RF_F0);
+  // (round 6: the LDS side of four consecutive chunks is one base + the instruction's immediate offset 0 / 1 / 2 / 3 KB; the offset moves the global side too, so the lane's
+  //  source offset of chunk t is kept MINUS (t mod 4) KB.  Only the last chunk has lanes without an element.)
+  static_assert(RF_NLOAD == 13 && (RF_TOTAL + 1) / 2 > 12 * 64, "forward fetch: twelve full chunks and a partial thirteenth");
 #pragma unroll
-    for (int t = 0; t < RF_NLOAD; ++t) if (fsrc[t] >= 0) qm_dma16(rec + fsrc[t], F + 128 * t);
+  for (int t = 0; t < RF_NLOAD; ++t) if (fsrc[t] >= 0) fsrc[t] -= 128 * (t & 3);
+  const qm_lds_ptr buf3 = qm_lds(buf);
+  auto fetch = [&](int k, int which) {
+    const double* rec = a.stage + ((size_t)b * a.nmax + k) * SR_SIZE; const qm_lds_ptr F = buf3 + 8 * (which ? RF_F1 : RF_F0);
+#pragma unroll
+    for (int t0 = 0; t0 < 12; t0 += 4) {
+      const qm_lds_ptr l3 = F + 1024 * t0;
+      qm_dma16_at<0>((const char*)(rec + fsrc[t0]), l3); qm_dma16_at<1024>((const char*)(rec + fsrc[t0 + 1]), l3);
+      qm_dma16_at<2048>((const char*)(rec + fsrc[t0 + 2]), l3); qm_dma16_at<3072>((const char*)(rec + fsrc[t0 + 3]), l3);
+    }
+    if (fsrc[12] >= 0) qm_dma16_at<0>((const char*)(rec + fsrc[12]), F + 1024 * 12);
   };
   int cur = 0;
   { int k0 = 0; while (k0 < n - 1 && evlist(k0) == QM_EV_PRE) ++k0; if (k0 < n - 1 && !(a.skip & 4)) fetch(k0, 0); }

@@ -210,6 +210,13 @@ __device__ __forceinline__ double qm_wave_max(double v) {
 // (cache policy 2 = nt, non-temporal: the copies stream stage records that are read once per sweep — measured K3 1.12 -> 1.05 ms against the default policy;
 // the scope bits sc0 / sc1 on top of it change nothing)
 __device__ __forceinline__ void qm_dma16(const double* g, double* lds_chunk) { __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_chunk, 16, 0, 2); }
+// The same with the instruction's IMMEDIATE OFFSET (bytes, 0 .. 4095): the hardware adds it to BOTH sides — global address and LDS address — so consecutive 1 KB chunks of a
+// segment that is contiguous on both sides share one global base and one LDS base (M0): offsets 0, 1024, 2048, 3072.  The LDS side is an address-space-3 pointer, formed
+// ONCE from the kernel's shared array: passing a generic pointer per chunk makes the compiler rebuild M0 through a generic -> LDS cast with a null check every time
+// (s_add_u32 / s_addc_u32 / s_cmp_lg_u64 / s_cselect: K3 issued ≈ 6 scalar instructions per 1 KB chunk, 35 chunks per stage, on a lone wave that pays for every one of them)
+typedef __attribute__((address_space(3))) char* qm_lds_ptr;
+__device__ __forceinline__ qm_lds_ptr qm_lds(double* p) { return (qm_lds_ptr)p; }
+template <int OFF> __device__ __forceinline__ void qm_dma16_at(const char* g, qm_lds_ptr lds_chunk) { static_assert(OFF >= 0 && OFF < 4096, "13-bit signed immediate"); __builtin_amdgcn_global_load_lds(g, lds_chunk, 16, OFF, 2); }
 __device__ __forceinline__ void qm_dma_wait() { __builtin_amdgcn_s_waitcnt(0x0F70); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }      // vmcnt(0)
 __device__ __forceinline__ void qm_lds_drain() { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }     // lgkmcnt(0): every ds_read has returned
 

@@ -78,8 +78,8 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_memrealtime() 0ull          /* 100 MHz reference clock / hardware slot id: profiling stamps of the instrumented instances only */
 #define __builtin_amdgcn_s_getreg(x) 0u
-// global_load_lds: lane l's `size` bytes land at lds_base + size * l
-#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char*)(l) + (size) * emu::cur().lane, (const char*)(g), (size))
+// global_load_lds: lane l's `size` bytes land at lds_base + size * l; the immediate offset `off` is added on BOTH sides
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) memcpy((char*)(l) + (off) + (size) * emu::cur().lane, (const char*)(g) + (off), (size))
 #define __ffsll(x) __builtin_ffsll(x)
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
 #define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
