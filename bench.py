@@ -84,7 +84,7 @@ class HipEngine:
         self.itf.synchronize(); self.device_bytes = int(free0 - torch.cuda.mem_get_info(local_rank)[0])    # MEASURED footprint of the contexts + uploaded inputs
         for key in ("riccati_skip", "wbc_stop", "lq_prof", "lq_debug", "lds_pad"):      # profiling-only switches make results meaningless: they must all be off
             assert self.itf.debug_get(key) == 0, key
-        for key, want in (("ls_device_tail", 1), ("fused_policy", 1), ("wbc_defer", 0), ("filler_at_lq", 0)):      # the product's launch order, not one of the A/B orders
+        for key, want in (("ls_device_tail", 1), ("fused_policy", 1), ("wbc_defer", 0), ("filler_at_lq", 0), ("r_dense", 0)):      # the product's launch order, not one of the A/B orders
             assert self.itf.debug_get(key) == want, key
 
     def upload(self, cfg):

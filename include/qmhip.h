@@ -258,7 +258,9 @@ int qmhip_debug_read(qmhip_ctx* ctx, const char* buffer, void* dst, size_t bytes
  * records stay as the LQ kernel wrote them), "wbc_stop", "lq_prof", "lq_debug" (1: the LQ kernel also writes the unprojected LQ model of every interval into the
  * buffer "lqdbg" and the null-space basis into the stage record — tests/test_gpu_lq_records.py); launch-order switches for same-box A/Bs and the bit-identity tests
  * (results do not depend on them): "ls_device_tail" (1: the line search's later trials in one launch on the device; 0: one host round trip per trial, rounds 1-5),
- * "fused_policy" (1: the policy at t0 from the deciding kernels, apply beside the WBC; 0: apply -> policy kernel -> WBC), "wbc_defer", "filler_*" (scheduling experiments) */
+ * "fused_policy" (1: the policy at t0 from the deciding kernels, apply beside the WBC; 0: apply -> policy kernel -> WBC), "r_dense" (1: the dense instances of the trial
+ * evaluation and of the LQ kernel's input-weight product although the table's R is block diagonal — same bits; readable: "r_blocks" = the structured instances run),
+ * "wbc_defer", "filler_*" (scheduling experiments) */
 int qmhip_debug_set(qmhip_ctx* ctx, const char* key, int value);
 /* read such a switch back (bench.py asserts they are all 0 before it times anything) */
 int qmhip_debug_get(const qmhip_ctx* ctx, const char* key, int* value);

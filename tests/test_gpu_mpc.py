@@ -119,6 +119,32 @@ def test_receding_horizon_closed_loop(blobs, oracle):
     itf.close()
 
 
+def test_structured_input_weight_paths_equal_the_dense_ones_on_the_device(blobs):
+    """Round 6: with the shipped block-diagonal input weight K1b forms r = R0 (u - u_nom) as a three-term row product in the order the dense path's DPP tree adds the same
+    terms (k_lq.h) and the trial evaluation multiplies 54 instead of 900 entries (k_ls.h).  Forced onto the dense instances (`r_dense` 1) the device must give the SAME BITS:
+    the whole primal solution, the merit terms and the step lengths over warm-started receding-horizon solves (a cold start has u = u_nom exactly and would not see a wrong
+    association — the first build of the structured product passed a cold-start test and failed this one: profiles/r06_ab_lq_regions.log)."""
+    from qm_control_amd import api, scenarios
+    B, steps, dt_mpc = 128, 3, 0.01
+    cfg = scenarios.make_config("C3", batch=B)
+
+    def run(dense):
+        itf = api.QMInterface(blobs=blobs, max_batch=B, max_nodes=128, max_ref_knots=2, max_events=cfg["ev"].shape[1]); itf.debug_set("r_dense", dense)
+        assert itf.debug_get("r_blocks") == (0 if dense else 1)
+        mpc = api.SqpMpc(itf); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
+        outs = []
+        for k in range(steps):
+            if k > 0: mpc.advance(dt_mpc)
+            mpc.solve_resident(cfg["horizon"], warm=(k > 0)); outs.append(mpc.download())
+        itf.close(); return outs
+
+    st, de = run(0), run(1)
+    assert np.abs(st[1]["u"][:, :, 12:24]).max() > 1e-3          # the warm solves do start from non-zero joint velocities
+    for k in range(steps):
+        for key in ("x", "u", "status", "t", "perf"):
+            assert np.array_equal(st[k][key], de[k][key]), (k, key)
+
+
 def test_device_line_search_tail_equals_the_host_driven_loop(blobs, oracle):
     """Round 6: after the first trial the line search finishes in ONE launch on the device (qm_ls_tail_kernel, k_ls.h) instead of one host round trip per trial.  On
     warm-started receding-horizon solves of the benchmark workload (256 instances, N = 100: ~ 15 % of the instances reject the full step, a few take three trials —
