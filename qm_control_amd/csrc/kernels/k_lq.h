@@ -212,7 +212,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_p
 #pragma unroll
     for (int I = 0; I < 2; ++I) { Y1[I][0] = PxA[I][1]; P1[I][0] = RPx[I][1]; }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) Y1[0][0][r] = (c == 14) ? S[LW_V_PE + g + 4 * r] : 0.0;
+    for (int r = 0; r < 3; ++r) Y1[0][0][r] = *((c == 14) ? S + LW_V_PE + g + 4 * r : S + LW_V_X + 30);      // (Pe in lane column 14, a zero elsewhere: read through a selected address, slot 30 of the state vector holds zero)
     qm_gemm_tn<2, 2, 1>(Rm, Y1, P1, 0, 3, false);
 #pragma unroll
     for (int I = 0; I < 2; ++I) RPx[I][1] = P1[I][0]; }
@@ -399,6 +399,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   if (l >= 32 && l < 39) in_ee = a.eeref[nb * 7 + (l - 32)];
   if (l >= 40 && l < 46) in_ee = kr[KR_EEG + (l - 40)];
   if (l >= 48 && l < 52) in_ee = kr[KR_QEE + (l - 48)];
+  double in_zv = 0.0, in_zp = 0.0;                     // swing-height references of contact l − 60 (the constraint values' lanes): loaded with everything else — in the constraint phase they were a memory round trip of their own, waited for on the spot
+  if (l >= 60) { in_zv = a.zvel[nb * 4 + (l - 60)]; in_zp = a.zpos[nb * 4 + (l - 60)]; }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int p = l + 64 * t;                                          // doubles 2 p, 2 p + 1
@@ -491,7 +493,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     } else {
       const int k = tk; const bool stance = mode_flag(mode, k); const int rr = row0[k];
       const double gz = (gain != 0.0) ? gain * pzk : 0.0;
-      double bb = -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * a.zpos[nb * 4 + k];
+      double bb = -in_zv; if (gain != 0.0) bb -= gain * in_zp;
       const double e0 = stance ? vk[0] : U[3 * k], e1 = stance ? vk[1] : U[3 * k + 1], e2 = stance ? vk[2] + gz : U[3 * k + 2], e3 = bb + vk[2] + gz;
       // e also rides in column 30 of the C rows: [C | e]
       S[LW_V_E + rr] = e0; T[rr * LW_TLD + 30] = e0; S[LW_V_E + rr + 1] = e1; T[(rr + 1) * LW_TLD + 30] = e1; S[LW_V_E + rr + 2] = e2; T[(rr + 2) * LW_TLD + 30] = e2;
@@ -571,7 +573,8 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     if (g == 0) {
       const int i0 = (type == 0) ? 3 * kk + t : ((type == 1) ? jc : ((type == 2) ? 24 + t : 0));
       S[LW_PD + j] = (double)i0;
-      S[LW_PD + 32 + 3 * j] = (type == 1) ? gg[3 + 3 * t] : ((type == 3) ? 0.0 : 1.0); S[LW_PD + 32 + 3 * j + 1] = (type == 1) ? gg[4 + 3 * t] : 0.0; S[LW_PD + 32 + 3 * j + 2] = (type == 1) ? gg[5 + 3 * t] : 0.0;
+      { const double m1 = (type == 1) ? 1.0 : 0.0, c0 = (type == 0 || type == 2) ? 1.0 : 0.0;      // (the three block entries are read by every lane of the group — in bounds for any t — and enter through a 0 / 1 factor)
+        S[LW_PD + 32 + 3 * j] = fma(m1, gg[3 + 3 * t], c0); S[LW_PD + 32 + 3 * j + 1] = m1 * gg[4 + 3 * t]; S[LW_PD + 32 + 3 * j + 2] = m1 * gg[5 + 3 * t]; }
     }
 #pragma unroll
     for (int I = 0; I < 2; ++I)
@@ -676,7 +679,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
 #pragma unroll
       for (int I = 0; I < 2; ++I) { Y1[I][0] = PxA[I][1]; P1[I][0] = ApA[I][1]; }
 #pragma unroll
-      for (int r = 0; r < 3; ++r) Y1[0][0][r] = (c == 14) ? S[LW_V_PE + g + 4 * r] : 0.0;
+      for (int r = 0; r < 3; ++r) Y1[0][0][r] = *((c == 14) ? S + LW_V_PE + g + 4 * r : S + LW_V_X + 30);      // (Pe in lane column 14, a zero elsewhere: read through a selected address, slot 30 of the state vector holds zero)
       qm_gemm_tn<2, 2, 1>(Bdt, Y1, P1, 0, 3, false);
 #pragma unroll
       for (int I = 0; I < 2; ++I) ApA[I][1] = P1[I][0]; }
@@ -691,8 +694,15 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   LQT()
   // ---- phase III: cost quadratic model (x dt) ----
   double cost = (l < 30) ? S[LW_V_RR + l] : 0.0;
+  // per-lane table entries of this phase, requested TOGETHER with R0 (one memory round trip instead of three: each was loaded where it is used and waited for on the spot):
+  // the three entries of the lane's row of R0 for the structured product below, the box limits of the lane's arm joint for the barriers
+  const int lr = (l < 30) ? l : 29; const bool rblk = lr >= 12 && lr < 24; const int lb = lr / 3, b0 = rblk ? 3 * lb : (lr < 27 ? lr : 27);
+  const double r0a = st[ST_R + 30 * lr + b0], r0b = st[ST_R + 30 * lr + b0 + 1], r0c = st[ST_R + 30 * lr + b0 + 2];
+  const bool boxv = l < 12, boxc = (l >= 32 && l < 44); const int kb = boxv ? l : (boxc ? l - 32 : 0); const bool pos = kb < 6; const int kj = pos ? kb : kb - 6;
+  const double box_lo = pos ? mb[MB_QLO + 12 + kj] : st[ST_JVEL_LO + kj], box_hi = pos ? mb[MB_QHI + 12 + kj] : st[ST_JVEL_HI + kj];
   qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);      // input cost weights (L2 / scalar-cache resident table)
-  if (l >= 32 && l < 38) EE[6 + (l - 32)] = ((l - 32) < 3 ? st[ST_MU_EE_POS] : st[ST_MU_EE_ORI]);
+  { const double mup = st[ST_MU_EE_POS], muo = st[ST_MU_EE_ORI];      // two scalar table reads + a select of the VALUES (a select between the two addresses is a vector load with its own wait)
+    if (l >= 32 && l < 38) EE[6 + (l - 32)] = ((l - 32) < 3) ? mup : muo; }
   qm_wave_sync();
   if (QM_LQ_RB_ONLY || a.rb) {
     // r = R0 (u − unom) with the block-diagonal R0 of the shipped task file (wave-uniform test): a row has at most three non-zero entries, lane = row.  Bit-identical to the
@@ -702,8 +712,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     // lanes changes nothing.  A diagonal row reads two exact zeros beside its entry (columns clamped to 27..29 for the last rows).
 #pragma clang fp contract(off)
     if (l < 30) {
-      const bool blk = l >= 12 && l < 24; const int lb = l / 3, b0 = blk ? 3 * lb : (l < 27 ? l : 27);
-      const double p0 = st[ST_R + 30 * l + b0] * S[LW_V_DU + b0], p1 = st[ST_R + 30 * l + b0 + 1] * S[LW_V_DU + b0 + 1], p2 = st[ST_R + 30 * l + b0 + 2] * S[LW_V_DU + b0 + 2];
+      const double p0 = r0a * S[LW_V_DU + b0], p1 = r0b * S[LW_V_DU + b0 + 1], p2 = r0c * S[LW_V_DU + b0 + 2];
       S[LW_V_RV + l] = (lb & 1) ? (p2 + p1) + p0 : p2 + (p1 + p0);          // leg blocks: lb = 4 .. 7
     }
   } else { // r = R0 (u − unom): a mat-vec on the register fragments — two partial products per lane and register, then a 16-lane DPP row sum
@@ -727,13 +736,13 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   // body serves lanes 0..11 (variable part of the boxes: lane < 6 position of arm joint l, else velocity), lanes 32..43 (the boxes' constant
   // offsets b(−lo) + b(hi): same code, other arguments) and lanes 16..19 (friction cone of contact l − 16); idle lanes evaluate h = 1.
   {
-    const bool boxv = l < 12, boxc = (l >= 32 && l < 44), fric = (l >= 16 && l < 20);
-    const int kb = boxv ? l : (boxc ? l - 32 : 0); const bool pos = kb < 6; const int k = pos ? kb : kb - 6;
+    const bool fric = (l >= 16 && l < 20); const int k = kj;
     const int kf = fric ? l - 16 : 0; const bool fon = fric && mode_flag(mode, kf);
     const double muf = st[ST_FRIC_COEF], reg = st[ST_FRIC_REG];
     const double Fx = U[3 * kf], Fy = U[3 * kf + 1], Fz = U[3 * kf + 2]; const double T2 = Fx * Fx + Fy * Fy + reg, Tn = sqrt(T2);
-    const double mu = fric ? st[ST_FRIC_MU] : (pos ? st[ST_JPOS_MU] : st[ST_JVEL_MU]), de = fric ? st[ST_FRIC_DELTA] : (pos ? st[ST_JPOS_DELTA] : st[ST_JVEL_DELTA]);
-    const double lo = pos ? mb[MB_QLO + 12 + k] : st[ST_JVEL_LO + k], hi = pos ? mb[MB_QHI + 12 + k] : st[ST_JVEL_HI + k], z = pos ? X[24 + k] : U[24 + k];
+    const double mu_f = st[ST_FRIC_MU], mu_p = st[ST_JPOS_MU], mu_v = st[ST_JVEL_MU], de_f = st[ST_FRIC_DELTA], de_p = st[ST_JPOS_DELTA], de_v = st[ST_JVEL_DELTA];      // scalar table reads, values selected per lane
+    const double mu = fric ? mu_f : (pos ? mu_p : mu_v), de = fric ? de_f : (pos ? de_p : de_v);
+    const double lo = box_lo, hi = box_hi, z = pos ? X[24 + k] : U[24 + k];
     const double h1 = boxv ? z - lo : (boxc ? -lo : (fon ? muf * Fz - Tn : 1.0)), h2 = boxv ? hi - z : (boxc ? hi : 1.0);
     double v1, v2, p1, p2, q1, q2;
     if (!IPM) { v1 = barrier_val(mu, de, h1); v2 = barrier_val(mu, de, h2); barrier_d12(mu, de, h1, p1, p2); barrier_d12(mu, de, h2, q1, q2); }
@@ -753,7 +762,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
       ipm_res = (act ? (h1 - s1) * (h1 - s1) : 0.0) + (boxv ? (h2 - s2) * (h2 - s2) : 0.0);
     }
     cost += IPM ? (v1 + v2) : (boxv ? v1 + v2 : (boxc ? -(v1 + v2) : (fon ? v1 : 0.0)));
-    if (boxv) { const double g1 = p1 - q1, g2 = p2 + q2; if (pos) { S[LW_V_QV + 24 + k] += g1; QD[24 + k] += g2; } else { S[LW_V_RV + 24 + k] += g1; RD[24 + k] += g2; } }
+    if (boxv) { const double g1 = p1 - q1, g2 = p2 + q2; double* pv = (pos ? S + LW_V_QV : S + LW_V_RV) + 24 + k; double* pd = (pos ? QD : RD) + 24 + k; *pv += g1; *pd += g2; }      // (one region, the target vector selected by address)
     else if (fric) {                                                     // one lane per contact (disjoint 3x3 blocks)
       double* fr = FR + 16 * kf; double ds = 0.0;
       for (int q = 0; q < 13; ++q) fr[q] = 0.0;
