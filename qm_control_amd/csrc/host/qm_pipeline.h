@@ -184,7 +184,7 @@ struct QmMpcPipeline {
     if (max_trials > QM_LS_MAX_TRIALS) max_trials = QM_LS_MAX_TRIALS;
     QmLqArgs q; q.mb = d.mb; q.st = d.st; q.B = B; q.nmax = d.nmax; q.n_nodes = d.n_nodes; q.node_ts = d.node_ts; q.node_dt = d.node_dt; q.node_ev = d.node_ev; q.node_mode = d.node_mode;
     q.zvel = d.zvel; q.zpos = d.zpos; q.xref = d.xref; q.eeref = d.eeref; q.x = d.x; q.u = d.u; q.stage = d.stage; q.perf = d.perf; q.dbg = d.lqdbg; q.kin = d.kin; q.prof = lq_prof; q.ncap = ncap;
-    q.ipm_s = d.ipm_s; q.ipm_l = d.ipm_l; q.ipm_info = d.ipm_info; q.rb = rblk() ? 1 : 0;
+    q.ipm_s = d.ipm_s; q.ipm_l = d.ipm_l; q.ipm_info = d.ipm_info; q.rb = rblk() ? 1 : 0; q.single_mt = has_m18 ? 0 : 1;
     q.i0 = 0;
     const int nsl = (ipm || d.lqdbg || lq_prof || lq_slices < 1) ? 1 : (lq_slices > ncap ? ncap : lq_slices);
     if (nsl > 1) {

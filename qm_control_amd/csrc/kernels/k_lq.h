@@ -53,6 +53,8 @@ struct QmLqArgs {
   int i0;                    // first node of the launch (node slices: K1a and K1b take the horizon in [i0, i0 + ncap) pieces so that a piece's kin records are consumed while they are still cached)
   // interior-point instances only (k_ipm.h): slack / dual of the node's QM_NH inequality rows [nmax][B][QM_NH], barrier parameter per instance info[b * 8]
   const double* ipm_s; const double* ipm_l; const double* ipm_info;
+  int single_mt;             // K1b product kernels: the host knows that NO node of the launch has more than 16 reduced inputs (K0 publishes it with the node capacity): qm_lq_kernel then takes every node without
+                             // first loading its contact mode to decide whether the node is its own — a memory round trip of its own in front of everything else (qm_lq_m18_kernel is not launched)
   int rb;                    // K1b: the input weight R0 of the settings table is block diagonal (diag(12) + four 3 x 3 leg blocks + diag(6): qm_r_is_block_diagonal, k_ls.h — the host checks the table entry by entry)
 };
 
@@ -386,9 +388,12 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
 #endif
   double* dbg = (DBG && a.dbg) ? a.dbg + ((size_t)b * a.nmax + i) * LQ_DBG_SIZE : nullptr;
   const double* kr = a.kin + (size_t)nb * KR_SIZE;
-  // every input address depends on (b, i) only: issue all loads before looking at the node's status (one memory round trip)
-  const int nn = a.n_nodes[b]; const int ev = a.node_ev[nb];
-  const double dt = a.node_dt[nb]; const int mode = a.node_mode[nb];
+  // every input address depends on (b, i) only: issue all loads before looking at the node's status (one memory round trip).  The node's status words are wave-uniform and
+  // nobody writes them in this kernel: read through the CONSTANT address space they are scalar loads (round 6) — as plain loads the compiler made them vector loads + a
+  // v_readfirstlane, whose wait (the vector memory counter) stood in front of every other load of the prologue: a second round trip
+  typedef const int __attribute__((address_space(4)))* qm_citab;
+  const int nn = ((qm_citab)a.n_nodes)[b], ev = ((qm_citab)a.node_ev)[nb], mode = ((qm_citab)a.node_mode)[nb];
+  const double dt = ((qm_ctab)a.node_dt)[nb];
   const int nxt = (i + 1 < a.nmax) ? ((i + 1) * a.B + b) : nb;
   double in_x = 0.0, in_u = 0.0, xn = 0.0, f1 = 0.0, f2 = 0.0, in_ee = 0.0, in_xref = 0.0, in_qd = 0.0;
   // the two kinematics workspaces of the kin record come in as PAIRS of doubles (16-byte global loads, 16-byte LDS stores: half the instructions of both kinds)
@@ -408,6 +413,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     in_k2[t] = (2 * p < KW_ARM) ? ((const double2*)(kr + KR_K2))[p] : double2{0.0, 0.0};      // (the stage-2 workspace ends in front of the arm block, at an odd index: the pair's second half is dropped below)
     if (2 * p + 1 >= KW_ARM) in_k2[t].y = 0.0;
   }
+  QM_SCALARS_READY(nn, ev, mode, dt);      // the four scalar loads are waited for HERE, together (left alone the compiler sinks each one to its first use: three waits in a row)
   if (i >= nn) return;
   const bool terminal = (i == nn - 1);
   if (!terminal && ev == QM_EV_PRE) {                 // event nodes carry no LQ data (identity jump, handled by K3): only clear their merit terms
@@ -887,7 +893,7 @@ __device__ __forceinline__ int qm_lq_node_mt(const QmLqArgs& a) {
 #ifndef QM_LQ_WAVES
 #define QM_LQ_WAVES 3      /* waves per SIMD the two product instances are compiled for */
 #endif
-__global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<false, 1>(a); }
+__global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_kernel(QmLqArgs a) { if (a.single_mt || qm_lq_node_mt(a) == 1) qm_lq_body<false, 1>(a); }
 __global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_m18_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 2) qm_lq_body<false, 2>(a); }
 __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_ipm_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<false, 1, true>(a); else qm_lq_body<false, 2, true>(a); }      // interior-point instance (solver 3, k_ipm.h)
 __global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_dbg_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<true, 1>(a); else qm_lq_body<true, 2>(a); }

@@ -38,6 +38,9 @@ typedef const double __attribute__((address_space(4)))* qm_ctab;
                                           plain `ds_read ... offset:imm` accesses, not a select between two absolute addresses at every access (K1b: 66 accesses, 198 instructions) */
 #define QM_LANE_OPAQUE(i) asm volatile("" : "+v"(i))
 #endif
+#ifndef QM_SCALARS_READY                /* "these wave-uniform values are in scalar registers here": an empty asm with scalar-register inputs (the host emulator defines it away) */
+#define QM_SCALARS_READY(a, b, c, d) asm volatile("" :: "s"(a), "s"(b), "s"(c), "s"(d))
+#endif
 #ifndef QM_LOADED                       /* "this double is loaded HERE, by every lane": without it the compiler sinks a load whose only use is one arm of a select into a lane-conditional
                                           region — s_and_saveexec / s_cbranch_execz / s_or per element, three scalar instructions and a branch around one ds_read (K1b had 300 such regions) */
 #define QM_LOADED(d) asm volatile("" : "+v"(d))

@@ -30,6 +30,7 @@
 #define QM_LANE_OPAQUE(i)             /* device-only register constraint */
 #define QM_PIN4(q) ((void)0)             /* device-only scheduling pin */
 #define QM_LOADED(d)                  /* device-only: "this value is loaded here" */
+#define QM_SCALARS_READY(a, b, c, d)  /* device-only: "these wave-uniform values are in scalar registers here" */
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 
