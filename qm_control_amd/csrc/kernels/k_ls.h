@@ -176,8 +176,10 @@ __device__ __forceinline__ void ls_node_terms(const QmLsArgs& a, const double* m
     double f1[12], f2[12];
     // the swing-height references of the four contacts, requested TOGETHER ahead of the legs (round 6: each swing leg loaded its own inside its turn of the loop — one
     // memory round trip per swing leg, waited for on the spot, with one leg scheduled at a time)
+    // (the structured product instance only: the dense and the interior-point instances, which are not on the benchmark's path, spill the eight extra doubles — 220 -> 368 B)
+    constexpr bool ZPRE = RB && !IPM;
     double zv4[4] = {0.0, 0.0, 0.0, 0.0}, zp4[4] = {0.0, 0.0, 0.0, 0.0};
-    if (dt > 0.0) { _Pragma("unroll") for (int k = 0; k < 4; ++k) zv4[k] = a.zvel[nb * 4 + k]; if (gain != 0.0) { _Pragma("unroll") for (int k = 0; k < 4; ++k) zp4[k] = a.zpos[nb * 4 + k]; } }
+    if (ZPRE && dt > 0.0) { _Pragma("unroll") for (int k = 0; k < 4; ++k) zv4[k] = a.zvel[nb * 4 + k]; if (gain != 0.0) { _Pragma("unroll") for (int k = 0; k < 4; ++k) zp4[k] = a.zpos[nb * 4 + k]; } }
     { double lin[3] = {0.0, 0.0, -9.81 * mass}, ang[3] = {0.0, 0.0, 0.0};
       _Pragma("unroll") for (int c = 0; c < 4; ++c) {
         kin_leg<true>(mb, c, x, u, K); const int k = chain_to_contact(c); const double* L = K + KW_LEG + KW_LEGSZ * c;
@@ -189,7 +191,7 @@ __device__ __forceinline__ void ls_node_terms(const QmLsArgs& a, const double* m
           if (mode_flag(mode, k)) { for (int r = 0; r < 3; ++r) { const double e = v[r] + ((r == 2 && gain != 0.0) ? gain * pz : 0.0); eq += e * e; } }
           else {
             for (int r = 0; r < 3; ++r) eq += u[3 * k + r] * u[3 * k + r];
-            double bb = -zv4[k]; if (gain != 0.0) bb -= gain * zp4[k];
+            double bb = ZPRE ? -zv4[k] : -a.zvel[nb * 4 + k]; if (gain != 0.0) bb -= gain * (ZPRE ? zp4[k] : a.zpos[nb * 4 + k]);
             const double e = bb + v[2] + (gain != 0.0 ? gain * pz : 0.0); eq += e * e;
           }
         }
