@@ -220,7 +220,7 @@ struct QmMpcPipeline {
       l.trial = 0; l.max_trials = max_trials;
       if (p0_enable && last && p0_x) { l.p0_x = p0_x; l.p0_u = p0_u; l.p0_mode = p0_mode; p0_done = true; bk.wbc_inputs_next(); }      // (the previous step's WBC has read its inputs before they are rewritten)
       if (rblk()) bk.launch(qm_ls_eval_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l); else bk.launch(qm_ls_eval_dense_kernel, (nodes_threads + 63) / 64, 64, LS_EVAL_LDS_BYTES, l);
-      { QmLsArgs ls = l; ls.with_alpha = 1; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }
+      { QmLsArgs ls = l; ls.with_alpha = 1; ls.tickets = nullptr; bk.launch(qm_perf_sum_kernel, B, 64, 0, ls); }      // (nobody waits for the published count of the instances still searching: no ticket, no fences)
       if (max_trials > 1) { QmLsArgs lt = l; lt.trial = 1;
         if (rblk()) bk.launch(qm_ls_tail_kernel, B, LS_TAIL_BLOCK, LS_TAIL_LDS_BYTES(d.nmax), lt); else bk.launch(qm_ls_tail_dense_kernel, B, LS_TAIL_BLOCK, LS_TAIL_LDS_BYTES(d.nmax), lt); }
       ls_trials_pending = true; ls_trials_cap = max_trials;

@@ -276,21 +276,27 @@ inline bool qm_r_is_block_diagonal(const double* st) {
 // Filter line-search decision of ONE instance for the trial at step length al0 with the sums {cost c, dynamics SSE d, equality SSE e} ([upstream ocs2_sqp
 // FilterLinesearch::acceptStep, recalled]): 1 = accepted (done = 1, out_perf), 2 = the search stops without a step (done = 2, alpha = 0), 0 = goes on
 // at alpha[b] = al0 / 2.  One thread per instance calls it (the deciding lane of qm_perf_sum_kernel, thread 0 of a tail block).
-__device__ __forceinline__ int qm_ls_filter_decide(const QmLsArgs& a, const int b, const double al0, const double c, const double d, const double e) {
+// (the _v form takes the instance's baseline sums {merit, -, dynamics SSE, equality SSE} and step figures {Armijo metric, |dx|², |du|²} as VALUES: qm_perf_sum_kernel requests them
+//  with everything else at its top instead of one memory round trip each on the deciding lane's chain)
+__device__ __forceinline__ int qm_ls_filter_decide_v(const QmLsArgs& a, const int b, const double al0, const double c, const double d, const double e, const double (&bs)[4], const double (&si)[3]) {
   const double gMax = qm_ms_param(a.st, ST_G_MAX), gMin = qm_ms_param(a.st, ST_G_MIN), gammaC = 1e-6, armijoFactor = 1e-4, alphaDecay = 0.5, alphaMin = 1e-4;
-  const double* bs = a.base_sum + b * 4; const double ps[4] = {c, c, d, e};
+  const double ps[4] = {c, c, d, e};
   const double theta0 = sqrt(bs[2] + bs[3]), theta = sqrt(ps[2] + ps[3]);
-  double al = al0; const double armijo = a.step_info[b * 4];
+  double al = al0; const double armijo = si[0];
   bool acc;
   if (theta > gMax) acc = theta < (1.0 - gammaC) * theta0;
   else if (theta < gMin && theta0 < gMin && al * armijo < 0.0) acc = ps[0] < bs[0] + armijoFactor * al * armijo;
   else acc = ps[0] < (bs[0] - gammaC * theta0) || theta < (1.0 - gammaC) * theta0;
   if (acc) { a.done[b] = 1; for (int q = 0; q < 4; ++q) a.out_perf[b * 10 + 4 + q] = ps[q]; a.out_perf[b * 10 + 8] = al; return 1; }
   al *= alphaDecay;
-  const double dxn = sqrt(a.step_info[b * 4 + 1]), dun = sqrt(a.step_info[b * 4 + 2]);
+  const double dxn = sqrt(si[1]), dun = sqrt(si[2]);
   if ((al * dun < qm_ms_param(a.st, ST_DELTA_TOL) && al * dxn < qm_ms_param(a.st, ST_DELTA_TOL)) || !(al >= alphaMin)) { a.done[b] = 2; a.alpha[b] = 0.0; return 2; }
   a.alpha[b] = al;
   return 0;
+}
+__device__ __forceinline__ int qm_ls_filter_decide(const QmLsArgs& a, const int b, const double al0, const double c, const double d, const double e) {
+  const double bs[4] = {a.base_sum[b * 4], a.base_sum[b * 4 + 1], a.base_sum[b * 4 + 2], a.base_sum[b * 4 + 3]}, si[3] = {a.step_info[b * 4], a.step_info[b * 4 + 1], a.step_info[b * 4 + 2]};
+  return qm_ls_filter_decide_v(a, b, al0, c, d, e, bs, si);
 }
 // entries of the primal solution of instance b for the step length al (0 when no step is taken) — the arithmetic of qm_ls_apply_kernel, which writes them for every node
 __device__ __forceinline__ double qm_ls_primal_x(const QmLsArgs& a, const int b, const int i, const int q, const double al) { const size_t nb = (size_t)i * a.B + b; return a.x[nb * 30 + q] + al * a.dx[nb * 30 + q]; }
@@ -315,14 +321,30 @@ __device__ __forceinline__ void qm_ls_policy_at_t0(const QmLsArgs& a, const int 
 // nodes, DPP wave reduction).  with_alpha == 0: baseline of the current iterate, also arms the line search (alpha = 1, done = 0);
 // with_alpha == 1: the trial point, followed by the filter line-search decision of this instance
 // ([upstream ocs2_sqp SqpSolver::takeStep / FilterLinesearch]): accept, halve alpha, or give up.
-// returns true when the instance is still searching after this trial
-__device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b, const int l) {
+// returns true when the instance is still searching after this trial; acc / al (meaningful on lane 0): the instance stands at an ACCEPTED step of length al after this
+// call (what `done[b] == 1 ? alpha[b] : 0` reads back — lane 0 knows it without the round trip)
+// Round 6: every load whose address depends on (b, l) only — the instance's state words, the first two node terms of the lane, its row of the initial-state defect, the
+// baseline sums and step figures the decision needs — is requested at the top, TOGETHER: the kernel is one dependent chain per instance, and each of those used to be a memory
+// round trip of its own on it (≈ 20 in a row: 31 µs for a few hundred flops).  Same sums in the same order.
+__device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b, const int l, int& acc, double& al_acc) {
   const int with_alpha = a.with_alpha;
-  if (with_alpha && a.done[b] != 0) return false;
-  const int n = a.n_nodes[b]; double c = 0.0, d = 0.0, e = 0.0;
-  for (int i = l; i < n; i += 64) { const double* pf = a.perf + (size_t)(i * a.B + b) * PF_SIZE; c += pf[0]; d += pf[1]; e += pf[2]; }
+  const int done0 = with_alpha ? a.done[b] : 0;
+  const int n = a.n_nodes[b];
   const double al0 = with_alpha ? a.alpha[b] : 0.0;
-  if (l < 30) { const double x0t = (with_alpha && a.xt) ? a.xt[b * 30 + l] : a.x[b * 30 + l] + al0 * a.dx[b * 30 + l]; const double dd = a.x0[(size_t)b * 30 + l] - x0t; d += dd * dd; }
+  const int j0 = (l < a.nmax) ? l : a.nmax - 1, j1 = (l + 64 < a.nmax) ? l + 64 : a.nmax - 1;      // (clamped: in bounds whatever n is)
+  const double* pf0 = a.perf + (size_t)(j0 * a.B + b) * PF_SIZE; const double* pf1 = a.perf + (size_t)(j1 * a.B + b) * PF_SIZE;
+  const double t00 = pf0[0], t01 = pf0[1], t02 = pf0[2], t10 = pf1[0], t11 = pf1[1], t12 = pf1[2];
+  double xa = 0.0, xb = 0.0, xc = 0.0;
+  if (l < 30) { xa = a.x0[(size_t)b * 30 + l]; if (with_alpha && a.xt) xb = a.xt[b * 30 + l]; else { xb = a.x[b * 30 + l]; xc = a.dx[b * 30 + l]; } }
+  double bs[4] = {0.0, 0.0, 0.0, 0.0}, si[3] = {0.0, 0.0, 0.0};
+  if (with_alpha) { bs[0] = a.base_sum[b * 4]; bs[1] = a.base_sum[b * 4 + 1]; bs[2] = a.base_sum[b * 4 + 2]; bs[3] = a.base_sum[b * 4 + 3]; si[0] = a.step_info[b * 4]; si[1] = a.step_info[b * 4 + 1]; si[2] = a.step_info[b * 4 + 2]; }
+  acc = (done0 == 1) ? 1 : 0; al_acc = acc ? al0 : 0.0;
+  if (with_alpha && done0 != 0) return false;
+  double c = 0.0, d = 0.0, e = 0.0;
+  if (l < n) { c += t00; d += t01; e += t02; }
+  if (l + 64 < n) { c += t10; d += t11; e += t12; }
+  for (int i = l + 128; i < n; i += 64) { const double* pf = a.perf + (size_t)(i * a.B + b) * PF_SIZE; c += pf[0]; d += pf[1]; e += pf[2]; }
+  if (l < 30) { const double x0t = (with_alpha && a.xt) ? xb : xb + al0 * xc; const double dd = xa - x0t; d += dd * dd; }
   c = qm_wave_sum(c); d = qm_wave_sum(d); e = qm_wave_sum(e);
   if (l != 0) return false;
   a.perf_sum[b * 4] = c; a.perf_sum[b * 4 + 1] = c; a.perf_sum[b * 4 + 2] = d; a.perf_sum[b * 4 + 3] = e;
@@ -332,25 +354,27 @@ __device__ __forceinline__ bool qm_perf_sum_body(const QmLsArgs& a, const int b,
     a.out_perf[b * 10 + 8] = 0.0;
     return false;
   }
-  if (a.trial == 0) a.out_perf[b * 10 + 9] = a.step_info[b * 4];
+  if (a.trial == 0) a.out_perf[b * 10 + 9] = si[0];
   if (a.ilqr) {
-    const double rho = a.st[ST_DDP_PENALTY]; const double* bs0 = a.base_sum + b * 4; const double armijo0 = a.step_info[b * 4];
-    const double m0 = bs0[1] + rho * sqrt(bs0[3]), mt = c + rho * sqrt(e);
+    const double rho = a.st[ST_DDP_PENALTY]; const double armijo0 = si[0];
+    const double m0 = bs[1] + rho * sqrt(bs[3]), mt = c + rho * sqrt(e);
     if (a.trial == 0) { a.out_perf[b * 10] = m0; a.out_perf[b * 10 + 4] = m0; }                       // (the Riccati prologue wrote the SQP's merit = cost)
-    if (mt < m0 + 1e-4 * al0 * armijo0) { a.done[b] = 1; a.out_perf[b * 10 + 4] = mt; a.out_perf[b * 10 + 5] = c; a.out_perf[b * 10 + 6] = d; a.out_perf[b * 10 + 7] = e; a.out_perf[b * 10 + 8] = al0; return false; }
+    if (mt < m0 + 1e-4 * al0 * armijo0) { a.done[b] = 1; a.out_perf[b * 10 + 4] = mt; a.out_perf[b * 10 + 5] = c; a.out_perf[b * 10 + 6] = d; a.out_perf[b * 10 + 7] = e; a.out_perf[b * 10 + 8] = al0; acc = 1; al_acc = al0; return false; }
     const double an = al0 * 0.5;
     if (!(an >= a.st[ST_DDP_MIN_STEP])) { a.done[b] = 2; a.alpha[b] = 0.0; return false; }
     a.alpha[b] = an; return true;
   }
-  return qm_ls_filter_decide(a, b, al0, c, d, e) == 0;
+  const int code = qm_ls_filter_decide_v(a, b, al0, c, d, e, bs, si);
+  acc = (code == 1) ? 1 : 0; al_acc = acc ? al0 : 0.0;
+  return code == 0;
 }
 __global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
   const int b = blockIdx.x, l = threadIdx.x & 63;
   if (b >= a.B) return;
-  const bool open = qm_perf_sum_body(a, b, l);
+  int acc = 0; double al = 0.0;
+  const bool open = qm_perf_sum_body(a, b, l, acc, al);
   if (a.with_alpha && a.p0_x) {      // the policy at t0 of what the decision stands at: the accepted step, or the iterate itself while the search goes on / when it gave up (qm_ls_tail overwrites it on acceptance)
-    int acc = 0; double al = 0.0; if (l == 0) { acc = a.done[b] == 1; al = acc ? a.alpha[b] : 0.0; }      // (lane 0 made the decision and reads its own stores)
-    acc = __shfl(acc, 0, 64); al = __shfl(al, 0, 64);
+    acc = __shfl(acc, 0, 64); al = __shfl(al, 0, 64);      // (lane 0 made the decision)
     qm_ls_policy_at_t0(a, b, l, al);
   }
   // the host only needs to know whether ANY instance is still searching: count them, and let the block that arrives last publish the count
@@ -358,8 +382,10 @@ __global__ void __launch_bounds__(64) qm_perf_sum_kernel(QmLsArgs a) {
   if (a.with_alpha && a.open_cnt && l == 0) {
     const int t = a.trial;
     if (open) atomicAdd(a.open_cnt + t, 1);
-    __threadfence();
-    if (atomicAdd(a.tickets + t, 1) == a.B - 1) { a.host_open[t] = atomicAdd(a.open_cnt + t, 0); __threadfence_system(); }
+    if (a.tickets) {      // (only the host-driven trial loop waits for the published count; with the device-side tail — tickets == nullptr — the counts are read back on demand)
+      __threadfence();
+      if (atomicAdd(a.tickets + t, 1) == a.B - 1) { a.host_open[t] = atomicAdd(a.open_cnt + t, 0); __threadfence_system(); }
+    }
   }
 }
 
