@@ -38,7 +38,7 @@ struct QmRiccatiArgs {
   // baseline performance of the current iterate (sum of K1b's node terms) + arming of the line search, done by the instance's wave before the sweep
   // (what a separate one-wave-per-instance launch did: qm_perf_sum_kernel with with_alpha == 0); perf == nullptr: skipped
   const double* perf; double* base_sum; double* alpha; int* done; double* out_perf; int* open_cnt; int* tickets;
-  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages, 64 lean operand prefetch (rw_prefetch), 128 nothing (the instrumented instance as it is): results are then
+  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages, 64 lean operand prefetch (rw_prefetch), 256 no gain stores, 128 nothing (the instrumented instance as it is): results are then
                                                // meaningless; 32: results intact, per-phase cycle counts are written to SR_K of each instance's first stage record)
 };
 
@@ -374,6 +374,20 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
       }
     { qm_d4 Kf[MT][2]; rw_zero<MT, 2>(Kf);
       rw_gemm_tn<MT, MT, 2>(Gs, W, Kf, (m + 3) >> 2, true);
+      if (MT == 1) {
+        // One tile row of reduced inputs (m = 14, 15, 16): EIGHT UNCONDITIONAL stores from two per-lane bases.  Left tile: K[row][c], rows g + 4 r at a stride of 4 x 30 doubles.
+        // Right tile: lane columns < 14 -> K[row][16 + c]; lane column 14 -> the offset k[row] (stride 4); lane column 15 (the tile's padding column) -> a slot of the
+        // record's profiling area nobody reads.  Rows m .. 15 exist in the record (the gain has 18 rows, the offset 18 entries) and are never read: their (finite) values
+        // go out with the rest.  (Round 6: one lane-conditional region and one 64-bit address per element cost this lone wave ≈ 650 cycles per stage, 3 % of the sweep —
+        // measured with the stores left out, profiles/r06_ab_riccati_dma.log)
+        if (!(PROF && (skip & 256))) {
+          double* p0 = rec + SR_PP + g * 30 + c;
+          double* p1 = (c < 14) ? rec + SR_PP + g * 30 + 16 + c : ((c == 14) ? rec + SR_KFF + g : rec + SR_K + 16 + g);
+          const int st1 = (c < 14) ? 120 : 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { p0[120 * r] = Kf[0][0][r]; p1[st1 * r] = Kf[0][1][r]; }
+        }
+      } else
 #pragma unroll
       for (int I = 0; I < MT; ++I)
 #pragma unroll
@@ -382,7 +396,7 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
 #pragma unroll
           for (int J = 0; J < 2; ++J) {
             const int col = 16 * J + c;
-            if (row < m) { if (col < 30) rec[SR_PP + row * 30 + col] = Kf[I][J][r]; else if (col == 30) rec[SR_KFF + row] = Kf[I][J][r]; }
+            if (row < m && !(PROF && (skip & 256))) { if (col < 30) rec[SR_PP + row * 30 + col] = Kf[I][J][r]; else if (col == 30) rec[SR_KFF + row] = Kf[I][J][r]; }      // (skip bit 256, instrumented instance only: the gain is NOT stored — what the stores' acknowledgements cost the next stage's operand wait; results meaningless)
           }
         } }
   } else rw_zero<MT, 2>(W);
