@@ -7,12 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np
 from qm_control_amd import api, scenarios
 if os.environ.get("QM_AB_LIB"): api.LIB_PATH = os.path.join(ROOT, os.environ["QM_AB_LIB"])
-B = 1024; nm = 128; SR = 7360; SRK = 4752
+sys.path.insert(0, os.path.join(ROOT, "tests")); import lq_record_check as LC
+B = 1024; nm = 128; SR = LC.SR["SR_SIZE"]; SRK = LC.SR["SR_K"]      # (record layout from the header: the stamps live in SR_K of every stage record)
 cfg = scenarios.make_config("C4", batch=B)
 itf = api.QMInterface(blobs=scenarios.load_blobs(), max_batch=B, max_nodes=nm, max_ref_knots=2, max_events=cfg["ev"].shape[1])
 mpc = api.SqpMpc(itf); mpc.set_problem(cfg["t0"], cfg["x0"], cfg["ref_t"], cfg["ref_x"], cfg["ev"], cfg["modes"])
 mpc.solve_resident(cfg["horizon"]); itf.synchronize()
-itf.debug_set("lq_prof", 1)
+itf.debug_set("lq_prof", 1); itf.debug_set("riccati_skip", 20)      # (K3 would overwrite nothing here, but its backward stage is skipped so that the records stay as K1b left them)
 mpc.solve_resident(cfg["horizon"]); itf.synchronize()
 rows = itf.debug_read("stage", (B * nm, SR)).reshape(B, nm, SR)[:, :, SRK:SRK + 18]
 valid = (rows[:, :, 10] > 1e2) & (rows[:, :, 10] < 1e6) & (rows[:, :, 9] > 1e3) & (rows[:, :, 9] < 1e7) & (rows[:, :, 12] > rows[:, :, 11])
