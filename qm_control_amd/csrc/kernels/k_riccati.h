@@ -38,7 +38,7 @@ struct QmRiccatiArgs {
   // baseline performance of the current iterate (sum of K1b's node terms) + arming of the line search, done by the instance's wave before the sweep
   // (what a separate one-wave-per-instance launch did: qm_perf_sum_kernel with with_alpha == 0); perf == nullptr: skipped
   const double* perf; double* base_sum; double* alpha; int* done; double* out_perf; int* open_cnt; int* tickets;
-  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages, 64 lean operand prefetch (rw_prefetch), 256 no gain stores, 128 nothing (the instrumented instance as it is): results are then
+  int skip;                                    // profiling only (bit mask: 1 Cholesky/solve, 2 matrix products, 4 forward, 8 symmetrise, 16 all regular backward stages, 64 lean operand prefetch (rw_prefetch), 256 no gain stores, 512 the rollout's fetch without its last two chunks, 128 nothing (the instrumented instance as it is): results are then
                                                // meaningless; 32: results intact, per-phase cycle counts are written to SR_K of each instance's first stage record)
 };
 
@@ -549,9 +549,9 @@ __device__ __forceinline__ void qm_riccati_body(QmRiccatiArgs a) {
     for (int t0 = 0; t0 < 12; t0 += 4) {
       const qm_lds_ptr l3 = F + 1024 * t0;
       qm_dma16_at<0>((const char*)(rec + fsrc[t0]), l3); qm_dma16_at<1024>((const char*)(rec + fsrc[t0 + 1]), l3);
-      qm_dma16_at<2048>((const char*)(rec + fsrc[t0 + 2]), l3); qm_dma16_at<3072>((const char*)(rec + fsrc[t0 + 3]), l3);
+      qm_dma16_at<2048>((const char*)(rec + fsrc[t0 + 2]), l3); if (!(PROF && (a.skip & 512) && t0 == 8)) qm_dma16_at<3072>((const char*)(rec + fsrc[t0 + 3]), l3);
     }
-    if (fsrc[12] >= 0) qm_dma16_at<0>((const char*)(rec + fsrc[12]), F + 1024 * 12);
+    if (fsrc[12] >= 0 && !(PROF && (a.skip & 512))) qm_dma16_at<0>((const char*)(rec + fsrc[12]), F + 1024 * 12);      // (skip bit 512, instrumented instance only: the rollout's fetch without its last two chunks — is the rollout bound by its bytes?)
   };
   int cur = 0;
   { int k0 = 0; while (k0 < n - 1 && evlist(k0) == QM_EV_PRE) ++k0; if (k0 < n - 1 && !(a.skip & 4)) fetch(k0, 0); }
