@@ -89,9 +89,6 @@ static_assert(KR_USED + 7 <= KR_SIZE && KR_SIZE % 8 == 0, "kin record: whole 64-
 
 // LDS carve (doubles) of one wave
 #define LW_BLOCK 64
-#ifndef QM_LQ_X
-#define QM_LQ_X 0
-#endif
 #define LW_TLD 33                   /* odd: the transposed fragment reads (lanes run down a column, stride LW_TLD doubles) then hit 16 different bank pairs; 34 made them 2-way conflicts (K1b − 0.5 %) */
 #define LW_T     0                    /* [32][LW_TLD] hand-over tile (columns from lanes -> fragments) */
 #define LW_V     (32 * LW_TLD)
@@ -169,14 +166,14 @@ __device__ __forceinline__ void lw_bp(double* S, double* rec, int m, const qm_d4
 #pragma unroll
     for (int J = 0; J < 2; ++J)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) QM_LDS_ST1(&T[(16 * I + g + 4 * r) * LW_TLD + 16 * J + c], Bdt[I][J][r]);
+      for (int r = 0; r < 4; ++r) T[(16 * I + g + 4 * r) * LW_TLD + 16 * J + c] = Bdt[I][J][r];
   qm_wave_sync();
   qm_d4 Bp[1][MT];                                             // rows 0..11 only
 #pragma unroll
   for (int J = 0; J < MT; ++J) {
     const int j = 16 * J + c; const int ci0 = (int)PD[j]; const double w0 = PD[32 + 3 * j], w1 = PD[33 + 3 * j], w2 = PD[34 + 3 * j];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int row = g + 4 * r; const double* src = T + ci0 * LW_TLD + row; Bp[0][J][r] = w0 * QM_LDS_LD1(src) + w1 * QM_LDS_LD1(src + LW_TLD) + w2 * QM_LDS_LD1(src + 2 * LW_TLD); }
+    for (int r = 0; r < 4; ++r) { const int row = g + 4 * r; const double* src = T + ci0 * LW_TLD + row; Bp[0][J][r] = w0 * src[0] + w1 * src[LW_TLD] + w2 * src[2 * LW_TLD]; }
   }
   qm_frag_store<1, MT, true>(Bp, rec + SR_BP, QM_MMAX, 12, m);
   qm_wave_sync();
@@ -208,7 +205,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_p
 #pragma unroll
       for (int J = 0; J < 2; ++J)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) QM_LDS_ST1(&T[(16 * I + g + 4 * r) * LW_TLD + 16 * J + c], F[I][J][r]);
+        for (int r = 0; r < 4; ++r) T[(16 * I + g + 4 * r) * LW_TLD + 16 * J + c] = F[I][J][r];
   };
   // [R Px | R Pe + r]: Px rows 12..23 (k-steps 3..5); Pe also has rows 0..11 (column 30 only -> tile column 1, k-steps 0..2)
   qm_d4 RPx[2][2]; qm_frag_zero<2, 2>(RPx);
@@ -251,7 +248,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_p
 #pragma unroll
       for (int J = 0; J < 2; ++J)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int j = 16 * I + g + 4 * r; const double* src = T + (int)PD[j] * LW_TLD + 16 * J + c; Pp[I][J][r] = PD[32 + 3 * j] * QM_LDS_LD1(src) + PD[33 + 3 * j] * QM_LDS_LD1(src + LW_TLD) + PD[34 + 3 * j] * QM_LDS_LD1(src + 2 * LW_TLD); }
+        for (int r = 0; r < 4; ++r) { const int j = 16 * I + g + 4 * r; const double* src = T + (int)PD[j] * LW_TLD + 16 * J + c; Pp[I][J][r] = PD[32 + 3 * j] * src[0] + PD[33 + 3 * j] * src[LW_TLD] + PD[34 + 3 * j] * src[2 * LW_TLD]; }
     // [Pp | rp]: rows >= m are zero in the record (K3's Wᵀ W runs over whole k-steps); of the second tile row only rows 16..19 (register 0) can be live (m <= 18)
 #pragma unroll
     for (int J = 0; J < 2; ++J) {
@@ -271,7 +268,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           double v = 0.0;
-          if (J < MT) { const double* src = T + (16 * I + g + 4 * r) * LW_TLD + ci0[J < MT ? J : 0]; v = cw[J < MT ? J : 0][0] * QM_LDS_LD1(src) + cw[J < MT ? J : 0][1] * QM_LDS_LD1(src + 1) + cw[J < MT ? J : 0][2] * QM_LDS_LD1(src + 2); }
+          if (J < MT) { const double* src = T + (16 * I + g + 4 * r) * LW_TLD + ci0[J < MT ? J : 0]; v = cw[J < MT ? J : 0][0] * src[0] + cw[J < MT ? J : 0][1] * src[1] + cw[J < MT ? J : 0][2] * src[2]; }
           RPu[I][J][r] = v;
         }
     qm_wave_sync(); tile_put(RPu); qm_wave_sync();
@@ -281,7 +278,7 @@ __device__ __forceinline__ void lw_project(double* S, double* rec, double* dbg_p
 #pragma unroll
       for (int J = 0; J < MT; ++J)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int j = 16 * I + g + 4 * r; const double* src = T + (int)PD[j] * LW_TLD + 16 * J + c; Rp[I][J][r] = PD[32 + 3 * j] * QM_LDS_LD1(src) + PD[33 + 3 * j] * QM_LDS_LD1(src + LW_TLD) + PD[34 + 3 * j] * QM_LDS_LD1(src + 2 * LW_TLD); }
+        for (int r = 0; r < 4; ++r) { const int j = 16 * I + g + 4 * r; const double* src = T + (int)PD[j] * LW_TLD + 16 * J + c; Rp[I][J][r] = PD[32 + 3 * j] * src[0] + PD[33 + 3 * j] * src[LW_TLD] + PD[34 + 3 * j] * src[2 * LW_TLD]; }
     // Rp: zero outside [0, m) x [0, m) (K3 puts the unit diagonal of the padding rows itself); the lower-left tile is never read (symmetric)
 #pragma unroll
     for (int r = 0; r < 4; ++r) QM_STREAM_ST(frag + SR_F_RP + r * 64, (g + 4 * r < m && c < m) ? Rp[0][0][r] : 0.0);
@@ -333,7 +330,7 @@ template <int N> __device__ __forceinline__ void kin_emit(const KinOut& o, int o
     qm_wave_sync();
   }
 }
-__global__ void __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
   const int l = threadIdx.x & 63;
   const size_t g0 = (size_t)a.i0 * a.B + (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
   size_t g = g0 + l; if (g >= nrows) g = nrows - 1;                             // (rows behind the arrays' end: the last wave of a launch that covers all nmax nodes)
@@ -896,7 +893,7 @@ __device__ __forceinline__ int qm_lq_node_mt(const QmLqArgs& a) {
 #ifndef QM_LQ_WAVES
 #define QM_LQ_WAVES 3      /* waves per SIMD the two product instances are compiled for */
 #endif
-__global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_kernel(QmLqArgs a) { if (a.single_mt || qm_lq_node_mt(a) == 1) qm_lq_body<false, 1>(a); }
-__global__ void __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_m18_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 2) qm_lq_body<false, 2>(a); }
-__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_ipm_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<false, 1, true>(a); else qm_lq_body<false, 2, true>(a); }      // interior-point instance (solver 3, k_ipm.h)
-__global__ void __launch_bounds__(LW_BLOCK, 2) qm_lq_dbg_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<true, 1>(a); else qm_lq_body<true, 2>(a); }
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_kernel(QmLqArgs a) { if (a.single_mt || qm_lq_node_mt(a) == 1) qm_lq_body<false, 1>(a); }
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_m18_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 2) qm_lq_body<false, 2>(a); }
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(LW_BLOCK, 2) qm_lq_ipm_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<false, 1, true>(a); else qm_lq_body<false, 2, true>(a); }      // interior-point instance (solver 3, k_ipm.h)
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(LW_BLOCK, 2) qm_lq_dbg_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<true, 1>(a); else qm_lq_body<true, 2>(a); }

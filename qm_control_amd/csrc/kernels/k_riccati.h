@@ -646,8 +646,8 @@ __device__ __forceinline__ void qm_riccati_body(QmRiccatiArgs a) {
   }
   if (l == 0) { a.step_info[b * 4] = arm; a.step_info[b * 4 + 1] = sx; a.step_info[b * 4 + 2] = su; a.step_info[b * 4 + 3] = (double)chol_fail; }
 }
-__global__ void __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) { qm_riccati_body<false>(a); }
-__global__ void __launch_bounds__(RW_BLOCK) qm_riccati_prof_kernel(QmRiccatiArgs a) { qm_riccati_body<true>(a); }      // profiling / parity switches only (a.skip != 0)
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(RW_BLOCK) qm_riccati_kernel(QmRiccatiArgs a) { qm_riccati_body<false>(a); }
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(RW_BLOCK) qm_riccati_prof_kernel(QmRiccatiArgs a) { qm_riccati_body<true>(a); }      // profiling / parity switches only (a.skip != 0)
 #undef mlist
 #undef evlist
 #undef modelist

@@ -1035,5 +1035,5 @@ __device__ __forceinline__ void qm_wbc_body(const QmWbcArgs& a) {
     if (l < 12) d[1098 + l] = TIP_A(tipsM + 27 * (l / 3))[l % 3];
   }
 }
-__global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) { qm_wbc_body<false>(a); }
-__global__ void __launch_bounds__(WBC_BLOCK) qm_wbc_prof_kernel(QmWbcArgs a) { qm_wbc_body<true>(a); }      // profiling only (a.stop < 0)
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(WBC_BLOCK) qm_wbc_kernel(QmWbcArgs a) { qm_wbc_body<false>(a); }
+__global__ void QM_UNPAIRED_LDS __launch_bounds__(WBC_BLOCK) qm_wbc_prof_kernel(QmWbcArgs a) { qm_wbc_body<true>(a); }      // profiling only (a.stop < 0)

@@ -45,11 +45,11 @@ typedef const double __attribute__((address_space(4)))* qm_ctab;
                                           region — s_and_saveexec / s_cbranch_execz / s_or per element, three scalar instructions and a branch around one ds_read (K1b had 300 such regions) */
 #define QM_LOADED(d) asm volatile("" : "+v"(d))
 #endif
-#ifndef QM_LDS_ST1                      /* an 8-byte LDS store / load the compiler may NOT pair into ds_write2_b64 / ds_read2_b64 (a relaxed wavefront-scope atomic: no fence, no wait, no cache
-                                          bits — only the merge is off).  Measured on gfx950 (tools/probes/lds_width_probe.hip): 16 bytes per lane cost 8.0 units as two ds_read_b64, 13.4 as ds_read2_b64;
-                                          15.1 as two ds_write_b64, 24.3 as ds_write2_b64 */
-#define QM_LDS_ST1(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
-#define QM_LDS_LD1(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+#ifndef QM_UNPAIRED_LDS                 /* kernel attribute: the backend's load/store optimizer does not pair this kernel's 8-byte LDS accesses into ds_read2_b64 / ds_write2_b64 (nor its
+                                          global ones into wider ones).  Measured on gfx950 (tools/probes/lds_width_probe.hip, profiles/r06_lds_width_probe.log): 16 bytes per lane cost the LDS 8.0 units
+                                          as two ds_read_b64 and 13.4 as one ds_read2_b64; 15.1 as two ds_write_b64, 24.3 as ds_write2_b64.  The IR-level vectorizer that forms the same pairs earlier is
+                                          switched off for the whole library by the build (qm_control_amd/build_flags.py) */
+#define QM_UNPAIRED_LDS __attribute__((target("no-load-store-opt")))
 #endif
 __device__ __forceinline__ const double* qm_table(const double* p) { qm_ctab c = (qm_ctab)(p); QM_TABLE_OPAQUE(c); return (const double*)c; }
 
@@ -318,7 +318,7 @@ __device__ __forceinline__ void qm_frag_load_tile(qm_d4 (&T)[IT][JT], const doub
 #pragma unroll
     for (int J = 0; J < JT; ++J)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; T[I][J][r] = QM_LDS_LD1(TR ? src + col * ld + row : src + row * ld + col); }
+      for (int r = 0; r < 4; ++r) { const int row = 16 * I + g + 4 * r, col = 16 * J + c; T[I][J][r] = TR ? src[col * ld + row] : src[row * ld + col]; }
 }
 // STREAMING data — written once by one kernel, read once by a later one, with gigabytes of other traffic in between (stage records K1b -> K3: 2.8 GB per launch) —
 // is stored with the non-temporal hint (global_store ... nt): the lines do not stay in L2 / MALL at the expense of what IS re-read (measured: K3 − 7 %, step − 3 %)

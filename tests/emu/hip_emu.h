@@ -27,8 +27,7 @@
 #define QM_MAX_VGPRS(n)            /* register caps mean nothing on the host */
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)   /* instruction-scheduling fence: no meaning on the host */
 #define QM_TABLE_OPAQUE(p)            /* device-only register constraint */
-#define QM_LDS_ST1(p, v) (*(p) = (v))  /* device-only: an unpaired LDS store / load */
-#define QM_LDS_LD1(p) (*(p))
+#define QM_UNPAIRED_LDS               /* device-only kernel attribute */
 #define QM_LANE_OPAQUE(i)             /* device-only register constraint */
 #define QM_PIN4(q) ((void)0)             /* device-only scheduling pin */
 #define QM_LOADED(d)                  /* device-only: "this value is loaded here" */

@@ -5,6 +5,8 @@ K1b is compiled with QM_LQ_RB_ONLY=1: without the dense R0 (u - u_nom) path a wa
 usage: python tools/isa_hist.py [--other] [--lines N] [kernel ...]      (default kernels: qm_lq_kernel qm_riccati_kernel qm_wbc_kernel)"""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from qm_control_amd.build_flags import HIPCC_FLAGS      # the product build's flags
 
 
 def classify(op):
@@ -23,7 +25,7 @@ def main(argv):
     if argv and argv[0] == '--lines': nlines = int(argv[1]); argv = argv[2:]
     kernels = argv or ['qm_lq_kernel', 'qm_riccati_kernel', 'qm_wbc_kernel']
     with tempfile.TemporaryDirectory() as d:
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-Wno-unused-value', '-Wno-unused-result'] + (['-gline-tables-only'] if nlines else []) +
+        subprocess.check_call(['/opt/rocm/bin/hipcc'] + HIPCC_FLAGS + (['-gline-tables-only'] if nlines else []) +
                               ['-DQM_LQ_RB_ONLY=1', '-I' + os.path.join(ROOT, 'include'), '--save-temps', '-c', os.path.join(ROOT, 'qm_control_amd', 'csrc', 'host', 'qmhip.hip'), '-o', os.path.join(d, 'q.o')], cwd=d, stderr=subprocess.DEVNULL)
         s = open(os.path.join(d, 'qmhip-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
     files = {int(m.group(1)): (m.group(3) or m.group(2)).split('/')[-1] for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', s)}

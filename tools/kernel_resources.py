@@ -3,11 +3,13 @@
 usage: python tools/kernel_resources.py [out.csv]"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from qm_control_amd.build_flags import HIPCC_FLAGS      # the product build's flags
 
 
 def main(out=None):
     with tempfile.TemporaryDirectory() as d:
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), "--save-temps", "-c",
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "--save-temps", "-c",
                                os.path.join(ROOT, "qm_control_amd", "csrc", "host", "qmhip.hip"), "-o", os.path.join(d, "qmhip.o")], cwd=d, stderr=subprocess.DEVNULL)
         s = open(os.path.join(d, "qmhip-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     lines = ["kernel,vgpr_total,accum_offset,sgpr,scratch_bytes_per_lane,waves_per_simd"]
