@@ -7,3 +7,9 @@ none relies on the pass for its global accesses (the wide ones are written as do
 nothing slower.  The machine-level pass that forms the same pairs later is switched off per kernel (QM_UNPAIRED_LDS in qm_dev_common.h) where that was measured to pay.
 """
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Wno-unused-result", "-mllvm", "-amdgpu-load-store-vectorizer=0"]
+
+# Translation units of the device library: (source relative to the repo root, extra flags).  K1b's instances are compiled with the max-ILP scheduling strategy
+# (qm_control_amd/csrc/host/qmhip_lq.hip says why); everything else with the default one.
+DEVICE_UNITS = [("qm_control_amd/csrc/host/qmhip.hip", []),
+                ("qm_control_amd/csrc/host/qmhip_lq.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])]
+HOST_UNITS = ["qm_control_amd/csrc/host/qm_model_io.cpp"]

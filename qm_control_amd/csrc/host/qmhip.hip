@@ -11,6 +11,7 @@
 #include <vector>
 #include "../../../include/qmhip.h"
 #include "qm_model_io.h"
+#define QM_LQ_KERNELS_EXTERN 1      /* K1b's instances live in qmhip_lq.hip */
 #include "qm_pipeline.h"
 #include "qm_wbc_pipeline.h"
 #include "qm_sim_pipeline.h"

@@ -330,6 +330,7 @@ template <int N> __device__ __forceinline__ void kin_emit(const KinOut& o, int o
     qm_wave_sync();
   }
 }
+#ifndef QM_LQ_ONLY_K1B      /* (qmhip_lq.hip, the translation unit of the K1b instances: K1a stays in the main one) */
 __global__ void QM_UNPAIRED_LDS __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqArgs a) {
   const int l = threadIdx.x & 63;
   const size_t g0 = (size_t)a.i0 * a.B + (size_t)blockIdx.x * 64, nrows = (size_t)a.nmax * a.B;      // first row of this wave's block (blockDim.x == 64)
@@ -367,6 +368,7 @@ __global__ void QM_UNPAIRED_LDS __launch_bounds__(64, 2) qm_lq_kin_kernel(QmLqAr
   flow_head_from_kin(mb2, x2, u, K, f);
   kin_emit<12>(o, KR_F2, f);
 }
+#endif
 
 // ---- K1b: one wavefront per node ----
 // DBG: the instance that also writes the debug records (a.dbg) and the phase cycle stamps (a.prof) — parity tests and profiling; the product instance has neither branch
@@ -893,7 +895,12 @@ __device__ __forceinline__ int qm_lq_node_mt(const QmLqArgs& a) {
 #ifndef QM_LQ_WAVES
 #define QM_LQ_WAVES 3      /* waves per SIMD the two product instances are compiled for */
 #endif
+#ifdef QM_LQ_KERNELS_EXTERN      /* the main translation unit (qmhip.hip): the four instances of the K1b body are compiled in qmhip_lq.hip with their own scheduling strategy
+                                    (qm_control_amd/build_flags.py: max-ilp pays for this kernel — 2.4 waves per SIMD — and costs the lone-wave kernels 5 %) */
+__global__ void qm_lq_kernel(QmLqArgs a); __global__ void qm_lq_m18_kernel(QmLqArgs a); __global__ void qm_lq_ipm_kernel(QmLqArgs a); __global__ void qm_lq_dbg_kernel(QmLqArgs a);
+#else
 __global__ void QM_UNPAIRED_LDS __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_kernel(QmLqArgs a) { if (a.single_mt || qm_lq_node_mt(a) == 1) qm_lq_body<false, 1>(a); }
 __global__ void QM_UNPAIRED_LDS __launch_bounds__(LW_BLOCK, QM_LQ_WAVES) qm_lq_m18_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 2) qm_lq_body<false, 2>(a); }
 __global__ void QM_UNPAIRED_LDS __launch_bounds__(LW_BLOCK, 2) qm_lq_ipm_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<false, 1, true>(a); else qm_lq_body<false, 2, true>(a); }      // interior-point instance (solver 3, k_ipm.h)
 __global__ void QM_UNPAIRED_LDS __launch_bounds__(LW_BLOCK, 2) qm_lq_dbg_kernel(QmLqArgs a) { if (qm_lq_node_mt(a) == 1) qm_lq_body<true, 1>(a); else qm_lq_body<true, 2>(a); }
+#endif

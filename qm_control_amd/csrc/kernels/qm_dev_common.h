@@ -49,7 +49,11 @@ typedef const double __attribute__((address_space(4)))* qm_ctab;
                                           global ones into wider ones).  Measured on gfx950 (tools/probes/lds_width_probe.hip, profiles/r06_lds_width_probe.log): 16 bytes per lane cost the LDS 8.0 units
                                           as two ds_read_b64 and 13.4 as one ds_read2_b64; 15.1 as two ds_write_b64, 24.3 as ds_write2_b64.  The IR-level vectorizer that forms the same pairs earlier is
                                           switched off for the whole library by the build (qm_control_amd/build_flags.py) */
+#if defined(__HIP_DEVICE_COMPILE__)
 #define QM_UNPAIRED_LDS __attribute__((target("no-load-store-opt")))
+#else
+#define QM_UNPAIRED_LDS      /* (the host pass of the same source: not a feature of the host target) */
+#endif
 #endif
 __device__ __forceinline__ const double* qm_table(const double* p) { qm_ctab c = (qm_ctab)(p); QM_TABLE_OPAQUE(c); return (const double*)c; }
 

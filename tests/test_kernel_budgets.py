@@ -12,20 +12,30 @@ LIB = os.path.join(ROOT, "qm_control_amd", "libqmhip.so")
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
-def _code_object():
-    blob = open(LIB, "rb").read(); i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__"); assert i >= 0, "no offload bundle in libqmhip.so"
-    n = struct.unpack_from("<Q", blob, i + 24)[0]; p = i + 32; co = None
-    for _ in range(n):
-        off, size, tl = struct.unpack_from("<QQQ", blob, p); p += 24; triple = blob[p:p + tl].decode(); p += tl
-        if "gfx950" in triple: co = blob[i + off:i + off + size]
-    assert co, "no gfx950 code object"
-    return co
+def _code_objects():
+    """the gfx950 code object of every translation unit of the library (one offload bundle each: qmhip.hip, qmhip_lq.hip — qm_control_amd/build_flags.py)"""
+    blob = open(LIB, "rb").read(); cos = []; i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__"); assert i >= 0, "no offload bundle in libqmhip.so"
+    while i >= 0:
+        n = struct.unpack_from("<Q", blob, i + 24)[0]; p = i + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, p); p += 24; triple = blob[p:p + tl].decode(); p += tl
+            if "gfx950" in triple and size > 0: cos.append(blob[i + off:i + off + size])
+        i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__", i + 1)
+    assert cos, "no gfx950 code object"
+    return cos
+
+
+def _readelf(args):
+    out = ""
+    for co in _code_objects():
+        with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+            f.write(co); f.flush(); out += subprocess.run([READELF] + args + [f.name], capture_output=True, text=True, check=True).stdout
+    return out
 
 
 def _code_bytes():
     """machine-code size of every kernel (symbol table of the gfx950 code object)"""
-    with tempfile.NamedTemporaryFile(suffix=".elf") as f:
-        f.write(_code_object()); f.flush(); syms = subprocess.run([READELF, "-s", "--wide", f.name], capture_output=True, text=True, check=True).stdout
+    syms = _readelf(["-s", "--wide"])
     out = {}
     for line in syms.splitlines():
         m = re.search(r"\s(\d+)\s+FUNC\s+\S+\s+\S+\s+\S+\s+_Z\d+(qm_\w+_kernel)\w*$", line)
@@ -34,9 +44,7 @@ def _code_bytes():
 
 
 def _kernels():
-    co = _code_object()
-    with tempfile.NamedTemporaryFile(suffix=".elf") as f:
-        f.write(co); f.flush(); notes = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+    notes = _readelf(["--notes"])
     out = {}
     for blk in notes.split("  - .agpr_count:")[1:]:
         g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))

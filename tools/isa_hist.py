@@ -6,7 +6,7 @@ usage: python tools/isa_hist.py [--other] [--lines N] [kernel ...]      (default
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from qm_control_amd.build_flags import HIPCC_FLAGS      # the product build's flags
+from qm_control_amd.build_flags import HIPCC_FLAGS, DEVICE_UNITS      # the product build's flags
 
 
 def classify(op):
@@ -25,13 +25,19 @@ def main(argv):
     if argv and argv[0] == '--lines': nlines = int(argv[1]); argv = argv[2:]
     kernels = argv or ['qm_lq_kernel', 'qm_riccati_kernel', 'qm_wbc_kernel']
     with tempfile.TemporaryDirectory() as d:
-        subprocess.check_call(['/opt/rocm/bin/hipcc'] + HIPCC_FLAGS + (['-gline-tables-only'] if nlines else []) +
-                              ['-DQM_LQ_RB_ONLY=1', '-I' + os.path.join(ROOT, 'include'), '--save-temps', '-c', os.path.join(ROOT, 'qm_control_amd', 'csrc', 'host', 'qmhip.hip'), '-o', os.path.join(d, 'q.o')], cwd=d, stderr=subprocess.DEVNULL)
-        s = open(os.path.join(d, 'qmhip-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
-    files = {int(m.group(1)): (m.group(3) or m.group(2)).split('/')[-1] for m in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', s)}
+        units = []
+        for src, extra in DEVICE_UNITS:      # every translation unit with its own flags (qm_control_amd/build_flags.py)
+            stem = os.path.splitext(os.path.basename(src))[0]
+            subprocess.check_call(['/opt/rocm/bin/hipcc'] + HIPCC_FLAGS + extra + (['-gline-tables-only'] if nlines else []) +
+                                  ['-DQM_LQ_RB_ONLY=1', '-I' + os.path.join(ROOT, 'include'), '--save-temps', '-c', os.path.join(ROOT, src), '-o', os.path.join(d, stem + '.o')], cwd=d, stderr=subprocess.DEVNULL)
+            units.append(open(os.path.join(d, stem + '-hip-amdgcn-amd-amdhsa-gfx950.s')).read())
     for name in kernels:
-        m = re.search(r'^(_Z\d+%s\w*):[^\n]*\n(.*?)\n\.Lfunc_end' % name, s, re.S | re.M)
+        m = None
+        for s in units:
+            m = re.search(r'^(_Z\d+%s\w*):[^\n]*\n(.*?)\n\.Lfunc_end' % name, s, re.S | re.M)
+            if m: break
         if not m: print(name, 'not found'); continue
+        files = {int(f.group(1)): (f.group(3) or f.group(2)).split('/')[-1] for f in re.finditer(r'\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', s)}
         cls = collections.Counter(); ops = collections.Counter(); per = collections.Counter(); perop = collections.defaultdict(collections.Counter); cur = None
         for line in m.group(2).split('\n'):
             t = line.strip()

@@ -4,14 +4,17 @@ usage: python tools/kernel_resources.py [out.csv]"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from qm_control_amd.build_flags import HIPCC_FLAGS      # the product build's flags
+from qm_control_amd.build_flags import HIPCC_FLAGS, DEVICE_UNITS      # the product build's flags
 
 
 def main(out=None):
     with tempfile.TemporaryDirectory() as d:
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "--save-temps", "-c",
-                               os.path.join(ROOT, "qm_control_amd", "csrc", "host", "qmhip.hip"), "-o", os.path.join(d, "qmhip.o")], cwd=d, stderr=subprocess.DEVNULL)
-        s = open(os.path.join(d, "qmhip-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+        s = ""
+        for src, extra in DEVICE_UNITS:      # every translation unit with its own flags (qm_control_amd/build_flags.py)
+            stem = os.path.splitext(os.path.basename(src))[0]
+            subprocess.check_call(["/opt/rocm/bin/hipcc"] + HIPCC_FLAGS + extra + ["-I" + os.path.join(ROOT, "include"), "--save-temps", "-c", os.path.join(ROOT, src), "-o", os.path.join(d, stem + ".o")],
+                                  cwd=d, stderr=subprocess.DEVNULL)
+            s += open(os.path.join(d, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     lines = ["kernel,vgpr_total,accum_offset,sgpr,scratch_bytes_per_lane,waves_per_simd"]
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
         body = m.group(2); g = lambda k: int((re.search(r"\.amdhsa_%s (\d+)" % k, body) or [None, "0"])[1])
