@@ -469,7 +469,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   // ---- phase II: equality rows + closed-form block projection ----
   // rows ordered per contact i = LF,RF,LH,RH: swing -> [F_i = 0 (3)] , stance -> [v_i = 0 (3)] , swing -> [v_iz = zvel_ref (1)]
   // tile rows 0..15 = C (state part), rows 16..31 = D (input part)
-  lw_zero<32 * LW_TLD>(T, l);
+  lw_zero<(DBG ? 32 : 16) * LW_TLD>(T, l);      // (the C half only: of the D half nothing but the joint-velocity blocks the lanes below write is ever read — the debug instance dumps all of it)
   qm_wave_sync();
   int row0[4]; int nc = 0; for (int k = 0; k < 4; ++k) { row0[k] = nc; nc += mode_flag(mode, k) ? 3 : 4; }
   const double gain = st[ST_POS_ERR_GAIN];
@@ -773,15 +773,16 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     if (boxv) { const double g1 = p1 - q1, g2 = p2 + q2; double* pv = (pos ? S + LW_V_QV : S + LW_V_RV) + 24 + k; double* pd = (pos ? QD : RD) + 24 + k; *pv += g1; *pd += g2; }      // (one region, the target vector selected by address)
     else if (fric) {                                                     // one lane per contact (disjoint 3x3 blocks)
       double* fr = FR + 16 * kf; double ds = 0.0;
-      for (int q = 0; q < 13; ++q) fr[q] = 0.0;
+      double fv[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // (the block is written ONCE: cleared first and then overwritten it cost this lane class 13 more LDS stores)
       if (fon) {
         const double shift = IPM ? 0.0 : st[ST_FRIC_SHIFT], iTn = IPM ? 1.0 / Tn : qm_frcp(Tn), iT3 = iTn * iTn * iTn;
         const double dh[3] = {-Fx * iTn, -Fy * iTn, muf};
         const double ddh[9] = {-(Fy * Fy + reg) * iT3, Fx * Fy * iT3, 0.0, Fx * Fy * iT3, -(Fx * Fx + reg) * iT3, 0.0, 0.0, 0.0, 0.0};
-        for (int r = 0; r < 3; ++r) { S[LW_V_RV + 3 * kf + r] += p1 * dh[r]; for (int q = 0; q < 3; ++q) fr[3 * r + q] = p2 * dh[r] * dh[q] + (IPM ? 0.0 : p1 * ddh[3 * r + q]); }
+        for (int r = 0; r < 3; ++r) { S[LW_V_RV + 3 * kf + r] += p1 * dh[r]; for (int q = 0; q < 3; ++q) fv[3 * r + q] = p2 * dh[r] * dh[q] + (IPM ? 0.0 : p1 * ddh[3 * r + q]); }
         ds = p1 * (-shift);
       }
-      fr[12] = ds;
+      for (int q = 0; q < 9; ++q) fr[q] = fv[q];
+      fr[9] = 0.0; fr[10] = 0.0; fr[11] = 0.0; fr[12] = ds;
     } else if (l == 24) { for (int q = 0; q < 6; ++q) cost += 0.5 * EE[6 + q] * EE[q] * EE[q]; }
   }
   qm_wave_sync();
