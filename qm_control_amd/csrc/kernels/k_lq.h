@@ -108,11 +108,14 @@ static_assert(KR_USED + 7 <= KR_SIZE && KR_SIZE % 8 == 0, "kin record: whole 64-
 #define LW_V_QD  (LW_V + 360)         /* diagonal additions of Q (32) */
 #define LW_V_RD  (LW_V + 392)         /* diagonal additions of R (32) */
 #define LW_K1    (LW_V + 424)
-#define LW_K2    (LW_K1 + KW_SIZE)
-#define LW_PD    (LW_K2 + KW_SIZE)      /* Pu column descriptors: first source row i0 as double [32], weights [32][3] */
-#define LW_LDS_DOUBLES (LW_PD + 128)
+#define LW_K2    (LW_K1 + KW_SIZE)     /* base + leg blocks of the second Heun stage: KW_ARM doubles (the arm block belongs to the node's own state only) */
+#define LW_K2SZ  148
+#define LW_PD    LW_K2                  /* Pu column descriptors: first source row i0 as double [32], weights [32][3].  ALIAS the stage-2 workspace: written behind phase I, its last reader */
+#define LW_JT    LW_K1                  /* [6][32] rows of the end-effector Jacobian (phase III).  ALIAS the node's kin workspace: written behind its last reader (ee_jac_col) */
+#define LW_LDS_DOUBLES (LW_K2 + LW_K2SZ)
 #define LQ_LDS_BYTES (LW_LDS_DOUBLES * 8)
-static_assert(LQ_LDS_BYTES <= 16384, "ten waves per CU (160 KB of LDS) need at most 16 KB each");
+static_assert(KW_ARM <= LW_K2SZ && 128 <= LW_K2SZ && 6 * 32 <= KW_SIZE && LW_K2SZ % 2 == 0, "aliases of the kin workspaces");
+static_assert(11 * LQ_LDS_BYTES <= 160 * 1024, "eleven waves per CU (160 KB of LDS): round 6 — with the LDS accesses un-paired the kernel gains 6 % from the eleventh wave (10 -> 11: 0.931 -> 0.871 ms, measured with an aliased layout before this one was built)");
 #define LQ_KIN_TILE (64 * 31)               /* K1a: [64][31] rows — the wave's inputs x (transposed on the way in), then the input u of each thread for the whole kernel ... */
 #define LQ_KIN_LDS_BYTES ((LQ_KIN_TILE + 64 * 9) * 8)      /* ... + the [64][9] hand-over tile of the record stores: 20 KB per wave, seven waves per CU (the benchmark launch has 6.45 per CU) */
 
@@ -439,7 +442,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   if (l >= 40 && l < 46) EE[l - 40] = in_ee;
   if (l >= 48 && l < 52) EE[12 + (l - 48)] = in_ee;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) { const int p = l + 64 * t; if (p < KW_SIZE / 2) { ((double2*)K1)[p] = in_k[t]; ((double2*)K2)[p] = terminal ? double2{0.0, 0.0} : in_k2[t]; } }
+  for (int t = 0; t < 2; ++t) { const int p = l + 64 * t; if (p < KW_SIZE / 2) ((double2*)K1)[p] = in_k[t]; if (p < LW_K2SZ / 2) ((double2*)K2)[p] = terminal ? double2{0.0, 0.0} : in_k2[t]; }
   qm_wave_sync();
 
   if (terminal) {
@@ -563,12 +566,9 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
   const int m = 3 * nst + 2 * (4 - nst) + 6;
-  qm_d4 PuF[2][2];
-#pragma unroll
-  for (int J = 0; J < 2; ++J) {
-    const int j = 16 * J + c;
-    // which block does column j belong to?  type 0: stance contact kk, component t; 1: swing contact kk, null-space column t; 2: arm joint t; 3: none
-    int type = 3, kk = 0, t = 0;
+  // which block does column j of Pu belong to?  type 0: stance contact kk, component t; 1: swing contact kk, null-space column t; 2: arm joint t; 3: none
+  auto pu_col_class = [&](int j, int& type, int& kk, int& t) {
+    type = 3; kk = 0; t = 0;
     if (j < 3 * nst) { type = 0; t = j % 3; int cnt = j / 3;
 #pragma unroll
       for (int k = 3; k >= 0; --k) { int before = 0; for (int q = 0; q < 4; ++q) if (q < k && mode_flag(mode, q)) ++before; if (mode_flag(mode, k) && before == cnt) kk = k; } }
@@ -576,14 +576,12 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
 #pragma unroll
       for (int k = 3; k >= 0; --k) { int before = 0; for (int q = 0; q < 4; ++q) if (q < k && !mode_flag(mode, q)) ++before; if (!mode_flag(mode, k) && before == cnt) kk = k; } }
     else if (j < m) { type = 2; t = j - (3 * nst + 2 * (4 - nst)); }
+  };
+  qm_d4 PuF[2][2];
+#pragma unroll
+  for (int J = 0; J < 2; ++J) {
+    int type, kk, t; pu_col_class(16 * J + c, type, kk, t);
     const int jc = 12 + 3 * contact_to_chain(kk); const double* gg = G + 12 * kk;
-    // column descriptor (every column of Pu is a unit vector or three consecutive entries): source row i0 and weights w0..w2
-    if (g == 0) {
-      const int i0 = (type == 0) ? 3 * kk + t : ((type == 1) ? jc : ((type == 2) ? 24 + t : 0));
-      S[LW_PD + j] = (double)i0;
-      { const double m1 = (type == 1) ? 1.0 : 0.0, c0 = (type == 0 || type == 2) ? 1.0 : 0.0;      // (the three block entries are read by every lane of the group — in bounds for any t — and enter through a 0 / 1 factor)
-        S[LW_PD + 32 + 3 * j] = fma(m1, gg[3 + 3 * t], c0); S[LW_PD + 32 + 3 * j + 1] = m1 * gg[4 + 3 * t]; S[LW_PD + 32 + 3 * j + 2] = m1 * gg[5 + 3 * t]; }
-    }
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -697,6 +695,20 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     for (int r = 0; r < 4; ++r) { const int row = gg2 + 4 * r; if (c == 14) rec[SR_BPV + row] = ApA[0][1][r]; }
     // rows 16..29 are joint rows: bp_j = b_j + dt Pe_j, the one non-zero term of the product (the second tile row of [Ap | bp] is never formed)
     if (l >= 16 && l < 30) rec[SR_BPV + l] = fma(dt, S[LW_V_PE + l], S[LW_V_B + l]);
+  }
+  // column descriptors of Pu (every column is a unit vector or three consecutive entries): source row i0 and weights w0..w2.  Written HERE, behind phase I: they live where the
+  // stage-2 kin workspace was (LW_PD = LW_K2 — the eleventh wave per CU)
+  qm_wave_sync();
+  if (g == 0) {
+#pragma unroll
+    for (int J = 0; J < 2; ++J) {
+      const int j = 16 * J + c; int type, kk, t; pu_col_class(j, type, kk, t);
+      const int jc = 12 + 3 * contact_to_chain(kk); const double* gg = G + 12 * kk;
+      const int i0 = (type == 0) ? 3 * kk + t : ((type == 1) ? jc : ((type == 2) ? 24 + t : 0));
+      S[LW_PD + j] = (double)i0;
+      { const double m1 = (type == 1) ? 1.0 : 0.0, c0 = (type == 0 || type == 2) ? 1.0 : 0.0;      // (the three block entries are read by every lane of the group — in bounds for any t — and enter through a 0 / 1 factor)
+        S[LW_PD + 32 + 3 * j] = fma(m1, gg[3 + 3 * t], c0); S[LW_PD + 32 + 3 * j + 1] = m1 * gg[4 + 3 * t]; S[LW_PD + 32 + 3 * j + 2] = m1 * gg[5 + 3 * t]; }
+    }
   }
   lw_bp<MT>(S, rec, m, Bdt);      // Bp = Bd Pu: the last use of the discrete-time Jacobians
   LQT()
@@ -812,9 +824,12 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   const double ineq2 = IPM ? qm_wave_sum(ipm_res) : 0.0;
   if (l == 0) { a.perf[nb * PF_SIZE] = ctot; a.perf[nb * PF_SIZE + 1] = dt * b2; a.perf[nb * PF_SIZE + 2] = dt * (eq2 + ineq2); }
   // keep Pu safe in registers?  It stays in the tile: the EE term uses its own small staging area (K2 is dead by now)
-  double* JT = K2;                                                      // [6][32] J rows, reuse of the stage-2 kin record
+  double* JT = S + LW_JT;                                               // [6][32] J rows, where the node's kin workspace was: every lane has READ it (ee_jac_col) before any lane writes a row
   qm_wave_sync();
-  if (l < 30) { double col[6]; ee_jac_col(X, K1, EE + 12, EE + 19, l, col); for (int r = 0; r < 6; ++r) JT[r * 32 + l] = col[r]; }
+  { double col[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (l < 30) ee_jac_col(X, K1, EE + 12, EE + 19, l, col);
+    qm_wave_sync();
+    if (l < 30) { for (int r = 0; r < 6; ++r) JT[r * 32 + l] = col[r]; } }
   if (l >= 30 && l < 32) for (int r = 0; r < 6; ++r) JT[r * 32 + l] = 0.0;
   qm_wave_sync();
   // [Q | q] = ([diag + shift | q] + Jᵀ mu [J | g]) dt
