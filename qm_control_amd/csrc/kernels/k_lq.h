@@ -94,28 +94,29 @@ static_assert(KR_USED + 7 <= KR_SIZE && KR_SIZE % 8 == 0, "kin record: whole 64-
 #define LW_V     (32 * LW_TLD)
 #define LW_V_X   (LW_V + 0)
 #define LW_V_U   (LW_V + 32)
-#define LW_V_B   (LW_V + 64)          /* b */
+#define LW_V_B   (LW_V + 64)          /* b (slots 30, 31 zero) */
+#define LW_V_RV  LW_V_B               /* r.  ALIASES b: the defect is dead once the projected dynamics are stored, r is formed after that (cost model); its slots 30, 31 are b's zeros */
 #define LW_V_E   (LW_V + 96)          /* e(16) */
-#define LW_V_FR  (LW_V + 64)          /* friction cone terms per contact: p2 dh dhᵀ + p1 ddh (9), p1 dh (3), ds (1) -> 4 x 16.  ALIASES b, e and 16 spare doubles: the defect and the
-                                         constraint values are dead once the projected dynamics are stored, the friction terms are formed after that (cost model) */
-#define LW_V_PE  (LW_V + 128)         /* Pe(32) */
-#define LW_V_DU  (LW_V + 160)         /* u − unom */
-#define LW_V_G   (LW_V + 192)         /* per contact: Ginv or g data (4 x 12) */
-#define LW_V_EE  (LW_V + 240)         /* g(6) mu(6) qee(4) ref(7) */
-#define LW_V_RV  (LW_V + 264)         /* r */
-#define LW_V_QV  (LW_V + 296)         /* q */
-#define LW_V_RR  (LW_V + 328)         /* r + R Pe (before the projection: the lanes' tracking cost) */
-#define LW_V_QD  (LW_V + 360)         /* diagonal additions of Q (32) */
-#define LW_V_RD  (LW_V + 392)         /* diagonal additions of R (32) */
-#define LW_K1    (LW_V + 424)
+#define LW_V_PE  (LW_V + 112)         /* Pe(32) */
+#define LW_V_G   (LW_V + 144)         /* per contact: Ginv or g data (4 x 12) */
+#define LW_V_EE  (LW_V + 192)         /* g(6) mu(6) qee(4) ref(7) */
+#define LW_V_QV  (LW_V + 216)         /* q */
+#define LW_V_RR  (LW_V + 248)         /* r + R Pe (before the projection: the lanes' tracking cost) */
+#define LW_V_SIZE 280
+/* what only the cost model (phase III) reads and writes lives in the hand-over tile, which nobody touches between Bp (lw_bp) and the projection (lw_project) — the twelfth wave per CU */
+#define LW3_QD   (LW_T + 0)           /* diagonal additions of Q (32) */
+#define LW3_RD   (LW_T + 32)          /* diagonal additions of R (32) */
+#define LW3_DU   (LW_T + 64)          /* u − unom (32; slots 30, 31 zero) */
+#define LW3_FR   (LW_T + 96)          /* friction cone terms per contact: p2 dh dhᵀ + p1 ddh (9), zeros (3), ds (1) -> 4 x 16 */
+#define LW3_JT   (LW_T + 160)         /* [6][32] rows of the end-effector Jacobian */
+#define LW_K1    (LW_V + LW_V_SIZE)
 #define LW_K2    (LW_K1 + KW_SIZE)     /* base + leg blocks of the second Heun stage: KW_ARM doubles (the arm block belongs to the node's own state only) */
 #define LW_K2SZ  148
 #define LW_PD    LW_K2                  /* Pu column descriptors: first source row i0 as double [32], weights [32][3].  ALIAS the stage-2 workspace: written behind phase I, its last reader */
-#define LW_JT    LW_K1                  /* [6][32] rows of the end-effector Jacobian (phase III).  ALIAS the node's kin workspace: written behind its last reader (ee_jac_col) */
 #define LW_LDS_DOUBLES (LW_K2 + LW_K2SZ)
 #define LQ_LDS_BYTES (LW_LDS_DOUBLES * 8)
-static_assert(KW_ARM <= LW_K2SZ && 128 <= LW_K2SZ && 6 * 32 <= KW_SIZE && LW_K2SZ % 2 == 0, "aliases of the kin workspaces");
-static_assert(11 * LQ_LDS_BYTES <= 160 * 1024, "eleven waves per CU (160 KB of LDS): round 6 — with the LDS accesses un-paired the kernel gains 6 % from the eleventh wave (10 -> 11: 0.931 -> 0.871 ms, measured with an aliased layout before this one was built)");
+static_assert(KW_ARM <= LW_K2SZ && 128 <= LW_K2SZ && LW_K2SZ % 2 == 0 && LW3_JT + 6 * 32 <= 32 * LW_TLD && LW_V_SIZE % 2 == 0, "aliases of the stage-2 kin workspace and of the hand-over tile");
+static_assert(12 * ((LQ_LDS_BYTES + 255) / 256 * 256) <= 160 * 1024, "twelve waves per CU (160 KB of LDS; three per SIMD is the register file's limit): round 6 — with the LDS accesses un-paired the kernel gains from every wave (10 -> 11 -> 12: 0.931 -> 0.871 -> 0.831 ms, measured with an aliased layout before this one was built)");
 #define LQ_KIN_TILE (64 * 31)               /* K1a: [64][31] rows — the wave's inputs x (transposed on the way in), then the input u of each thread for the whole kernel ... */
 #define LQ_KIN_LDS_BYTES ((LQ_KIN_TILE + 64 * 9) * 8)      /* ... + the [64][9] hand-over tile of the record stores: 20 KB per wave, seven waves per CU (the benchmark launch has 6.45 per CU) */
 
@@ -457,16 +458,13 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   }
   // what the prologue's loads are needed for is formed HERE and only the results stay live (three waves per SIMD: 168 registers): the defect b, the tracking terms
   // of the cost (state weights are diagonal) and u − u_nom
-  double* QD = S + LW_V_QD; double* RD = S + LW_V_RD; double* FR = S + LW_V_FR;
+  double* QD = S + LW3_QD; double* RD = S + LW3_RD; double* FR = S + LW3_FR;      // (phase III only: in the hand-over tile)
   const double bl = (l < 30) ? X[l] + 0.5 * dt * ((l < 12) ? f1 : U[l]) + 0.5 * dt * ((l < 12) ? f2 : U[l]) - xn : 0.0;
   if (l < 32) S[LW_V_B + l] = bl;
   if (l < 30) {
     const double dx = X[l] - in_xref; const double qd = in_qd;
-    S[LW_V_QV + l] = qd * dx; QD[l] = qd; RD[l] = 0.0; S[LW_V_RR + l] = 0.5 * qd * dx * dx;      // the lane's tracking cost waits in the (idle) r + R Pe slot: one register pair less across the Jacobians
-    int nst = 0; for (int k = 0; k < 4; ++k) nst += mode_flag(mode, k);
-    double unom = 0.0; if (l < 12 && (l % 3) == 2 && mode_flag(mode, l / 3) && nst > 0) unom = mb[MB_ROBOTMASS] * 9.81 / nst;
-    S[LW_V_DU + l] = U[l] - unom;
-  }
+    S[LW_V_QV + l] = qd * dx; S[LW_V_RR + l] = 0.5 * qd * dx * dx;      // the lane's tracking cost waits in the (idle) r + R Pe slot: one register pair less across the Jacobians
+  }      // (the diagonal of Q, the zero diagonal additions of R and u − unom are formed at the start of phase III: nothing reads them before, and there they fit into the idle tile)
   qm_wave_sync();
   LQT()
   // ---- phase II: equality rows + closed-form block projection ----
@@ -720,6 +718,11 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   const double r0a = st[ST_R + 30 * lr + b0], r0b = st[ST_R + 30 * lr + b0 + 1], r0c = st[ST_R + 30 * lr + b0 + 2];
   const bool boxv = l < 12, boxc = (l >= 32 && l < 44); const int kb = boxv ? l : (boxc ? l - 32 : 0); const bool pos = kb < 6; const int kj = pos ? kb : kb - 6;
   const double box_lo = pos ? mb[MB_QLO + 12 + kj] : st[ST_JVEL_LO + kj], box_hi = pos ? mb[MB_QHI + 12 + kj] : st[ST_JVEL_HI + kj];
+  const double qd3 = st[ST_Q + lr];                                       // the lane's state weight again (the prologue's copy went into q and the tracking cost)
+  if (l < 32) {      // phase III's own vectors, in the idle hand-over tile (the last reader of the tile — lw_bp — ended with a wave sync)
+    double unom = 0.0; if (l < 12 && (l % 3) == 2 && mode_flag(mode, l / 3) && nst > 0) unom = mb[MB_ROBOTMASS] * 9.81 / nst;
+    QD[l] = (l < 30) ? qd3 : 0.0; RD[l] = 0.0; S[LW3_DU + l] = (l < 30) ? U[l] - unom : 0.0;
+  }
   qm_d4 Rm[2][2]; qm_frag_load<2, 2, false>(Rm, st + ST_R, 30, 30, 30);      // input cost weights (L2 / scalar-cache resident table)
   { const double mup = st[ST_MU_EE_POS], muo = st[ST_MU_EE_ORI];      // two scalar table reads + a select of the VALUES (a select between the two addresses is a vector load with its own wait)
     if (l >= 32 && l < 38) EE[6 + (l - 32)] = ((l - 32) < 3) ? mup : muo; }
@@ -732,12 +735,12 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
     // lanes changes nothing.  A diagonal row reads two exact zeros beside its entry (columns clamped to 27..29 for the last rows).
 #pragma clang fp contract(off)
     if (l < 30) {
-      const double p0 = r0a * S[LW_V_DU + b0], p1 = r0b * S[LW_V_DU + b0 + 1], p2 = r0c * S[LW_V_DU + b0 + 2];
+      const double p0 = r0a * S[LW3_DU + b0], p1 = r0b * S[LW3_DU + b0 + 1], p2 = r0c * S[LW3_DU + b0 + 2];
       S[LW_V_RV + l] = (lb & 1) ? (p2 + p1) + p0 : p2 + (p1 + p0);          // leg blocks: lb = 4 .. 7
     }
   } else { // r = R0 (u − unom): a mat-vec on the register fragments — two partial products per lane and register, then a 16-lane DPP row sum
     // (as an MFMA it would spend 16 issues of 64 cycles on a single useful column; f64 MFMA and f64 VALU run at the same rate on gfx950)
-    const double d0 = S[LW_V_DU + c], d1 = S[LW_V_DU + 16 + c];
+    const double d0 = S[LW3_DU + c], d1 = S[LW3_DU + 16 + c];
 #pragma unroll
     for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -749,7 +752,7 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
       }
   }
   qm_wave_sync();
-  if (l < 30) cost += 0.5 * S[LW_V_DU + l] * S[LW_V_RV + l];
+  if (l < 30) cost += 0.5 * S[LW3_DU + l] * S[LW_V_RV + l];
   qm_wave_sync();
   double ipm_res = 0.0;                                                  // interior-point instance: this lane's (h − s)² terms
   // arm soft box (a6), joint-velocity box, friction cone barrier (a7).  All three are "relaxed barrier of h" evaluations: ONE branch-free
@@ -824,12 +827,9 @@ __device__ __forceinline__ void qm_lq_body(QmLqArgs a) {
   const double ineq2 = IPM ? qm_wave_sum(ipm_res) : 0.0;
   if (l == 0) { a.perf[nb * PF_SIZE] = ctot; a.perf[nb * PF_SIZE + 1] = dt * b2; a.perf[nb * PF_SIZE + 2] = dt * (eq2 + ineq2); }
   // keep Pu safe in registers?  It stays in the tile: the EE term uses its own small staging area (K2 is dead by now)
-  double* JT = S + LW_JT;                                               // [6][32] J rows, where the node's kin workspace was: every lane has READ it (ee_jac_col) before any lane writes a row
+  double* JT = S + LW3_JT;                                              // [6][32] J rows, in the idle hand-over tile
   qm_wave_sync();
-  { double col[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    if (l < 30) ee_jac_col(X, K1, EE + 12, EE + 19, l, col);
-    qm_wave_sync();
-    if (l < 30) { for (int r = 0; r < 6; ++r) JT[r * 32 + l] = col[r]; } }
+  if (l < 30) { double col[6]; ee_jac_col(X, K1, EE + 12, EE + 19, l, col); for (int r = 0; r < 6; ++r) JT[r * 32 + l] = col[r]; }
   if (l >= 30 && l < 32) for (int r = 0; r < 6; ++r) JT[r * 32 + l] = 0.0;
   qm_wave_sync();
   // [Q | q] = ([diag + shift | q] + Jᵀ mu [J | g]) dt
