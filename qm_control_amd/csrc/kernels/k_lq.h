@@ -5,7 +5,7 @@
 // OCP of qm_interface/src/QMInterface.cpp:79-142 (SURVEY.md §8 a2–a8, a11; Appendix B.6 steps 2–3):
 //   K1a qm_lq_kin_kernel (one THREAD per node): all scalar kinematics — both Heun/RK2 stages, flow values, EE pose
 //       error — written as a 4 KB "kin record" per node (lanes = instances: no idle lanes, no barriers)
-//   K1b qm_lq_kernel / qm_lq_m18_kernel (one WAVEFRONT per node, 64-thread workgroups, 15.6 KB LDS, 168 registers: three waves per SIMD): every matrix lives in the wave's registers as
+//   K1b qm_lq_kernel / qm_lq_m18_kernel (one WAVEFRONT per node, 64-thread workgroups, 13.1 KB LDS, 168 registers: three waves per SIMD, twelve per CU): every matrix lives in the wave's registers as
 //       f64-MFMA D-fragments (qm_dev_common.h), all products are P = Zᵀ Y chains, the vectors ride in column 30 of the 32-wide
 //       tiles, and LDS is only the hand-over point between the lane-per-column analytic Jacobians and the fragments.  No
 //       workgroup barrier anywhere: the 100k nodes of a batch are independent waves.
