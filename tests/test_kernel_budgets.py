@@ -94,3 +94,26 @@ def test_lds_budgets_fit_the_intended_waves_per_cu():
     cu = 160 * 1024
     lq, ric, kin, ev, wbc, sim = (lib.emu_sizes(i) for i in (3, 4, 6, 7, 8, 9))
     assert 12 * ((lq + 255) // 256 * 256) <= cu and 4 * ric <= cu and 7 * kin <= cu and 8 * ev <= cu and 4 * wbc <= cu and 4 * sim <= cu, (lq, ric, kin, ev, wbc, sim)      # (K1a: seven waves per CU hold the benchmark launch's 6.45 per CU; K1b: TWELVE since round 6 — 13440 B per wave, the register file's three per SIMD — worth 11 % of the kernel against ten)
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="libqmhip.so / llvm-objdump not available")
+def test_no_paired_lds_accesses_in_the_lds_heavy_kernels():
+    """gfx950 executes ds_read2_b64 / ds_write2_b64 at 1.6 x the LDS cycles of the two single accesses (tools/probes/lds_width_probe.hip, DESIGN.md section 7.0 "LDS pairs"); the
+    compiler forms them from neighbouring 8-byte accesses unless the build switches the IR-level vectorizer off (qm_control_amd/build_flags.py) and the kernel carries
+    QM_UNPAIRED_LDS.  A library built without either is correct and ~ 4 % slower per step: this is the guard."""
+    pairs = {}
+    for co in _code_objects():
+        with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+            f.write(co); f.flush(); dis = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <_Z\d+(qm_\w+_kernel)\w*>:", line)
+            if m: cur = m.group(1); pairs.setdefault(cur, 0); continue
+            if cur and re.search(r"\bds_(read|write)2(st64)?_b64\b", line): pairs[cur] += 1
+    for name in ("qm_lq_kernel", "qm_lq_m18_kernel", "qm_lq_kin_kernel", "qm_riccati_kernel", "qm_wbc_kernel"):
+        assert name in pairs, (name, sorted(pairs))
+        assert pairs[name] == 0, (name, pairs[name])
+
