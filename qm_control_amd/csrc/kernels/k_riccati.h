@@ -302,6 +302,63 @@ __device__ __forceinline__ void rw_stage(double* rec, int m, const double* nrec,
         }
     auto recip = [](double d) { double x = __builtin_amdgcn_rcp(d); const double e = fma(-d, x, 1.0); return fma(fma(e, e, e), x, x); };   // 2^-24 estimate + one third-order step
     constexpr int NBLK = (MT == 1) ? 4 : 5;                              // m <= 16: rows 0..15;  m = 17, 18: one more block in the second tile row
+    if (MT == 1) {
+      // ---- ONE tile row (m <= 16), SOFTWARE PIPELINED over the blocks (round 6).  A wave issues in order, so the seven MFMAs of a block written back to back (as the general
+      // loop below is compiled) are followed by the next block's pivot chain — read the 4 x 4 diagonal block with v_readlane, four dependent reciprocals — with the matrix
+      // pipe idle.  Only the two MFMAs on Huu are on the path to the next block's pivots; the six on [Hux | hu] and on the identity tile are not.  So: the two Huu MFMAs
+      // first, then the next block's pivot chain in five pieces with one of the six other MFMAs in front of each piece (scheduling barriers keep the order; the operand
+      // selects are flat — a nested select compiles into lane-conditional branches, which end the scheduling region and let the MFMAs clump again).  Same operations on
+      // the same operands in the same per-tile order: same bits.  Measured − 1.3 % of the kernel (profiles/r06_ab_riccati_chol_pipeline.log), a quarter of what the cycle
+      // budget of the two chains promised: the FP64 vector instructions of the pivot chain and the f64 MFMA share the FP64 datapath on gfx950 (equal peak rates), so only
+      // the chain's lane reads, selects and moves run beside an MFMA.
+      qm_d4& Hd = Huu[0][0];
+      double d0, d1, d2, d3, rd0, rd1, rd2, rd3, M10, M20, M21, M30, M31, M32;
+      double D00, D01, D02, D03, D11, D12, D13, D22, D23, D33, l10, l20, l30, t12, t13, l21, l31, t23, l32;
+#define RW_SB() __builtin_amdgcn_sched_barrier(0)
+#define RW_PIV1(rb_) { const int q0_ = 4 * (rb_); D00 = qm_bcast(Hd[rb_], q0_); D01 = qm_bcast(Hd[rb_], q0_ + 1); D02 = qm_bcast(Hd[rb_], q0_ + 2); D03 = qm_bcast(Hd[rb_], q0_ + 3); \
+        D11 = qm_bcast(Hd[rb_], 16 + q0_ + 1); D12 = qm_bcast(Hd[rb_], 16 + q0_ + 2); D13 = qm_bcast(Hd[rb_], 16 + q0_ + 3); \
+        D22 = qm_bcast(Hd[rb_], 32 + q0_ + 2); D23 = qm_bcast(Hd[rb_], 32 + q0_ + 3); D33 = qm_bcast(Hd[rb_], 48 + q0_ + 3); \
+        d0 = D00; rd0 = (d0 > 0.0) ? recip(d0) : 0.0; }
+#define RW_PIV2() { l10 = D01 * rd0; l20 = D02 * rd0; l30 = D03 * rd0; d1 = fma(-l10, D01, D11); rd1 = (d1 > 0.0) ? recip(d1) : 0.0; }
+#define RW_PIV3() { t12 = fma(-l20, D01, D12); t13 = fma(-l30, D01, D13); l21 = t12 * rd1; l31 = t13 * rd1; d2 = fma(-l21, t12, fma(-l20, D02, D22)); rd2 = (d2 > 0.0) ? recip(d2) : 0.0; }
+#define RW_PIV4() { t23 = fma(-l31, t12, fma(-l30, D02, D23)); l32 = t23 * rd2; d3 = fma(-l32, t23, fma(-l31, t13, fma(-l30, D03, D33))); rd3 = (d3 > 0.0) ? recip(d3) : 0.0; }
+#define RW_PIV5() { chol_fail |= ((d0 > 0.0) & (d1 > 0.0) & (d2 > 0.0) & (d3 > 0.0)) ? 0 : failbit; \
+        M10 = -l10; M21 = -l21; M32 = -l32; M20 = fma(l21, l10, -l20); M31 = fma(l32, l21, -l31); M30 = -(l30 + l31 * M10 + l32 * M20); }
+      RW_PIV1(0) RW_PIV2() RW_PIV3() RW_PIV4() RW_PIV5()
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int c0 = 4 * rb, ri = c - c0;
+        double a1 = 0.0;                                                  // A[i = c][k = g] = (L~⁻¹ − I)[ri][g]: flat selects — the nested form compiles into lane-conditional branches, which end the scheduling region
+        a1 = (ri == 1 && g == 0) ? M10 : a1; a1 = (ri == 2 && g == 0) ? M20 : a1; a1 = (ri == 2 && g == 1) ? M21 : a1;
+        a1 = (ri == 3 && g == 0) ? M30 : a1; a1 = (ri == 3 && g == 1) ? M31 : a1; a1 = (ri == 3 && g == 2) ? M32 : a1;
+        const double dg = (g == 0) ? d0 : ((g == 1) ? d1 : ((g == 2) ? d2 : d3)), rdg = (g == 0) ? rd0 : ((g == 1) ? rd1 : ((g == 2) ? rd2 : rd3));
+        dsel[0][rb] = dg;
+        Hd = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Hd[rb], Hd, 0, 0, 0);
+        double a2 = 0.0;
+        if (rb < 3) { a2 = (c > c0 + 3) ? -rdg * Hd[rb] : 0.0; Hd = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Hd[rb], Hd, 0, 0, 0); }
+        RW_SB();
+        // the six MFMAs off the pivots' path, one in front of each piece of the next block's pivot chain
+        Hux[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Hux[0][0][rb], Hux[0][0], 0, 0, 0); RW_SB();
+        if (rb < 3) { RW_PIV1(rb + 1) RW_SB(); }
+        Hux[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, Hux[0][1][rb], Hux[0][1], 0, 0, 0); RW_SB();
+        if (rb < 3) { RW_PIV2() RW_SB(); }
+        E[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, E[0][0][rb], E[0][0], 0, 0, 0); RW_SB();
+        if (rb < 3) {
+          RW_PIV3() RW_SB();
+          Hux[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Hux[0][0][rb], Hux[0][0], 0, 0, 0); RW_SB();
+          RW_PIV4() RW_SB();
+          Hux[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, Hux[0][1][rb], Hux[0][1], 0, 0, 0); RW_SB();
+          RW_PIV5() RW_SB();
+          E[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, E[0][0][rb], E[0][0], 0, 0, 0); RW_SB();
+        }
+      }
+#undef RW_PIV1
+#undef RW_PIV2
+#undef RW_PIV3
+#undef RW_PIV4
+#undef RW_PIV5
+#undef RW_SB
+    } else
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
       const int I = b >> 2, rb = b & 3, c0 = 4 * rb;
